@@ -1,0 +1,204 @@
+"""Shared between tools/make_golden.py (runs the real reference, in the build
+container only) and the tests (which never see the reference): how golden
+cases are named, how their inputs and parameters are regenerated from a seed.
+
+Inputs and parameters come from numpy's default_rng so they are bit-identical
+on every host; the .npz fixtures hold only OUTPUTS (full tensors for small
+cases, a fixed sample of elements + L2 norms for wide ones).
+"""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def fill_params(module, seed):
+    """Overwrite every parameter/buffer of `module` from default_rng(seed).
+    Keys are visited in sorted order so two modules with the same state_dict
+    schema (reference / oracle / product) get identical values."""
+    rng = np.random.default_rng(seed)
+    sd = module.state_dict()
+    new = {}
+    for key in sorted(sd.keys()):
+        t = sd[key]
+        shape = tuple(t.shape)
+        x = rng.standard_normal(shape)
+        leaf = key.split('.')[-2] if '.' in key else key
+        if t.ndim >= 2:
+            x = x * (0.7 / np.sqrt(shape[-1]))
+            if 'embed' in key and 'gbf' not in key:
+                x = rng.standard_normal(shape) * 0.3
+            if key.endswith('gbf.means.weight') or key.endswith('gbf.stds.weight'):
+                x = rng.uniform(0.2, 3.0, shape)
+            if key.endswith('gbf.mul.weight'):
+                x = 1.0 + 0.1 * rng.standard_normal(shape)
+            if key.endswith('gbf.bias.weight'):
+                x = 0.1 * rng.standard_normal(shape)
+        elif key.endswith('.weight') and ('ln' in leaf):
+            x = 1.0 + 0.1 * x
+        elif key == 'angular_freqs' or key.endswith('angular_freqs'):
+            new[key] = t.clone()
+            continue
+        else:
+            x = 0.1 * x
+        new[key] = torch.from_numpy(np.ascontiguousarray(x)).to(t.dtype)
+    module.load_state_dict(new, strict=True)
+    return module
+
+
+def additive_mask(num_nodes, N, dtype):
+    """(B,N,N,1) mask = (1-edge_mask)*finfo.min, as EmbedInput builds it
+    (reference lib/models/pcqm/layers.py:78-80)."""
+    nm = (torch.arange(N)[None, :] < torch.as_tensor(num_nodes)[:, None])
+    em = (nm[:, :, None] & nm[:, None, :]).to(dtype)
+    return ((1 - em) * torch.finfo(dtype).min).unsqueeze(-1)
+
+
+def op_inputs(B, N, W, C, num_nodes, seed, dtype=torch.float64):
+    rng = np.random.default_rng(seed)
+    h = torch.from_numpy(rng.standard_normal((B, N, W))).to(dtype)
+    e = torch.from_numpy(rng.standard_normal((B, N, N, C))).to(dtype)
+    gh = torch.from_numpy(rng.standard_normal((B, N, W))).to(dtype)      # cotangents
+    ge = torch.from_numpy(rng.standard_normal((B, N, N, C))).to(dtype)
+    mask = additive_mask(num_nodes, N, dtype)
+    return h, e, mask, gh, ge
+
+
+# name -> (class name, ctor kwargs, geometry)
+SMALL = dict(B=2, N=6, W=48, C=32, num_nodes=[6, 4])
+WIDE = dict(B=2, N=20, W=768, C=256, num_nodes=[20, 13])
+
+OP_CASES = {
+    # tiny, full tensors
+    'egt_small': ('EGT_Attention', dict(node_width=48, edge_width=32, num_heads=4), SMALL),
+    'egt_small_nodeg': ('EGT_Attention', dict(node_width=48, edge_width=32, num_heads=4, scale_degree=False, edge_update=False), SMALL),
+    'edgeupd_small': ('EdgeUpdate', dict(node_width=48, edge_width=32, num_heads=4), SMALL),
+    'tri_att_small': ('TripletAttention', dict(edge_width=32, num_heads=4), SMALL),
+    'tri_att_ungated_small': ('TripletAttentionUngated', dict(edge_width=32, num_heads=4), SMALL),
+    'axial_small': ('AxialAttention', dict(edge_width=32, num_heads=4), SMALL),
+    'tri_agg_small': ('TripletAggregate', dict(edge_width=32, num_heads=4), SMALL),
+    'tri_agg_ungated_small': ('TripletAggregateUngated', dict(edge_width=32, num_heads=4), SMALL),
+    'triupd_small': ('TriangularUpdate', dict(edge_width=32, num_heads=4), SMALL),
+    'ffn_small': ('FFN', dict(width=32, multiplier=2., activation='gelu'), SMALL),
+    'ffn_geglu_small': ('FFN', dict(width=32, multiplier=1., activation='geglu'), SMALL),
+    # BASELINE widths, sampled
+    'egt_wide': ('EGT_Attention', dict(node_width=768, edge_width=256, num_heads=64), WIDE),
+    'tri_att_wide': ('TripletAttention', dict(edge_width=256, num_heads=16), WIDE),
+    'tri_agg_wide': ('TripletAggregate', dict(edge_width=256, num_heads=16), WIDE),
+}
+
+NODE_OPS = {'EGT_Attention', 'EdgeUpdate'}
+N_SAMPLES = 512
+
+
+def sample_index(numel, seed=7):
+    rng = np.random.default_rng(seed + numel)
+    return rng.integers(0, numel, size=min(N_SAMPLES, numel))
+
+
+def summarize(t, full):
+    """What is stored for tensor t: everything (small) or samples + norm."""
+    a = t.detach().double().cpu().numpy()
+    if full:
+        return dict(full=a)
+    flat = a.reshape(-1)
+    return dict(samples=flat[sample_index(flat.size)], norm=np.array(np.linalg.norm(flat)),
+                shape=np.array(a.shape))
+
+
+def run_op_case(cls, kwargs, geom, seed):
+    """Build module (float64), run forward + backward with fixed cotangents.
+    Returns dict name -> tensor (outputs, input grads, parameter grads)."""
+    mod = fill_params(cls(**kwargs).double(), seed)
+    mod.eval()
+    h, e, mask, gh, ge = op_inputs(geom['B'], geom['N'], geom['W'], geom['C'],
+                                   geom['num_nodes'], seed + 1)
+    h.requires_grad_(True)
+    e.requires_grad_(True)
+    name = cls.__name__
+    res = {}
+    if name in NODE_OPS:
+        ho, eo = mod(h, e, mask)
+        loss = 0.
+        if ho is not h:
+            res['out_h'] = ho
+            loss = loss + (ho * gh).sum()
+        if eo is not e:
+            res['out_e'] = eo
+            loss = loss + (eo * ge).sum()
+    elif name == 'FFN':
+        eo = mod(e)
+        res['out_e'] = eo
+        loss = (eo * ge).sum()
+    else:
+        eo = mod(e, mask)
+        res['out_e'] = eo
+        loss = (eo * ge).sum()
+    loss.backward()
+    if h.grad is not None:
+        res['grad_h'] = h.grad
+    if e.grad is not None:
+        res['grad_e'] = e.grad
+    for k, p in mod.named_parameters():
+        if p.grad is not None:
+            res['pgrad.' + k] = p.grad
+    return res
+
+
+# ---- model-level cases ----------------------------------------------------
+TINY_LAYER_CFG = dict(node_width=48, edge_width=32, num_heads=4, activation='gelu',
+                      scale_degree=True, triplet_heads=4, triplet_dropout=0,
+                      node_ffn_multiplier=1., edge_ffn_multiplier=1.,
+                      source_dropout=0, drop_path=0, node_act_dropout=0, edge_act_dropout=0)
+
+MODEL_CASES = {
+    # name: (class, kwargs, batch geometry)
+    'multi_at_tiny': ('TGT_Multi', dict(model_height=3, layer_multiplier=1, upto_hop=32,
+                                        embed_3d_type='gaussian', num_3d_kernels=16, num_dist_bins=24,
+                                        triplet_type='attention', **TINY_LAYER_CFG),
+                      dict(B=3, N=7, num_nodes=[7, 5, 3])),
+    'dist_agx2_tiny': ('TGT_Distance', dict(model_height=3, layer_multiplier=2, upto_hop=32,
+                                            embed_3d_type='gaussian', num_3d_kernels=16, num_dist_bins=24,
+                                            triplet_type='aggregate', **TINY_LAYER_CFG),
+                       dict(B=3, N=7, num_nodes=[7, 5, 3])),
+    'gap_at_tiny': ('TGT_Gap', dict(model_height=3, layer_multiplier=1, upto_hop=32,
+                                    embed_3d_type='fourier', num_3d_kernels=16,
+                                    triplet_type='attention', **TINY_LAYER_CFG),
+                    dict(B=3, N=7, num_nodes=[7, 5, 3])),
+}
+
+# full TGT-At 24L width (BASELINE cfg 2 architecture) on a 2-graph batch; sampled
+FULL_AT_CFG = dict(model_height=24, layer_multiplier=1, upto_hop=32, embed_3d_type='gaussian',
+                   num_3d_kernels=128, num_dist_bins=512, node_width=768, edge_width=256,
+                   num_heads=64, activation='gelu', scale_degree=True, triplet_heads=16,
+                   triplet_type='attention', triplet_dropout=0, node_ffn_multiplier=1.,
+                   edge_ffn_multiplier=1., source_dropout=0, drop_path=0,
+                   node_act_dropout=0, edge_act_dropout=0)
+
+
+def model_batch(geom, seed):
+    """Synthetic batch + the two keys the scheme adds on device
+    (reference lib/training_schemes/pcqm/pretrain/scheme.py:60-76), without
+    coordinate noise so that the case is deterministic."""
+    from tgt_amd.training.synthetic import make_batch
+    b = make_batch(geom['B'], geom['N'], seed, num_nodes=geom['num_nodes'])
+    nm = b['node_mask']
+    b['edge_mask'] = nm.unsqueeze(-1) * nm.unsqueeze(-2)
+    c = b['dft_coords']
+    b['dist_input'] = torch.norm(c.unsqueeze(-2) - c.unsqueeze(-3), dim=-1)
+    return b
+
+
+GRAD_PROBE_KEYS = [
+    'encoder.TGT_layers.0.update.lin_QKV.weight',
+    'encoder.TGT_layers.0.update.lin_EG.weight',
+    'encoder.TGT_layers.0.update.lin_O_e.weight',
+    'encoder.TGT_layers.1.tria.tri_ln_e.weight',
+    'encoder.TGT_layers.1.tria.lin_O.weight',
+    'encoder.TGT_layers.1.edge_ffn.lin_W1.bias',
+    'encoder.TGT_layers.2.node_ffn.lin_W2.weight',
+    'input_embed.dist_embed.weight',
+    'input_embed.nodef_embed.weight',
+]

@@ -1,0 +1,168 @@
+"""Pin the oracle: oracle/ (torch restatement + explicit numpy form) against the
+golden vectors captured from the real reference (tools/make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from oracle import core, explicit_np, modules as om
+
+
+def load(name):
+    z = np.load(os.path.join(gu.GOLDEN_DIR, name + '.npz'), allow_pickle=False)
+    out = {}
+    for k in z.files:
+        base, kind = k.split('::')
+        out.setdefault(base, {})[kind] = z[k]
+    return out
+
+
+def check(t, ref, rtol, what):
+    a = t.detach().double().cpu().numpy()
+    if 'full' in ref:
+        r = ref['full']
+        assert a.shape == r.shape, what
+        err = np.abs(a - r).max()
+        scale = max(np.abs(r).max(), 1e-30)
+        assert err <= rtol * scale + 1e-13, f'{what}: max-abs {err:.3e} vs scale {scale:.3e}'
+    else:
+        flat = a.reshape(-1)
+        assert tuple(ref['shape']) == a.shape, what
+        s = flat[gu.sample_index(flat.size)]
+        scale = max(np.abs(ref['samples']).max(), 1e-30)
+        assert np.abs(s - ref['samples']).max() <= rtol * scale + 1e-13, what
+        assert abs(np.linalg.norm(flat) - ref['norm']) <= rtol * ref['norm'], what
+
+
+@pytest.mark.parametrize('name', list(gu.OP_CASES))
+def test_op_case_matches_reference(name):
+    cls_name, kwargs, geom = gu.OP_CASES[name]
+    i = list(gu.OP_CASES).index(name)
+    res = gu.run_op_case(getattr(om, cls_name), kwargs, geom, seed=100 + i)
+    gold = load('op_' + name)
+    assert set(res) == set(gold), (sorted(res), sorted(gold))
+    for k, t in res.items():
+        check(t, gold[k], 1e-11, f'{name}:{k}')
+
+
+def pretrain_loss(out, batch, num_bins):
+    gap, logits = out
+    prim = torch.nn.functional.l1_loss(gap, batch['target'])
+    dl = core.binned_distance_xent(logits, core.pairwise_dist(batch['dft_coords']),
+                                   batch['edge_mask'], num_bins, 8)
+    return prim + 0.1 * dl
+
+
+@pytest.mark.parametrize('name', list(gu.MODEL_CASES))
+def test_model_case_matches_reference(name):
+    cls_name, kwargs, geom = gu.MODEL_CASES[name]
+    i = list(gu.MODEL_CASES).index(name)
+    model = gu.fill_params(getattr(om, cls_name)(**kwargs).double(), seed=500 + i)
+    model.train()
+    batch = gu.model_batch(geom, seed=600 + i)
+    batch['dist_input'] = batch['dist_input'].double()
+    out = model(batch)
+    res = {}
+    if cls_name == 'TGT_Multi':
+        res['gap'], res['logits'] = out
+        loss = pretrain_loss(out, batch, kwargs['num_dist_bins'])
+    elif cls_name == 'TGT_Distance':
+        res['logits'] = out
+        loss = core.binned_distance_xent(out, core.pairwise_dist(batch['dft_coords']),
+                                         batch['edge_mask'], kwargs['num_dist_bins'], 8)
+    else:
+        res['gap'] = out
+        loss = torch.nn.functional.l1_loss(out, batch['target'])
+    assert loss.dtype == torch.float64          # quirk Q9
+    res['loss'] = loss
+    loss.backward()
+    named = dict(model.named_parameters())
+    for k in gu.GRAD_PROBE_KEYS:
+        if k in named and named[k].grad is not None:
+            res['pgrad.' + k] = named[k].grad
+    gold = load('model_' + name)
+    assert set(res) == set(gold), (sorted(res), sorted(gold))
+    for k, t in res.items():
+        check(t, gold[k], 1e-10, f'{name}:{k}')
+
+
+def test_full_width_24L_fp32_forward():
+    geom = dict(B=2, N=12, num_nodes=[12, 9])
+    model = gu.fill_params(om.TGT_Multi(**gu.FULL_AT_CFG), seed=900)
+    model.eval()
+    batch = gu.model_batch(geom, seed=901)
+    with torch.no_grad():
+        gap, logits = model(batch)
+    gold = load('model_full_at_24L_fp32')
+    # fp32 vs fp32 run of the reference on the same host library: tight
+    check(gap, gold['gap'], 1e-4, 'gap')
+    check(logits, gold['logits'], 1e-3, 'logits')
+    agree = (logits.argmax(-1).numpy() == gold['logits_argmax']['full']).mean()
+    assert agree > 0.995
+
+
+def test_state_dict_manifest_matches_reference():
+    gold = load('misc')
+    sd = om.TGT_Multi(**gu.FULL_AT_CFG).state_dict()
+    assert list(sd.keys()) == list(gold['manifest_keys']['full'])
+    assert [','.join(map(str, v.shape)) for v in sd.values()] == list(gold['manifest_shapes']['full'])
+
+
+def test_misc_functions():
+    gold = load('misc')
+    rng = np.random.default_rng(4242)
+    coords = torch.from_numpy(rng.standard_normal((2, 5, 3)).astype(np.float32))
+    d = core.pairwise_dist(coords)
+    np.testing.assert_allclose(d.numpy(), gold['coords2dist']['full'], rtol=1e-6, atol=1e-6)
+    logits = torch.from_numpy(rng.standard_normal((2, 5, 5, 16)))
+    em = torch.ones(2, 5, 5, dtype=torch.uint8)
+    em[1, 3:, :] = 0
+    em[1, :, 3:] = 0
+    np.testing.assert_allclose(core.binned_distance_xent(logits, d.double(), em, 16, 8).numpy(),
+                               gold['xent_reduced']['full'], rtol=1e-12)
+    np.testing.assert_allclose(core.binned_distance_xent(logits, d.double(), em, 16, 8, reduce=False).numpy(),
+                               gold['xent_per_graph']['full'], rtol=1e-12)
+    bins = torch.from_numpy(gold['bins_in']['full'])
+    np.testing.assert_allclose(core.bins_to_dist(bins, 8 / 15).numpy(), gold['bins2dist']['full'], rtol=1e-6)
+
+
+# ---- the two oracle forms against each other (and hence both vs golden) ----
+def _rand_core_inputs(B, N, W, C, Hn, Ht, seed):
+    rng = np.random.default_rng(seed)
+    r = lambda *s: torch.from_numpy(rng.standard_normal(s))
+    num_nodes = [N, max(1, N - 2)][:B] + [N] * max(0, B - 2)
+    mask = gu.additive_mask(num_nodes, N, torch.float64)
+    return dict(qkv=r(B, N, 3 * W), eg=r(B, N, N, 2 * Hn), tq_in=r(B, N, N, 3 * C), te_in=r(B, N, N, 2 * Ht),
+                tq_out=r(B, N, N, 3 * C), te_out=r(B, N, N, 2 * Ht), v2=r(B, N, N, 2 * C),
+                eg4=r(B, N, N, 4 * Ht), mask=mask)
+
+
+def test_explicit_numpy_form_agrees_with_torch_form():
+    B, N, W, C, Hn, Ht = 2, 5, 24, 16, 4, 2
+    x = _rand_core_inputs(B, N, W, C, Hn, Ht, 3)
+    m3 = x['mask'][..., 0].numpy()
+    v_att, h_hat = core.egt_attention_core(x['qkv'], x['eg'], x['mask'], Hn)
+    v2, h2 = explicit_np.egt_attention(x['qkv'].numpy(), x['eg'].numpy(), m3, Hn)
+    np.testing.assert_allclose(v_att.numpy(), v2, rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(h_hat.numpy(), h2, rtol=1e-12, atol=1e-13)
+    va = core.triplet_attention_core(x['tq_in'], x['te_in'], x['tq_out'], x['te_out'], x['mask'], Ht)
+    va2 = explicit_np.triplet_attention(x['tq_in'].numpy(), x['te_in'].numpy(), x['tq_out'].numpy(),
+                                        x['te_out'].numpy(), m3, Ht)
+    np.testing.assert_allclose(va.numpy(), va2, rtol=1e-12, atol=1e-13)
+    ag = core.triplet_aggregate_core(x['v2'], x['eg4'], x['mask'], Ht)
+    ag2 = explicit_np.triplet_aggregate(x['v2'].numpy(), x['eg4'].numpy(), m3, Ht)
+    np.testing.assert_allclose(ag.numpy(), ag2, rtol=1e-12, atol=1e-13)
+
+
+def test_fully_padded_rows_stay_finite():
+    """Q6: padded query rows give a finite uniform softmax and a zero gate."""
+    x = _rand_core_inputs(2, 6, 24, 16, 4, 2, 5)
+    for k in ('qkv', 'eg', 'tq_in', 'te_in', 'tq_out', 'te_out', 'mask'):
+        x[k] = x[k].float()
+    x['mask'] = gu.additive_mask([6, 3], 6, torch.float32)
+    v_att, h_hat = core.egt_attention_core(x['qkv'], x['eg'], x['mask'], 4)
+    va = core.triplet_attention_core(x['tq_in'], x['te_in'], x['tq_out'], x['te_out'], x['mask'], 2)
+    assert torch.isfinite(v_att).all() and torch.isfinite(h_hat).all() and torch.isfinite(va).all()
+    assert v_att[1, 3:].abs().max() == 0

@@ -1,0 +1,163 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REAL reference on CPU.
+
+Runs only in the build container (needs /root/reference, which never travels
+to the GPU box).  Usage:  python tools/make_golden.py [/root/reference]
+
+Nothing from the reference is copied: it is imported, driven with inputs and
+parameters regenerated from numpy seeds (tests/golden_util.py), and only its
+numerical OUTPUTS are stored.  numba is absent here; the reference's scheme
+modules are not needed for these vectors (lib.tgt, lib.models.pcqm and
+lib.training_schemes.pcqm.commons import without it).
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = sys.argv[1] if len(sys.argv) > 1 else '/root/reference'
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, REF)
+
+import golden_util as gu                                            # noqa: E402
+from lib.tgt.layers import layers as ref_layers                    # noqa: E402
+from lib.tgt.layers import triplet as ref_triplet                  # noqa: E402
+from lib.models.pcqm.multitask import TGT_Multi                    # noqa: E402
+from lib.models.pcqm.distance_predictor import TGT_Distance        # noqa: E402
+from lib.models.pcqm.gap_predictor import TGT_Gap                  # noqa: E402
+from lib.training_schemes.pcqm import commons as ref_commons       # noqa: E402
+
+torch.set_num_threads(8)
+REF_CLASSES = {}
+for modl in (ref_layers, ref_triplet):
+    for k in dir(modl):
+        v = getattr(modl, k)
+        if isinstance(v, type) and issubclass(v, torch.nn.Module):
+            REF_CLASSES[k] = v
+REF_CLASSES.update(TGT_Multi=TGT_Multi, TGT_Distance=TGT_Distance, TGT_Gap=TGT_Gap)
+
+
+def save(name, arrays):
+    os.makedirs(gu.GOLDEN_DIR, exist_ok=True)
+    path = os.path.join(gu.GOLDEN_DIR, name + '.npz')
+    np.savez_compressed(path, **arrays)
+    print(f'  wrote {path}  ({os.path.getsize(path)/1024:.1f} KiB)')
+
+
+def flatten(res, full):
+    out = {}
+    for k, t in res.items():
+        for kk, a in gu.summarize(t, full).items():
+            out[f'{k}::{kk}'] = a
+    return out
+
+
+def op_cases():
+    for i, (name, (cls_name, kwargs, geom)) in enumerate(gu.OP_CASES.items()):
+        t0 = time.time()
+        res = gu.run_op_case(REF_CLASSES[cls_name], kwargs, geom, seed=100 + i)
+        full = geom is gu.SMALL
+        print(f'{name}: {cls_name} {time.time()-t0:.1f}s')
+        save('op_' + name, flatten(res, full))
+
+
+def pretrain_loss(outputs, batch, num_bins, range_bins=8, weight=0.1):
+    """reference lib/training_schemes/pcqm/pretrain/scheme.py:78-88"""
+    gap, logits = outputs
+    prim = torch.nn.functional.l1_loss(gap, batch['target'])
+    dist_targ = ref_commons.coords2dist(batch['dft_coords'])
+    dl = ref_commons.DiscreteDistLoss(num_bins, range_bins)(logits, dist_targ, batch['edge_mask'])
+    return prim + weight * dl
+
+
+def model_cases():
+    for i, (name, (cls_name, kwargs, geom)) in enumerate(gu.MODEL_CASES.items()):
+        model = gu.fill_params(REF_CLASSES[cls_name](**kwargs).double(), seed=500 + i)
+        model.train()            # all dropout rates are 0 -> deterministic (training_step runs in train mode)
+        batch = gu.model_batch(geom, seed=600 + i)
+        batch['dist_input'] = batch['dist_input'].double()
+        out = model(batch)
+        res = {}
+        if cls_name == 'TGT_Multi':
+            res['gap'], res['logits'] = out
+            loss = pretrain_loss(out, batch, kwargs['num_dist_bins'])
+        elif cls_name == 'TGT_Distance':
+            res['logits'] = out
+            dist_targ = ref_commons.coords2dist(batch['dft_coords'])
+            loss = ref_commons.DiscreteDistLoss(kwargs['num_dist_bins'], 8)(out, dist_targ, batch['edge_mask'])
+        else:
+            res['gap'] = out
+            loss = torch.nn.functional.l1_loss(out, batch['target'])
+        res['loss'] = loss
+        loss.backward()
+        named = dict(model.named_parameters())
+        for k in gu.GRAD_PROBE_KEYS:
+            if k in named and named[k].grad is not None:
+                res['pgrad.' + k] = named[k].grad
+        print(f'{name}: {cls_name} loss={float(loss):.6f} dtype={loss.dtype}')
+        save('model_' + name, flatten(res, True))
+
+
+def full_width_case():
+    """TGT-At 24L at BASELINE widths, fp32 (as the CPU reference path runs it),
+    B=2 N=12 ragged; eval-mode forward only; sampled."""
+    geom = dict(B=2, N=12, num_nodes=[12, 9])
+    torch.manual_seed(0)
+    model = gu.fill_params(TGT_Multi(**gu.FULL_AT_CFG), seed=900)
+    model.eval()
+    batch = gu.model_batch(geom, seed=901)
+    t0 = time.time()
+    with torch.no_grad():
+        gap, logits = model(batch)
+    print(f'full_at_24L fwd {time.time()-t0:.1f}s gap={gap.tolist()}')
+    res = dict(gap=gap, logits=logits)
+    out = {}
+    for kk, a in gu.summarize(gap, True).items():
+        out[f'gap::{kk}'] = a
+    for kk, a in gu.summarize(logits, False).items():
+        out[f'logits::{kk}'] = a
+    out['logits_argmax::full'] = logits.argmax(-1).numpy().astype(np.int16)
+    save('model_full_at_24L_fp32', out)
+
+
+def misc_cases():
+    rng = np.random.default_rng(4242)
+    coords = torch.from_numpy(rng.standard_normal((2, 5, 3)).astype(np.float32))
+    d = ref_commons.coords2dist(coords)
+    logits = torch.from_numpy(rng.standard_normal((2, 5, 5, 16)))
+    em = torch.ones(2, 5, 5, dtype=torch.uint8)
+    em[1, 3:, :] = 0
+    em[1, :, 3:] = 0
+    lossfn = ref_commons.DiscreteDistLoss(16, 8)
+    out = {
+        'coords2dist::full': d.numpy(),
+        'xent_reduced::full': lossfn(logits, d.double(), em).numpy(),
+        'xent_per_graph::full': lossfn(logits, d.double(), em, reduce=False).numpy(),
+        'discrete_dist::full': ref_commons.discrete_dist(d, 16, 8).numpy(),
+    }
+    bp = ref_commons.BinsProcessor.__new__(ref_commons.BinsProcessor)
+    bp.shift_half, bp.zero_diag, bp.bin_size = True, True, 8 / 15
+    bins = torch.from_numpy(np.triu(rng.integers(0, 16, size=(2, 5, 5)), 1))
+    out['bins2dist::full'] = bp.bins2dist(bins).numpy()
+    out['bins_in::full'] = bins.numpy()
+    # state_dict schema manifest: key -> shape, TGT-At Multi
+    sd = TGT_Multi(**gu.FULL_AT_CFG).state_dict()
+    out['manifest_keys::full'] = np.array(list(sd.keys()))
+    out['manifest_shapes::full'] = np.array([','.join(map(str, v.shape)) for v in sd.values()])
+    save('misc', out)
+
+
+if __name__ == '__main__':
+    which = sys.argv[2:] or ['op', 'model', 'misc', 'full']
+    if 'op' in which:
+        op_cases()
+    if 'model' in which:
+        model_cases()
+    if 'misc' in which:
+        misc_cases()
+    if 'full' in which:
+        full_width_case()
