@@ -1,0 +1,171 @@
+/*
+ * tgt_hip.h -- C ABI of libtgt_hip.so: the MI355X (gfx950) kernels underneath
+ * the TGT layer modules.
+ *
+ * The reference (shamim-hussain/tgt) has no FFI: its seam is Python module
+ * substitution (lib/tgt/layers/layers.py:219-251 instantiates
+ * `EGT_Attention` / `get_triplet_layer(...)`), and all arithmetic is ATen
+ * calls inside those modules' forward().  Each entry point below replaces the
+ * ATen call sequence of one such forward (cited per function); the Python
+ * mirror in tgt_amd/tgt/ binds them with ctypes.
+ *
+ * Conventions
+ *  - plain pointers to DEVICE memory + sizes; no framework types.
+ *  - tensors are borrowed for the call; nothing is retained or allocated.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *  - every function returns 0 on success, non-zero on error
+ *    (TGT_ERR_*); tgt_last_error() gives a thread-local message.
+ *  - kernels are stateless and re-entrant; launches are asynchronous.
+ *  - element type is chosen by `dtype` (TGT_F32 / TGT_BF16 / TGT_F16); masks,
+ *    softmax statistics and reductions are always float32.
+ *  - channel layouts: the triplet ops take HEAD-MAJOR channels (c = h*D + d);
+ *    the node-attention ops take the reference's HEAD-MINOR channels
+ *    (c = d*H + h).  The Python mirror permutes the projection weights, not
+ *    the activations, to get head-major triplet operands.
+ */
+#ifndef TGT_HIP_H
+#define TGT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { TGT_F32 = 0, TGT_BF16 = 1, TGT_F16 = 2 };
+enum { TGT_OK = 0, TGT_ERR_INVALID = 1, TGT_ERR_UNSUPPORTED = 2, TGT_ERR_LAUNCH = 3 };
+
+/* flags for the triplet ops */
+enum {
+    TGT_TRI_BIASED      = 1,   /* third-arm bias E present      */
+    TGT_TRI_GATED       = 2,   /* third-arm sigmoid gate present */
+    TGT_TRI_MASK_OUT    = 4,   /* aggregate only: mask the outward direction (ungated variant) */
+};
+
+const char* tgt_last_error(void);
+/* ABI version of this header; bump on any signature change. */
+int tgt_abi_version(void);
+
+/* ------------------------------------------------------------------------
+ * Triplet attention core (TripletAttention / TripletAttentionUngated /
+ * AxialAttention).  Replaces reference lib/tgt/layers/triplet.py:213-246
+ * (the two einsum+softmax+gate+einsum chains) and its autograd backward.
+ *
+ * For dir in {0 = inward, 1 = outward}, per graph b, head h, edge (i,j):
+ *   inward : S[k] = s * Q[i,j,h,:]·K[j,k,h,:] + E[i,k,h] + M[i,k]
+ *            O[i,j,h,:] = sum_k softmax_k(S)[k] * sigmoid(G[i,k,h]+M[i,k]) * V[j,k,h,:]
+ *   outward: S[k] = s * Q[i,j,h,:]·K[k,j,h,:] + E[k,i,h] + M[k,i]
+ *            O[i,j,h,:] = sum_k softmax_k(S)[k] * sigmoid(G[k,i,h]+M[k,i]) * V[k,j,h,:]
+ *
+ * qkv[dir] : (B,N,N,ld_qkv[dir]) rows; Q,K,V of head h start at element
+ *            q_off/k_off/v_off[dir] + h*D (head-major, D contiguous).
+ * eg[dir]  : (B,N,N,ld_eg[dir]) rows; E[.,.,h] at e_off[dir]+h, G at g_off[dir]+h
+ *            (ignored when the BIASED/GATED flags are clear).
+ * mask     : (B,N,N) float32 additive mask (0 / finfo.min).
+ * out      : (B,N,N,ld_out) rows; O of (dir,h) at o_off[dir] + h*D.
+ * Nothing is saved for backward: softmax statistics are recomputed.
+ * Backward adds: d_out (same layout as out), and writes d_qkv[dir]
+ * (same layout as qkv[dir]: every Q,K,V element is written), d_eg[dir]
+ * (E and G columns written; same layout as eg[dir]).
+ * Supported: N <= 64, D in {8,16,32}, any H.
+ * ---------------------------------------------------------------------- */
+typedef struct tgt_triplet_attention_args {
+    int32_t B, N, H, D;
+    int32_t dtype, flags;
+    float   scale;                    /* D^-0.5 */
+    int32_t _pad0;
+    const void* qkv[2];  int64_t ld_qkv[2];  int32_t q_off[2], k_off[2], v_off[2];
+    const void* eg[2];   int64_t ld_eg[2];   int32_t e_off[2], g_off[2];
+    const float* mask;
+    void*   out;         int64_t ld_out;     int32_t o_off[2];
+    /* backward only */
+    const void* d_out;
+    void*   d_qkv[2];
+    void*   d_eg[2];
+} tgt_triplet_attention_args;
+
+int tgt_triplet_attention_fwd(const tgt_triplet_attention_args* a, void* stream);
+int tgt_triplet_attention_bwd(const tgt_triplet_attention_args* a, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Triplet aggregate core (TripletAggregate / TripletAggregateUngated).
+ * Replaces reference lib/tgt/layers/triplet.py:56-70 (gated; outward
+ * direction unmasked) and :107-123 (ungated; TGT_TRI_MASK_OUT).
+ *   inward : A[i,k,h] = softmax_k(E_in[i,k,h]+M[i,k]) * sigmoid(G_in[i,k,h]+M[i,k])
+ *            O[i,j,h,:] = sum_k A[i,k,h] V_in[j,k,h,:]
+ *   outward: A[k,i,h] = softmax_k(E_out[k,i,h] (+M[k,i])) * sigmoid(G_out[k,i,h] (+M[k,i]))
+ *            O[i,j,h,:] = sum_k A[k,i,h] V_out[k,j,h,:]
+ * v[dir] : (B,N,N,ld_v[dir]) rows, V of head h at v_off[dir] + h*D.
+ * eg / mask / out as above.  No saved statistics (weights are recomputed).
+ * ---------------------------------------------------------------------- */
+typedef struct tgt_triplet_aggregate_args {
+    int32_t B, N, H, D;
+    int32_t dtype, flags;
+    const void* v[2];    int64_t ld_v[2];    int32_t v_off[2];
+    const void* eg[2];   int64_t ld_eg[2];   int32_t e_off[2], g_off[2];
+    const float* mask;
+    void*   out;         int64_t ld_out;     int32_t o_off[2];
+    /* backward only */
+    const void* d_out;
+    void*   d_v[2];
+    void*   d_eg[2];
+} tgt_triplet_aggregate_args;
+
+int tgt_triplet_aggregate_fwd(const tgt_triplet_aggregate_args* a, void* stream);
+int tgt_triplet_aggregate_bwd(const tgt_triplet_aggregate_args* a, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Node attention with edge bias + gate (EGT_Attention) and the logits-only
+ * EdgeUpdate.  Replaces reference lib/tgt/layers/layers.py:62-77 (and
+ * :120-124 for EdgeUpdate) and its autograd backward.
+ *   H_hat[l,m,h] = s * sum_d Q[l,d,h] K[m,d,h] + E[l,m,h]          (written, T)
+ *   A[l,m,h]     = softmax_m(H_hat + M[l,m]) * sigmoid(G[l,m,h] + M[l,m])
+ *   V_att[l,d,h] = (sum_m A[l,m,h] V[m,d,h]) * (scale_degree ? log(1+sum_m gate) : 1)
+ * qkv  : (B,N,ld_qkv) rows, HEAD-MINOR: Q[l,d,h] at q_off + d*H + h (k_off, v_off alike)
+ * eg   : (B,N,N,ld_eg) rows; E at e_off+h, G at g_off+h
+ * mask : (B,N,N) float32 (already includes the source-dropout mask, if any)
+ * vatt : (B,N,W=D*H) head-minor;  hhat: (B,N,N,H) (may be NULL: no edge update)
+ * lse  : (B,N,H) float32;  gsum: (B,N,H) float32 (sum_m gate)   [saved for bwd]
+ * logits_only != 0: EdgeUpdate -- only hhat is produced (V, G, mask, vatt unused).
+ * Backward: d_vatt (B,N,W), d_hhat (B,N,N,H, may be NULL) -> d_qkv (B,N,ld_qkv;
+ * Q,K,V columns written), d_eg (B,N,N,ld_eg; E,G columns written).
+ * Supported: any N, D <= 32, any H.
+ * ---------------------------------------------------------------------- */
+typedef struct tgt_node_attention_args {
+    int32_t B, N, H, D;
+    int32_t dtype, scale_degree, logits_only, _pad0;
+    float   scale;                    /* D^-0.5 */
+    int32_t _pad1;
+    const void* qkv;   int64_t ld_qkv;  int32_t q_off, k_off, v_off, _pad2;
+    const void* eg;    int64_t ld_eg;   int32_t e_off, g_off;
+    const float* mask;
+    void*  vatt;
+    void*  hhat;
+    float* lse;
+    float* gsum;
+    /* backward only */
+    const void* d_vatt;
+    const void* d_hhat;
+    void*  d_qkv;
+    void*  d_eg;
+} tgt_node_attention_args;
+
+int tgt_node_attention_fwd(const tgt_node_attention_args* a, void* stream);
+int tgt_node_attention_bwd(const tgt_node_attention_args* a, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Flat-buffer Adam step (replaces apex.optimizers.FusedAdam, reference
+ * lib/training/training.py:159-171; adam_w_mode with weight_decay=0 ==
+ * torch.optim.Adam).  All buffers float32 of length n.
+ *   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g
+ *   p -= lr * (m/(1-b1^t)) / (sqrt(v/(1-b2^t)) + eps)   [+ lr*wd*p decoupled]
+ * grad_scale multiplies g first (1/world_size or AMP unscale).
+ * ---------------------------------------------------------------------- */
+int tgt_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                  int64_t n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int32_t step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TGT_HIP_H */

@@ -1,0 +1,215 @@
+"""Parity of the HIP kernels (through the C ABI) against the oracle, on the GPU.
+
+fp32 kernels: <= 2e-5 rel-L2 vs the float64 oracle (exact-f32 matrix core +
+fast exp/rcp).  bf16/fp16 kernels: <= 2e-2 / 5e-3 (the reference's own
+bf16-autocast drift on one TripletAttention is 4.5e-3); gradients
+2x the forward tolerance.
+"""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from oracle import core
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2, torch.float16: 5e-3}
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    a, b = a.detach(), b.detach()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def rnd(rng, *shape, scale=1.0):
+    return torch.from_numpy(rng.standard_normal(shape) * scale)
+
+
+def to_ref(x_hm, idx):
+    out = torch.empty_like(x_hm)
+    out[..., idx] = x_hm
+    return out
+
+
+def from_ref(x_ref, idx):
+    return x_ref[..., idx]
+
+
+CASES = [  # B, N, num_nodes, C, H
+    (2, 6, [6, 4], 32, 4),
+    (2, 20, [20, 13], 256, 16),
+    (3, 32, [32, 17, 32], 256, 16),
+    (1, 9, [9], 128, 4),          # D = 32
+    (2, 5, [5, 1], 48, 3),        # H not a multiple of 4 (D = 16)
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('case', CASES)
+@pytest.mark.parametrize('variant', ['gated', 'ungated', 'axial'])
+def test_triplet_attention(case, dtype, variant):
+    from tgt_amd import ops, layout
+    B, N, nn_, C, H = case
+    gated, biased = variant == 'gated', variant != 'axial'
+    L = ops.TripletLayout(C, H, gated=gated, biased=biased)
+    rng = np.random.default_rng(hash((B, N, C, H)) % 1000)
+    fused = rnd(rng, B, N, N, L.width).to(dtype)          # values as the kernel will see them
+    d_out = rnd(rng, B, N, N, 2 * C).to(dtype)
+    mask = gu.additive_mask(nn_, N, torch.float32)
+
+    # ---- oracle (float64, reference layout) ----
+    f64 = fused.double().requires_grad_(True)
+    idx, oidx = layout.head_major_index(C, H), layout.va_cols_head_major(C, H)
+    def blk(lo):
+        return torch.cat([to_ref(f64[..., lo + p * C: lo + (p + 1) * C], idx) for p in range(3)], -1)
+    qkv_in, qkv_out = blk(0), blk(3 * C)
+    nb = (2 if gated else 1) * H
+    eg_in = f64[..., 6 * C: 6 * C + nb] if biased else None   # (pad columns past L.used are ignored)
+    eg_out = f64[..., 6 * C + nb: 6 * C + 2 * nb] if biased else None
+    va_ref = core.triplet_attention_core(qkv_in, eg_in, qkv_out, eg_out, mask.double(), H, gated, biased)
+    va_ref_hm = from_ref(va_ref, oidx)
+    (va_ref_hm * d_out.double()).sum().backward()
+
+    # ---- HIP ----
+    fx = fused.cuda().requires_grad_(True)
+    va = ops.triplet_attention(fx, mask.reshape(B, N, N).cuda(), L)
+    va.backward(d_out.cuda())
+    torch.cuda.synchronize()
+    tol = TOL[dtype]
+    assert torch.isfinite(va).all()
+    assert rel(va, va_ref_hm) < tol, ('fwd', rel(va, va_ref_hm))
+    g, gr = fx.grad, f64.grad
+    assert torch.isfinite(g).all()
+    assert rel(g[..., :6 * C], gr[..., :6 * C]) < 2 * tol, ('dqkv', rel(g[..., :6 * C], gr[..., :6 * C]))
+    if biased:
+        assert rel(g[..., 6 * C:L.used], gr[..., 6 * C:L.used]) < 2 * tol, ('deg', rel(g[..., 6 * C:L.used], gr[..., 6 * C:L.used]))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('case', CASES)
+@pytest.mark.parametrize('gated', [True, False])
+def test_triplet_aggregate(case, dtype, gated):
+    from tgt_amd import ops, layout
+    B, N, nn_, C, H = case
+    L = ops.AggregateLayout(C, H, gated=gated)
+    rng = np.random.default_rng(hash((B, N, C, H, 1)) % 1000)
+    fused = rnd(rng, B, N, N, L.width).to(dtype)
+    d_out = rnd(rng, B, N, N, 2 * C).to(dtype)
+    mask = gu.additive_mask(nn_, N, torch.float32)
+    f64 = fused.double().requires_grad_(True)
+    idx, oidx = layout.head_major_index(C, H), layout.va_cols_head_major(C, H)
+    v_both = torch.cat([to_ref(f64[..., p * C:(p + 1) * C], idx) for p in range(2)], -1)
+    va_ref = core.triplet_aggregate_core(v_both, f64[..., 2 * C:L.used], mask.double(), H, gated)
+    va_ref_hm = from_ref(va_ref, oidx)
+    (va_ref_hm * d_out.double()).sum().backward()
+
+    fx = fused.cuda().requires_grad_(True)
+    va = ops.triplet_aggregate(fx, mask.reshape(B, N, N).cuda(), L)
+    va.backward(d_out.cuda())
+    torch.cuda.synchronize()
+    tol = TOL[dtype]
+    assert rel(va, va_ref_hm) < tol, ('fwd', rel(va, va_ref_hm))
+    g, gr = fx.grad, f64.grad
+    assert torch.isfinite(g).all()
+    assert rel(g[..., :2 * C], gr[..., :2 * C]) < 2 * tol, ('dv', rel(g[..., :2 * C], gr[..., :2 * C]))
+    assert rel(g[..., 2 * C:L.used], gr[..., 2 * C:L.used]) < 2 * tol, ('deg', rel(g[..., 2 * C:L.used], gr[..., 2 * C:L.used]))
+
+
+NODE_CASES = [  # B, N, num_nodes, W, H
+    (2, 6, [6, 4], 48, 4),
+    (2, 20, [20, 13], 768, 64),
+    (3, 32, [32, 17, 32], 768, 64),
+    (2, 7, [7, 2], 96, 12),       # H not a power of two
+    (1, 40, [33], 64, 8),         # N > 32
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('case', NODE_CASES)
+@pytest.mark.parametrize('scale_degree,want_edges', [(True, True), (False, False)])
+def test_node_attention(case, dtype, scale_degree, want_edges):
+    from tgt_amd import ops
+    B, N, nn_, W, H = case
+    rng = np.random.default_rng(hash((B, N, W, H)) % 1000)
+    qkv = rnd(rng, B, N, 3 * W).to(dtype)
+    eg = rnd(rng, B, N, N, 2 * H).to(dtype)
+    d_v = rnd(rng, B, N, W).to(dtype)
+    d_h = rnd(rng, B, N, N, H).to(dtype)
+    mask = gu.additive_mask(nn_, N, torch.float32)
+
+    q64, e64 = qkv.double().requires_grad_(True), eg.double().requires_grad_(True)
+    v_ref, h_ref = core.egt_attention_core(q64, e64, mask.double(), H, scale_degree)
+    loss = (v_ref * d_v.double()).sum()
+    if want_edges:
+        loss = loss + (h_ref * d_h.double()).sum()
+    loss.backward()
+
+    qx, ex = qkv.cuda().requires_grad_(True), eg.cuda().requires_grad_(True)
+    v, hh = ops.node_attention(qx, ex, mask.reshape(B, N, N).cuda(), H, scale_degree, want_edges)
+    loss = (v.float() * d_v.cuda().float()).sum()
+    if want_edges:
+        loss = loss + (hh.float() * d_h.cuda().float()).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    tol = TOL[dtype]
+    assert rel(v, v_ref) < tol, ('vatt', rel(v, v_ref))
+    if want_edges:
+        assert rel(hh, h_ref) < tol, ('hhat', rel(hh, h_ref))
+    assert rel(qx.grad, q64.grad) < 2 * tol, ('dqkv', rel(qx.grad, q64.grad))
+    assert rel(ex.grad, e64.grad) < 2 * tol, ('deg', rel(ex.grad, e64.grad))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_edge_logits(dtype):
+    from tgt_amd import ops
+    B, N, W, H = 2, 9, 48, 4
+    rng = np.random.default_rng(11)
+    qk, eb, d_h = rnd(rng, B, N, 2 * W).to(dtype), rnd(rng, B, N, N, H).to(dtype), rnd(rng, B, N, N, H).to(dtype)
+    q64, e64 = qk.double().requires_grad_(True), eb.double().requires_grad_(True)
+    ref = core.edge_update_core(q64, e64, H)
+    (ref * d_h.double()).sum().backward()
+    qx, ex = qk.cuda().requires_grad_(True), eb.cuda().requires_grad_(True)
+    out = ops.edge_logits(qx, ex, H)
+    out.backward(d_h.cuda())
+    tol = TOL[dtype]
+    assert rel(out, ref) < tol
+    assert rel(qx.grad, q64.grad) < 2 * tol
+    assert rel(ex.grad, e64.grad) < 2 * tol
+
+
+def test_padded_rows_finite_and_zero():
+    """Q6: fully padded query rows -> finite output, zero contribution."""
+    from tgt_amd import ops
+    B, N, C, H = 2, 8, 64, 4
+    L = ops.TripletLayout(C, H)
+    rng = np.random.default_rng(5)
+    fused = rnd(rng, B, N, N, L.width).float().cuda()
+    mask = gu.additive_mask([8, 3], N, torch.float32).reshape(B, N, N).cuda()
+    va = ops.triplet_attention(fused, mask, L)
+    assert torch.isfinite(va).all()
+    assert va[1, 3:, :, :C].abs().max() == 0          # inward rows i >= 3 of graph 1: gate 0
+
+
+def test_cpu_tensor_is_rejected():
+    from tgt_amd import ops
+    L = ops.TripletLayout(32, 4)
+    with pytest.raises(RuntimeError):
+        ops.triplet_attention(torch.zeros(1, 4, 4, L.width), torch.zeros(1, 4, 4), L)
+
+
+def test_adam_matches_torch():
+    from tgt_amd import ops
+    torch.manual_seed(0)
+    n = 100_003
+    p = torch.randn(n, device='cuda')
+    ref = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-2, betas=(0.9, 0.999), eps=1e-8)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 4):
+        g = torch.randn(n, device='cuda')
+        ref.grad = g.clone()
+        opt.step()
+        ops.adam_step_(p, g, m, v, step, 1e-2)
+    assert rel(p, ref.detach()) < 1e-6

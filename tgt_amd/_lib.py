@@ -1,0 +1,128 @@
+"""ctypes binding of libtgt_hip.so (C ABI: include/tgt_hip.h).
+
+There is NO fallback: if the shared library is missing or a call fails, a
+RuntimeError is raised.  The library is built in-tree by `build_library()`
+(`__graft_entry__.build()` calls it) with hipcc for gfx950.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libtgt_hip.so')
+CSRC = os.path.join(_HERE, 'csrc')
+SOURCES = ['capi.hip', 'triplet_attention.hip', 'triplet_aggregate.hip', 'node_attention.hip']
+ABI_VERSION = 1
+
+TGT_F32, TGT_BF16, TGT_F16 = 0, 1, 2
+TRI_BIASED, TRI_GATED, TRI_MASK_OUT = 1, 2, 4
+
+_i32, _i64, _f32, _vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class TripletAttentionArgs(C.Structure):
+    _fields_ = [
+        ('B', _i32), ('N', _i32), ('H', _i32), ('D', _i32),
+        ('dtype', _i32), ('flags', _i32), ('scale', _f32), ('_pad0', _i32),
+        ('qkv', _vp * 2), ('ld_qkv', _i64 * 2), ('q_off', _i32 * 2), ('k_off', _i32 * 2), ('v_off', _i32 * 2),
+        ('eg', _vp * 2), ('ld_eg', _i64 * 2), ('e_off', _i32 * 2), ('g_off', _i32 * 2),
+        ('mask', _vp),
+        ('out', _vp), ('ld_out', _i64), ('o_off', _i32 * 2),
+        ('d_out', _vp), ('d_qkv', _vp * 2), ('d_eg', _vp * 2),
+    ]
+
+
+class TripletAggregateArgs(C.Structure):
+    _fields_ = [
+        ('B', _i32), ('N', _i32), ('H', _i32), ('D', _i32),
+        ('dtype', _i32), ('flags', _i32),
+        ('v', _vp * 2), ('ld_v', _i64 * 2), ('v_off', _i32 * 2),
+        ('eg', _vp * 2), ('ld_eg', _i64 * 2), ('e_off', _i32 * 2), ('g_off', _i32 * 2),
+        ('mask', _vp),
+        ('out', _vp), ('ld_out', _i64), ('o_off', _i32 * 2),
+        ('d_out', _vp), ('d_v', _vp * 2), ('d_eg', _vp * 2),
+    ]
+
+
+class NodeAttentionArgs(C.Structure):
+    _fields_ = [
+        ('B', _i32), ('N', _i32), ('H', _i32), ('D', _i32),
+        ('dtype', _i32), ('scale_degree', _i32), ('logits_only', _i32), ('_pad0', _i32),
+        ('scale', _f32), ('_pad1', _i32),
+        ('qkv', _vp), ('ld_qkv', _i64), ('q_off', _i32), ('k_off', _i32), ('v_off', _i32), ('_pad2', _i32),
+        ('eg', _vp), ('ld_eg', _i64), ('e_off', _i32), ('g_off', _i32),
+        ('mask', _vp),
+        ('vatt', _vp), ('hhat', _vp), ('lse', _vp), ('gsum', _vp),
+        ('d_vatt', _vp), ('d_hhat', _vp), ('d_qkv', _vp), ('d_eg', _vp),
+    ]
+
+
+# symbol -> (restype, argtypes); every symbol include/tgt_hip.h declares
+SYMBOLS = {
+    'tgt_last_error': (C.c_char_p, []),
+    'tgt_abi_version': (C.c_int, []),
+    'tgt_triplet_attention_fwd': (C.c_int, [C.POINTER(TripletAttentionArgs), _vp]),
+    'tgt_triplet_attention_bwd': (C.c_int, [C.POINTER(TripletAttentionArgs), _vp]),
+    'tgt_triplet_aggregate_fwd': (C.c_int, [C.POINTER(TripletAggregateArgs), _vp]),
+    'tgt_triplet_aggregate_bwd': (C.c_int, [C.POINTER(TripletAggregateArgs), _vp]),
+    'tgt_node_attention_fwd': (C.c_int, [C.POINTER(NodeAttentionArgs), _vp]),
+    'tgt_node_attention_bwd': (C.c_int, [C.POINTER(NodeAttentionArgs), _vp]),
+    'tgt_adam_step': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
+}
+
+_lib = None
+
+
+def build_library(force=False, verbose=False):
+    """hipcc -> tgt_amd/libtgt_hip.so (gfx950).  Cross-compiles without a GPU."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith('.hpp')] + \
+        [os.path.join(os.path.dirname(_HERE), 'include', 'tgt_hip.h')]
+    if not force and os.path.exists(LIB_PATH) and \
+            os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    objs = []
+    procs = []
+    os.makedirs(os.path.join(_HERE, 'build'), exist_ok=True)
+    for s in srcs:
+        o = os.path.join(_HERE, 'build', os.path.basename(s) + '.o')
+        objs.append(o)
+        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', s, '-o', o]
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode:
+            raise RuntimeError('hipcc failed: ' + ' '.join(cmd) + '\n' + out.decode(errors='replace'))
+        if verbose and out:
+            print(out.decode(errors='replace'))
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode:
+        raise RuntimeError('link failed: ' + ' '.join(cmd) + '\n' + r.stdout.decode(errors='replace'))
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises (loudly) when it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} is missing: the TGT HIP kernels are not built. Run '
+                f'`python -c "import __graft_entry__ as g; g.build()"` (needs hipcc). '
+                f'There is no CPU/eager fallback for the tgt_amd ops.')
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)          # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        if L.tgt_abi_version() != ABI_VERSION:
+            raise RuntimeError(f'libtgt_hip.so ABI {L.tgt_abi_version()} != binding {ABI_VERSION}; rebuild')
+        _lib = L
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().tgt_last_error().decode(errors='replace')
+        raise RuntimeError(f'{what} failed (code {code}): {msg}')

@@ -1,0 +1,109 @@
+// extern "C" entry points of libtgt_hip.so (include/tgt_hip.h) + error plumbing
+// + the flat-buffer Adam kernel.
+#include <cstdarg>
+#include <cstdio>
+#include "common.hpp"
+
+namespace tgt {
+
+static thread_local char g_err[512] = "";
+
+int set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(TGT_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return TGT_OK;
+}
+
+int triplet_attention_run(const tgt_triplet_attention_args* a, bool bwd, hipStream_t st);
+int triplet_aggregate_run(const tgt_triplet_aggregate_args* a, bool bwd, hipStream_t st);
+int node_attention_run(const tgt_node_attention_args* a, bool bwd, hipStream_t st);
+
+// Adam over flat float32 buffers: 4 reads + 3 writes per element, HBM-bound.
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                   float lr, float b1, float b2, float eps, float wd,
+                                                   float bc1, float bc2_rsqrt, float gscale) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 4 <= n) {
+            float4 pp = *reinterpret_cast<float4*>(p + i), gg = *reinterpret_cast<const float4*>(g + i);
+            float4 mm = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
+            float* P = &pp.x; float* Gp = &gg.x; float* M = &mm.x; float* V = &vv.x;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float gr = Gp[t] * gscale;
+                M[t] = b1 * M[t] + (1.f - b1) * gr;
+                V[t] = b2 * V[t] + (1.f - b2) * gr * gr;
+                const float denom = sqrtf(V[t]) * bc2_rsqrt + eps;
+                P[t] = P[t] * (1.f - lr * wd) - (lr / bc1) * (M[t] / denom);
+            }
+            *reinterpret_cast<float4*>(p + i) = pp;
+            *reinterpret_cast<float4*>(m + i) = mm;
+            *reinterpret_cast<float4*>(v + i) = vv;
+        } else {
+            for (int64_t k = i; k < n; ++k) {
+                const float gr = g[k] * gscale;
+                m[k] = b1 * m[k] + (1.f - b1) * gr;
+                v[k] = b2 * v[k] + (1.f - b2) * gr * gr;
+                const float denom = sqrtf(v[k]) * bc2_rsqrt + eps;
+                p[k] = p[k] * (1.f - lr * wd) - (lr / bc1) * (m[k] / denom);
+            }
+        }
+    }
+}
+
+}  // namespace tgt
+
+using namespace tgt;
+
+extern "C" {
+
+const char* tgt_last_error(void) { return g_err; }
+int tgt_abi_version(void) { return 1; }
+
+int tgt_triplet_attention_fwd(const tgt_triplet_attention_args* a, void* stream) {
+    return triplet_attention_run(a, false, reinterpret_cast<hipStream_t>(stream));
+}
+int tgt_triplet_attention_bwd(const tgt_triplet_attention_args* a, void* stream) {
+    return triplet_attention_run(a, true, reinterpret_cast<hipStream_t>(stream));
+}
+int tgt_triplet_aggregate_fwd(const tgt_triplet_aggregate_args* a, void* stream) {
+    return triplet_aggregate_run(a, false, reinterpret_cast<hipStream_t>(stream));
+}
+int tgt_triplet_aggregate_bwd(const tgt_triplet_aggregate_args* a, void* stream) {
+    return triplet_aggregate_run(a, true, reinterpret_cast<hipStream_t>(stream));
+}
+int tgt_node_attention_fwd(const tgt_node_attention_args* a, void* stream) {
+    return node_attention_run(a, false, reinterpret_cast<hipStream_t>(stream));
+}
+int tgt_node_attention_bwd(const tgt_node_attention_args* a, void* stream) {
+    return node_attention_run(a, true, reinterpret_cast<hipStream_t>(stream));
+}
+
+int tgt_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_scale,
+                  void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n < 0 || step < 1)
+        return set_error(TGT_ERR_INVALID, "adam: null buffer or bad n/step");
+    if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16)
+        return set_error(TGT_ERR_INVALID, "adam: buffers must be 16-byte aligned");
+    if (n == 0) return TGT_OK;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), param,
+                       grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (float)bc1,
+                       (float)(1.0 / sqrt(bc2)), grad_scale);
+    return check_launch("adam_kernel");
+}
+
+}  // extern "C"

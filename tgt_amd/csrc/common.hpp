@@ -1,0 +1,100 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) TGT kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/tgt_hip.h"
+
+namespace tgt {
+
+typedef __bf16   bf16_t;
+typedef _Float16 f16_t;
+
+typedef __attribute__((ext_vector_type(8)))  __bf16   bf16x8;
+typedef __attribute__((ext_vector_type(8)))  _Float16 f16x8;
+typedef __attribute__((ext_vector_type(8)))  float    f32x8;
+typedef __attribute__((ext_vector_type(4)))  float    f32x4;
+typedef __attribute__((ext_vector_type(16))) float    f32x16;
+
+// ---------------------------------------------------------------------------
+// 32x32 matrix-core tile:  C[m][n] += sum_kk A[m][kk] * B[kk][n],  kk in [0,16)
+//
+// Operand fragment = 8 elements per lane.  Lane l = (r = l & 31, hi = l >> 5)
+// supplies A[m = r][kk = 8*hi + t] / B[kk = 8*hi + t][n = r], t = 0..7.
+// 16-bit types: one v_mfma_f32_32x32x16_{bf16,f16}.  float: eight exact-f32
+// v_mfma_f32_32x32x2_f32 (instruction t contracts kk = {t, 8+t}); same
+// fragment shape, so the kernels are written once.
+// Result layout (all types): lane (r,hi), register q in [0,16) holds
+//   C[m = (q & 3) + 8*(q >> 2) + 4*hi][n = r].
+// ---------------------------------------------------------------------------
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> { typedef bf16x8 type; };
+template <> struct Frag<f16_t>  { typedef f16x8 type; };
+template <> struct Frag<float>  { typedef f32x8 type; };
+template <typename T> using frag_t = typename Frag<T>::type;
+
+__device__ __forceinline__ f32x16 mma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mma32(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mma32(f32x8 a, f32x8 b, f32x16 c) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], c, 0, 0, 0);
+    return c;
+}
+
+// row index held by accumulator register q of lane-half hi
+__device__ __forceinline__ int acc_row(int q, int hi) { return (q & 3) + 8 * (q >> 2) + 4 * hi; }
+
+template <typename T> __device__ __forceinline__ T from_f32(float x) { return static_cast<T>(x); }
+template <typename T> __device__ __forceinline__ float to_f32(T x) { return static_cast<float>(x); }
+
+// registers [8c, 8c+8) of an accumulator -> operand fragment of k-chunk c
+template <typename T>
+__device__ __forceinline__ typename Frag<T>::type pack_chunk(const f32x16& v, int c) {
+    typename Frag<T>::type f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) f[t] = from_f32<T>(v[8 * c + t]);
+    return f;
+}
+template <typename T>
+__device__ __forceinline__ typename Frag<T>::type zero_frag() {
+    typename Frag<T>::type f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) f[t] = from_f32<T>(0.f);
+    return f;
+}
+
+// 8 contiguous elements from LDS / global (16-byte aligned for 16-bit types,
+// 32-byte span = two 16-byte pieces for float).
+template <typename T>
+__device__ __forceinline__ typename Frag<T>::type load_frag(const T* p) {
+    typename Frag<T>::type f;
+    if constexpr (sizeof(T) == 2) {
+        uint4 raw = *reinterpret_cast<const uint4*>(p);
+        __builtin_memcpy(&f, &raw, 16);
+    } else {
+        uint4 r0 = *reinterpret_cast<const uint4*>(p);
+        uint4 r1 = *reinterpret_cast<const uint4*>(p + 4);
+        __builtin_memcpy(&f, &r0, 16);
+        __builtin_memcpy(reinterpret_cast<char*>(&f) + 16, &r1, 16);
+    }
+    return f;
+}
+
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
+// exchange with the lane holding the other half of the same column (l ^ 32)
+__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
+
+template <typename T> struct DType;
+template <> struct DType<float>  { static constexpr int id = TGT_F32; };
+template <> struct DType<bf16_t> { static constexpr int id = TGT_BF16; };
+template <> struct DType<f16_t>  { static constexpr int id = TGT_F16; };
+
+// host-side error plumbing (capi.hip)
+int set_error(int code, const char* fmt, ...);
+int check_launch(const char* what);
+
+}  // namespace tgt

@@ -1,0 +1,382 @@
+// Triplet attention core for gfx950 -- forward and backward.
+//
+// Replaces the two einsum -> +bias -> +mask -> softmax -> *gate -> einsum
+// chains of reference lib/tgt/layers/triplet.py:213-246 (and the autograd
+// backward of that chain).  Math: SURVEY.md App. A.2 / A.4.
+//
+// Decomposition (one kernel serves both directions):
+//   workgroup = (graph b, direction, group of HG heads); wave w = head g*HG+w.
+//   The workgroup walks the shared node j = 0..N-1.  For each j it needs three
+//   "slabs": rows Q[i,j], i=0..N-1; the partner rows K/V[j,k] (inward) or
+//   K/V[k,j] (outward), k=0..N-1.  Only this group's HG*D channels of each
+//   row are touched (HG*D*sizeof(T) >= 128 B for the shipped shapes, i.e.
+//   whole cache lines).  Slabs for j+1 are fetched HBM->registers while the
+//   waves work on j out of LDS (one LDS buffer; the prefetch lives in VGPRs).
+//   The third-arm bias E, gate sigmoid(G+M) and mask M do not depend on j:
+//   each wave keeps its 32x32 (i,k) tile of them in registers for the whole
+//   walk, and in the backward accumulates dE/dG over j in registers --
+//   no atomics, no workspace, deterministic.
+//
+// Matrix-core mapping (N <= 32 per tile, Dt = 16 -> one 32x32x16 MFMA):
+//   S^T[k][i]  = K[k,:] . Q[i,:]          A = K rows, B = Q rows (both read
+//                                         as natural d-contiguous fragments)
+//   lane (i = l&31, hi = l>>5) then owns column i of S^T: 16 of the 32 k's;
+//   its partner lane l^32 owns the other 16 -> softmax over k is an in-lane
+//   reduction plus ONE cross-lane exchange.
+//   V^T        = V . I                    transposes V through the matrix core
+//                                         (exact: x*1 + 0), giving lane d the
+//                                         k-vector the P.V product needs
+//   O^T[d][i]  = sum_k V^T[d][k] P^T[k][i]
+//   The register->row map of an MFMA result equals the k-order of the next
+//   MFMA's operand fragment, so no cross-lane data movement is needed at all.
+//   Backward uses the same trick to re-layout dS and A (multiply by I).
+#include "triplet_common.hpp"
+
+namespace tgt {
+
+struct TriCtx {
+    int b, dir, g, h, N;
+    SlabSrc q, k, v;
+};
+
+template <typename T, int D, int HG>
+__device__ __forceinline__ TriCtx tri_ctx(const tgt_triplet_attention_args& a, int wave) {
+    TriCtx c;
+    const int ngroups = a.H / HG;
+    int bid = blockIdx.x;
+    c.g = bid % ngroups;
+    bid /= ngroups;
+    c.dir = bid & 1;
+    c.b = bid >> 1;
+    c.h = c.g * HG + wave;
+    c.N = a.N;
+    const int64_t N = a.N, ld = a.ld_qkv[c.dir], sz = sizeof(T);
+    const char* base = reinterpret_cast<const char*>(a.qkv[c.dir]) + ((int64_t)c.b * N * N * ld + c.g * HG * D) * sz;
+    c.q = {base + (int64_t)a.q_off[c.dir] * sz, N * ld * sz, ld * sz};
+    if (c.dir == 0) {   // partner rows (j,k): contiguous rows of graph row j
+        c.k = {base + (int64_t)a.k_off[c.dir] * sz, ld * sz, N * ld * sz};
+        c.v = {base + (int64_t)a.v_off[c.dir] * sz, ld * sz, N * ld * sz};
+    } else {            // partner rows (k,j): column j
+        c.k = {base + (int64_t)a.k_off[c.dir] * sz, N * ld * sz, ld * sz};
+        c.v = {base + (int64_t)a.v_off[c.dir] * sz, N * ld * sz, ld * sz};
+    }
+    return c;
+}
+
+__device__ __forceinline__ ThirdArm tri_third_arm(const tgt_triplet_attention_args& a, int dir) {
+    return ThirdArm{a.eg[dir], a.ld_eg[dir], a.e_off[dir], a.g_off[dir], a.mask,
+                    (a.flags & TGT_TRI_BIASED) != 0, (a.flags & TGT_TRI_GATED) != 0};
+}
+
+// ---------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------
+template <typename T, int D, int HG>
+__global__ void __launch_bounds__(HG * 64) tri_att_fwd_kernel(const tgt_triplet_attention_args a) {
+    using G = TriGeo<T, D, HG>;
+    using F = frag_t<T>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sQ = smem;
+    char* sK = smem + G::kSlabBytes;
+    char* sV = smem + 2 * G::kSlabBytes;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hi = lane >> 5;
+    const TriCtx c = tri_ctx<T, D, HG>(a, wave);
+    const int N = c.N;
+
+    float biasM[16], gate[16];
+    const ThirdArm ta = tri_third_arm(a, c.dir);
+    load_third_arm<T, false>(ta, c.b, c.dir, c.h, N, r, hi, biasM, gate);
+    F ident_d[G::kDC];
+    make_ident_d<T, G::kDC>(ident_d, r, hi);
+
+    const int64_t sz = sizeof(T);
+    char* obase = reinterpret_cast<char*>(a.out) + ((int64_t)c.b * N * N * a.ld_out + a.o_off[c.dir] + c.g * HG * D) * sz;
+    const int64_t o_row = (int64_t)N * a.ld_out * sz, o_j = a.ld_out * sz;
+
+    uint4 pq[G::kIters], pk[G::kIters], pv[G::kIters];
+    slab_issue<G>(pq, c.q, 0, N, tid);
+    slab_issue<G>(pk, c.k, 0, N, tid);
+    slab_issue<G>(pv, c.v, 0, N, tid);
+    slab_commit<G>(pq, sQ, tid);
+    slab_commit<G>(pk, sK, tid);
+    slab_commit<G>(pv, sV, tid);
+    __syncthreads();
+
+    for (int j = 0; j < N; ++j) {
+        if (j + 1 < N) {
+            slab_issue<G>(pq, c.q, j + 1, N, tid);
+            slab_issue<G>(pk, c.k, j + 1, N, tid);
+            slab_issue<G>(pv, c.v, j + 1, N, tid);
+        }
+        F fq[G::kDC], fk[G::kDC], fv[G::kDC];
+        read_frags<T, D, HG>(fq, sQ, wave, r, hi);
+        read_frags<T, D, HG>(fk, sK, wave, r, hi);
+        read_frags<T, D, HG>(fv, sV, wave, r, hi);
+
+        f32x16 s = {0}, vt = {0};
+#pragma unroll
+        for (int dc = 0; dc < G::kDC; ++dc) s = mma32(fk[dc], fq[dc], s);          // S^T[k][i]
+#pragma unroll
+        for (int dc = 0; dc < G::kDC; ++dc) vt = mma32(fv[dc], ident_d[dc], vt);   // V[k][d] -> lane d
+
+        float mx = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            s[q] = s[q] * a.scale + biasM[q];
+            mx = fmaxf(mx, s[q]);
+        }
+        mx = fmaxf(mx, xhalf(mx));
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            s[q] = fast_exp(s[q] - mx);
+            sum += s[q];
+        }
+        sum += xhalf(sum);
+        const float inv = __frcp_rn(sum);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s[q] = s[q] * inv * gate[q];
+
+        f32x16 o = {0};
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) o = mma32(pack_chunk<T>(vt, cc), pack_chunk<T>(s, cc), o);   // O^T[d][i]
+        write_rows<T, D, HG>(sQ, o, wave, r, hi);     // in place of this head's Q columns
+        __syncthreads();
+        slab_store<G>(sQ, obase, o_row, o_j, j, N, tid);
+        if (j + 1 < N) {
+            slab_commit<G>(pq, sQ, tid);
+            slab_commit<G>(pk, sK, tid);
+            slab_commit<G>(pv, sV, tid);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// backward.  Per (b,dir,h,j), with P recomputed from the
+// saved log-sum-exp:
+//   dA^T[k][i] = V[k,:].dO[i,:]         dP = dA*g      delta_i = sum_k P dP
+//   dS = P (dP - delta)                  dE += dS       dG += dA P g (1-g)
+//   dQ^T[d][i] = s sum_k K^T[d][k] dS^T[k][i]
+//   dK^T[d][k] = s sum_i Q^T[d][i] dS[i][k]     dV^T[d][k] = sum_i dO^T[d][i] A[i][k]
+// dS and A are produced in (lane = i) layout and re-laid out to (lane = k)
+// by a multiply with the identity on the matrix core.
+// ---------------------------------------------------------------------------
+template <typename T, int D, int HG>
+__global__ void __launch_bounds__(HG * 64) tri_att_bwd_kernel(const tgt_triplet_attention_args a) {
+    using G = TriGeo<T, D, HG>;
+    using F = frag_t<T>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sQ = smem;
+    char* sK = smem + G::kSlabBytes;
+    char* sV = smem + 2 * G::kSlabBytes;
+    char* sO = smem + 3 * G::kSlabBytes;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hi = lane >> 5;
+    const TriCtx c = tri_ctx<T, D, HG>(a, wave);
+    const int N = c.N;
+    const bool biased = a.flags & TGT_TRI_BIASED, gated = a.flags & TGT_TRI_GATED;
+
+    float biasM[16], gate[16], dE[16], dG[16];
+    const ThirdArm ta = tri_third_arm(a, c.dir);
+    load_third_arm<T, true>(ta, c.b, c.dir, c.h, N, r, hi, biasM, gate);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) dE[q] = dG[q] = 0.f;
+    F ident_d[G::kDC], ident_k[2];
+    make_ident_d<T, G::kDC>(ident_d, r, hi);
+    make_ident_k<T>(ident_k, r, hi);
+
+    const int64_t sz = sizeof(T), Nl = N;
+    const SlabSrc dO = {reinterpret_cast<const char*>(a.d_out) +
+                            ((int64_t)c.b * Nl * Nl * a.ld_out + a.o_off[c.dir] + c.g * HG * D) * sz,
+                        Nl * a.ld_out * sz, a.ld_out * sz};
+    // gradient slabs mirror the source slabs inside d_qkv
+    const int64_t shift = reinterpret_cast<const char*>(a.d_qkv[c.dir]) - reinterpret_cast<const char*>(a.qkv[c.dir]);
+    char* dq_base = const_cast<char*>(c.q.base) + shift;
+    char* dk_base = const_cast<char*>(c.k.base) + shift;
+    char* dv_base = const_cast<char*>(c.v.base) + shift;
+
+    uint4 pq[G::kIters], pk[G::kIters], pv[G::kIters], po[G::kIters];
+    slab_issue<G>(pq, c.q, 0, N, tid);
+    slab_issue<G>(pk, c.k, 0, N, tid);
+    slab_issue<G>(pv, c.v, 0, N, tid);
+    slab_issue<G>(po, dO, 0, N, tid);
+    slab_commit<G>(pq, sQ, tid);
+    slab_commit<G>(pk, sK, tid);
+    slab_commit<G>(pv, sV, tid);
+    slab_commit<G>(po, sO, tid);
+    __syncthreads();
+
+    for (int j = 0; j < N; ++j) {
+        if (j + 1 < N) {
+            slab_issue<G>(pq, c.q, j + 1, N, tid);
+            slab_issue<G>(pk, c.k, j + 1, N, tid);
+            slab_issue<G>(pv, c.v, j + 1, N, tid);
+            slab_issue<G>(po, dO, j + 1, N, tid);
+        }
+        F fq[G::kDC], fk[G::kDC], fv[G::kDC], fo[G::kDC];
+        read_frags<T, D, HG>(fq, sQ, wave, r, hi);
+        read_frags<T, D, HG>(fk, sK, wave, r, hi);
+        read_frags<T, D, HG>(fv, sV, wave, r, hi);
+        read_frags<T, D, HG>(fo, sO, wave, r, hi);
+
+        f32x16 s = {0}, da = {0};
+#pragma unroll
+        for (int dc = 0; dc < G::kDC; ++dc) s = mma32(fk[dc], fq[dc], s);     // S^T[k][i]
+#pragma unroll
+        for (int dc = 0; dc < G::kDC; ++dc) da = mma32(fv[dc], fo[dc], da);   // dA^T[k][i]
+
+        // softmax statistics are recomputed (16 in-lane values + the partner lane); saving a
+        // log-sum-exp instead would lose log(sum) next to a finfo.min-sized row maximum.
+        float mx = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            s[q] = s[q] * a.scale + biasM[q];
+            mx = fmaxf(mx, s[q]);
+        }
+        mx = fmaxf(mx, xhalf(mx));
+        if (mx == -INFINITY) mx = 0.f;           // padding column: every weight is exactly 0
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            s[q] = fast_exp(s[q] - mx);
+            sum += s[q];
+        }
+        sum += xhalf(sum);
+        const float inv = sum > 0.f ? __frcp_rn(sum) : 0.f;
+        // s -> P, then A;  da -> dS
+        float delta = 0.f;
+        f32x16 att;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float p = s[q] * inv;
+            const float dp = da[q] * gate[q];
+            delta += p * dp;
+            att[q] = p * gate[q];
+            s[q] = p;
+            if (gated) dG[q] += da[q] * att[q] * (1.f - gate[q]);
+            da[q] = dp;
+        }
+        delta += xhalf(delta);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float ds = s[q] * (da[q] - delta);
+            if (biased) dE[q] += ds;
+            s[q] = ds * a.scale;
+        }
+        F dsf[2], af[2];
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            dsf[cc] = pack_chunk<T>(s, cc);
+            af[cc] = pack_chunk<T>(att, cc);
+        }
+
+        // dQ^T[d][i] = sum_k K^T[d][k] dS^T[k][i]
+        f32x16 t0 = {0}, dq = {0};
+#pragma unroll
+        for (int dc = 0; dc < G::kDC; ++dc) t0 = mma32(fk[dc], ident_d[dc], t0);   // K^T
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) dq = mma32(pack_chunk<T>(t0, cc), dsf[cc], dq);
+
+        // re-layout dS, A to lane = k:  X[i][k] = sum_kk X^T-frag[i][kk] I[kk][k]
+        f32x16 ds2 = {0}, a2 = {0};
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            ds2 = mma32(dsf[cc], ident_k[cc], ds2);
+            a2 = mma32(af[cc], ident_k[cc], a2);
+        }
+        // dK^T[d][k] = sum_i Q^T[d][i] dS[i][k]
+        f32x16 t1 = {0}, dk = {0};
+#pragma unroll
+        for (int dc = 0; dc < G::kDC; ++dc) t1 = mma32(fq[dc], ident_d[dc], t1);   // Q^T
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) dk = mma32(pack_chunk<T>(t1, cc), pack_chunk<T>(ds2, cc), dk);
+        // dV^T[d][k] = sum_i dO^T[d][i] A[i][k]
+        f32x16 t2 = {0}, dv = {0};
+#pragma unroll
+        for (int dc = 0; dc < G::kDC; ++dc) t2 = mma32(fo[dc], ident_d[dc], t2);   // dO^T
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) dv = mma32(pack_chunk<T>(t2, cc), pack_chunk<T>(a2, cc), dv);
+
+        write_rows<T, D, HG>(sQ, dq, wave, r, hi);
+        write_rows<T, D, HG>(sK, dk, wave, r, hi);
+        write_rows<T, D, HG>(sV, dv, wave, r, hi);
+        __syncthreads();
+        slab_store<G>(sQ, dq_base, c.q.row_stride, c.q.j_stride, j, N, tid);
+        slab_store<G>(sK, dk_base, c.k.row_stride, c.k.j_stride, j, N, tid);
+        slab_store<G>(sV, dv_base, c.v.row_stride, c.v.j_stride, j, N, tid);
+        if (j + 1 < N) {
+            slab_commit<G>(pq, sQ, tid);
+            slab_commit<G>(pk, sK, tid);
+            slab_commit<G>(pv, sV, tid);
+            slab_commit<G>(po, sO, tid);
+        }
+        __syncthreads();
+    }
+
+    // third-arm gradients, summed over j in registers
+    store_third_arm_grad<T>(ta, a.d_eg[c.dir], c.b, c.dir, c.h, N, r, hi, dE, dG);
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+template <typename T, int D, int HG>
+static int launch_tri(const tgt_triplet_attention_args& a, bool bwd, hipStream_t st) {
+    using G = TriGeo<T, D, HG>;
+    const int grid = a.B * 2 * (a.H / HG);
+    if (!bwd) {
+        hipLaunchKernelGGL((tri_att_fwd_kernel<T, D, HG>), dim3(grid), dim3(G::kThreads), 3 * G::kSlabBytes, st, a);
+    } else {
+        hipLaunchKernelGGL((tri_att_bwd_kernel<T, D, HG>), dim3(grid), dim3(G::kThreads), 4 * G::kSlabBytes, st, a);
+    }
+    return check_launch(bwd ? "tri_att_bwd_kernel" : "tri_att_fwd_kernel");
+}
+
+template <typename T, int D>
+static int dispatch_hg(const tgt_triplet_attention_args& a, bool bwd, hipStream_t st) {
+    if (a.H % 4 == 0) return launch_tri<T, D, 4>(a, bwd, st);
+    if constexpr (D * sizeof(T) >= 16) return launch_tri<T, D, 1>(a, bwd, st);
+    return set_error(TGT_ERR_UNSUPPORTED, "triplet attention: H=%d not a multiple of 4 with D=%d", a.H, D);
+}
+
+template <typename T>
+static int dispatch_d(const tgt_triplet_attention_args& a, bool bwd, hipStream_t st) {
+    switch (a.D) {
+        case 8: return dispatch_hg<T, 8>(a, bwd, st);
+        case 16: return dispatch_hg<T, 16>(a, bwd, st);
+        case 32: return dispatch_hg<T, 32>(a, bwd, st);
+        default: return set_error(TGT_ERR_UNSUPPORTED, "triplet attention: D=%d not in {8,16,32}", a.D);
+    }
+}
+
+int triplet_attention_run(const tgt_triplet_attention_args* a, bool bwd, hipStream_t st) {
+    if (!a) return set_error(TGT_ERR_INVALID, "triplet attention: null args");
+    if (a->B <= 0 || a->N <= 0 || a->H <= 0) return set_error(TGT_ERR_INVALID, "triplet attention: bad sizes B=%d N=%d H=%d", a->B, a->N, a->H);
+    if (a->N > 32) return set_error(TGT_ERR_UNSUPPORTED, "triplet attention: N=%d > 32 not supported yet", a->N);
+    const int64_t esz = a->dtype == TGT_F32 ? 4 : 2;
+    for (int dir = 0; dir < 2; ++dir) {
+        if (!a->qkv[dir] || !a->out || !a->mask) return set_error(TGT_ERR_INVALID, "triplet attention: null tensor");
+        if ((a->ld_qkv[dir] * esz) % 16 || (a->q_off[dir] * esz) % 16 || (a->k_off[dir] * esz) % 16 ||
+            (a->v_off[dir] * esz) % 16 || (a->ld_out * esz) % 16 || (a->o_off[dir] * esz) % 16 ||
+            ((uintptr_t)a->qkv[dir] % 16) || ((uintptr_t)a->out % 16))
+            return set_error(TGT_ERR_INVALID, "triplet attention: rows/offsets must be 16-byte aligned");
+        if ((a->flags & (TGT_TRI_BIASED | TGT_TRI_GATED)) && !a->eg[dir]) return set_error(TGT_ERR_INVALID, "triplet attention: eg missing");
+        if (bwd) {
+            if (!a->d_out || !a->d_qkv[dir] || ((uintptr_t)a->d_qkv[dir] % 16) || ((uintptr_t)a->d_out % 16))
+                return set_error(TGT_ERR_INVALID, "triplet attention bwd: null/misaligned gradient tensor");
+            if ((a->flags & (TGT_TRI_BIASED | TGT_TRI_GATED)) && !a->d_eg[dir]) return set_error(TGT_ERR_INVALID, "triplet attention bwd: d_eg missing");
+        }
+    }
+    switch (a->dtype) {
+        case TGT_F32: return dispatch_d<float>(*a, bwd, st);
+        case TGT_BF16: return dispatch_d<bf16_t>(*a, bwd, st);
+        case TGT_F16: return dispatch_d<f16_t>(*a, bwd, st);
+        default: return set_error(TGT_ERR_INVALID, "triplet attention: bad dtype %d", a->dtype);
+    }
+}
+
+}  // namespace tgt

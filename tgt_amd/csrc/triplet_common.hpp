@@ -1,0 +1,199 @@
+// Shared machinery of the triplet kernels (attention + aggregate) for gfx950:
+// slab geometry, HBM<->register<->LDS staging, matrix-core operand fragments.
+// See triplet_attention.hip for the design notes.
+#pragma once
+#include "common.hpp"
+
+namespace tgt {
+
+template <typename T, int D, int HG>
+struct TriGeo {
+    static constexpr int kThreads = HG * 64;
+    static constexpr int kRowBytes = HG * D * (int)sizeof(T);   // this group's bytes of one row
+    static constexpr int kSlots = kRowBytes / 16;               // 16-byte slots per row
+    static constexpr int kSlabBytes = 32 * kRowBytes;
+    static constexpr int kChunks = 32 * kSlots;
+    static constexpr int kIters = (kChunks + kThreads - 1) / kThreads;
+    static constexpr int kRowsPerBankRow = kRowBytes >= 256 ? 1 : 256 / kRowBytes;
+    static constexpr int kSwzMask = (kSlots < 16 ? kSlots : 16) - 1;
+    static constexpr int kDC = (D + 15) / 16;                   // 16-wide d chunks
+    static_assert(kRowBytes % 16 == 0, "row piece must be a multiple of 16 bytes");
+    static_assert(D % 8 == 0 && D <= 32, "D in {8,16,24,32}");
+
+    // XOR swizzle of the 16-byte slot index so that ds_read_b128 of one slot
+    // column over 16 different rows is bank-conflict free.
+    __device__ static __forceinline__ int lds_off(int row, int slot) {
+        const int f = (row / kRowsPerBankRow) & kSwzMask;
+        return row * kRowBytes + ((slot ^ f) << 4);
+    }
+    // byte offset (inside a slab) of element `col` (in T units, < HG*D) of `row`
+    __device__ static __forceinline__ int lds_elem(int row, int col) {
+        const int bo = col * (int)sizeof(T);
+        return lds_off(row, bo >> 4) + (bo & 15);
+    }
+};
+
+struct SlabSrc {
+    const char* base;      // points at (b, row 0, j 0, this group's first channel)
+    int64_t row_stride;    // bytes between consecutive slab rows
+    int64_t j_stride;      // bytes between consecutive j
+};
+
+template <typename G>
+__device__ __forceinline__ void slab_issue(uint4 (&pre)[G::kIters], const SlabSrc& s, int j, int N, int tid) {
+#pragma unroll
+    for (int it = 0; it < G::kIters; ++it) {
+        const int c = it * G::kThreads + tid;
+        const int row = c / G::kSlots, slot = c % G::kSlots;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (c < G::kChunks && row < N)
+            v = *reinterpret_cast<const uint4*>(s.base + j * s.j_stride + row * s.row_stride + slot * 16);
+        pre[it] = v;
+    }
+}
+template <typename G>
+__device__ __forceinline__ void slab_commit(const uint4 (&pre)[G::kIters], char* slab, int tid) {
+#pragma unroll
+    for (int it = 0; it < G::kIters; ++it) {
+        const int c = it * G::kThreads + tid;
+        const int row = c / G::kSlots, slot = c % G::kSlots;
+        if (c < G::kChunks) *reinterpret_cast<uint4*>(slab + G::lds_off(row, slot)) = pre[it];
+    }
+}
+template <typename G>
+__device__ __forceinline__ void slab_store(const char* slab, char* dst_base, int64_t row_stride,
+                                           int64_t j_stride, int j, int N, int tid) {
+#pragma unroll
+    for (int it = 0; it < G::kIters; ++it) {
+        const int c = it * G::kThreads + tid;
+        const int row = c / G::kSlots, slot = c % G::kSlots;
+        if (c < G::kChunks && row < N)
+            *reinterpret_cast<uint4*>(dst_base + j * j_stride + row * row_stride + slot * 16) =
+                *reinterpret_cast<const uint4*>(slab + G::lds_off(row, slot));
+    }
+}
+
+// operand fragments of head `wave` for slab row r: d in [16*dc + 8*hi, +8)
+template <typename T, int D, int HG>
+__device__ __forceinline__ void read_frags(frag_t<T> (&f)[(D + 15) / 16], const char* slab,
+                                           int wave, int r, int hi) {
+    using G = TriGeo<T, D, HG>;
+#pragma unroll
+    for (int dc = 0; dc < G::kDC; ++dc) {
+        const int d0 = 16 * dc + 8 * hi;
+        if (d0 < D) {
+            if constexpr (sizeof(T) == 2) {
+                f[dc] = load_frag<T>(reinterpret_cast<const T*>(slab + G::lds_elem(r, wave * D + d0)));
+            } else {
+                frag_t<T> v;
+                uint4 r0 = *reinterpret_cast<const uint4*>(slab + G::lds_elem(r, wave * D + d0));
+                uint4 r1 = *reinterpret_cast<const uint4*>(slab + G::lds_elem(r, wave * D + d0 + 4));
+                __builtin_memcpy(&v, &r0, 16);
+                __builtin_memcpy(reinterpret_cast<char*>(&v) + 16, &r1, 16);
+                f[dc] = v;
+            }
+        } else {
+            f[dc] = zero_frag<T>();
+        }
+    }
+}
+
+// write a transposed result tile X^T[d][row] (lane = row r, registers = d) as
+// T into columns [wave*D, wave*D + D) of slab row r.
+template <typename T, int D, int HG>
+__device__ __forceinline__ void write_rows(char* slab, const f32x16& acc, int wave, int r, int hi) {
+    using G = TriGeo<T, D, HG>;
+#pragma unroll
+    for (int q = 0; q < D / 8; ++q) {
+        const int d0 = 8 * q + 4 * hi;      // registers 4q..4q+3 hold d0..d0+3
+        T tmp[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) tmp[t] = from_f32<T>(acc[4 * q + t]);
+        char* dst = slab + G::lds_elem(r, wave * D + d0);
+        if constexpr (sizeof(T) == 2) {
+            uint2 v;
+            __builtin_memcpy(&v, tmp, 8);
+            *reinterpret_cast<uint2*>(dst) = v;
+        } else {
+            uint4 v;
+            __builtin_memcpy(&v, tmp, 16);
+            *reinterpret_cast<uint4*>(dst) = v;
+        }
+    }
+}
+
+// identity fragments.  ident_d[dc]: B[kk = d][n = d'] = (d == d') for the d-chunk dc.
+template <typename T, int DC>
+__device__ __forceinline__ void make_ident_d(frag_t<T> (&f)[DC], int r, int hi) {
+#pragma unroll
+    for (int dc = 0; dc < DC; ++dc)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) f[dc][t] = from_f32<T>(r == 16 * dc + 8 * hi + t ? 1.f : 0.f);
+}
+// ident_k[c]: B[kk][n = k'] = 1 where the fragment element (hi,t) of chunk c
+// stands for row k' in the accumulator order: k = 16c + (t&3) + 8(t>>2) + 4hi.
+template <typename T>
+__device__ __forceinline__ void make_ident_k(frag_t<T> (&f)[2], int r, int hi) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) f[c][t] = from_f32<T>(r == acc_row(8 * c + t, hi) ? 1.f : 0.f);
+}
+
+
+// ---------------------------------------------------------------------------
+// Third-arm tile (bias E, gate logit G, additive mask M over node pairs) of one
+// head in accumulator layout: lane column i = r, register q <-> k = acc_row(q,hi).
+//   inward  (dir 0): element (i,k) is stored at pair (x,y) = (i,k)
+//   outward (dir 1): element (i,k) is stored at pair (x,y) = (k,i)
+// biasM = E + M (or -inf past N), gate = sigmoid(G + M) (1 if ungated).
+// Entries past N: k >= N gets -inf (weight exactly 0).  Lanes i >= N are padding
+// columns whose results are never stored; PAD_COLS_NEG_INF makes their weights
+// exactly 0 (backward, where they feed reductions over i).
+// ---------------------------------------------------------------------------
+struct ThirdArm {
+    const void* eg;
+    int64_t ld;
+    int e_off, g_off;
+    const float* mask;     // (B,N,N) or nullptr (no mask in this direction)
+    bool biased, gated;
+};
+
+template <typename T, bool PAD_COLS_NEG_INF>
+__device__ __forceinline__ void load_third_arm(const ThirdArm& ta, int b, int dir, int h, int N, int r, int hi,
+                                               float (&biasM)[16], float (&gate)[16]) {
+    const T* eg = reinterpret_cast<const T*>(ta.eg);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int k = acc_row(q, hi), i = r;
+        const bool valid = i < N && k < N;
+        const int x = dir == 0 ? i : k, y = dir == 0 ? k : i;
+        const int64_t idx = ((int64_t)b * N + x) * N + y;
+        const float m = (valid && ta.mask) ? ta.mask[idx] : 0.f;
+        float e = 0.f, gl = 0.f;
+        if (valid && ta.biased) e = to_f32(eg[idx * ta.ld + ta.e_off + h]);
+        if (valid && ta.gated) gl = to_f32(eg[idx * ta.ld + ta.g_off + h]);
+        biasM[q] = (k < N && (!PAD_COLS_NEG_INF || i < N)) ? e + m : -INFINITY;
+        gate[q] = valid ? (ta.gated ? fast_sigmoid(gl + m) : 1.f) : 0.f;
+    }
+}
+
+// scatter a per-head (i,k) tile of third-arm gradients back (as T)
+template <typename T>
+__device__ __forceinline__ void store_third_arm_grad(const ThirdArm& ta, void* d_eg, int b, int dir, int h, int N,
+                                                     int r, int hi, const float (&dE)[16], const float (&dG)[16]) {
+    if (!(ta.biased || ta.gated)) return;
+    T* deg = reinterpret_cast<T*>(d_eg);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int k = acc_row(q, hi), i = r;
+        if (i < N && k < N) {
+            const int x = dir == 0 ? i : k, y = dir == 0 ? k : i;
+            const int64_t idx = ((int64_t)b * N + x) * N + y;
+            if (ta.biased) deg[idx * ta.ld + ta.e_off + h] = from_f32<T>(dE[q]);
+            if (ta.gated) deg[idx * ta.ld + ta.g_off + h] = from_f32<T>(dG[q]);
+        }
+    }
+}
+
+}  // namespace tgt

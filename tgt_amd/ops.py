@@ -1,0 +1,301 @@
+"""torch.autograd bindings of the HIP kernels (C ABI in include/tgt_hip.h).
+
+These functions are the only way the tgt_amd modules do the hot-path
+arithmetic.  They require HIP device tensors and libtgt_hip.so; there is no
+eager / CPU fallback (a missing library or a CPU tensor raises).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+_DT = {torch.float32: _lib.TGT_F32, torch.bfloat16: _lib.TGT_BF16, torch.float16: _lib.TGT_F16}
+
+
+def _dev(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('tgt_amd ops run on the MI355X only: got a CPU tensor '
+                               '(there is no CPU fallback; the CPU restatement lives in oracle/ and is test-only)')
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _pair(cls, a, b):
+    return (cls * 2)(a, b)
+
+
+def as_mask3(mask, B, N):
+    """(B,N,N,1) additive mask of any float dtype -> contiguous float32 (B,N,N)."""
+    m = mask.reshape(B, N, N)
+    if m.dtype != torch.float32:
+        m = m.float()
+    return m.contiguous()
+
+
+# ---------------------------------------------------------------------------
+# triplet attention
+# ---------------------------------------------------------------------------
+class TripletLayout:
+    """Column offsets (elements) inside the fused projection row
+    [Q_in|K_in|V_in|Q_out|K_out|V_out|E_in|G_in|E_out|G_out] (head-major Q/K/V)."""
+
+    def __init__(self, C_, H, gated=True, biased=True):
+        self.C, self.H, self.D = C_, H, C_ // H
+        self.gated, self.biased = gated, biased
+        self.q = (0, 3 * C_)
+        self.k = (C_, 4 * C_)
+        self.v = (2 * C_, 5 * C_)
+        nb = (2 if gated else 1) * H if biased else 0
+        self.e = (6 * C_, 6 * C_ + nb)
+        self.g = (6 * C_ + H, 6 * C_ + nb + H) if gated else (0, 0)
+        self.used = 6 * C_ + 2 * nb
+        self.width = -(-self.used // 8) * 8           # rows stay 16-byte aligned for every dtype
+        self.flags = (_lib.TRI_BIASED if biased else 0) | (_lib.TRI_GATED if gated else 0)
+
+
+def _tri_args(fused, mask3, out, L, d_out=None, d_fused=None):
+    B, N = fused.shape[0], fused.shape[1]
+    a = _lib.TripletAttentionArgs()
+    a.B, a.N, a.H, a.D = B, N, L.H, L.D
+    a.dtype, a.flags, a.scale = _DT[fused.dtype], L.flags, float(L.D) ** -0.5
+    p = fused.data_ptr()
+    a.qkv = _pair(C.c_void_p, p, p)
+    a.ld_qkv = _pair(C.c_int64, L.width, L.width)
+    a.q_off, a.k_off, a.v_off = _pair(C.c_int32, *L.q), _pair(C.c_int32, *L.k), _pair(C.c_int32, *L.v)
+    a.eg = _pair(C.c_void_p, p, p)
+    a.ld_eg = _pair(C.c_int64, L.width, L.width)
+    a.e_off, a.g_off = _pair(C.c_int32, *L.e), _pair(C.c_int32, *L.g)
+    a.mask = mask3.data_ptr()
+    a.out, a.ld_out = out.data_ptr(), 2 * L.C
+    a.o_off = _pair(C.c_int32, 0, L.C)
+    if d_out is not None:
+        a.d_out = d_out.data_ptr()
+        dp = d_fused.data_ptr()
+        a.d_qkv = _pair(C.c_void_p, dp, dp)
+        a.d_eg = _pair(C.c_void_p, dp, dp)
+    return a
+
+
+class _TripletAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fused, mask3, L):
+        _dev(fused, mask3)
+        fused = fused.contiguous()
+        B, N = fused.shape[0], fused.shape[1]
+        assert fused.shape == (B, N, N, L.width), (fused.shape, L.width)
+        out = torch.empty(B, N, N, 2 * L.C, dtype=fused.dtype, device=fused.device)
+        a = _tri_args(fused, mask3, out, L)
+        _lib.check(_lib.lib().tgt_triplet_attention_fwd(C.byref(a), _stream()), 'tgt_triplet_attention_fwd')
+        ctx.save_for_backward(fused, mask3, out)
+        ctx.L = L
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        fused, mask3, out = ctx.saved_tensors
+        d_out = d_out.contiguous()
+        d_fused = torch.empty_like(fused)          # every used column is written by the kernel
+        if ctx.L.width > ctx.L.used:
+            d_fused[..., ctx.L.used:] = 0
+        a = _tri_args(fused, mask3, out, ctx.L, d_out, d_fused)
+        _lib.check(_lib.lib().tgt_triplet_attention_bwd(C.byref(a), _stream()), 'tgt_triplet_attention_bwd')
+        return d_fused, None, None
+
+
+def triplet_attention(fused, mask3, layout):
+    """fused: (B,N,N,layout.width) fused projections (head-major Q/K/V), mask3:
+    (B,N,N) float32.  Returns Va (B,N,N,2C) with channel = dir*C + h*D + d.
+    Reference arithmetic: lib/tgt/layers/triplet.py:213-246."""
+    return _TripletAttention.apply(fused, mask3, layout)
+
+
+# ---------------------------------------------------------------------------
+# triplet aggregate
+# ---------------------------------------------------------------------------
+class AggregateLayout:
+    """[V_in|V_out|E_in|G_in|E_out|G_out] gated, [V_in|V_out|E_in|E_out] ungated."""
+
+    def __init__(self, C_, H, gated=True):
+        self.C, self.H, self.D, self.gated = C_, H, C_ // H, gated
+        self.v = (0, C_)
+        if gated:
+            self.e = (2 * C_, 2 * C_ + 2 * H)
+            self.g = (2 * C_ + H, 2 * C_ + 3 * H)
+            self.used = 2 * C_ + 4 * H
+            self.flags = _lib.TRI_BIASED | _lib.TRI_GATED
+        else:
+            self.e = (2 * C_, 2 * C_ + H)
+            self.g = (0, 0)
+            self.used = 2 * C_ + 2 * H
+            self.flags = _lib.TRI_BIASED | _lib.TRI_MASK_OUT
+        self.width = -(-self.used // 8) * 8
+
+
+def _agg_args(fused, mask3, out, L, d_out=None, d_fused=None):
+    B, N = fused.shape[0], fused.shape[1]
+    a = _lib.TripletAggregateArgs()
+    a.B, a.N, a.H, a.D = B, N, L.H, L.D
+    a.dtype, a.flags = _DT[fused.dtype], L.flags
+    p = fused.data_ptr()
+    a.v = _pair(C.c_void_p, p, p)
+    a.ld_v = _pair(C.c_int64, L.width, L.width)
+    a.v_off = _pair(C.c_int32, *L.v)
+    a.eg = _pair(C.c_void_p, p, p)
+    a.ld_eg = _pair(C.c_int64, L.width, L.width)
+    a.e_off, a.g_off = _pair(C.c_int32, *L.e), _pair(C.c_int32, *L.g)
+    a.mask = mask3.data_ptr()
+    a.out, a.ld_out = out.data_ptr(), 2 * L.C
+    a.o_off = _pair(C.c_int32, 0, L.C)
+    if d_out is not None:
+        a.d_out = d_out.data_ptr()
+        dp = d_fused.data_ptr()
+        a.d_v = _pair(C.c_void_p, dp, dp)
+        a.d_eg = _pair(C.c_void_p, dp, dp)
+    return a
+
+
+class _TripletAggregate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fused, mask3, L):
+        _dev(fused, mask3)
+        fused = fused.contiguous()
+        B, N = fused.shape[0], fused.shape[1]
+        assert fused.shape == (B, N, N, L.width), (fused.shape, L.width)
+        out = torch.empty(B, N, N, 2 * L.C, dtype=fused.dtype, device=fused.device)
+        a = _agg_args(fused, mask3, out, L)
+        _lib.check(_lib.lib().tgt_triplet_aggregate_fwd(C.byref(a), _stream()), 'tgt_triplet_aggregate_fwd')
+        ctx.save_for_backward(fused, mask3, out)
+        ctx.L = L
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        fused, mask3, out = ctx.saved_tensors
+        d_out = d_out.contiguous()
+        d_fused = torch.empty_like(fused)
+        if ctx.L.width > ctx.L.used:
+            d_fused[..., ctx.L.used:] = 0
+        a = _agg_args(fused, mask3, out, ctx.L, d_out, d_fused)
+        _lib.check(_lib.lib().tgt_triplet_aggregate_bwd(C.byref(a), _stream()), 'tgt_triplet_aggregate_bwd')
+        return d_fused, None, None
+
+
+def triplet_aggregate(fused, mask3, layout):
+    """Reference arithmetic: lib/tgt/layers/triplet.py:56-70 / :107-123."""
+    return _TripletAggregate.apply(fused, mask3, layout)
+
+
+# ---------------------------------------------------------------------------
+# node attention (EGT_Attention core) and EdgeUpdate logits
+# ---------------------------------------------------------------------------
+def _node_args(qkv, eg, mask3, H, scale_degree, logits_only):
+    B, N = qkv.shape[0], qkv.shape[1]
+    W = qkv.shape[2] // (2 if logits_only else 3)
+    a = _lib.NodeAttentionArgs()
+    a.B, a.N, a.H, a.D = B, N, H, W // H
+    a.dtype, a.scale_degree, a.logits_only = _DT[qkv.dtype], int(bool(scale_degree)), int(bool(logits_only))
+    a.scale = float(W // H) ** -0.5
+    a.qkv, a.ld_qkv = qkv.data_ptr(), qkv.shape[2]
+    a.q_off, a.k_off, a.v_off = 0, W, (0 if logits_only else 2 * W)
+    a.eg, a.ld_eg = eg.data_ptr(), eg.shape[3]
+    a.e_off, a.g_off = 0, (0 if logits_only else H)
+    a.mask = None if mask3 is None else mask3.data_ptr()
+    return a, W
+
+
+class _NodeAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, eg, mask3, H, scale_degree, want_edges):
+        _dev(qkv, eg, mask3)
+        qkv, eg = qkv.contiguous(), eg.contiguous()
+        if eg.dtype != qkv.dtype:
+            eg = eg.to(qkv.dtype)
+        B, N = qkv.shape[0], qkv.shape[1]
+        a, W = _node_args(qkv, eg, mask3, H, scale_degree, False)
+        vatt = torch.empty(B, N, W, dtype=qkv.dtype, device=qkv.device)
+        hhat = torch.empty(B, N, N, H, dtype=qkv.dtype, device=qkv.device) if want_edges else None
+        lse = torch.empty(B, N, H, dtype=torch.float32, device=qkv.device)
+        gsum = torch.empty(B, N, H, dtype=torch.float32, device=qkv.device)
+        a.vatt, a.hhat, a.lse, a.gsum = vatt.data_ptr(), _ptr(hhat), lse.data_ptr(), gsum.data_ptr()
+        _lib.check(_lib.lib().tgt_node_attention_fwd(C.byref(a), _stream()), 'tgt_node_attention_fwd')
+        ctx.save_for_backward(qkv, eg, mask3, lse, gsum)
+        ctx.cfg = (H, scale_degree, want_edges)
+        if want_edges:
+            return vatt, hhat
+        return vatt, None
+
+    @staticmethod
+    def backward(ctx, d_vatt, d_hhat):
+        qkv, eg, mask3, lse, gsum = ctx.saved_tensors
+        H, scale_degree, want_edges = ctx.cfg
+        a, W = _node_args(qkv, eg, mask3, H, scale_degree, False)
+        d_vatt = torch.zeros_like(qkv[..., :W]).contiguous() if d_vatt is None else d_vatt.contiguous()
+        if d_hhat is not None:
+            d_hhat = d_hhat.contiguous()
+        d_qkv, d_eg = torch.empty_like(qkv), torch.empty_like(eg)
+        a.lse, a.gsum = lse.data_ptr(), gsum.data_ptr()
+        a.d_vatt, a.d_hhat, a.d_qkv, a.d_eg = d_vatt.data_ptr(), _ptr(d_hhat), d_qkv.data_ptr(), d_eg.data_ptr()
+        _lib.check(_lib.lib().tgt_node_attention_bwd(C.byref(a), _stream()), 'tgt_node_attention_bwd')
+        return d_qkv, d_eg, None, None, None, None
+
+
+def node_attention(qkv, eg, mask3, num_heads, scale_degree=True, want_edges=True):
+    """qkv (B,N,3W) and eg (B,N,N,2H) in the reference's head-minor layout;
+    returns V_att (B,N,W) and H_hat (B,N,N,H) (or None).
+    Reference arithmetic: lib/tgt/layers/layers.py:62-77."""
+    return _NodeAttention.apply(qkv, eg, mask3, num_heads, scale_degree, want_edges)
+
+
+class _EdgeLogits(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qk, e_bias, H):
+        _dev(qk, e_bias)
+        qk, e_bias = qk.contiguous(), e_bias.contiguous()
+        if e_bias.dtype != qk.dtype:
+            e_bias = e_bias.to(qk.dtype)
+        B, N = qk.shape[0], qk.shape[1]
+        a, W = _node_args(qk, e_bias, None, H, False, True)
+        hhat = torch.empty(B, N, N, H, dtype=qk.dtype, device=qk.device)
+        a.hhat = hhat.data_ptr()
+        _lib.check(_lib.lib().tgt_node_attention_fwd(C.byref(a), _stream()), 'tgt_node_attention_fwd(logits)')
+        ctx.save_for_backward(qk, e_bias)
+        ctx.H = H
+        return hhat
+
+    @staticmethod
+    def backward(ctx, d_hhat):
+        qk, e_bias = ctx.saved_tensors
+        a, W = _node_args(qk, e_bias, None, ctx.H, False, True)
+        d_hhat = d_hhat.contiguous()
+        d_qk, d_e = torch.empty_like(qk), torch.empty_like(e_bias)
+        a.d_hhat, a.d_qkv, a.d_eg = d_hhat.data_ptr(), d_qk.data_ptr(), d_e.data_ptr()
+        _lib.check(_lib.lib().tgt_node_attention_bwd(C.byref(a), _stream()), 'tgt_node_attention_bwd(logits)')
+        return d_qk, d_e, None
+
+
+def edge_logits(qk, e_bias, num_heads):
+    """EdgeUpdate logits: s*QK^T + E.  Reference lib/tgt/layers/layers.py:120-124."""
+    return _EdgeLogits.apply(qk, e_bias, num_heads)
+
+
+# ---------------------------------------------------------------------------
+# flat Adam
+# ---------------------------------------------------------------------------
+def adam_step_(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8,
+               weight_decay=0.0, grad_scale=1.0):
+    """In-place Adam on flat float32 buffers (replaces apex FusedAdam,
+    reference lib/training/training.py:159-171)."""
+    _dev(param, grad, exp_avg, exp_avg_sq)
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == param.numel()
+    _lib.check(_lib.lib().tgt_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq),
+                                        param.numel(), lr, betas[0], betas[1], eps, weight_decay,
+                                        int(step), grad_scale, _stream()), 'tgt_adam_step')
