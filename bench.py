@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""Headline benchmark: graphs/sec of one full TGT-At 24L training step
+(BASELINE.json `metric`; workload = configs[1]: batch 256 per GPU, N = 32,
+bf16 autocast, random-init weights, synthetic PCQM-schema graphs).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = preprocess (edge mask, coordinate noise, distances) + forward + loss +
+backward (+ RCCL all-reduce of gradient buckets) + Adam, exactly the sequence of
+the reference's train loop (lib/training/training.py:439-470).  Inputs are
+resident in HBM before the timed region.  One process per GPU; graphs are
+independent, so each rank steps its own 256 graphs (weak scaling) and the only
+exchange is the gradient all-reduce.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     : the dominant hand-written kernel (triplet attention backward or
+                 forward), algorithmic HBM bytes / HIP-event time inside the timed steps
+  cpu_baseline : the oracle (CPU restatement of the reference) timed on this
+                 host on a bounded sample of the same workload (N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def algorithmic_bytes(kind, B, N, C, Ht, esz=2):
+    """HBM bytes one launch must move (both directions), SURVEY §8(d):
+    fwd: 2 dirs x (Q,K,V in + O out = 4 N^2 C, E,G = 2 N^2 Ht) elements + mask
+    bwd: 2 dirs x (Q,K,V,dO in + dQ,dK,dV out = 7 N^2 C, E,G in + dE,dG out = 4 N^2 Ht) + mask"""
+    n2 = N * N
+    if kind == 'fwd':
+        per_graph = 2 * (4 * n2 * C + 2 * n2 * Ht) * esz + n2 * 4
+    else:
+        per_graph = 2 * (7 * n2 * C + 4 * n2 * Ht) * esz + n2 * 4
+    return B * per_graph
+
+
+def cpu_baseline(batch_graphs=8, nodes=32, budget_s=12.0, max_steps=3):
+    """The oracle's TGT-At 24L training step on the host CPU (fp32), micro-batch
+    of `batch_graphs` graphs of the same synthetic workload."""
+    from oracle import modules as om, core
+    from tgt_amd.training.configs import tgt_at_24l
+    from tgt_amd.training.synthetic import make_batch, batch_seed
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    model = om.TGT_Multi(**tgt_at_24l()).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+
+    def one_step(step):
+        b = make_batch(batch_graphs, nodes, batch_seed(step))
+        nm = b['node_mask']
+        b['edge_mask'] = nm.unsqueeze(-1) * nm.unsqueeze(-2)
+        coords = core.smoothed_coord_noise(b['dft_coords'], b['edge_mask'], 0.2, 1.0)
+        b['dist_input'] = core.pairwise_dist(coords)
+        opt.zero_grad(set_to_none=True)
+        gap, logits = model(b)
+        loss = torch.nn.functional.l1_loss(gap, b['target']) + 0.1 * core.binned_distance_xent(
+            logits, core.pairwise_dist(b['dft_coords']), b['edge_mask'], 512, 8)
+        loss.backward()
+        opt.step()
+
+    one_step(0)                                   # untimed warm-up (allocator, thread pool)
+    t0, n = time.perf_counter(), 0
+    while n < max_steps and (n == 0 or time.perf_counter() - t0 < budget_s):
+        one_step(1 + n)
+        n += 1
+    dt = time.perf_counter() - t0
+    return dict(value=round(batch_graphs * n / dt, 3), unit='graphs/s', cores=threads, kind='port',
+                sample=f'oracle TGT-At 24L train step (fwd+loss+bwd+Adam), fp32, {n} step(s) of '
+                       f'{batch_graphs} synthetic N={nodes} graphs, dropouts on')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=256, help='graphs per GPU')
+    ap.add_argument('--nodes', type=int, default=32)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp16', 'fp32'])
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the TGT kernels have no CPU path')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+
+    from tgt_amd import ops
+    from tgt_amd.pcqm import TGT_Multi
+    from tgt_amd.training.configs import tgt_at_24l
+    from tgt_amd.training.step import Trainer, StepConfig, preprocess_batch
+    from tgt_amd.training.synthetic import make_batch, batch_seed
+
+    mcfg = tgt_at_24l()
+    torch.manual_seed(0)
+    model = TGT_Multi(**mcfg).to(dev).train()
+    cfg = StepConfig(mixed_precision=None if args.precision == 'fp32' else args.precision)
+    trainer = Trainer(model, cfg)
+
+    # synthetic batches, resident in HBM before timing (4 distinct ones, cycled)
+    pool = [{k: v.to(dev) for k, v in make_batch(args.batch, args.nodes, batch_seed(s, rank)).items()}
+            for s in range(4)]
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+
+    def step(i):
+        batch = preprocess_batch(pool[i % len(pool)], dev, cfg, training=True, generator=gen)
+        return trainer.training_step(batch)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    prof = ops.profile_kernels(True)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        _, loss = step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    ops.profile_kernels(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_val = float(loss.detach())
+
+    if rank == 0:
+        times = ops.kernel_times_ms(prof)
+        C, Ht = mcfg['edge_width'], mcfg['triplet_heads']
+        esz = 4 if args.precision == 'fp32' else 2
+        cand = {}
+        for name, kind in (('tgt_triplet_attention_bwd', 'bwd'), ('tgt_triplet_attention_fwd', 'fwd')):
+            if name in times and times[name]:
+                avg_ms = sum(times[name]) / len(times[name])
+                cand[name] = (sum(times[name]), avg_ms, algorithmic_bytes(kind, args.batch, args.nodes, C, Ht, esz))
+        roofline = None
+        if cand:
+            name = max(cand, key=lambda k: cand[k][0])
+            tot, avg_ms, nbytes = cand[name]
+            ach = nbytes / (avg_ms * 1e-3) / 1e9
+            roofline = dict(bound='hbm', kernel=name, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+                            frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
+                            avg_launch_ms=round(avg_ms, 4), launches=len(times[name]),
+                            algorithmic_bytes_per_launch=nbytes,
+                            share_of_step=round(tot / (dt * 1e3), 4),
+                            other_kernels={k: dict(avg_launch_ms=round(v[1], 4),
+                                                   achieved=round(v[2] / (v[1] * 1e-3) / 1e9, 1))
+                                           for k, v in cand.items() if k != name})
+        out = dict(
+            metric='graphs/sec training step, TGT-At 24L PCQM batch 256',
+            value=round(args.batch * world * args.steps / dt, 2), unit='graphs/s',
+            n_gpus=world, steps=args.steps, warmup=args.warmup,
+            ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling='weak',
+            vs_baseline=None, dtype=args.precision, data='synthetic',
+            config=dict(workload='TGT-At 24L (TGT_Multi, 103.6M params, 512 dist bins) train step; '
+                                 f'{args.batch} synthetic N={args.nodes} graphs per GPU; dropouts of tgt_at_tp.yaml on',
+                        global_batch=args.batch * world, nodes=args.nodes,
+                        parallelism=f'dp{world}', precision=f'{args.precision} autocast, fp32 params/Adam'),
+            final_loss=round(loss_val, 5),
+            roofline=roofline,
+        )
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

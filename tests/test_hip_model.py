@@ -1,0 +1,179 @@
+"""Module- and model-level parity of the HIP-backed mirror (tgt_amd.tgt,
+tgt_amd.pcqm) against the oracle and the committed golden vectors, on the GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from oracle import core, modules as om
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def load_gold(name):
+    z = np.load(os.path.join(gu.GOLDEN_DIR, name + '.npz'))
+    return {k.split('::')[0]: z[k] for k in z.files if k.endswith('::full')}
+
+
+def product_class(name):
+    from tgt_amd.tgt.layers import layers as L, triplet as T
+    from tgt_amd import pcqm
+    for mod in (L, T, pcqm):
+        if hasattr(mod, name):
+            return getattr(mod, name)
+    raise KeyError(name)
+
+
+SMALL_OPS = [k for k, v in gu.OP_CASES.items() if v[2] is gu.SMALL and v[0] != 'TriangularUpdate']
+
+
+@pytest.mark.parametrize('name', SMALL_OPS)
+def test_module_matches_reference_golden_fp32(name):
+    """HIP-backed module in fp32 vs the reference's own float64 outputs/gradients."""
+    cls_name, kwargs, geom = gu.OP_CASES[name]
+    i = list(gu.OP_CASES).index(name)
+    mod = gu.fill_params(product_class(cls_name)(**kwargs), seed=100 + i).cuda().eval()
+    h, e, mask, gh, ge = (t.float().cuda() for t in gu.op_inputs(geom['B'], geom['N'], geom['W'], geom['C'],
+                                                               geom['num_nodes'], 100 + i + 1))
+    # finfo(float64).min would overflow to -inf in float32: build the mask as the model does, in fp32
+    mask = gu.additive_mask(geom['num_nodes'], geom['N'], torch.float32).cuda()
+    h.requires_grad_(True)
+    e.requires_grad_(True)
+    gold = load_gold('op_' + name)
+    res = {}
+    if cls_name in gu.NODE_OPS:
+        ho, eo = mod(h, e, mask)
+        loss = 0.
+        if ho is not h:
+            res['out_h'] = ho
+            loss = loss + (ho * gh).sum()
+        if eo is not e:
+            res['out_e'] = eo
+            loss = loss + (eo * ge).sum()
+    elif cls_name == 'FFN':
+        res['out_e'] = mod(e)
+        loss = (res['out_e'] * ge).sum()
+    else:
+        res['out_e'] = mod(e, mask)
+        loss = (res['out_e'] * ge).sum()
+    loss.backward()
+    if h.grad is not None:
+        res['grad_h'] = h.grad
+    if e.grad is not None:
+        res['grad_e'] = e.grad
+    for k, p in mod.named_parameters():
+        if p.grad is not None:
+            res['pgrad.' + k] = p.grad
+    assert set(res) == set(gold)
+    for k, t in res.items():
+        g = torch.from_numpy(gold[k])
+        if g.abs().max() < 1e-12:
+            assert t.abs().max() < 1e-4, k
+        else:
+            assert rel(t, g) < 2e-4, (k, rel(t, g))
+
+
+@pytest.mark.parametrize('name', list(gu.MODEL_CASES))
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+def test_task_model_matches_reference_golden(name, mode):
+    from tgt_amd.training.step import pretrain_loss, binned_distance_loss, coords2dist, StepConfig
+    cls_name, kwargs, geom = gu.MODEL_CASES[name]
+    i = list(gu.MODEL_CASES).index(name)
+    model = gu.fill_params(product_class(cls_name)(**kwargs), seed=500 + i).cuda().train()
+    batch = {k: v.cuda() for k, v in gu.model_batch(geom, seed=600 + i).items()}
+    gold = load_gold('model_' + name)
+    cfg = StepConfig(num_dist_bins=kwargs.get('num_dist_bins', 0), range_dist_bins=8, dist_loss_weight=0.1)
+    ctx = torch.autocast('cuda', dtype=torch.bfloat16) if mode == 'bf16' else torch.autocast('cuda', enabled=False)
+    with ctx:
+        out = model(batch)
+        if cls_name == 'TGT_Multi':
+            res = dict(gap=out[0], logits=out[1])
+            loss = pretrain_loss(out, batch, cfg)
+        elif cls_name == 'TGT_Distance':
+            res = dict(logits=out)
+            loss = binned_distance_loss(out, coords2dist(batch['dft_coords']), batch['edge_mask'], cfg.num_dist_bins, 8)
+        else:
+            res = dict(gap=out)
+            loss = torch.nn.functional.l1_loss(out, batch['target'])
+    assert loss.dtype == torch.float64 or cls_name == 'TGT_Distance'
+    res['loss'] = loss
+    loss.backward()
+    named = dict(model.named_parameters())
+    for k in gu.GRAD_PROBE_KEYS:
+        if k in named and named[k].grad is not None:
+            res['pgrad.' + k] = named[k].grad
+    assert set(res) == set(gold)
+    # fp32 HIP path vs fp64 reference; bf16: ~2x the reference's own bf16 drift
+    tol_out, tol_grad = (3e-4, 2e-3) if mode == 'fp32' else (3e-2, 1.5e-1)
+    for k, t in res.items():
+        g = torch.from_numpy(gold[k])
+        tol = tol_grad if k.startswith('pgrad.') else tol_out
+        assert rel(t, g) < tol, (k, rel(t, g))
+
+
+def test_full_width_24L_forward_vs_reference_golden():
+    """TGT-At 24L at BASELINE widths: eval forward vs the reference's fp32 CPU forward."""
+    from tgt_amd.pcqm import TGT_Multi
+    geom = dict(B=2, N=12, num_nodes=[12, 9])
+    model = gu.fill_params(TGT_Multi(**gu.FULL_AT_CFG), seed=900).cuda().eval()
+    batch = {k: v.cuda() for k, v in gu.model_batch(geom, seed=901).items()}
+    z = np.load(os.path.join(gu.GOLDEN_DIR, 'model_full_at_24L_fp32.npz'))
+    with torch.no_grad():
+        gap, logits = model(batch)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            gap16, logits16 = model(batch)
+    flat = logits.double().cpu().numpy().reshape(-1)
+    idx = gu.sample_index(flat.size)
+    ref_s, ref_norm = z['logits::samples'], float(z['logits::norm'])
+    assert np.abs(flat[idx] - ref_s).max() <= 2e-3 * np.abs(ref_s).max()
+    assert abs(np.linalg.norm(flat) - ref_norm) <= 1e-3 * ref_norm
+    assert np.abs(gap.double().cpu().numpy() - z['gap::full']).max() < 1e-3
+    agree = (logits.argmax(-1).cpu().numpy() == z['logits_argmax::full']).mean()
+    assert agree > 0.99
+    # stated bf16 tolerance: <= 3e-2 rel-L2 on the 24L logits, gap <= 1e-2 (SURVEY §8c anchors)
+    f16 = logits16.double().cpu().numpy().reshape(-1)
+    assert np.linalg.norm(f16[idx] - ref_s) <= 3e-2 * np.linalg.norm(ref_s)
+    assert np.abs(gap16.double().cpu().numpy() - z['gap::full']).max() < 5e-2
+
+
+def test_state_dict_roundtrip_with_oracle():
+    """A checkpoint written by the reference-schema model loads strictly."""
+    from tgt_amd.pcqm import TGT_Multi
+    kwargs = gu.MODEL_CASES['multi_at_tiny'][1]
+    src = om.TGT_Multi(**kwargs)
+    dst = TGT_Multi(**kwargs)
+    dst.load_state_dict(src.state_dict(), strict=True)
+
+
+def test_trainer_step_runs_and_matches_torch_adam():
+    from tgt_amd.pcqm import TGT_Multi
+    from tgt_amd.training.step import Trainer, StepConfig, preprocess_batch
+    from tgt_amd.training.synthetic import make_batch
+    kwargs = gu.MODEL_CASES['multi_at_tiny'][1]
+    cfg = StepConfig(num_dist_bins=24, mixed_precision=None, coords_noise=0.0, lr_warmup_steps=10, lr_total_steps=100)
+    torch.manual_seed(0)
+    m1 = gu.fill_params(TGT_Multi(**kwargs), seed=3).cuda()
+    m2 = gu.fill_params(TGT_Multi(**kwargs), seed=3).cuda()
+    tr = Trainer(m1, cfg)
+    opt = torch.optim.Adam(m2.parameters(), lr=1.0)
+    from tgt_amd.training.step import pretrain_loss, lr_at
+    for step in range(1, 4):
+        batch = preprocess_batch(make_batch(3, 7, seed=40 + step, ragged=True), 'cuda', cfg, training=False)
+        _, loss1 = tr.training_step(batch)
+        for g in opt.param_groups:
+            g['lr'] = lr_at(step, cfg)
+        opt.zero_grad(set_to_none=True)
+        loss2 = pretrain_loss(m2(batch), batch, cfg)
+        loss2.backward()
+        opt.step()
+        assert abs(float(loss1) - float(loss2)) < 1e-4 * abs(float(loss2))
+    p1 = torch.cat([p.detach().reshape(-1) for p in m1.parameters()])
+    p2 = torch.cat([p.detach().reshape(-1) for p in m2.parameters()])
+    assert rel(p1, p2) < 1e-4

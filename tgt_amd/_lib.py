@@ -112,6 +112,9 @@ def lib():
                 f'{LIB_PATH} is missing: the TGT HIP kernels are not built. Run '
                 f'`python -c "import __graft_entry__ as g; g.build()"` (needs hipcc). '
                 f'There is no CPU/eager fallback for the tgt_amd ops.')
+        # torch bundles its own libamdhip64.so.7; it must be the process's HIP runtime BEFORE
+        # this library is mapped, or two runtimes (two HSA instances) end up in one process.
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)          # AttributeError if the symbol is not exported

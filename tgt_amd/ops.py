@@ -13,6 +13,33 @@ from . import _lib
 _DT = {torch.float32: _lib.TGT_F32, torch.bfloat16: _lib.TGT_BF16, torch.float16: _lib.TGT_F16}
 
 
+# optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg)
+_PROFILE = None
+
+
+def profile_kernels(enable=True):
+    """Start (returns the dict that will fill with name -> [(start,end) events]) or stop."""
+    global _PROFILE
+    _PROFILE = {} if enable else None
+    return _PROFILE
+
+
+def kernel_times_ms(prof):
+    """After torch.cuda.synchronize(): name -> list of per-launch durations (ms)."""
+    return {k: [s.elapsed_time(e) for s, e in v] for k, v in prof.items()}
+
+
+def _call(name, fn, args):
+    if _PROFILE is None:
+        _lib.check(fn(C.byref(args), _stream()), name)
+        return
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    _lib.check(fn(C.byref(args), _stream()), name)
+    e.record()
+    _PROFILE.setdefault(name, []).append((s, e))
+
+
 def _dev(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
@@ -93,7 +120,7 @@ class _TripletAttention(torch.autograd.Function):
         assert fused.shape == (B, N, N, L.width), (fused.shape, L.width)
         out = torch.empty(B, N, N, 2 * L.C, dtype=fused.dtype, device=fused.device)
         a = _tri_args(fused, mask3, out, L)
-        _lib.check(_lib.lib().tgt_triplet_attention_fwd(C.byref(a), _stream()), 'tgt_triplet_attention_fwd')
+        _call('tgt_triplet_attention_fwd', _lib.lib().tgt_triplet_attention_fwd, a)
         ctx.save_for_backward(fused, mask3, out)
         ctx.L = L
         return out
@@ -106,7 +133,7 @@ class _TripletAttention(torch.autograd.Function):
         if ctx.L.width > ctx.L.used:
             d_fused[..., ctx.L.used:] = 0
         a = _tri_args(fused, mask3, out, ctx.L, d_out, d_fused)
-        _lib.check(_lib.lib().tgt_triplet_attention_bwd(C.byref(a), _stream()), 'tgt_triplet_attention_bwd')
+        _call('tgt_triplet_attention_bwd', _lib.lib().tgt_triplet_attention_bwd, a)
         return d_fused, None, None
 
 
@@ -171,7 +198,7 @@ class _TripletAggregate(torch.autograd.Function):
         assert fused.shape == (B, N, N, L.width), (fused.shape, L.width)
         out = torch.empty(B, N, N, 2 * L.C, dtype=fused.dtype, device=fused.device)
         a = _agg_args(fused, mask3, out, L)
-        _lib.check(_lib.lib().tgt_triplet_aggregate_fwd(C.byref(a), _stream()), 'tgt_triplet_aggregate_fwd')
+        _call('tgt_triplet_aggregate_fwd', _lib.lib().tgt_triplet_aggregate_fwd, a)
         ctx.save_for_backward(fused, mask3, out)
         ctx.L = L
         return out
@@ -184,7 +211,7 @@ class _TripletAggregate(torch.autograd.Function):
         if ctx.L.width > ctx.L.used:
             d_fused[..., ctx.L.used:] = 0
         a = _agg_args(fused, mask3, out, ctx.L, d_out, d_fused)
-        _lib.check(_lib.lib().tgt_triplet_aggregate_bwd(C.byref(a), _stream()), 'tgt_triplet_aggregate_bwd')
+        _call('tgt_triplet_aggregate_bwd', _lib.lib().tgt_triplet_aggregate_bwd, a)
         return d_fused, None, None
 
 
@@ -225,7 +252,7 @@ class _NodeAttention(torch.autograd.Function):
         lse = torch.empty(B, N, H, dtype=torch.float32, device=qkv.device)
         gsum = torch.empty(B, N, H, dtype=torch.float32, device=qkv.device)
         a.vatt, a.hhat, a.lse, a.gsum = vatt.data_ptr(), _ptr(hhat), lse.data_ptr(), gsum.data_ptr()
-        _lib.check(_lib.lib().tgt_node_attention_fwd(C.byref(a), _stream()), 'tgt_node_attention_fwd')
+        _call('tgt_node_attention_fwd', _lib.lib().tgt_node_attention_fwd, a)
         ctx.save_for_backward(qkv, eg, mask3, lse, gsum)
         ctx.cfg = (H, scale_degree, want_edges)
         if want_edges:
@@ -243,7 +270,7 @@ class _NodeAttention(torch.autograd.Function):
         d_qkv, d_eg = torch.empty_like(qkv), torch.empty_like(eg)
         a.lse, a.gsum = lse.data_ptr(), gsum.data_ptr()
         a.d_vatt, a.d_hhat, a.d_qkv, a.d_eg = d_vatt.data_ptr(), _ptr(d_hhat), d_qkv.data_ptr(), d_eg.data_ptr()
-        _lib.check(_lib.lib().tgt_node_attention_bwd(C.byref(a), _stream()), 'tgt_node_attention_bwd')
+        _call('tgt_node_attention_bwd', _lib.lib().tgt_node_attention_bwd, a)
         return d_qkv, d_eg, None, None, None, None
 
 
@@ -265,7 +292,7 @@ class _EdgeLogits(torch.autograd.Function):
         a, W = _node_args(qk, e_bias, None, H, False, True)
         hhat = torch.empty(B, N, N, H, dtype=qk.dtype, device=qk.device)
         a.hhat = hhat.data_ptr()
-        _lib.check(_lib.lib().tgt_node_attention_fwd(C.byref(a), _stream()), 'tgt_node_attention_fwd(logits)')
+        _call('tgt_node_attention_fwd(logits)', _lib.lib().tgt_node_attention_fwd, a)
         ctx.save_for_backward(qk, e_bias)
         ctx.H = H
         return hhat
@@ -277,7 +304,7 @@ class _EdgeLogits(torch.autograd.Function):
         d_hhat = d_hhat.contiguous()
         d_qk, d_e = torch.empty_like(qk), torch.empty_like(e_bias)
         a.d_hhat, a.d_qkv, a.d_eg = d_hhat.data_ptr(), d_qk.data_ptr(), d_e.data_ptr()
-        _lib.check(_lib.lib().tgt_node_attention_bwd(C.byref(a), _stream()), 'tgt_node_attention_bwd(logits)')
+        _call('tgt_node_attention_bwd(logits)', _lib.lib().tgt_node_attention_bwd, a)
         return d_qk, d_e, None
 
 

@@ -1,0 +1,184 @@
+"""TGT layer modules on the HIP kernels.  API / state_dict = reference
+lib/tgt/layers/layers.py; the attention arithmetic is libtgt_hip.so."""
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from ... import ops
+from .activations import get_activation
+from .triplet import get_triplet_layer
+
+
+class EGT_Attention(nn.Module):
+    """Node attention biased and gated by edge channels.
+    Reference lib/tgt/layers/layers.py:15-84."""
+
+    def __init__(self, node_width, edge_width, num_heads, source_dropout=0,
+                 scale_degree=True, edge_update=True):
+        super().__init__()
+        self.node_width = node_width
+        self.edge_width = edge_width
+        self.num_heads = num_heads
+        self.source_dropout = source_dropout
+        self.scale_degree = scale_degree
+        self.edge_update = edge_update
+        assert not (node_width % num_heads), 'node_width must be divisible by num_heads'
+        self._dot_dim = node_width // num_heads
+        self._scale_factor = self._dot_dim ** -0.5
+
+        self.mha_ln_h = nn.LayerNorm(node_width)
+        self.mha_ln_e = nn.LayerNorm(edge_width)
+        self.lin_QKV = nn.Linear(node_width, node_width * 3)
+        self.lin_EG = nn.Linear(edge_width, num_heads * 2)
+        self.lin_O_h = nn.Linear(node_width, node_width)
+        if edge_update:
+            self.lin_O_e = nn.Linear(num_heads, edge_width)
+
+    def forward(self, h, e, mask):
+        B, N = h.shape[0], h.shape[1]
+        qkv = self.lin_QKV(self.mha_ln_h(h))
+        eg = self.lin_EG(self.mha_ln_e(e))
+        mask3 = ops.as_mask3(mask, B, N)
+        if self.source_dropout > 0 and self.training:
+            # per-key-node drop shared by all queries/heads (layers.py:55-59); the
+            # caller's mask is left untouched (the triplet module sees it un-dropped)
+            drop = torch.empty(B, 1, N, dtype=torch.float32, device=h.device)
+            drop = drop.bernoulli_(self.source_dropout) * torch.finfo(mask.dtype).min
+            mask3 = mask3 + drop
+        v_att, h_hat = ops.node_attention(qkv, eg, mask3, self.num_heads,
+                                          self.scale_degree, self.edge_update)
+        h = self.lin_O_h(v_att)
+        if self.edge_update:
+            e = self.lin_O_e(h_hat)
+        return h, e
+
+
+class EdgeUpdate(nn.Module):
+    """Edge channels from node dot products only.  Reference layers.py:87-130."""
+
+    def __init__(self, node_width, edge_width, num_heads):
+        super().__init__()
+        self.node_width = node_width
+        self.edge_width = edge_width
+        self.num_heads = num_heads
+        assert not (node_width % num_heads), 'node_width must be divisible by num_heads'
+        self._dot_dim = node_width // num_heads
+        self._scale_factor = self._dot_dim ** -0.5
+        self.mha_ln_h = nn.LayerNorm(node_width)
+        self.mha_ln_e = nn.LayerNorm(edge_width)
+        self.lin_QK = nn.Linear(node_width, node_width * 2)
+        self.lin_E = nn.Linear(edge_width, num_heads)
+        self.lin_O_e = nn.Linear(num_heads, edge_width)
+
+    def forward(self, h, e, mask):
+        qk = self.lin_QK(self.mha_ln_h(h))
+        bias = self.lin_E(self.mha_ln_e(e))
+        return h, self.lin_O_e(ops.edge_logits(qk, bias, self.num_heads))
+
+
+class FFN(nn.Module):
+    """Reference lib/tgt/layers/layers.py:134-160."""
+
+    def __init__(self, width, multiplier=1., act_dropout=0., activation='gelu'):
+        super().__init__()
+        self.width = width
+        self.multiplier = multiplier
+        self.act_dropout = act_dropout
+        self.activation = activation
+        self.ffn_fn, self.act_mul = get_activation(activation)
+        inner_dim = round(width * multiplier)
+        self.ffn_ln = nn.LayerNorm(width)
+        self.lin_W1 = nn.Linear(width, inner_dim * self.act_mul)
+        self.lin_W2 = nn.Linear(inner_dim, width)
+        self.dropout = nn.Dropout(act_dropout)
+
+    def forward(self, x):
+        x = self.ffn_fn(self.lin_W1(self.ffn_ln(x)))
+        return self.lin_W2(self.dropout(x))
+
+
+class DropPath(nn.Module):
+    """Per-sample stochastic depth.  Reference lib/tgt/layers/layers.py:163-177."""
+
+    def __init__(self, drop_path=0.):
+        super().__init__()
+        self.drop_path = drop_path
+        self._keep_prob = 1 - drop_path
+
+    def forward(self, x):
+        if self.drop_path > 0 and self.training:
+            shape = [x.size(0)] + [1] * (x.ndim - 1)
+            keep = x.new_empty(shape).bernoulli_(self._keep_prob)
+            x = x.div(self._keep_prob) * keep
+        return x
+
+    def __repr__(self):
+        return f'{self.__class__.__name__}(drop_path={self.drop_path})'
+
+
+class TGT_Layer(nn.Module):
+    """Reference lib/tgt/layers/layers.py:180-302."""
+
+    def __init__(self, node_width, edge_width, num_heads, activation='gelu',
+                 scale_degree=True, node_update=True, edge_update=True,
+                 triplet_heads=0, triplet_type='aggregate', triplet_dropout=0,
+                 node_ffn_multiplier=1., edge_ffn_multiplier=1., source_dropout=0,
+                 drop_path=0, node_act_dropout=0, edge_act_dropout=0):
+        super().__init__()
+        self.node_width = node_width
+        self.edge_width = edge_width
+        self.num_heads = num_heads
+        self.activation = activation
+        self.node_ffn_multiplier = node_ffn_multiplier
+        self.edge_ffn_multiplier = edge_ffn_multiplier
+        self.node_act_dropout = node_act_dropout
+        self.edge_act_dropout = edge_act_dropout
+        self.source_dropout = source_dropout
+        self.scale_degree = scale_degree
+        self.node_update = node_update
+        self.edge_update = edge_update
+        self.triplet_heads = triplet_heads
+        self.triplet_type = triplet_type
+        self.triplet_dropout = triplet_dropout
+        self._triplet_update = triplet_heads > 0
+
+        if node_update:
+            self.update = EGT_Attention(node_width=node_width, edge_width=edge_width,
+                                        num_heads=num_heads, source_dropout=source_dropout,
+                                        scale_degree=scale_degree, edge_update=edge_update)
+        elif edge_update:
+            self.update = EdgeUpdate(node_width=node_width, edge_width=edge_width, num_heads=num_heads)
+        else:
+            raise ValueError('At least one of node_update and edge_update must be True')
+
+        if node_update:
+            self.node_ffn = FFN(width=node_width, multiplier=node_ffn_multiplier,
+                                act_dropout=node_act_dropout, activation=activation)
+        if edge_update:
+            if self._triplet_update:
+                self.tria = get_triplet_layer(triplet_type)(edge_width=edge_width,
+                                                            num_heads=triplet_heads,
+                                                            attention_dropout=triplet_dropout)
+            self.edge_ffn = FFN(width=edge_width, multiplier=edge_ffn_multiplier,
+                                act_dropout=edge_act_dropout, activation=activation)
+        self.drop_path = DropPath(drop_path)
+
+    def forward(self, g):
+        h, e, mask = g.h, g.e, g.mask
+        h_in, e_in = h, e
+        h, e = self.update(h, e, mask)
+        if self.node_update:
+            h = self.drop_path(h).add_(h_in)
+            h = self.drop_path(self.node_ffn(h)).add_(h)
+        if self.edge_update:
+            e = self.drop_path(e).add_(e_in)
+            if self._triplet_update:
+                e = self.drop_path(self.tria(e, mask)).add_(e)
+            e = self.drop_path(self.edge_ffn(e)).add_(e)
+        g = g.copy()
+        g.h, g.e = h, e
+        return g
+
+    def __repr__(self):
+        rep = super().__repr__()
+        return rep + f' (activation: {self.activation}, source_dropout: {self.source_dropout})'

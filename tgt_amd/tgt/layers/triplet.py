@@ -1,0 +1,178 @@
+"""Triplet edge-update modules on the HIP kernels.
+
+Module API, parameter names and shapes = reference lib/tgt/layers/triplet.py
+(so `model_state.pt` files load unchanged); the einsum/softmax/gate chains of
+the reference's forward() are one call into libtgt_hip.so each.
+
+How the projections feed the kernels: the reference splits channels
+HEAD-MINOR (c = d*H + h); the matrix-core kernels want each head's D values
+contiguous.  Instead of permuting (B,N,N,C) activations, the rows of the
+projection WEIGHTS are gathered into head-major order every step (a few
+hundred KB), all projections of the module are fused into ONE GEMM whose
+output row is [Q_in|K_in|V_in|Q_out|K_out|V_out|E_in|G_in|E_out|G_out], and the
+columns of lin_O are gathered to match the kernel's output order.  Autograd
+sends the gradients back through the gathers to the canonical parameters.
+"""
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from ... import layout, ops
+
+
+def _no_attention_dropout(mod):
+    if mod.attention_dropout > 0 and mod.training:
+        raise NotImplementedError(
+            'attention_dropout > 0 inside the fused triplet kernels is not implemented '
+            '(0 in every shipped config: lib/training_schemes/pcqm/tgt_training.py:35)')
+
+
+class _TripletBase(nn.Module):
+    def __init__(self, edge_width, num_heads, attention_dropout=0):
+        super().__init__()
+        self.edge_width = edge_width
+        self.num_heads = num_heads
+        self.attention_dropout = attention_dropout
+        self._idx = {}
+
+    def _index(self, name, make, device):
+        key = (name, device)
+        if key not in self._idx:
+            self._idx[key] = make().to(device)
+        return self._idx[key]
+
+    def _out_proj(self, va):
+        """lin_O on the kernel's [dir][h][d] channel order (reference order is
+        d*2H + dir*H + h, triplet.py:248)."""
+        cols = self._index('va', lambda: layout.va_cols_head_major(self.edge_width, self.num_heads), va.device)
+        return F.linear(va, self.lin_O.weight[:, cols], self.lin_O.bias)
+
+
+class TripletAttention(_TripletBase):
+    """Reference lib/tgt/layers/triplet.py:179-250."""
+    gated, biased = True, True
+
+    def __init__(self, edge_width, num_heads, attention_dropout=0):
+        super().__init__(edge_width, num_heads, attention_dropout)
+        assert not (edge_width % num_heads), 'edge_width must be divisible by num_heads'
+        self._dot_dim = edge_width // num_heads
+        self._scale_factor = self._dot_dim ** -0.5
+        nb = num_heads * (2 if self.gated else 1)
+        bias_name = 'lin_EG' if self.gated else 'lin_E'
+        self.tri_ln_e = nn.LayerNorm(edge_width)
+        self.lin_QKV_in = nn.Linear(edge_width, edge_width * 3)
+        if self.biased:
+            setattr(self, bias_name + '_in', nn.Linear(edge_width, nb))
+        self.lin_QKV_out = nn.Linear(edge_width, edge_width * 3)
+        if self.biased:
+            setattr(self, bias_name + '_out', nn.Linear(edge_width, nb))
+        self.lin_O = nn.Linear(edge_width * 2, edge_width)
+        self._bias_name = bias_name
+        self._layout = ops.TripletLayout(edge_width, num_heads, gated=self.gated, biased=self.biased)
+
+    def _fused_projection(self, device):
+        rows = self._index('qkv', lambda: layout.qkv_rows_head_major(self.edge_width, self.num_heads), device)
+        ws = [self.lin_QKV_in.weight[rows], self.lin_QKV_out.weight[rows]]
+        bs = [self.lin_QKV_in.bias[rows], self.lin_QKV_out.bias[rows]]
+        if self.biased:
+            for which in ('_in', '_out'):
+                lin = getattr(self, self._bias_name + which)
+                ws.append(lin.weight)
+                bs.append(lin.bias)
+        pad = self._layout.width - self._layout.used
+        if pad:
+            ws.append(ws[0].new_zeros(pad, self.edge_width))
+            bs.append(bs[0].new_zeros(pad))
+        return torch.cat(ws, 0), torch.cat(bs, 0)
+
+    def forward(self, e, mask):
+        _no_attention_dropout(self)
+        B, N = e.shape[0], e.shape[1]
+        x = self.tri_ln_e(e)
+        w, b = self._fused_projection(e.device)
+        fused = F.linear(x, w, b)
+        va = ops.triplet_attention(fused, ops.as_mask3(mask, B, N), self._layout)
+        return self._out_proj(va)
+
+
+class TripletAttentionUngated(TripletAttention):
+    """Reference lib/tgt/layers/triplet.py:253-322 (params lin_E_in / lin_E_out)."""
+    gated, biased = False, True
+
+
+class AxialAttention(TripletAttention):
+    """Reference lib/tgt/layers/triplet.py:325-387 (no third-arm bias or gate)."""
+    gated, biased = False, False
+
+
+class TripletAggregate(_TripletBase):
+    """Reference lib/tgt/layers/triplet.py:22-73."""
+    gated = True
+
+    def __init__(self, edge_width, num_heads, attention_dropout=0):
+        super().__init__(edge_width, num_heads, attention_dropout)
+        assert not (edge_width % num_heads), 'edge_width must be divisible by num_heads'
+        self._dot_dim = edge_width // num_heads
+        self._scale_factor = self._dot_dim ** -0.5
+        self.tri_ln_e = nn.LayerNorm(edge_width)
+        self.lin_V = nn.Linear(edge_width, edge_width * 2)
+        if self.gated:
+            self.lin_EG = nn.Linear(edge_width, num_heads * 4)
+        else:
+            self.lin_E = nn.Linear(edge_width, num_heads * 2)
+        self.lin_O = nn.Linear(edge_width * 2, edge_width)
+        self._layout = ops.AggregateLayout(edge_width, num_heads, gated=self.gated)
+
+    def forward(self, e, mask):
+        _no_attention_dropout(self)
+        B, N = e.shape[0], e.shape[1]
+        x = self.tri_ln_e(e)
+        rows = self._index('v', lambda: layout.qkv_rows_head_major(self.edge_width, self.num_heads, parts=2), e.device)
+        lin_b = self.lin_EG if self.gated else self.lin_E
+        ws, bs = [self.lin_V.weight[rows], lin_b.weight], [self.lin_V.bias[rows], lin_b.bias]
+        pad = self._layout.width - self._layout.used
+        if pad:
+            ws.append(ws[0].new_zeros(pad, self.edge_width))
+            bs.append(bs[0].new_zeros(pad))
+        fused = F.linear(x, torch.cat(ws, 0), torch.cat(bs, 0))
+        va = ops.triplet_aggregate(fused, ops.as_mask3(mask, B, N), self._layout)
+        return self._out_proj(va)
+
+
+class TripletAggregateUngated(TripletAggregate):
+    """Reference lib/tgt/layers/triplet.py:77-127."""
+    gated = False
+
+
+class TriangularUpdate(_TripletBase):
+    """Reference lib/tgt/layers/triplet.py:134-176.  Parameters and state_dict
+    keys are kept; no HIP kernel exists for its scalar-value contraction yet
+    (no shipped config selects it), so forward() refuses to run rather than
+    fall back to eager ops."""
+
+    def __init__(self, edge_width, num_heads, attention_dropout=0):
+        super().__init__(edge_width, num_heads, attention_dropout)
+        self.tri_ln_e = nn.LayerNorm(edge_width)
+        self.lin_V = nn.Linear(edge_width, num_heads * 4)
+        self.lin_E = nn.Linear(edge_width, num_heads * 4)
+        self.lin_O = nn.Linear(num_heads * 2, edge_width * 2)
+
+    def forward(self, e, mask):
+        raise NotImplementedError("triplet_type 'tiangular_update' has no HIP kernel yet")
+
+
+_LAYERS = {
+    'aggregate': TripletAggregate,
+    'aggregate_ungated': TripletAggregateUngated,
+    'attention': TripletAttention,
+    'attention_ungated': TripletAttentionUngated,
+    'tiangular_update': TriangularUpdate,        # spelling of the reference factory (triplet.py:15)
+    'axial_attention': AxialAttention,
+}
+
+
+def get_triplet_layer(layer_type):
+    """Reference lib/tgt/layers/triplet.py:6-20."""
+    if layer_type not in _LAYERS:
+        raise ValueError(f'Invalid layer_type: {layer_type}')
+    return _LAYERS[layer_type]

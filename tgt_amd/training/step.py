@@ -1,0 +1,242 @@
+"""The training step the metric is defined on, MI355X-first.
+
+Semantics follow the reference's hot loop
+(lib/training/training.py:439-470 `training_step`, :410-418 + pretrain/scheme.py:60-88
+`preprocess_batch` / `calculate_loss`, training_mixins.py:292-317 LR schedule,
+training.py:152 DDP gradient averaging), re-designed for one process per GPU:
+
+ * parameters, gradients and Adam moments live in FLAT float32 buffers;
+   `p.data` / `p.grad` are views, so zeroing grads is one memset, the
+   optimizer is one HIP kernel launch (tgt_adam_step) instead of 883 tensors,
+   and the data-parallel exchange is an RCCL all-reduce of contiguous buckets
+   launched from autograd hooks while the backward of earlier layers is still
+   running (xGMI is point-to-point: few large messages, not 883 small ones).
+ * no per-step host sync: the loss stays on the device; `.item()` only when
+   the caller logs.
+"""
+import math
+from dataclasses import dataclass, field
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from .. import ops
+
+
+@dataclass
+class StepConfig:
+    # optimizer / schedule (reference defaults: tgt_at_tp.yaml, training_mixins.py:276-288)
+    max_lr: float = 2e-3
+    min_lr: float = 1e-6
+    lr_warmup_steps: int = 15000
+    lr_total_steps: int = 300000
+    cosine_halfwave: bool = False
+    betas: tuple = (0.9, 0.999)
+    eps: float = 1e-8
+    weight_decay: float = 0.0
+    # pretrain scheme (reference pretrain/scheme.py:14-27, tgt_at_tp.yaml)
+    coords_noise: float = 0.2
+    coords_noise_smooth: float = 1.0
+    num_dist_bins: int = 512
+    range_dist_bins: float = 8
+    dist_loss_weight: float = 0.1
+    # precision: None (fp32) | 'bf16' | 'fp16'
+    mixed_precision: str = 'bf16'
+    bucket_mbytes: int = 64
+
+
+def lr_at(step, cfg):
+    """reference lib/training/training_mixins.py:292-317"""
+    if step <= cfg.lr_warmup_steps:
+        return cfg.min_lr + (cfg.max_lr - cfg.min_lr) * (step / cfg.lr_warmup_steps)
+    t = (step - cfg.lr_warmup_steps) / (cfg.lr_total_steps - cfg.lr_warmup_steps)
+    if cfg.cosine_halfwave:
+        return float(cfg.min_lr + (cfg.max_lr - cfg.min_lr) * math.cos(0.5 * math.pi * t))
+    return float(cfg.min_lr + (cfg.max_lr - cfg.min_lr) * (1 + math.cos(math.pi * t)) * 0.5)
+
+
+def coords2dist(coords):
+    return torch.norm(coords.unsqueeze(-2) - coords.unsqueeze(-3), dim=-1)
+
+
+def preprocess_batch(batch, device, cfg, training=True, generator=None):
+    """host batch -> device, + edge_mask, + noised distance input
+    (reference training.py:410-418, pretrain/scheme.py:60-76, commons.py:10-16)."""
+    b = {k: v.to(device, non_blocking=True) for k, v in batch.items()}
+    nm = b['node_mask']
+    em = nm.unsqueeze(-1) * nm.unsqueeze(-2)
+    b['edge_mask'] = em
+    coords = b['dft_coords']
+    if training and cfg.coords_noise > 0:
+        noise = torch.randn(coords.shape, dtype=coords.dtype, device=coords.device, generator=generator)
+        noise = noise * cfg.coords_noise
+        dm = coords2dist(coords) + (1 - em.float()) * 1e9
+        noise = torch.softmax(-dm / cfg.coords_noise_smooth, dim=-1) @ noise
+        coords = coords + noise
+    b['dist_input'] = coords2dist(coords)
+    return b
+
+
+def binned_distance_loss(logits, dist_target, edge_mask, num_bins, range_bins):
+    """reference lib/training_schemes/pcqm/commons.py:19-48"""
+    bsz = logits.size(0)
+    bins = (dist_target * ((num_bins - 1) / range_bins)).long().clamp(0, num_bins - 1)
+    xent = F.cross_entropy(logits.reshape(-1, num_bins), bins.reshape(-1), reduction='none').view(bsz, -1)
+    m = edge_mask.to(xent.dtype).view(bsz, -1)
+    return (xent * m).sum() / (m.sum() + 1e-9)
+
+
+def pretrain_loss(outputs, batch, cfg):
+    """L1(gap) + w * binned-distance x-ent (reference pretrain/scheme.py:78-88);
+    the target is float64, so the loss is too (quirk Q9)."""
+    gap, logits = outputs
+    prim = F.l1_loss(gap, batch['target'])
+    dl = binned_distance_loss(logits, coords2dist(batch['dft_coords']), batch['edge_mask'],
+                              cfg.num_dist_bins, cfg.range_dist_bins)
+    return prim + cfg.dist_loss_weight * dl
+
+
+class FlatState:
+    """Flat float32 parameter / gradient / Adam-moment buffers with per-tensor views."""
+
+    def __init__(self, model, align=64):
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        seen, uniq = set(), []
+        for p in self.params:
+            if id(p) not in seen:
+                seen.add(id(p))
+                uniq.append(p)
+        self.params = uniq
+        dev = self.params[0].device
+        self.offsets, off = [], 0
+        for p in self.params:
+            assert p.dtype == torch.float32, 'parameters stay float32 (mixed precision casts per op)'
+            self.offsets.append(off)
+            off += -(-p.numel() // align) * align
+        self.numel = off
+        self.param = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=dev)
+        for p, o in zip(self.params, self.offsets):
+            self.param[o:o + p.numel()].view_as(p).copy_(p.data)
+            p.data = self.param[o:o + p.numel()].view_as(p)
+            p.grad = self.grad[o:o + p.numel()].view_as(p)
+
+    def rebind_grads(self):
+        for p, o in zip(self.params, self.offsets):
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad[o:o + p.numel()].view_as(p)
+
+
+class Trainer:
+    def __init__(self, model, cfg=None, loss_fn=pretrain_loss, process_group=None):
+        self.model, self.cfg, self.loss_fn = model, (cfg or StepConfig()), loss_fn
+        self.flat = FlatState(model)
+        self.global_step = 0
+        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if self.distributed else 1
+        self.loss_scale = 65536.0 if self.cfg.mixed_precision == 'fp16' else 1.0
+        self._good_steps = 0
+        self._handles = []
+        self._armed = False
+        if self.distributed:
+            # replicas start from rank 0's parameters (DDP's broadcast at wrap, training.py:152)
+            dist.broadcast(self.flat.param, src=0, group=self.pg)
+            self._setup_buckets()
+
+    # ---- data-parallel gradient exchange ---------------------------------
+    def _setup_buckets(self):
+        f, limit = self.flat, self.cfg.bucket_mbytes * (1 << 20) // 4
+        shared = getattr(self.model, 'layer_multiplier', 1) > 1 or \
+            getattr(getattr(self.model, 'encoder', None), 'layer_multiplier', 1) > 1
+        self.buckets = []          # [start, end, n_params_pending]
+        self._bucket_of = {}
+        if shared:                 # weight-shared repeats accumulate several times: reduce after backward
+            self.buckets = None
+            return
+        start, count = 0, 0
+        ends = [o + (-(-p.numel() // 64) * 64) for p, o in zip(f.params, f.offsets)]
+        for i, (p, o) in enumerate(zip(f.params, f.offsets)):
+            self._bucket_of[id(p)] = len(self.buckets)
+            count += 1
+            if ends[i] - start >= limit or i == len(f.params) - 1:
+                self.buckets.append([start, ends[i], count])
+                start, count = ends[i], 0
+        self._pending = [b[2] for b in self.buckets]
+        for p in f.params:
+            p.register_post_accumulate_grad_hook(self._grad_ready)
+
+    def _grad_ready(self, p):
+        if not self._armed:
+            return
+        k = self._bucket_of[id(p)]
+        self._pending[k] -= 1
+        if self._pending[k] == 0:
+            s, e, _ = self.buckets[k]
+            self._handles.append(dist.all_reduce(self.flat.grad[s:e], group=self.pg, async_op=True))
+
+    def _finish_reduce(self):
+        if not self.distributed:
+            return
+        if self.buckets is None:
+            dist.all_reduce(self.flat.grad, group=self.pg)
+            return
+        # parameters that received no gradient this step never fire their hook
+        for k, left in enumerate(self._pending):
+            if left > 0:
+                s, e, _ = self.buckets[k]
+                self._handles.append(dist.all_reduce(self.flat.grad[s:e], group=self.pg, async_op=True))
+        for h in self._handles:
+            h.wait()
+        self._handles.clear()
+        self._pending = [b[2] for b in self.buckets]
+
+    # ---- one step ----------------------------------------------------------
+    def autocast(self):
+        mp = self.cfg.mixed_precision
+        if mp is None:
+            return torch.autocast('cuda', enabled=False)
+        return torch.autocast('cuda', dtype=torch.bfloat16 if mp == 'bf16' else torch.float16)
+
+    def compute_gradients(self, batch):
+        """zero grads -> autocast forward + loss -> backward (+ overlapped RCCL
+        all-reduce of gradient buckets).  Leaves SUMMED gradients in flat.grad."""
+        cfg, f = self.cfg, self.flat
+        f.grad.zero_()
+        f.rebind_grads()
+        self._armed = True
+        with self.autocast():
+            outputs = self.model(batch)
+            loss = self.loss_fn(outputs, batch, cfg)
+        (loss * self.loss_scale if self.loss_scale != 1.0 else loss).backward()
+        self._armed = False
+        self._finish_reduce()
+        return outputs, loss
+
+    def apply_gradients(self):
+        """Adam on the flat buffers (one HIP kernel); averages over ranks and
+        undoes the fp16 loss scale via grad_scale."""
+        cfg, f = self.cfg, self.flat
+        lr = lr_at(self.global_step, cfg)
+        grad_scale = 1.0 / (self.world * self.loss_scale)
+        if cfg.mixed_precision == 'fp16':                    # GradScaler semantics (training.py:467-469)
+            if not bool(torch.isfinite(f.grad.sum())):
+                self.loss_scale, self._good_steps = self.loss_scale / 2, 0
+                return False
+            self._good_steps += 1
+            if self._good_steps >= 2000:
+                self.loss_scale, self._good_steps = self.loss_scale * 2, 0
+        ops.adam_step_(f.param, f.grad, f.exp_avg, f.exp_avg_sq, self.global_step, lr,
+                       betas=cfg.betas, eps=cfg.eps, weight_decay=cfg.weight_decay, grad_scale=grad_scale)
+        return True
+
+    def training_step(self, batch):
+        """batch: device tensors incl. edge_mask / dist_input (see preprocess_batch).
+        Returns (outputs, loss) like the reference's training_step (training.py:439-470)."""
+        self.global_step += 1
+        outputs, loss = self.compute_gradients(batch)
+        self.apply_gradients()
+        return outputs, loss
