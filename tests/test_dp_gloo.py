@@ -1,0 +1,110 @@
+"""Data-parallel path on CPU: world_size-2 gloo.  The exchange logic of
+tgt_amd.training.step.Trainer (flat gradient buffer, bucketed all-reduce fired
+from autograd hooks, rank-0 parameter broadcast) is backend-agnostic; here it
+drives the oracle model (CPU) because the HIP kernels need a GPU.  Property
+checked: gradients of a 2-rank run on disjoint half-batches,
+divided by world size, equal the 1-rank gradients on the concatenated batch
+when the loss is a per-graph mean."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import golden_util as gu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gap_l1(outputs, batch, cfg):
+    return torch.nn.functional.l1_loss(outputs, batch['target'])
+
+
+def _make(kwargs, seed):
+    from oracle import modules as om
+    return gu.fill_params(om.TGT_Gap(**kwargs), seed=seed).train()
+
+
+def _batch(B, N, seed):
+    return gu.model_batch(dict(B=B, N=N, num_nodes=[N] * B), seed)
+
+
+def _slice(batch, lo, hi):
+    return {k: v[lo:hi] for k, v in batch.items()}
+
+
+def _worker(rank, world, port, kwargs, bucket_mb, result):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from tgt_amd.training.step import Trainer, StepConfig
+    torch.set_num_threads(2)
+    model = _make(kwargs, seed=11 + rank)            # ranks start DIFFERENT: broadcast must fix it
+    tr = Trainer(model, StepConfig(mixed_precision=None, bucket_mbytes=bucket_mb), loss_fn=_gap_l1)
+    full = _batch(4, 6, seed=5)
+    part = _slice(full, 2 * rank, 2 * rank + 2)
+    tr.global_step += 1
+    tr.compute_gradients(part)
+    if rank == 0:
+        result['grad'] = (tr.flat.grad / world).clone()
+        result['param'] = tr.flat.param.clone()
+        result['nbuckets'] = -1 if tr.buckets is None else len(tr.buckets)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('variant', ['bucketed', 'shared_weights'])
+def test_two_rank_gradients_equal_single_rank(variant):
+    kwargs = dict(gu.MODEL_CASES['gap_at_tiny'][1])
+    kwargs['embed_3d_type'] = 'none'
+    if variant == 'shared_weights':
+        kwargs['layer_multiplier'] = 2                 # weight-shared repeats: single post-backward all-reduce
+    bucket_mb = 0 if variant == 'bucketed' else 64     # 0 MB -> every parameter closes its own bucket
+    mgr = mp.Manager()
+    result = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), kwargs, bucket_mb, result), nprocs=2, join=True)
+
+    from tgt_amd.training.step import Trainer, StepConfig
+    model = _make(kwargs, seed=11)                     # rank 0's initial parameters
+    tr = Trainer(model, StepConfig(mixed_precision=None), loss_fn=_gap_l1)
+    assert torch.equal(result['param'], tr.flat.param)
+    tr.compute_gradients(_batch(4, 6, seed=5))
+    ref = tr.flat.grad
+    err = (result['grad'] - ref).abs().max() / ref.abs().max()
+    assert err < 1e-5, err
+    if variant == 'bucketed':
+        assert result['nbuckets'] > 10
+    else:
+        assert result['nbuckets'] == -1
+
+
+def test_flat_state_views_alias_parameters():
+    from tgt_amd.training.step import FlatState
+    m = torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+    before = [p.detach().clone() for p in m.parameters()]
+    f = FlatState(m)
+    for p, b in zip(m.parameters(), before):
+        assert torch.equal(p, b)
+    f.param.mul_(2)
+    for p, b in zip(m.parameters(), before):
+        assert torch.equal(p, 2 * b)
+    m(torch.ones(1, 5)).sum().backward()
+    assert f.grad.abs().sum() > 0
+    assert all(p.grad.data_ptr() >= f.grad.data_ptr() for p in m.parameters())
+
+
+def test_lr_schedule_matches_reference_formula():
+    from tgt_amd.training.step import lr_at, StepConfig
+    cfg = StepConfig(max_lr=2e-3, min_lr=1e-6, lr_warmup_steps=100, lr_total_steps=1000)
+    assert abs(lr_at(0, cfg) - 1e-6) < 1e-12
+    assert abs(lr_at(100, cfg) - 2e-3) < 1e-12
+    assert abs(lr_at(1000, cfg) - 1e-6) < 1e-9
+    assert abs(lr_at(550, cfg) - (1e-6 + (2e-3 - 1e-6) * 0.5)) < 1e-9
