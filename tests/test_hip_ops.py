@@ -43,6 +43,9 @@ CASES = [  # B, N, num_nodes, C, H
     (3, 32, [32, 17, 32], 256, 16),
     (1, 9, [9], 128, 4),          # D = 32
     (2, 5, [5, 1], 48, 3),        # H not a multiple of 4 (D = 16)
+    (2, 48, [48, 37], 64, 4),     # two node tiles (BASELINE cfg 4: N up to 48)
+    (1, 64, [64], 32, 4),         # N = 64, D = 8
+    (2, 33, [33, 20], 256, 16),   # one node past a tile, BASELINE width
 ]
 
 

@@ -44,82 +44,104 @@ __device__ __forceinline__ AggCtx agg_ctx(const tgt_triplet_aggregate_args& a, i
     return c;
 }
 
-// softmax over k of biasM (column i of this lane), in place -> P
-__device__ __forceinline__ void column_softmax(float (&x)[16]) {
+// weights of query tile it / key tile kt in (lane = i) layout: softmax over ALL key tiles
+template <typename T, int NT, bool PAD>
+__device__ __forceinline__ void agg_weights(const AggCtx& c, int N, int r, int hi, int i0, float (&p)[NT][16],
+                                            float (&gate)[NT][16]) {
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+        load_third_arm<T, PAD>(c.ta, c.b, c.dir, c.h, N, r, hi, p[kt], gate[kt], i0, 32 * kt);
     float mx = -INFINITY;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) mx = fmaxf(mx, x[q]);
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) mx = fmaxf(mx, p[kt][q]);
     mx = fmaxf(mx, xhalf(mx));
     if (mx == -INFINITY) mx = 0.f;               // padding column: all weights exactly 0
     float sum = 0.f;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        x[q] = fast_exp(x[q] - mx);
-        sum += x[q];
-    }
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            p[kt][q] = fast_exp(p[kt][q] - mx);
+            sum += p[kt][q];
+        }
     sum += xhalf(sum);
     const float inv = sum > 0.f ? __frcp_rn(sum) : 0.f;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) x[q] *= inv;
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) p[kt][q] *= inv;
 }
 
-template <typename T, int D, int HG>
+template <typename T, int D, int HG, int NT>
 __global__ void __launch_bounds__(HG * 64) tri_agg_fwd_kernel(const tgt_triplet_aggregate_args a) {
     using G = TriGeo<T, D, HG>;
     using F = frag_t<T>;
+    constexpr int KR = 32 * NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sV = smem;
+    char* sOut = smem + NT * G::kSlabBytes;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hi = lane >> 5;
     const AggCtx c = agg_ctx<T, D, HG>(a, wave);
     const int N = c.N;
-
-    F pa[2];
-    {
-        float p[16], gate[16];
-        load_third_arm<T, false>(c.ta, c.b, c.dir, c.h, N, r, hi, p, gate);
-        column_softmax(p);
-        f32x16 w;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) w[q] = p[q] * gate[q];
-        pa[0] = pack_chunk<T>(w, 0);
-        pa[1] = pack_chunk<T>(w, 1);
-    }
     F ident_d[G::kDC];
     make_ident_d<T, G::kDC>(ident_d, r, hi);
-
     const int64_t sz = sizeof(T);
     char* obase = reinterpret_cast<char*>(a.out) + ((int64_t)c.b * N * N * a.ld_out + a.o_off[c.dir] + c.g * HG * D) * sz;
     const int64_t o_row = (int64_t)N * a.ld_out * sz, o_j = a.ld_out * sz;
 
-    uint4 pv[G::kIters];
-    slab_issue<G>(pv, c.v, 0, N, tid);
-    slab_commit<G>(pv, sV, tid);
-    __syncthreads();
-    for (int j = 0; j < N; ++j) {
-        if (j + 1 < N) slab_issue<G>(pv, c.v, j + 1, N, tid);
-        F fv[G::kDC];
-        read_frags<T, D, HG>(fv, sV, wave, r, hi);
-        f32x16 vt = {0}, o = {0};
+    for (int it = 0; it < NT; ++it) {
+        const int i0 = 32 * it;
+        if (i0 >= N) break;
+        F pa[NT][2];
+        {
+            float p[NT][16], gate[NT][16];
+            agg_weights<T, NT, false>(c, N, r, hi, i0, p, gate);
 #pragma unroll
-        for (int dc = 0; dc < G::kDC; ++dc) vt = mma32(fv[dc], ident_d[dc], vt);
+            for (int kt = 0; kt < NT; ++kt) {
+                f32x16 w;
 #pragma unroll
-        for (int cc = 0; cc < 2; ++cc) o = mma32(pack_chunk<T>(vt, cc), pa[cc], o);
-        write_rows<T, D, HG>(sV, o, wave, r, hi);
+                for (int q = 0; q < 16; ++q) w[q] = p[kt][q] * gate[kt][q];
+                pa[kt][0] = pack_chunk<T>(w, 0);
+                pa[kt][1] = pack_chunk<T>(w, 1);
+            }
+        }
+        uint4 pv[SlabIO<G, KR>::kIters];
+        slab_issue<G, KR>(pv, c.v, 0, 0, N, tid);
+        slab_commit<G, KR>(pv, sV, tid);
         __syncthreads();
-        slab_store<G>(sV, obase, o_row, o_j, j, N, tid);
-        if (j + 1 < N) slab_commit<G>(pv, sV, tid);
-        __syncthreads();
+        for (int j = 0; j < N; ++j) {
+            if (j + 1 < N) slab_issue<G, KR>(pv, c.v, j + 1, 0, N, tid);
+            f32x16 o = {0};
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                F fv[G::kDC];
+                read_frags<T, D, HG>(fv, sV, wave, 32 * kt + r, hi);
+                f32x16 vt = {0};
+#pragma unroll
+                for (int dc = 0; dc < G::kDC; ++dc) vt = mma32(fv[dc], ident_d[dc], vt);
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) o = mma32(pack_chunk<T>(vt, cc), pa[kt][cc], o);
+            }
+            write_rows<T, D, HG>(sOut, o, wave, r, hi);
+            __syncthreads();
+            slab_store<G, 32>(sOut, obase, o_row, o_j, j, i0, N, tid);
+            if (j + 1 < N) slab_commit<G, KR>(pv, sV, tid);
+            __syncthreads();
+        }
     }
 }
 
-template <typename T, int D, int HG>
+template <typename T, int D, int HG, int NT>
 __global__ void __launch_bounds__(HG * 64) tri_agg_bwd_kernel(const tgt_triplet_aggregate_args a) {
     using G = TriGeo<T, D, HG>;
     using F = frag_t<T>;
+    constexpr int KR = 32 * NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sV = smem;
-    char* sO = smem + G::kSlabBytes;
+    char* sO = smem;
+    char* sV = smem + G::kSlabBytes;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hi = lane >> 5;
     const AggCtx c = agg_ctx<T, D, HG>(a, wave);
@@ -127,87 +149,132 @@ __global__ void __launch_bounds__(HG * 64) tri_agg_bwd_kernel(const tgt_triplet_
 
     F ident_d[G::kDC];
     make_ident_d<T, G::kDC>(ident_d, r, hi);
-    // weights in (lane = k, registers = i) layout, as operand fragments over i
-    F a2f[2];
-    {
-        float p[16], gate[16];
-        load_third_arm<T, true>(c.ta, c.b, c.dir, c.h, N, r, hi, p, gate);
-        column_softmax(p);
-        f32x16 w;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) w[q] = p[q] * gate[q];
-        F ident_k[2];
-        make_ident_k<T>(ident_k, r, hi);
-        f32x16 a2 = {0};
-#pragma unroll
-        for (int cc = 0; cc < 2; ++cc) a2 = mma32(pack_chunk<T>(w, cc), ident_k[cc], a2);
-        a2f[0] = pack_chunk<T>(a2, 0);
-        a2f[1] = pack_chunk<T>(a2, 1);
-    }
-
     const int64_t sz = sizeof(T), Nl = N;
     const SlabSrc dO = {reinterpret_cast<const char*>(a.d_out) +
                             ((int64_t)c.b * Nl * Nl * a.ld_out + a.o_off[c.dir] + c.g * HG * D) * sz,
                         Nl * a.ld_out * sz, a.ld_out * sz};
     const int64_t shift = reinterpret_cast<const char*>(a.d_v[c.dir]) - reinterpret_cast<const char*>(a.v[c.dir]);
-    char* dv_base = const_cast<char*>(c.v.base) + shift;
+    const SlabSrc dV = {c.v.base + shift, c.v.row_stride, c.v.j_stride};
 
-    f32x16 dacc = {0};          // dA^T[k][i], summed over j
-    uint4 pv[G::kIters], po[G::kIters];
-    slab_issue<G>(pv, c.v, 0, N, tid);
-    slab_issue<G>(po, dO, 0, N, tid);
-    slab_commit<G>(pv, sV, tid);
-    slab_commit<G>(po, sO, tid);
-    __syncthreads();
-    for (int j = 0; j < N; ++j) {
-        if (j + 1 < N) {
-            slab_issue<G>(pv, c.v, j + 1, N, tid);
-            slab_issue<G>(po, dO, j + 1, N, tid);
+    for (int it = 0; it < NT; ++it) {
+        const int i0 = 32 * it;
+        if (i0 >= N) break;
+        // weights in (lane = k, registers = i) layout, as operand fragments over i
+        F a2f[NT][2];
+        {
+            float p[NT][16], gate[NT][16];
+            agg_weights<T, NT, true>(c, N, r, hi, i0, p, gate);
+            F ident_k[2];
+            make_ident_k<T>(ident_k, r, hi);
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                f32x16 w, a2 = {0};
+#pragma unroll
+                for (int q = 0; q < 16; ++q) w[q] = p[kt][q] * gate[kt][q];
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) a2 = mma32(pack_chunk<T>(w, cc), ident_k[cc], a2);
+                a2f[kt][0] = pack_chunk<T>(a2, 0);
+                a2f[kt][1] = pack_chunk<T>(a2, 1);
+            }
         }
-        F fv[G::kDC], fo[G::kDC];
-        read_frags<T, D, HG>(fv, sV, wave, r, hi);
-        read_frags<T, D, HG>(fo, sO, wave, r, hi);
+        f32x16 dacc[NT];          // dA^T[k][i], summed over j
 #pragma unroll
-        for (int dc = 0; dc < G::kDC; ++dc) dacc = mma32(fv[dc], fo[dc], dacc);
-        f32x16 t2 = {0}, dv = {0};
+        for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-        for (int dc = 0; dc < G::kDC; ++dc) t2 = mma32(fo[dc], ident_d[dc], t2);   // dO^T
-#pragma unroll
-        for (int cc = 0; cc < 2; ++cc) dv = mma32(pack_chunk<T>(t2, cc), a2f[cc], dv);
-        write_rows<T, D, HG>(sV, dv, wave, r, hi);
-        __syncthreads();
-        slab_store<G>(sV, dv_base, c.v.row_stride, c.v.j_stride, j, N, tid);
-        if (j + 1 < N) {
-            slab_commit<G>(pv, sV, tid);
-            slab_commit<G>(po, sO, tid);
-        }
-        __syncthreads();
-    }
+            for (int q = 0; q < 16; ++q) dacc[kt][q] = 0.f;
 
-    // softmax*gate backward on the accumulated dA (recompute P, g)
-    float p[16], gate[16], dE[16], dG[16];
-    load_third_arm<T, true>(c.ta, c.b, c.dir, c.h, N, r, hi, p, gate);
-    column_softmax(p);
-    float delta = 0.f;
+        uint4 pv[SlabIO<G, KR>::kIters], po[SlabIO<G, 32>::kIters];
+        uint4 prv[NT > 1 ? SlabIO<G, KR>::kIters : 1];
+        slab_issue<G, KR>(pv, c.v, 0, 0, N, tid);
+        slab_issue<G, 32>(po, dO, 0, i0, N, tid);
+        if constexpr (NT > 1) {
+            if (it > 0) slab_issue<G, KR>(prv, dV, 0, 0, N, tid);
+        }
+        slab_commit<G, KR>(pv, sV, tid);
+        slab_commit<G, 32>(po, sO, tid);
+        __syncthreads();
+        for (int j = 0; j < N; ++j) {
+            uint4 curv[NT > 1 ? SlabIO<G, KR>::kIters : 1];
+            if constexpr (NT > 1) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        dG[q] = dacc[q] * p[q] * gate[q] * (1.f - gate[q]);
-        dacc[q] *= gate[q];
-        delta += p[q] * dacc[q];
+                for (int x = 0; x < SlabIO<G, KR>::kIters; ++x) curv[x] = prv[x];
+            }
+            if (j + 1 < N) {
+                slab_issue<G, KR>(pv, c.v, j + 1, 0, N, tid);
+                slab_issue<G, 32>(po, dO, j + 1, i0, N, tid);
+                if constexpr (NT > 1) {
+                    if (it > 0) slab_issue<G, KR>(prv, dV, j + 1, 0, N, tid);
+                }
+            }
+            F fo[G::kDC];
+            read_frags<T, D, HG>(fo, sO, wave, r, hi);
+            f32x16 t2 = {0};
+#pragma unroll
+            for (int dc = 0; dc < G::kDC; ++dc) t2 = mma32(fo[dc], ident_d[dc], t2);   // dO^T
+            F oTf[2] = {pack_chunk<T>(t2, 0), pack_chunk<T>(t2, 1)};
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                F fv[G::kDC];
+                read_frags<T, D, HG>(fv, sV, wave, 32 * kt + r, hi);
+#pragma unroll
+                for (int dc = 0; dc < G::kDC; ++dc) dacc[kt] = mma32(fv[dc], fo[dc], dacc[kt]);
+                f32x16 dv = {0};
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) dv = mma32(oTf[cc], a2f[kt][cc], dv);
+                write_rows<T, D, HG>(sV, dv, wave, 32 * kt + r, hi);
+            }
+            __syncthreads();
+            bool plain = true;
+            if constexpr (NT > 1) {
+                if (it > 0) {
+                    plain = false;
+                    slab_store_add<G, KR, T>(sV, curv, const_cast<char*>(dV.base), dV.row_stride, dV.j_stride, j, 0, N, tid);
+                }
+            }
+            if (plain) slab_store<G, KR>(sV, const_cast<char*>(dV.base), dV.row_stride, dV.j_stride, j, 0, N, tid);
+            if (j + 1 < N) {
+                slab_commit<G, KR>(pv, sV, tid);
+                slab_commit<G, 32>(po, sO, tid);
+            }
+            __syncthreads();
+        }
+
+        // softmax*gate backward on the accumulated dA (recompute P, g)
+        float p[NT][16], gate[NT][16];
+        agg_weights<T, NT, true>(c, N, r, hi, i0, p, gate);
+        float delta = 0.f;
+        float dG[NT][16];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                dG[kt][q] = dacc[kt][q] * p[kt][q] * gate[kt][q] * (1.f - gate[kt][q]);
+                dacc[kt][q] *= gate[kt][q];
+                delta += p[kt][q] * dacc[kt][q];
+            }
+        delta += xhalf(delta);
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            float dE[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) dE[q] = p[kt][q] * (dacc[kt][q] - delta);
+            store_third_arm_grad<T>(c.ta, a.d_eg[c.dir], c.b, c.dir, c.h, N, r, hi, dE, dG[kt], i0, 32 * kt);
+        }
     }
-    delta += xhalf(delta);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) dE[q] = p[q] * (dacc[q] - delta);
-    store_third_arm_grad<T>(c.ta, a.d_eg[c.dir], c.b, c.dir, c.h, N, r, hi, dE, dG);
 }
 
-template <typename T, int D, int HG>
-static int launch_agg(const tgt_triplet_aggregate_args& a, bool bwd, hipStream_t st) {
+template <typename T, int D, int HG, int NT>
+static int launch_agg_nt(const tgt_triplet_aggregate_args& a, bool bwd, hipStream_t st) {
     using G = TriGeo<T, D, HG>;
     const int grid = a.B * 2 * (a.H / HG);
-    if (!bwd) hipLaunchKernelGGL((tri_agg_fwd_kernel<T, D, HG>), dim3(grid), dim3(G::kThreads), G::kSlabBytes, st, a);
-    else      hipLaunchKernelGGL((tri_agg_bwd_kernel<T, D, HG>), dim3(grid), dim3(G::kThreads), 2 * G::kSlabBytes, st, a);
+    if (!bwd) hipLaunchKernelGGL((tri_agg_fwd_kernel<T, D, HG, NT>), dim3(grid), dim3(G::kThreads), (NT + 1) * G::kSlabBytes, st, a);
+    else      hipLaunchKernelGGL((tri_agg_bwd_kernel<T, D, HG, NT>), dim3(grid), dim3(G::kThreads), (NT + 1) * G::kSlabBytes, st, a);
     return check_launch(bwd ? "tri_agg_bwd_kernel" : "tri_agg_fwd_kernel");
+}
+template <typename T, int D, int HG>
+static int launch_agg(const tgt_triplet_aggregate_args& a, bool bwd, hipStream_t st) {
+    if (a.N <= 32) return launch_agg_nt<T, D, HG, 1>(a, bwd, st);
+    return launch_agg_nt<T, D, HG, 2>(a, bwd, st);
 }
 template <typename T, int D>
 static int agg_dispatch_hg(const tgt_triplet_aggregate_args& a, bool bwd, hipStream_t st) {
@@ -228,7 +295,7 @@ static int agg_dispatch_d(const tgt_triplet_aggregate_args& a, bool bwd, hipStre
 int triplet_aggregate_run(const tgt_triplet_aggregate_args* a, bool bwd, hipStream_t st) {
     if (!a) return set_error(TGT_ERR_INVALID, "triplet aggregate: null args");
     if (a->B <= 0 || a->N <= 0 || a->H <= 0) return set_error(TGT_ERR_INVALID, "triplet aggregate: bad sizes");
-    if (a->N > 32) return set_error(TGT_ERR_UNSUPPORTED, "triplet aggregate: N=%d > 32 not supported yet", a->N);
+    if (a->N > 64) return set_error(TGT_ERR_UNSUPPORTED, "triplet aggregate: N=%d > 64 not supported", a->N);
     const int64_t esz = a->dtype == TGT_F32 ? 4 : 2;
     for (int dir = 0; dir < 2; ++dir) {
         if (!a->v[dir] || !a->eg[dir] || !a->out || !a->mask) return set_error(TGT_ERR_INVALID, "triplet aggregate: null tensor");

@@ -69,25 +69,24 @@ __device__ __forceinline__ ThirdArm tri_third_arm(const tgt_triplet_attention_ar
 }
 
 // ---------------------------------------------------------------------------
-// forward
+// forward.  NT = node tiles of 32 (N <= 32*NT).  The workgroup makes one pass
+// per query tile `it`; inside a pass the key axis spans all NT tiles.
 // ---------------------------------------------------------------------------
-template <typename T, int D, int HG>
+template <typename T, int D, int HG, int NT>
 __global__ void __launch_bounds__(HG * 64) tri_att_fwd_kernel(const tgt_triplet_attention_args a) {
     using G = TriGeo<T, D, HG>;
     using F = frag_t<T>;
+    constexpr int KR = 32 * NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sQ = smem;
     char* sK = smem + G::kSlabBytes;
-    char* sV = smem + 2 * G::kSlabBytes;
+    char* sV = sK + NT * G::kSlabBytes;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hi = lane >> 5;
     const TriCtx c = tri_ctx<T, D, HG>(a, wave);
     const int N = c.N;
-
-    float biasM[16], gate[16];
     const ThirdArm ta = tri_third_arm(a, c.dir);
-    load_third_arm<T, false>(ta, c.b, c.dir, c.h, N, r, hi, biasM, gate);
     F ident_d[G::kDC];
     make_ident_d<T, G::kDC>(ident_d, r, hi);
 
@@ -95,96 +94,113 @@ __global__ void __launch_bounds__(HG * 64) tri_att_fwd_kernel(const tgt_triplet_
     char* obase = reinterpret_cast<char*>(a.out) + ((int64_t)c.b * N * N * a.ld_out + a.o_off[c.dir] + c.g * HG * D) * sz;
     const int64_t o_row = (int64_t)N * a.ld_out * sz, o_j = a.ld_out * sz;
 
-    uint4 pq[G::kIters], pk[G::kIters], pv[G::kIters];
-    slab_issue<G>(pq, c.q, 0, N, tid);
-    slab_issue<G>(pk, c.k, 0, N, tid);
-    slab_issue<G>(pv, c.v, 0, N, tid);
-    slab_commit<G>(pq, sQ, tid);
-    slab_commit<G>(pk, sK, tid);
-    slab_commit<G>(pv, sV, tid);
-    __syncthreads();
+    for (int it = 0; it < NT; ++it) {
+        const int i0 = 32 * it;
+        if (i0 >= N) break;
+        float biasM[NT][16], gate[NT][16];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+            load_third_arm<T, false>(ta, c.b, c.dir, c.h, N, r, hi, biasM[kt], gate[kt], i0, 32 * kt);
 
-    for (int j = 0; j < N; ++j) {
-        if (j + 1 < N) {
-            slab_issue<G>(pq, c.q, j + 1, N, tid);
-            slab_issue<G>(pk, c.k, j + 1, N, tid);
-            slab_issue<G>(pv, c.v, j + 1, N, tid);
-        }
-        F fq[G::kDC], fk[G::kDC], fv[G::kDC];
-        read_frags<T, D, HG>(fq, sQ, wave, r, hi);
-        read_frags<T, D, HG>(fk, sK, wave, r, hi);
-        read_frags<T, D, HG>(fv, sV, wave, r, hi);
-
-        f32x16 s = {0}, vt = {0};
-#pragma unroll
-        for (int dc = 0; dc < G::kDC; ++dc) s = mma32(fk[dc], fq[dc], s);          // S^T[k][i]
-#pragma unroll
-        for (int dc = 0; dc < G::kDC; ++dc) vt = mma32(fv[dc], ident_d[dc], vt);   // V[k][d] -> lane d
-
-        float mx = -INFINITY;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            s[q] = s[q] * a.scale + biasM[q];
-            mx = fmaxf(mx, s[q]);
-        }
-        mx = fmaxf(mx, xhalf(mx));
-        float sum = 0.f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            s[q] = fast_exp(s[q] - mx);
-            sum += s[q];
-        }
-        sum += xhalf(sum);
-        const float inv = __frcp_rn(sum);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) s[q] = s[q] * inv * gate[q];
-
-        f32x16 o = {0};
-#pragma unroll
-        for (int cc = 0; cc < 2; ++cc) o = mma32(pack_chunk<T>(vt, cc), pack_chunk<T>(s, cc), o);   // O^T[d][i]
-        write_rows<T, D, HG>(sQ, o, wave, r, hi);     // in place of this head's Q columns
+        uint4 pq[SlabIO<G, 32>::kIters], pk[SlabIO<G, KR>::kIters], pv[SlabIO<G, KR>::kIters];
+        slab_issue<G, 32>(pq, c.q, 0, i0, N, tid);
+        slab_issue<G, KR>(pk, c.k, 0, 0, N, tid);
+        slab_issue<G, KR>(pv, c.v, 0, 0, N, tid);
+        slab_commit<G, 32>(pq, sQ, tid);
+        slab_commit<G, KR>(pk, sK, tid);
+        slab_commit<G, KR>(pv, sV, tid);
         __syncthreads();
-        slab_store<G>(sQ, obase, o_row, o_j, j, N, tid);
-        if (j + 1 < N) {
-            slab_commit<G>(pq, sQ, tid);
-            slab_commit<G>(pk, sK, tid);
-            slab_commit<G>(pv, sV, tid);
+
+        for (int j = 0; j < N; ++j) {
+            if (j + 1 < N) {
+                slab_issue<G, 32>(pq, c.q, j + 1, i0, N, tid);
+                slab_issue<G, KR>(pk, c.k, j + 1, 0, N, tid);
+                slab_issue<G, KR>(pv, c.v, j + 1, 0, N, tid);
+            }
+            F fq[G::kDC];
+            read_frags<T, D, HG>(fq, sQ, wave, r, hi);
+            f32x16 s[NT], vt[NT];
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                F fk[G::kDC], fv[G::kDC];
+                read_frags<T, D, HG>(fk, sK, wave, 32 * kt + r, hi);
+                read_frags<T, D, HG>(fv, sV, wave, 32 * kt + r, hi);
+                f32x16 z0 = {0}, z1 = {0};
+#pragma unroll
+                for (int dc = 0; dc < G::kDC; ++dc) z0 = mma32(fk[dc], fq[dc], z0);        // S^T[k][i]
+#pragma unroll
+                for (int dc = 0; dc < G::kDC; ++dc) z1 = mma32(fv[dc], ident_d[dc], z1);   // V[k][d] -> lane d
+                s[kt] = z0;
+                vt[kt] = z1;
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    s[kt][q] = s[kt][q] * a.scale + biasM[kt][q];
+                    mx = fmaxf(mx, s[kt][q]);
+                }
+            mx = fmaxf(mx, xhalf(mx));
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    s[kt][q] = fast_exp(s[kt][q] - mx);
+                    sum += s[kt][q];
+                }
+            sum += xhalf(sum);
+            const float inv = __frcp_rn(sum);
+            f32x16 o = {0};
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) s[kt][q] = s[kt][q] * inv * gate[kt][q];
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) o = mma32(pack_chunk<T>(vt[kt], cc), pack_chunk<T>(s[kt], cc), o);   // O^T[d][i]
+            }
+            write_rows<T, D, HG>(sQ, o, wave, r, hi);     // in place of this head's Q columns
+            __syncthreads();
+            slab_store<G, 32>(sQ, obase, o_row, o_j, j, i0, N, tid);
+            if (j + 1 < N) {
+                slab_commit<G, 32>(pq, sQ, tid);
+                slab_commit<G, KR>(pk, sK, tid);
+                slab_commit<G, KR>(pv, sV, tid);
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
 }
 
 // ---------------------------------------------------------------------------
-// backward.  Per (b,dir,h,j), with P recomputed from the
-// saved log-sum-exp:
+// backward.  Per (b,dir,h,j), with P recomputed:
 //   dA^T[k][i] = V[k,:].dO[i,:]         dP = dA*g      delta_i = sum_k P dP
 //   dS = P (dP - delta)                  dE += dS       dG += dA P g (1-g)
 //   dQ^T[d][i] = s sum_k K^T[d][k] dS^T[k][i]
 //   dK^T[d][k] = s sum_i Q^T[d][i] dS[i][k]     dV^T[d][k] = sum_i dO^T[d][i] A[i][k]
 // dS and A are produced in (lane = i) layout and re-laid out to (lane = k)
 // by a multiply with the identity on the matrix core.
+// NT > 1: one pass per query tile; dK/dV sum over query tiles, so pass `it > 0`
+// adds its partial to what pass it-1 stored (same thread wrote that address).
 // ---------------------------------------------------------------------------
-template <typename T, int D, int HG>
+template <typename T, int D, int HG, int NT>
 __global__ void __launch_bounds__(HG * 64) tri_att_bwd_kernel(const tgt_triplet_attention_args a) {
     using G = TriGeo<T, D, HG>;
     using F = frag_t<T>;
+    constexpr int KR = 32 * NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sQ = smem;
-    char* sK = smem + G::kSlabBytes;
-    char* sV = smem + 2 * G::kSlabBytes;
-    char* sO = smem + 3 * G::kSlabBytes;
+    char* sO = smem + G::kSlabBytes;
+    char* sK = smem + 2 * G::kSlabBytes;
+    char* sV = sK + NT * G::kSlabBytes;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hi = lane >> 5;
     const TriCtx c = tri_ctx<T, D, HG>(a, wave);
     const int N = c.N;
-    const bool biased = a.flags & TGT_TRI_BIASED, gated = a.flags & TGT_TRI_GATED;
-
-    float biasM[16], gate[16], dE[16], dG[16];
     const ThirdArm ta = tri_third_arm(a, c.dir);
-    load_third_arm<T, true>(ta, c.b, c.dir, c.h, N, r, hi, biasM, gate);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) dE[q] = dG[q] = 0.f;
+    const bool biased = ta.biased, gated = ta.gated;
     F ident_d[G::kDC], ident_k[2];
     make_ident_d<T, G::kDC>(ident_d, r, hi);
     make_ident_k<T>(ident_k, r, hi);
@@ -196,144 +212,211 @@ __global__ void __launch_bounds__(HG * 64) tri_att_bwd_kernel(const tgt_triplet_
     // gradient slabs mirror the source slabs inside d_qkv
     const int64_t shift = reinterpret_cast<const char*>(a.d_qkv[c.dir]) - reinterpret_cast<const char*>(a.qkv[c.dir]);
     char* dq_base = const_cast<char*>(c.q.base) + shift;
-    char* dk_base = const_cast<char*>(c.k.base) + shift;
-    char* dv_base = const_cast<char*>(c.v.base) + shift;
+    const SlabSrc dK = {c.k.base + shift, c.k.row_stride, c.k.j_stride};
+    const SlabSrc dV = {c.v.base + shift, c.v.row_stride, c.v.j_stride};
 
-    uint4 pq[G::kIters], pk[G::kIters], pv[G::kIters], po[G::kIters];
-    slab_issue<G>(pq, c.q, 0, N, tid);
-    slab_issue<G>(pk, c.k, 0, N, tid);
-    slab_issue<G>(pv, c.v, 0, N, tid);
-    slab_issue<G>(po, dO, 0, N, tid);
-    slab_commit<G>(pq, sQ, tid);
-    slab_commit<G>(pk, sK, tid);
-    slab_commit<G>(pv, sV, tid);
-    slab_commit<G>(po, sO, tid);
-    __syncthreads();
-
-    for (int j = 0; j < N; ++j) {
-        if (j + 1 < N) {
-            slab_issue<G>(pq, c.q, j + 1, N, tid);
-            slab_issue<G>(pk, c.k, j + 1, N, tid);
-            slab_issue<G>(pv, c.v, j + 1, N, tid);
-            slab_issue<G>(po, dO, j + 1, N, tid);
-        }
-        F fq[G::kDC], fk[G::kDC], fv[G::kDC], fo[G::kDC];
-        read_frags<T, D, HG>(fq, sQ, wave, r, hi);
-        read_frags<T, D, HG>(fk, sK, wave, r, hi);
-        read_frags<T, D, HG>(fv, sV, wave, r, hi);
-        read_frags<T, D, HG>(fo, sO, wave, r, hi);
-
-        f32x16 s = {0}, da = {0};
+    for (int it = 0; it < NT; ++it) {
+        const int i0 = 32 * it;
+        if (i0 >= N) break;
+        float biasM[NT][16], gate[NT][16], dE[NT][16], dG[NT][16];
 #pragma unroll
-        for (int dc = 0; dc < G::kDC; ++dc) s = mma32(fk[dc], fq[dc], s);     // S^T[k][i]
+        for (int kt = 0; kt < NT; ++kt) {
+            load_third_arm<T, true>(ta, c.b, c.dir, c.h, N, r, hi, biasM[kt], gate[kt], i0, 32 * kt);
 #pragma unroll
-        for (int dc = 0; dc < G::kDC; ++dc) da = mma32(fv[dc], fo[dc], da);   // dA^T[k][i]
-
-        // softmax statistics are recomputed (16 in-lane values + the partner lane); saving a
-        // log-sum-exp instead would lose log(sum) next to a finfo.min-sized row maximum.
-        float mx = -INFINITY;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            s[q] = s[q] * a.scale + biasM[q];
-            mx = fmaxf(mx, s[q]);
-        }
-        mx = fmaxf(mx, xhalf(mx));
-        if (mx == -INFINITY) mx = 0.f;           // padding column: every weight is exactly 0
-        float sum = 0.f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            s[q] = fast_exp(s[q] - mx);
-            sum += s[q];
-        }
-        sum += xhalf(sum);
-        const float inv = sum > 0.f ? __frcp_rn(sum) : 0.f;
-        // s -> P, then A;  da -> dS
-        float delta = 0.f;
-        f32x16 att;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const float p = s[q] * inv;
-            const float dp = da[q] * gate[q];
-            delta += p * dp;
-            att[q] = p * gate[q];
-            s[q] = p;
-            if (gated) dG[q] += da[q] * att[q] * (1.f - gate[q]);
-            da[q] = dp;
-        }
-        delta += xhalf(delta);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const float ds = s[q] * (da[q] - delta);
-            if (biased) dE[q] += ds;
-            s[q] = ds * a.scale;
-        }
-        F dsf[2], af[2];
-#pragma unroll
-        for (int cc = 0; cc < 2; ++cc) {
-            dsf[cc] = pack_chunk<T>(s, cc);
-            af[cc] = pack_chunk<T>(att, cc);
+            for (int q = 0; q < 16; ++q) dE[kt][q] = dG[kt][q] = 0.f;
         }
 
-        // dQ^T[d][i] = sum_k K^T[d][k] dS^T[k][i]
-        f32x16 t0 = {0}, dq = {0};
-#pragma unroll
-        for (int dc = 0; dc < G::kDC; ++dc) t0 = mma32(fk[dc], ident_d[dc], t0);   // K^T
-#pragma unroll
-        for (int cc = 0; cc < 2; ++cc) dq = mma32(pack_chunk<T>(t0, cc), dsf[cc], dq);
-
-        // re-layout dS, A to lane = k:  X[i][k] = sum_kk X^T-frag[i][kk] I[kk][k]
-        f32x16 ds2 = {0}, a2 = {0};
-#pragma unroll
-        for (int cc = 0; cc < 2; ++cc) {
-            ds2 = mma32(dsf[cc], ident_k[cc], ds2);
-            a2 = mma32(af[cc], ident_k[cc], a2);
+        uint4 pq[SlabIO<G, 32>::kIters], po[SlabIO<G, 32>::kIters];
+        uint4 pk[SlabIO<G, KR>::kIters], pv[SlabIO<G, KR>::kIters];
+        uint4 prk[NT > 1 ? SlabIO<G, KR>::kIters : 1], prv[NT > 1 ? SlabIO<G, KR>::kIters : 1];
+        slab_issue<G, 32>(pq, c.q, 0, i0, N, tid);
+        slab_issue<G, 32>(po, dO, 0, i0, N, tid);
+        slab_issue<G, KR>(pk, c.k, 0, 0, N, tid);
+        slab_issue<G, KR>(pv, c.v, 0, 0, N, tid);
+        if constexpr (NT > 1) {
+            if (it > 0) {
+                slab_issue<G, KR>(prk, dK, 0, 0, N, tid);
+                slab_issue<G, KR>(prv, dV, 0, 0, N, tid);
+            }
         }
-        // dK^T[d][k] = sum_i Q^T[d][i] dS[i][k]
-        f32x16 t1 = {0}, dk = {0};
-#pragma unroll
-        for (int dc = 0; dc < G::kDC; ++dc) t1 = mma32(fq[dc], ident_d[dc], t1);   // Q^T
-#pragma unroll
-        for (int cc = 0; cc < 2; ++cc) dk = mma32(pack_chunk<T>(t1, cc), pack_chunk<T>(ds2, cc), dk);
-        // dV^T[d][k] = sum_i dO^T[d][i] A[i][k]
-        f32x16 t2 = {0}, dv = {0};
-#pragma unroll
-        for (int dc = 0; dc < G::kDC; ++dc) t2 = mma32(fo[dc], ident_d[dc], t2);   // dO^T
-#pragma unroll
-        for (int cc = 0; cc < 2; ++cc) dv = mma32(pack_chunk<T>(t2, cc), pack_chunk<T>(a2, cc), dv);
-
-        write_rows<T, D, HG>(sQ, dq, wave, r, hi);
-        write_rows<T, D, HG>(sK, dk, wave, r, hi);
-        write_rows<T, D, HG>(sV, dv, wave, r, hi);
+        slab_commit<G, 32>(pq, sQ, tid);
+        slab_commit<G, 32>(po, sO, tid);
+        slab_commit<G, KR>(pk, sK, tid);
+        slab_commit<G, KR>(pv, sV, tid);
         __syncthreads();
-        slab_store<G>(sQ, dq_base, c.q.row_stride, c.q.j_stride, j, N, tid);
-        slab_store<G>(sK, dk_base, c.k.row_stride, c.k.j_stride, j, N, tid);
-        slab_store<G>(sV, dv_base, c.v.row_stride, c.v.j_stride, j, N, tid);
-        if (j + 1 < N) {
-            slab_commit<G>(pq, sQ, tid);
-            slab_commit<G>(pk, sK, tid);
-            slab_commit<G>(pv, sV, tid);
-            slab_commit<G>(po, sO, tid);
+
+        for (int j = 0; j < N; ++j) {
+            // partial dK/dV of the previous query tile for THIS j (consumed at the store below)
+            uint4 curk[NT > 1 ? SlabIO<G, KR>::kIters : 1], curv[NT > 1 ? SlabIO<G, KR>::kIters : 1];
+            if constexpr (NT > 1) {
+#pragma unroll
+                for (int x = 0; x < SlabIO<G, KR>::kIters; ++x) { curk[x] = prk[x]; curv[x] = prv[x]; }
+            }
+            if (j + 1 < N) {
+                slab_issue<G, 32>(pq, c.q, j + 1, i0, N, tid);
+                slab_issue<G, 32>(po, dO, j + 1, i0, N, tid);
+                slab_issue<G, KR>(pk, c.k, j + 1, 0, N, tid);
+                slab_issue<G, KR>(pv, c.v, j + 1, 0, N, tid);
+                if constexpr (NT > 1) {
+                    if (it > 0) {
+                        slab_issue<G, KR>(prk, dK, j + 1, 0, N, tid);
+                        slab_issue<G, KR>(prv, dV, j + 1, 0, N, tid);
+                    }
+                }
+            }
+            F fq[G::kDC], fo[G::kDC];
+            read_frags<T, D, HG>(fq, sQ, wave, r, hi);
+            read_frags<T, D, HG>(fo, sO, wave, r, hi);
+
+            f32x16 s[NT], da[NT], kT[NT];
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                F fk[G::kDC], fv[G::kDC];
+                read_frags<T, D, HG>(fk, sK, wave, 32 * kt + r, hi);
+                read_frags<T, D, HG>(fv, sV, wave, 32 * kt + r, hi);
+                f32x16 z0 = {0}, z1 = {0}, z2 = {0};
+#pragma unroll
+                for (int dc = 0; dc < G::kDC; ++dc) z0 = mma32(fk[dc], fq[dc], z0);         // S^T[k][i]
+#pragma unroll
+                for (int dc = 0; dc < G::kDC; ++dc) z1 = mma32(fv[dc], fo[dc], z1);         // dA^T[k][i]
+#pragma unroll
+                for (int dc = 0; dc < G::kDC; ++dc) z2 = mma32(fk[dc], ident_d[dc], z2);    // K^T
+                s[kt] = z0;
+                da[kt] = z1;
+                kT[kt] = z2;
+            }
+
+            // softmax statistics are recomputed (in-lane values + the partner lane); saving a
+            // log-sum-exp instead would lose log(sum) next to a finfo.min-sized row maximum.
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    s[kt][q] = s[kt][q] * a.scale + biasM[kt][q];
+                    mx = fmaxf(mx, s[kt][q]);
+                }
+            mx = fmaxf(mx, xhalf(mx));
+            if (mx == -INFINITY) mx = 0.f;           // padding column: every weight is exactly 0
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    s[kt][q] = fast_exp(s[kt][q] - mx);
+                    sum += s[kt][q];
+                }
+            sum += xhalf(sum);
+            const float inv = sum > 0.f ? __frcp_rn(sum) : 0.f;
+            // s -> P, then A;  da -> dS
+            float delta = 0.f;
+            f32x16 att[NT];
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float p = s[kt][q] * inv;
+                    const float dp = da[kt][q] * gate[kt][q];
+                    delta += p * dp;
+                    att[kt][q] = p * gate[kt][q];
+                    s[kt][q] = p;
+                    if (gated) dG[kt][q] += da[kt][q] * att[kt][q] * (1.f - gate[kt][q]);
+                    da[kt][q] = dp;
+                }
+            delta += xhalf(delta);
+            f32x16 dq = {0};
+            F dsf[NT][2], af[NT][2];
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float ds = s[kt][q] * (da[kt][q] - delta);
+                    if (biased) dE[kt][q] += ds;
+                    s[kt][q] = ds * a.scale;
+                }
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    dsf[kt][cc] = pack_chunk<T>(s[kt], cc);
+                    af[kt][cc] = pack_chunk<T>(att[kt], cc);
+                    // dQ^T[d][i] += sum_k K^T[d][k] dS^T[k][i]
+                    dq = mma32(pack_chunk<T>(kT[kt], cc), dsf[kt][cc], dq);
+                }
+            }
+            write_rows<T, D, HG>(sQ, dq, wave, r, hi);
+
+            f32x16 qT = {0}, oT = {0};
+#pragma unroll
+            for (int dc = 0; dc < G::kDC; ++dc) qT = mma32(fq[dc], ident_d[dc], qT);   // Q^T
+#pragma unroll
+            for (int dc = 0; dc < G::kDC; ++dc) oT = mma32(fo[dc], ident_d[dc], oT);   // dO^T
+            F qTf[2] = {pack_chunk<T>(qT, 0), pack_chunk<T>(qT, 1)};
+            F oTf[2] = {pack_chunk<T>(oT, 0), pack_chunk<T>(oT, 1)};
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                // re-layout dS, A to lane = k:  X[i][k] = sum_kk X^T-frag[i][kk] I[kk][k]
+                f32x16 ds2 = {0}, a2 = {0}, dk = {0}, dv = {0};
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    ds2 = mma32(dsf[kt][cc], ident_k[cc], ds2);
+                    a2 = mma32(af[kt][cc], ident_k[cc], a2);
+                }
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    dk = mma32(qTf[cc], pack_chunk<T>(ds2, cc), dk);   // dK^T[d][k] = sum_i Q^T[d][i] dS[i][k]
+                    dv = mma32(oTf[cc], pack_chunk<T>(a2, cc), dv);    // dV^T[d][k] = sum_i dO^T[d][i] A[i][k]
+                }
+                write_rows<T, D, HG>(sK, dk, wave, 32 * kt + r, hi);
+                write_rows<T, D, HG>(sV, dv, wave, 32 * kt + r, hi);
+            }
+            __syncthreads();
+            slab_store<G, 32>(sQ, dq_base, c.q.row_stride, c.q.j_stride, j, i0, N, tid);
+            bool plain = true;
+            if constexpr (NT > 1) {
+                if (it > 0) {
+                    plain = false;
+                    slab_store_add<G, KR, T>(sK, curk, const_cast<char*>(dK.base), dK.row_stride, dK.j_stride, j, 0, N, tid);
+                    slab_store_add<G, KR, T>(sV, curv, const_cast<char*>(dV.base), dV.row_stride, dV.j_stride, j, 0, N, tid);
+                }
+            }
+            if (plain) {
+                slab_store<G, KR>(sK, const_cast<char*>(dK.base), dK.row_stride, dK.j_stride, j, 0, N, tid);
+                slab_store<G, KR>(sV, const_cast<char*>(dV.base), dV.row_stride, dV.j_stride, j, 0, N, tid);
+            }
+            if (j + 1 < N) {
+                slab_commit<G, 32>(pq, sQ, tid);
+                slab_commit<G, 32>(po, sO, tid);
+                slab_commit<G, KR>(pk, sK, tid);
+                slab_commit<G, KR>(pv, sV, tid);
+            }
+            __syncthreads();
         }
-        __syncthreads();
+        // third-arm gradients of this query tile, summed over j in registers
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+            store_third_arm_grad<T>(ta, a.d_eg[c.dir], c.b, c.dir, c.h, N, r, hi, dE[kt], dG[kt], i0, 32 * kt);
     }
-
-    // third-arm gradients, summed over j in registers
-    store_third_arm_grad<T>(ta, a.d_eg[c.dir], c.b, c.dir, c.h, N, r, hi, dE, dG);
 }
 
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-template <typename T, int D, int HG>
-static int launch_tri(const tgt_triplet_attention_args& a, bool bwd, hipStream_t st) {
+template <typename T, int D, int HG, int NT>
+static int launch_tri_nt(const tgt_triplet_attention_args& a, bool bwd, hipStream_t st) {
     using G = TriGeo<T, D, HG>;
     const int grid = a.B * 2 * (a.H / HG);
     if (!bwd) {
-        hipLaunchKernelGGL((tri_att_fwd_kernel<T, D, HG>), dim3(grid), dim3(G::kThreads), 3 * G::kSlabBytes, st, a);
+        hipLaunchKernelGGL((tri_att_fwd_kernel<T, D, HG, NT>), dim3(grid), dim3(G::kThreads),
+                           (1 + 2 * NT) * G::kSlabBytes, st, a);
     } else {
-        hipLaunchKernelGGL((tri_att_bwd_kernel<T, D, HG>), dim3(grid), dim3(G::kThreads), 4 * G::kSlabBytes, st, a);
+        hipLaunchKernelGGL((tri_att_bwd_kernel<T, D, HG, NT>), dim3(grid), dim3(G::kThreads),
+                           (2 + 2 * NT) * G::kSlabBytes, st, a);
     }
     return check_launch(bwd ? "tri_att_bwd_kernel" : "tri_att_fwd_kernel");
+}
+template <typename T, int D, int HG>
+static int launch_tri(const tgt_triplet_attention_args& a, bool bwd, hipStream_t st) {
+    if (a.N <= 32) return launch_tri_nt<T, D, HG, 1>(a, bwd, st);
+    return launch_tri_nt<T, D, HG, 2>(a, bwd, st);
 }
 
 template <typename T, int D>
@@ -356,7 +439,7 @@ static int dispatch_d(const tgt_triplet_attention_args& a, bool bwd, hipStream_t
 int triplet_attention_run(const tgt_triplet_attention_args* a, bool bwd, hipStream_t st) {
     if (!a) return set_error(TGT_ERR_INVALID, "triplet attention: null args");
     if (a->B <= 0 || a->N <= 0 || a->H <= 0) return set_error(TGT_ERR_INVALID, "triplet attention: bad sizes B=%d N=%d H=%d", a->B, a->N, a->H);
-    if (a->N > 32) return set_error(TGT_ERR_UNSUPPORTED, "triplet attention: N=%d > 32 not supported yet", a->N);
+    if (a->N > 64) return set_error(TGT_ERR_UNSUPPORTED, "triplet attention: N=%d > 64 not supported", a->N);
     const int64_t esz = a->dtype == TGT_F32 ? 4 : 2;
     for (int dir = 0; dir < 2; ++dir) {
         if (!a->qkv[dir] || !a->out || !a->mask) return set_error(TGT_ERR_INVALID, "triplet attention: null tensor");

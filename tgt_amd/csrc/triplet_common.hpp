@@ -39,37 +39,69 @@ struct SlabSrc {
     int64_t j_stride;      // bytes between consecutive j
 };
 
-template <typename G>
-__device__ __forceinline__ void slab_issue(uint4 (&pre)[G::kIters], const SlabSrc& s, int j, int N, int tid) {
+// Slab staging.  ROWS = rows of the slab (32 per node tile); slab row `row`
+// is global row `row0 + row` (rows >= N are zero-filled / not stored).
+template <typename G, int ROWS>
+struct SlabIO {
+    static constexpr int kChunks = ROWS * G::kSlots;
+    static constexpr int kIters = (kChunks + G::kThreads - 1) / G::kThreads;
+};
+
+template <typename G, int ROWS, int IT = SlabIO<G, ROWS>::kIters>
+__device__ __forceinline__ void slab_issue(uint4 (&pre)[IT], const SlabSrc& s, int j,
+                                           int row0, int N, int tid) {
 #pragma unroll
-    for (int it = 0; it < G::kIters; ++it) {
+    for (int it = 0; it < SlabIO<G, ROWS>::kIters; ++it) {
         const int c = it * G::kThreads + tid;
         const int row = c / G::kSlots, slot = c % G::kSlots;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (c < G::kChunks && row < N)
-            v = *reinterpret_cast<const uint4*>(s.base + j * s.j_stride + row * s.row_stride + slot * 16);
+        if (c < SlabIO<G, ROWS>::kChunks && row0 + row < N)
+            v = *reinterpret_cast<const uint4*>(s.base + j * s.j_stride + (row0 + row) * s.row_stride + slot * 16);
         pre[it] = v;
     }
 }
-template <typename G>
-__device__ __forceinline__ void slab_commit(const uint4 (&pre)[G::kIters], char* slab, int tid) {
+template <typename G, int ROWS, int IT = SlabIO<G, ROWS>::kIters>
+__device__ __forceinline__ void slab_commit(const uint4 (&pre)[IT], char* slab, int tid) {
 #pragma unroll
-    for (int it = 0; it < G::kIters; ++it) {
+    for (int it = 0; it < SlabIO<G, ROWS>::kIters; ++it) {
         const int c = it * G::kThreads + tid;
         const int row = c / G::kSlots, slot = c % G::kSlots;
-        if (c < G::kChunks) *reinterpret_cast<uint4*>(slab + G::lds_off(row, slot)) = pre[it];
+        if (c < SlabIO<G, ROWS>::kChunks) *reinterpret_cast<uint4*>(slab + G::lds_off(row, slot)) = pre[it];
     }
 }
-template <typename G>
-__device__ __forceinline__ void slab_store(const char* slab, char* dst_base, int64_t row_stride,
-                                           int64_t j_stride, int j, int N, int tid) {
+template <typename G, int ROWS>
+__device__ __forceinline__ void slab_store(const char* slab, char* dst_base, int64_t row_stride, int64_t j_stride,
+                                           int j, int row0, int N, int tid) {
 #pragma unroll
-    for (int it = 0; it < G::kIters; ++it) {
+    for (int it = 0; it < SlabIO<G, ROWS>::kIters; ++it) {
         const int c = it * G::kThreads + tid;
         const int row = c / G::kSlots, slot = c % G::kSlots;
-        if (c < G::kChunks && row < N)
-            *reinterpret_cast<uint4*>(dst_base + j * j_stride + row * row_stride + slot * 16) =
+        if (c < SlabIO<G, ROWS>::kChunks && row0 + row < N)
+            *reinterpret_cast<uint4*>(dst_base + j * j_stride + (row0 + row) * row_stride + slot * 16) =
                 *reinterpret_cast<const uint4*>(slab + G::lds_off(row, slot));
+    }
+}
+// store slab + prior (element-wise in T): the second node-tile pass of the
+// backward adds its partial dK/dV to what the first pass stored.
+template <typename G, int ROWS, typename T, int IT = SlabIO<G, ROWS>::kIters>
+__device__ __forceinline__ void slab_store_add(const char* slab, const uint4 (&prior)[IT],
+                                               char* dst_base, int64_t row_stride, int64_t j_stride, int j,
+                                               int row0, int N, int tid) {
+    constexpr int E = 16 / (int)sizeof(T);
+#pragma unroll
+    for (int it = 0; it < SlabIO<G, ROWS>::kIters; ++it) {
+        const int c = it * G::kThreads + tid;
+        const int row = c / G::kSlots, slot = c % G::kSlots;
+        if (c < SlabIO<G, ROWS>::kChunks && row0 + row < N) {
+            uint4 a = *reinterpret_cast<const uint4*>(slab + G::lds_off(row, slot)), b = prior[it], o;
+            T xa[E], xb[E];
+            __builtin_memcpy(xa, &a, 16);
+            __builtin_memcpy(xb, &b, 16);
+#pragma unroll
+            for (int t = 0; t < E; ++t) xa[t] = from_f32<T>(to_f32(xa[t]) + to_f32(xb[t]));
+            __builtin_memcpy(&o, xa, 16);
+            *reinterpret_cast<uint4*>(dst_base + j * j_stride + (row0 + row) * row_stride + slot * 16) = o;
+        }
     }
 }
 
@@ -161,11 +193,11 @@ struct ThirdArm {
 
 template <typename T, bool PAD_COLS_NEG_INF>
 __device__ __forceinline__ void load_third_arm(const ThirdArm& ta, int b, int dir, int h, int N, int r, int hi,
-                                               float (&biasM)[16], float (&gate)[16]) {
+                                               float (&biasM)[16], float (&gate)[16], int i0 = 0, int k0 = 0) {
     const T* eg = reinterpret_cast<const T*>(ta.eg);
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        const int k = acc_row(q, hi), i = r;
+        const int k = k0 + acc_row(q, hi), i = i0 + r;
         const bool valid = i < N && k < N;
         const int x = dir == 0 ? i : k, y = dir == 0 ? k : i;
         const int64_t idx = ((int64_t)b * N + x) * N + y;
@@ -181,12 +213,13 @@ __device__ __forceinline__ void load_third_arm(const ThirdArm& ta, int b, int di
 // scatter a per-head (i,k) tile of third-arm gradients back (as T)
 template <typename T>
 __device__ __forceinline__ void store_third_arm_grad(const ThirdArm& ta, void* d_eg, int b, int dir, int h, int N,
-                                                     int r, int hi, const float (&dE)[16], const float (&dG)[16]) {
+                                                     int r, int hi, const float (&dE)[16], const float (&dG)[16],
+                                                     int i0 = 0, int k0 = 0) {
     if (!(ta.biased || ta.gated)) return;
     T* deg = reinterpret_cast<T*>(d_eg);
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        const int k = acc_row(q, hi), i = r;
+        const int k = k0 + acc_row(q, hi), i = i0 + r;
         if (i < N && k < N) {
             const int x = dir == 0 ? i : k, y = dir == 0 ? k : i;
             const int64_t idx = ((int64_t)b * N + x) * N + y;
