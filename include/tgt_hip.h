@@ -165,6 +165,25 @@ int tgt_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   int64_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int32_t step, float grad_scale, void* stream);
 
+/* ------------------------------------------------------------------------
+ * LayerNorm over the last axis (the five per-layer norms of the TGT layer:
+ * reference lib/tgt/layers/layers.py:37-38,:150, lib/tgt/layers/triplet.py:195,
+ * i.e. the ATen layer_norm forward/backward behind nn.LayerNorm).
+ *   x (rows, C) of x_dtype -> y (rows, C) of y_dtype; gamma/beta float32 (C);
+ *   mean/rstd float32 (rows) are saved for backward.  C multiple of 8, <= 2048.
+ * Backward: dy (dy_dtype) -> dx (dx_dtype), dgamma/dbeta float32 (C).
+ * `partial` is caller-provided scratch of tgt_layer_norm_parts()*2*C floats
+ * (fixed-order two-stage reduction: deterministic, no atomics).
+ * ---------------------------------------------------------------------- */
+int tgt_layer_norm_parts(void);
+int tgt_layer_norm_fwd(const void* x, int32_t x_dtype, const float* gamma, const float* beta,
+                       void* y, int32_t y_dtype, float* mean, float* rstd,
+                       int64_t rows, int32_t C, float eps, void* stream);
+int tgt_layer_norm_bwd(const void* dy, int32_t dy_dtype, const void* x, int32_t x_dtype,
+                       const float* gamma, const float* mean, const float* rstd,
+                       void* dx, int32_t dx_dtype, float* dgamma, float* dbeta, float* partial,
+                       int64_t rows, int32_t C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

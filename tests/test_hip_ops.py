@@ -216,3 +216,63 @@ def test_adam_matches_torch():
         opt.step()
         ops.adam_step_(p, g, m, v, step, 1e-2)
     assert rel(p, ref.detach()) < 1e-6
+
+
+@pytest.mark.parametrize('xdt,ydt', [(torch.float32, torch.float32), (torch.float32, torch.bfloat16),
+                                     (torch.bfloat16, torch.bfloat16), (torch.float16, torch.float16)])
+@pytest.mark.parametrize('shape', [(3, 5, 5, 32), (2, 7, 48), (4, 33, 256), (2, 6, 6, 768), (1, 3, 1024), (5, 8)])
+def test_layer_norm(shape, xdt, ydt):
+    from tgt_amd import ops
+    rng = np.random.default_rng(sum(shape))
+    C = shape[-1]
+    x = (rnd(rng, *shape) * 2 + 0.5).to(xdt)
+    w, b = (1 + 0.2 * rnd(rng, C)).float(), (0.1 * rnd(rng, C)).float()
+    dy = rnd(rng, *shape).to(ydt)
+    x64, w64, b64 = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(x64, (C,), w64, b64, 1e-5)
+    ref.backward(dy.double())
+    xg, wg, bg = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    y = ops.layer_norm(xg, wg, bg, 1e-5, out_dtype=ydt)
+    assert y.dtype == ydt
+    y.backward(dy.cuda())
+    tol = max(TOL[xdt], TOL[ydt])
+    assert rel(y, ref) < tol
+    assert rel(xg.grad, x64.grad) < 2 * tol
+    assert rel(wg.grad, w64.grad) < 2 * tol and rel(bg.grad, b64.grad) < 2 * tol
+
+
+def test_multi_hot_embed_matches_embedding_sum():
+    from tgt_amd import ops
+    rng = np.random.default_rng(3)
+    V, C = 29, 16
+    w = rnd(rng, V, C).float()
+    idx = torch.from_numpy(rng.integers(0, V, size=(2, 5, 5, 3)))
+    idx[0, 0] = 0
+    g = rnd(rng, 2, 5, 5, C).float()
+    emb = torch.nn.Embedding(V, C, padding_idx=0)
+    emb.weight.data.copy_(w)
+    ref = emb(idx).sum(-2)
+    ref.backward(g)
+    wg = w.cuda().requires_grad_(True)
+    out = ops.multi_hot_embed(idx.cuda(), wg, padding_idx=0)
+    out.backward(g.cuda())
+    assert rel(out, ref) < 1e-6
+    assert rel(wg.grad, emb.weight.grad) < 1e-6
+    assert wg.grad[0].abs().max() == 0
+
+
+def test_drop_path_add():
+    from tgt_amd import ops
+    torch.manual_seed(0)
+    x, r = torch.randn(64, 3, 3, 8, device='cuda'), torch.randn(64, 3, 3, 8, device='cuda')
+    out = ops.drop_path_add_(x.clone(), r, 0.0, True)
+    assert torch.equal(out, x + r)
+    out = ops.drop_path_add_(x.clone(), r, 0.25, False)
+    assert torch.equal(out, x + r)
+    ones = torch.ones_like(x)
+    out = ops.drop_path_add_(ones, r, 0.25, True)
+    per = (out - r).reshape(64, -1)           # per-sample factor: 0 or 1/keep
+    assert torch.allclose(per, per[:, :1].expand_as(per), atol=1e-5)
+    f = per[:, 0]
+    assert bool(((f.abs() < 1e-5) | ((f - 1 / 0.75).abs() < 1e-4)).all())
+    assert 0 < int((f.abs() < 1e-5).sum()) < 64

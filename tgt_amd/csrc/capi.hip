@@ -25,6 +25,12 @@ int check_launch(const char* what) {
 int triplet_attention_run(const tgt_triplet_attention_args* a, bool bwd, hipStream_t st);
 int triplet_aggregate_run(const tgt_triplet_aggregate_args* a, bool bwd, hipStream_t st);
 int node_attention_run(const tgt_node_attention_args* a, bool bwd, hipStream_t st);
+int layer_norm_parts();
+int layer_norm_fwd_run(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
+                       float* mean, float* rstd, int64_t rows, int C, float eps, hipStream_t st);
+int layer_norm_bwd_run(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, const float* mean,
+                       const float* rstd, void* dx, int dx_dtype, float* dgamma, float* dbeta, float* partial,
+                       int64_t rows, int C, hipStream_t st);
 
 // Adam over flat float32 buffers: 4 reads + 3 writes per element, HBM-bound.
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -67,7 +73,7 @@ using namespace tgt;
 extern "C" {
 
 const char* tgt_last_error(void) { return g_err; }
-int tgt_abi_version(void) { return 1; }
+int tgt_abi_version(void) { return 2; }
 
 int tgt_triplet_attention_fwd(const tgt_triplet_attention_args* a, void* stream) {
     return triplet_attention_run(a, false, reinterpret_cast<hipStream_t>(stream));
@@ -86,6 +92,19 @@ int tgt_node_attention_fwd(const tgt_node_attention_args* a, void* stream) {
 }
 int tgt_node_attention_bwd(const tgt_node_attention_args* a, void* stream) {
     return node_attention_run(a, true, reinterpret_cast<hipStream_t>(stream));
+}
+
+int tgt_layer_norm_parts(void) { return layer_norm_parts(); }
+int tgt_layer_norm_fwd(const void* x, int32_t x_dtype, const float* gamma, const float* beta, void* y, int32_t y_dtype,
+                       float* mean, float* rstd, int64_t rows, int32_t C, float eps, void* stream) {
+    return layer_norm_fwd_run(x, x_dtype, gamma, beta, y, y_dtype, mean, rstd, rows, C, eps,
+                              reinterpret_cast<hipStream_t>(stream));
+}
+int tgt_layer_norm_bwd(const void* dy, int32_t dy_dtype, const void* x, int32_t x_dtype, const float* gamma,
+                       const float* mean, const float* rstd, void* dx, int32_t dx_dtype, float* dgamma, float* dbeta,
+                       float* partial, int64_t rows, int32_t C, void* stream) {
+    return layer_norm_bwd_run(dy, dy_dtype, x, x_dtype, gamma, mean, rstd, dx, dx_dtype, dgamma, dbeta, partial, rows, C,
+                              reinterpret_cast<hipStream_t>(stream));
 }
 
 int tgt_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,

@@ -1,0 +1,294 @@
+// LayerNorm over the channel axis, forward and backward, for gfx950.
+//
+// The TGT layer opens every sub-block with a LayerNorm over the (B,N,N,C=256)
+// edge tensor or the (B,N,W=768) node tensor (reference lib/tgt/layers/layers.py:37-38,
+// :150, triplet.py:195): five per layer.  It is pure HBM streaming, so the kernel
+// reads the row in its storage type (bf16/fp16/fp32), keeps it in registers for
+// the two statistics passes, and writes the result directly in the type the
+// consuming GEMM wants -- no fp32 round trip through HBM.
+//   forward : y = (x - mean) * rstd * gamma + beta          (stats in fp32, saved)
+//   backward: g = dy*gamma; dx = rstd*(g - mean(g) - xhat*mean(g*xhat))
+//             dgamma = sum_rows dy*xhat, dbeta = sum_rows dy
+// Mapping: LPR lanes share one row (8 contiguous channels = 16 B per lane and
+// vector), 64/LPR rows per wave, shuffle reductions inside the LPR-lane group.
+// dgamma/dbeta: each lane owns fixed channels and accumulates over the rows it
+// visits (grid-stride); a workgroup folds its partials through LDS and writes
+// ONE row of a (parts, 2C) fp32 buffer; a second tiny kernel sums the parts in
+// a fixed order (deterministic, no atomics).
+#include "common.hpp"
+
+namespace tgt {
+
+constexpr int kLnParts = 1024;
+
+__device__ __forceinline__ void ln_load8(const void* p, int dtype, int64_t idx, float (&v)[8]) {
+    if (dtype == TGT_F32) {
+        const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + idx);
+        float4 a = q[0], b = q[1];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+        uint4 raw = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p) + idx);
+        if (dtype == TGT_BF16) {
+            bf16_t t[8];
+            __builtin_memcpy(t, &raw, 16);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = to_f32(t[i]);
+        } else {
+            f16_t t[8];
+            __builtin_memcpy(t, &raw, 16);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = to_f32(t[i]);
+        }
+    }
+}
+
+__device__ __forceinline__ void ln_store8(void* p, int dtype, int64_t idx, const float (&v)[8]) {
+    if (dtype == TGT_F32) {
+        float4* q = reinterpret_cast<float4*>(reinterpret_cast<float*>(p) + idx);
+        q[0] = make_float4(v[0], v[1], v[2], v[3]);
+        q[1] = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+        uint4 raw;
+        if (dtype == TGT_BF16) {
+            bf16_t t[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t[i] = from_f32<bf16_t>(v[i]);
+            __builtin_memcpy(&raw, t, 16);
+        } else {
+            f16_t t[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t[i] = from_f32<f16_t>(v[i]);
+            __builtin_memcpy(&raw, t, 16);
+        }
+        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p) + idx) = raw;
+    }
+}
+
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+struct LnArgs {
+    const void* x; const void* dy; void* y; void* dx;
+    const float* gamma; const float* beta;
+    float* mean; float* rstd; float* partial;
+    int64_t rows; int C; float eps;
+    int x_dtype, y_dtype, dy_dtype, dx_dtype;
+};
+
+template <int LPR, int VPL>
+__global__ void __launch_bounds__(256) ln_fwd_kernel(const LnArgs a) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, sub = lane / LPR, gl = lane % LPR;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    const float invC = 1.f / a.C;
+    float gam[VPL][8], bet[VPL][8];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        const int col = (v * LPR + gl) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            gam[v][i] = col < a.C ? a.gamma[col + i] : 0.f;
+            bet[v][i] = col < a.C ? a.beta[col + i] : 0.f;
+        }
+    }
+    for (int64_t row = wave * RPW + sub; row < a.rows; row += nwaves * RPW) {
+        float x[VPL][8];
+        float s = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            const int col = (v * LPR + gl) * 8;
+            if (col < a.C) ln_load8(a.x, a.x_dtype, row * a.C + col, x[v]);
+            else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[v][i] = 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += x[v][i];
+        }
+        const float mean = group_sum<LPR>(s) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            const int col = (v * LPR + gl) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float d = col < a.C ? x[v][i] - mean : 0.f;
+                q += d * d;
+            }
+        }
+        const float rstd = rsqrtf(group_sum<LPR>(q) * invC + a.eps);
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            const int col = (v * LPR + gl) * 8;
+            if (col < a.C) {
+                float y[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) y[i] = (x[v][i] - mean) * rstd * gam[v][i] + bet[v][i];
+                ln_store8(a.y, a.y_dtype, row * a.C + col, y);
+            }
+        }
+        if (gl == 0) {
+            a.mean[row] = mean;
+            a.rstd[row] = rstd;
+        }
+    }
+}
+
+template <int LPR, int VPL>
+__global__ void __launch_bounds__(256) ln_bwd_kernel(const LnArgs a) {
+    constexpr int RPW = 64 / LPR;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);        // [4 waves][RPW][2][VPL*LPR*8]
+    const int lane = threadIdx.x & 63, sub = lane / LPR, gl = lane % LPR, w = threadIdx.x >> 6;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + w, nwaves = (int64_t)gridDim.x * 4;
+    const float invC = 1.f / a.C;
+    float gam[VPL][8], dgam[VPL][8], dbet[VPL][8];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        const int col = (v * LPR + gl) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            gam[v][i] = col < a.C ? a.gamma[col + i] : 0.f;
+            dgam[v][i] = dbet[v][i] = 0.f;
+        }
+    }
+    for (int64_t row = wave * RPW + sub; row < a.rows; row += nwaves * RPW) {
+        const float mean = a.mean[row], rstd = a.rstd[row];
+        float xh[VPL][8], g[VPL][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            const int col = (v * LPR + gl) * 8;
+            if (col < a.C) {
+                float dy[8];
+                ln_load8(a.x, a.x_dtype, row * a.C + col, xh[v]);
+                ln_load8(a.dy, a.dy_dtype, row * a.C + col, dy);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    xh[v][i] = (xh[v][i] - mean) * rstd;
+                    g[v][i] = dy[i] * gam[v][i];
+                    dgam[v][i] += dy[i] * xh[v][i];
+                    dbet[v][i] += dy[i];
+                    s1 += g[v][i];
+                    s2 += g[v][i] * xh[v][i];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) xh[v][i] = g[v][i] = 0.f;
+            }
+        }
+        const float c1 = group_sum<LPR>(s1) * invC, c2 = group_sum<LPR>(s2) * invC;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            const int col = (v * LPR + gl) * 8;
+            if (col < a.C) {
+                float dx[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) dx[i] = rstd * (g[v][i] - c1 - xh[v][i] * c2);
+                ln_store8(a.dx, a.dx_dtype, row * a.C + col, dx);
+            }
+        }
+    }
+    // fold the 4*RPW row-groups of this workgroup, fixed order
+    constexpr int CW = VPL * LPR * 8;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int col = (v * LPR + gl) * 8 + i;
+            red[((w * RPW + sub) * 2 + 0) * CW + col] = dgam[v][i];
+            red[((w * RPW + sub) * 2 + 1) * CW + col] = dbet[v][i];
+        }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 2 * a.C; idx += 256) {
+        const int which = idx / a.C, col = idx % a.C;
+        float s = 0.f;
+        for (int gidx = 0; gidx < 4 * RPW; ++gidx) s += red[(gidx * 2 + which) * CW + col];
+        a.partial[(int64_t)blockIdx.x * 2 * a.C + idx] = s;
+    }
+}
+
+// sum the (parts, 2C) partials: block = 16 columns x 16 part-slices, fixed order
+__global__ void __launch_bounds__(256) ln_bwd_finalize_kernel(const float* partial, int parts, int C, float* dgamma,
+                                                              float* dbeta) {
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int idx = blockIdx.x * 16 + cl;
+    float s = 0.f;
+    if (idx < 2 * C)
+        for (int p = sl; p < parts; p += 16) s += partial[(int64_t)p * 2 * C + idx];
+    red[sl][cl] = s;
+    __syncthreads();
+    if (sl == 0 && idx < 2 * C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][cl];
+        if (idx < C) dgamma[idx] = t;
+        else dbeta[idx - C] = t;
+    }
+}
+
+template <int LPR, int VPL>
+static int ln_launch(const LnArgs& a, bool bwd, float* dgamma, float* dbeta, hipStream_t st) {
+    constexpr int RPW = 64 / LPR;
+    int64_t blocks = (a.rows + 4 * RPW - 1) / (4 * RPW);
+    if (!bwd) {
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL((ln_fwd_kernel<LPR, VPL>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        return check_launch("ln_fwd_kernel");
+    }
+    const int parts = kLnParts;          // fixed grid: the partial buffer has exactly kLnParts rows
+    const size_t lds = (size_t)4 * RPW * 2 * VPL * LPR * 8 * sizeof(float);
+    hipLaunchKernelGGL((ln_bwd_kernel<LPR, VPL>), dim3(parts), dim3(256), lds, st, a);
+    if (int e = check_launch("ln_bwd_kernel")) return e;
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((2 * a.C + 15) / 16), dim3(256), 0, st, a.partial, parts, a.C,
+                       dgamma, dbeta);
+    return check_launch("ln_bwd_finalize_kernel");
+}
+
+static int ln_dispatch(const LnArgs& a, bool bwd, float* dgamma, float* dbeta, hipStream_t st) {
+    if (a.C % 8 || a.C <= 0 || a.C > 2048) return set_error(TGT_ERR_UNSUPPORTED, "layer norm: C=%d must be a multiple of 8, <= 2048", a.C);
+    const int v8 = a.C / 8;
+    if (v8 <= 4) return ln_launch<4, 1>(a, bwd, dgamma, dbeta, st);
+    if (v8 <= 8) return ln_launch<8, 1>(a, bwd, dgamma, dbeta, st);
+    if (v8 <= 16) return ln_launch<16, 1>(a, bwd, dgamma, dbeta, st);
+    if (v8 <= 32) return ln_launch<32, 1>(a, bwd, dgamma, dbeta, st);
+    if (v8 <= 64) return ln_launch<64, 1>(a, bwd, dgamma, dbeta, st);
+    if (v8 <= 128) return ln_launch<64, 2>(a, bwd, dgamma, dbeta, st);
+    return ln_launch<64, 4>(a, bwd, dgamma, dbeta, st);
+}
+
+static bool bad_dtype(int d) { return d != TGT_F32 && d != TGT_BF16 && d != TGT_F16; }
+
+int layer_norm_fwd_run(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
+                       float* mean, float* rstd, int64_t rows, int C, float eps, hipStream_t st) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd || rows < 0) return set_error(TGT_ERR_INVALID, "layer norm fwd: null tensor");
+    if (bad_dtype(x_dtype) || bad_dtype(y_dtype)) return set_error(TGT_ERR_INVALID, "layer norm fwd: bad dtype");
+    if (((uintptr_t)x | (uintptr_t)y) % 16) return set_error(TGT_ERR_INVALID, "layer norm fwd: x/y must be 16-byte aligned");
+    if (rows == 0) return TGT_OK;
+    LnArgs a = {};
+    a.x = x; a.y = y; a.gamma = gamma; a.beta = beta; a.mean = mean; a.rstd = rstd;
+    a.rows = rows; a.C = C; a.eps = eps; a.x_dtype = x_dtype; a.y_dtype = y_dtype;
+    return ln_dispatch(a, false, nullptr, nullptr, st);
+}
+
+int layer_norm_bwd_run(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, const float* mean,
+                       const float* rstd, void* dx, int dx_dtype, float* dgamma, float* dbeta, float* partial,
+                       int64_t rows, int C, hipStream_t st) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !partial || rows < 0)
+        return set_error(TGT_ERR_INVALID, "layer norm bwd: null tensor");
+    if (bad_dtype(x_dtype) || bad_dtype(dy_dtype) || bad_dtype(dx_dtype)) return set_error(TGT_ERR_INVALID, "layer norm bwd: bad dtype");
+    if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) % 16) return set_error(TGT_ERR_INVALID, "layer norm bwd: tensors must be 16-byte aligned");
+    LnArgs a = {};
+    a.x = x; a.dy = dy; a.dx = dx; a.gamma = gamma; a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd);
+    a.partial = partial; a.rows = rows; a.C = C; a.x_dtype = x_dtype; a.dy_dtype = dy_dtype; a.dx_dtype = dx_dtype;
+    return ln_dispatch(a, true, dgamma, dbeta, st);
+}
+
+int layer_norm_parts() { return kLnParts; }
+
+}  // namespace tgt

@@ -30,6 +30,7 @@
 //   The register->row map of an MFMA result equals the k-order of the next
 //   MFMA's operand fragment, so no cross-lane data movement is needed at all.
 //   Backward uses the same trick to re-layout dS and A (multiply by I).
+#include <cstdlib>
 #include "triplet_common.hpp"
 
 namespace tgt {
@@ -72,15 +73,15 @@ __device__ __forceinline__ ThirdArm tri_third_arm(const tgt_triplet_attention_ar
 // forward.  NT = node tiles of 32 (N <= 32*NT).  The workgroup makes one pass
 // per query tile `it`; inside a pass the key axis spans all NT tiles.
 // ---------------------------------------------------------------------------
-template <typename T, int D, int HG, int NT>
-__global__ void __launch_bounds__(HG * 64) tri_att_fwd_kernel(const tgt_triplet_attention_args a) {
+template <typename T, int D, int HG, int NT, int PF>
+__global__ void __launch_bounds__(HG * 64, (NT == 1 && sizeof(T) == 2) ? 4 : 1) tri_att_fwd_kernel(const tgt_triplet_attention_args a) {
     using G = TriGeo<T, D, HG>;
     using F = frag_t<T>;
     constexpr int KR = 32 * NT;
+    // two LDS sets {Q | K | V}: set j&1 is computed on while j+1 lands in the other one,
+    // so ONE barrier per j suffices (see the hazard notes at the loop).
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sQ = smem;
-    char* sK = smem + G::kSlabBytes;
-    char* sV = sK + NT * G::kSlabBytes;
+    constexpr int kSet = (1 + 2 * NT) * G::kSlabBytes;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hi = lane >> 5;
@@ -98,24 +99,57 @@ __global__ void __launch_bounds__(HG * 64) tri_att_fwd_kernel(const tgt_triplet_
         const int i0 = 32 * it;
         if (i0 >= N) break;
         float biasM[NT][16], gate[NT][16];
+        arm_stage_load<T, HG, NT>(ta, c.b, c.dir, c.g, N, i0, smem, tid);
+        __syncthreads();
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
-            load_third_arm<T, false>(ta, c.b, c.dir, c.h, N, r, hi, biasM[kt], gate[kt], i0, 32 * kt);
-
-        uint4 pq[SlabIO<G, 32>::kIters], pk[SlabIO<G, KR>::kIters], pv[SlabIO<G, KR>::kIters];
-        slab_issue<G, 32>(pq, c.q, 0, i0, N, tid);
-        slab_issue<G, KR>(pk, c.k, 0, 0, N, tid);
-        slab_issue<G, KR>(pv, c.v, 0, 0, N, tid);
-        slab_commit<G, 32>(pq, sQ, tid);
-        slab_commit<G, KR>(pk, sK, tid);
-        slab_commit<G, KR>(pv, sV, tid);
+            arm_stage_read<T, HG, NT, false>(ta, smem, c.dir, wave, N, r, hi, i0, kt, biasM[kt], gate[kt]);
         __syncthreads();
 
-        for (int j = 0; j < N; ++j) {
+        // PF register stages of prefetch: stage A holds slab j+1 (j+2 in B) when iteration j starts
+        uint4 pqA[SlabIO<G, 32>::kIters], pkA[SlabIO<G, KR>::kIters], pvA[SlabIO<G, KR>::kIters];
+        uint4 pqB[PF > 1 ? SlabIO<G, 32>::kIters : 1], pkB[PF > 1 ? SlabIO<G, KR>::kIters : 1],
+            pvB[PF > 1 ? SlabIO<G, KR>::kIters : 1];
+        slab_issue<G, 32>(pqA, c.q, 0, i0, N, tid);
+        slab_issue<G, KR>(pkA, c.k, 0, 0, N, tid);
+        slab_issue<G, KR>(pvA, c.v, 0, 0, N, tid);
+        slab_commit<G, 32>(pqA, smem, tid);
+        slab_commit<G, KR>(pkA, smem + G::kSlabBytes, tid);
+        slab_commit<G, KR>(pvA, smem + (1 + NT) * G::kSlabBytes, tid);
+        if (N > 1) {
+            slab_issue<G, 32>(pqA, c.q, 1, i0, N, tid);
+            slab_issue<G, KR>(pkA, c.k, 1, 0, N, tid);
+            slab_issue<G, KR>(pvA, c.v, 1, 0, N, tid);
+        }
+        if constexpr (PF > 1) {
+            if (N > 2) {
+                slab_issue<G, 32>(pqB, c.q, 2, i0, N, tid);
+                slab_issue<G, KR>(pkB, c.k, 2, 0, N, tid);
+                slab_issue<G, KR>(pvB, c.v, 2, 0, N, tid);
+            }
+        }
+        __syncthreads();
+
+        // Hazards with one barrier per j (B_j = the barrier of iteration j):
+        //  * set[cur^1] is overwritten at the top of iteration j.  Its K/V were last read by
+        //    compute(j-1), finished before B_{j-1}; its Q slab holds O(j-1), which is stored after
+        //    B_{j-1} by the SAME thread (same chunk map) that now overwrites that chunk.
+        //  * compute(j) reads set[cur], committed before B_{j-1}.
+        //  * O(j) goes into this wave's own columns of set[cur].Q and is read after B_j.
+        auto step = [&](int j, auto& pq, auto& pk, auto& pv) {
+            char* sQ = smem + (j & 1) * kSet;
+            char* sK = sQ + G::kSlabBytes;
+            char* sV = sK + NT * G::kSlabBytes;
             if (j + 1 < N) {
-                slab_issue<G, 32>(pq, c.q, j + 1, i0, N, tid);
-                slab_issue<G, KR>(pk, c.k, j + 1, 0, N, tid);
-                slab_issue<G, KR>(pv, c.v, j + 1, 0, N, tid);
+                char* nQ = smem + ((j + 1) & 1) * kSet;
+                slab_commit<G, 32>(pq, nQ, tid);
+                slab_commit<G, KR>(pk, nQ + G::kSlabBytes, tid);
+                slab_commit<G, KR>(pv, nQ + (1 + NT) * G::kSlabBytes, tid);
+            }
+            if (j + 1 + PF < N) {
+                slab_issue<G, 32>(pq, c.q, j + 1 + PF, i0, N, tid);
+                slab_issue<G, KR>(pk, c.k, j + 1 + PF, 0, N, tid);
+                slab_issue<G, KR>(pv, c.v, j + 1 + PF, 0, N, tid);
             }
             F fq[G::kDC];
             read_frags<T, D, HG>(fq, sQ, wave, r, hi);
@@ -163,13 +197,14 @@ __global__ void __launch_bounds__(HG * 64) tri_att_fwd_kernel(const tgt_triplet_
             write_rows<T, D, HG>(sQ, o, wave, r, hi);     // in place of this head's Q columns
             __syncthreads();
             slab_store<G, 32>(sQ, obase, o_row, o_j, j, i0, N, tid);
-            if (j + 1 < N) {
-                slab_commit<G, 32>(pq, sQ, tid);
-                slab_commit<G, KR>(pk, sK, tid);
-                slab_commit<G, KR>(pv, sV, tid);
+        };
+        for (int j = 0; j < N; j += PF) {
+            step(j, pqA, pkA, pvA);
+            if constexpr (PF > 1) {
+                if (j + 1 < N) step(j + 1, pqB, pkB, pvB);
             }
-            __syncthreads();
         }
+        __syncthreads();      // the next query-tile pass re-fills both sets
     }
 }
 
@@ -184,16 +219,13 @@ __global__ void __launch_bounds__(HG * 64) tri_att_fwd_kernel(const tgt_triplet_
 // NT > 1: one pass per query tile; dK/dV sum over query tiles, so pass `it > 0`
 // adds its partial to what pass it-1 stored (same thread wrote that address).
 // ---------------------------------------------------------------------------
-template <typename T, int D, int HG, int NT>
-__global__ void __launch_bounds__(HG * 64) tri_att_bwd_kernel(const tgt_triplet_attention_args a) {
+template <typename T, int D, int HG, int NT, int OCC>
+__global__ void __launch_bounds__(HG * 64, OCC) tri_att_bwd_kernel(const tgt_triplet_attention_args a) {
     using G = TriGeo<T, D, HG>;
     using F = frag_t<T>;
     constexpr int KR = 32 * NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sQ = smem;
-    char* sO = smem + G::kSlabBytes;
-    char* sK = smem + 2 * G::kSlabBytes;
-    char* sV = sK + NT * G::kSlabBytes;
+    constexpr int kSet = (2 + 2 * NT) * G::kSlabBytes;       // {Q | dO | K | V}, two sets (see forward)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hi = lane >> 5;
@@ -219,49 +251,58 @@ __global__ void __launch_bounds__(HG * 64) tri_att_bwd_kernel(const tgt_triplet_
         const int i0 = 32 * it;
         if (i0 >= N) break;
         float biasM[NT][16], gate[NT][16], dE[NT][16], dG[NT][16];
+        arm_stage_load<T, HG, NT>(ta, c.b, c.dir, c.g, N, i0, smem, tid);
+        __syncthreads();
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
-            load_third_arm<T, true>(ta, c.b, c.dir, c.h, N, r, hi, biasM[kt], gate[kt], i0, 32 * kt);
+            arm_stage_read<T, HG, NT, true>(ta, smem, c.dir, wave, N, r, hi, i0, kt, biasM[kt], gate[kt]);
 #pragma unroll
             for (int q = 0; q < 16; ++q) dE[kt][q] = dG[kt][q] = 0.f;
         }
+        __syncthreads();
 
         uint4 pq[SlabIO<G, 32>::kIters], po[SlabIO<G, 32>::kIters];
         uint4 pk[SlabIO<G, KR>::kIters], pv[SlabIO<G, KR>::kIters];
-        uint4 prk[NT > 1 ? SlabIO<G, KR>::kIters : 1], prv[NT > 1 ? SlabIO<G, KR>::kIters : 1];
         slab_issue<G, 32>(pq, c.q, 0, i0, N, tid);
         slab_issue<G, 32>(po, dO, 0, i0, N, tid);
         slab_issue<G, KR>(pk, c.k, 0, 0, N, tid);
         slab_issue<G, KR>(pv, c.v, 0, 0, N, tid);
-        if constexpr (NT > 1) {
-            if (it > 0) {
-                slab_issue<G, KR>(prk, dK, 0, 0, N, tid);
-                slab_issue<G, KR>(prv, dV, 0, 0, N, tid);
-            }
+        slab_commit<G, 32>(pq, smem, tid);
+        slab_commit<G, 32>(po, smem + G::kSlabBytes, tid);
+        slab_commit<G, KR>(pk, smem + 2 * G::kSlabBytes, tid);
+        slab_commit<G, KR>(pv, smem + (2 + NT) * G::kSlabBytes, tid);
+        if (N > 1) {
+            slab_issue<G, 32>(pq, c.q, 1, i0, N, tid);
+            slab_issue<G, 32>(po, dO, 1, i0, N, tid);
+            slab_issue<G, KR>(pk, c.k, 1, 0, N, tid);
+            slab_issue<G, KR>(pv, c.v, 1, 0, N, tid);
         }
-        slab_commit<G, 32>(pq, sQ, tid);
-        slab_commit<G, 32>(po, sO, tid);
-        slab_commit<G, KR>(pk, sK, tid);
-        slab_commit<G, KR>(pv, sV, tid);
         __syncthreads();
 
         for (int j = 0; j < N; ++j) {
-            // partial dK/dV of the previous query tile for THIS j (consumed at the store below)
+            char* sQ = smem + (j & 1) * kSet;
+            char* sO = sQ + G::kSlabBytes;
+            char* sK = sQ + 2 * G::kSlabBytes;
+            char* sV = sK + NT * G::kSlabBytes;
+            if (j + 1 < N) {
+                char* nQ = smem + ((j + 1) & 1) * kSet;
+                slab_commit<G, 32>(pq, nQ, tid);
+                slab_commit<G, 32>(po, nQ + G::kSlabBytes, tid);
+                slab_commit<G, KR>(pk, nQ + 2 * G::kSlabBytes, tid);
+                slab_commit<G, KR>(pv, nQ + (2 + NT) * G::kSlabBytes, tid);
+            }
+            if (j + 2 < N) {
+                slab_issue<G, 32>(pq, c.q, j + 2, i0, N, tid);
+                slab_issue<G, 32>(po, dO, j + 2, i0, N, tid);
+                slab_issue<G, KR>(pk, c.k, j + 2, 0, N, tid);
+                slab_issue<G, KR>(pv, c.v, j + 2, 0, N, tid);
+            }
+            // partial dK/dV the previous query-tile pass stored for THIS j (added at the store below)
             uint4 curk[NT > 1 ? SlabIO<G, KR>::kIters : 1], curv[NT > 1 ? SlabIO<G, KR>::kIters : 1];
             if constexpr (NT > 1) {
-#pragma unroll
-                for (int x = 0; x < SlabIO<G, KR>::kIters; ++x) { curk[x] = prk[x]; curv[x] = prv[x]; }
-            }
-            if (j + 1 < N) {
-                slab_issue<G, 32>(pq, c.q, j + 1, i0, N, tid);
-                slab_issue<G, 32>(po, dO, j + 1, i0, N, tid);
-                slab_issue<G, KR>(pk, c.k, j + 1, 0, N, tid);
-                slab_issue<G, KR>(pv, c.v, j + 1, 0, N, tid);
-                if constexpr (NT > 1) {
-                    if (it > 0) {
-                        slab_issue<G, KR>(prk, dK, j + 1, 0, N, tid);
-                        slab_issue<G, KR>(prv, dV, j + 1, 0, N, tid);
-                    }
+                if (it > 0) {
+                    slab_issue<G, KR>(curk, dK, j, 0, N, tid);
+                    slab_issue<G, KR>(curv, dV, j, 0, N, tid);
                 }
             }
             F fq[G::kDC], fo[G::kDC];
@@ -382,18 +423,14 @@ __global__ void __launch_bounds__(HG * 64) tri_att_bwd_kernel(const tgt_triplet_
                 slab_store<G, KR>(sK, const_cast<char*>(dK.base), dK.row_stride, dK.j_stride, j, 0, N, tid);
                 slab_store<G, KR>(sV, const_cast<char*>(dV.base), dV.row_stride, dV.j_stride, j, 0, N, tid);
             }
-            if (j + 1 < N) {
-                slab_commit<G, 32>(pq, sQ, tid);
-                slab_commit<G, 32>(po, sO, tid);
-                slab_commit<G, KR>(pk, sK, tid);
-                slab_commit<G, KR>(pv, sV, tid);
-            }
-            __syncthreads();
         }
-        // third-arm gradients of this query tile, summed over j in registers
+        __syncthreads();      // the next query-tile pass re-fills both sets
+        // third-arm gradients of this query tile (summed over j in registers) leave through LDS
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
-            store_third_arm_grad<T>(ta, a.d_eg[c.dir], c.b, c.dir, c.h, N, r, hi, dE[kt], dG[kt], i0, 32 * kt);
+        for (int kt = 0; kt < NT; ++kt) arm_stage_put_grad<T, HG, NT>(smem, c.dir, wave, r, hi, kt, dE[kt], dG[kt]);
+        __syncthreads();
+        arm_stage_store_grad<T, HG, NT>(ta, a.d_eg[c.dir], c.b, c.dir, c.g, N, i0, smem, tid);
+        __syncthreads();
     }
 }
 
@@ -404,12 +441,26 @@ template <typename T, int D, int HG, int NT>
 static int launch_tri_nt(const tgt_triplet_attention_args& a, bool bwd, hipStream_t st) {
     using G = TriGeo<T, D, HG>;
     const int grid = a.B * 2 * (a.H / HG);
+    constexpr int kArm = ArmStage<T, HG, NT>::kBytes;
+    constexpr int kFwdLds = 2 * (1 + 2 * NT) * G::kSlabBytes > kArm ? 2 * (1 + 2 * NT) * G::kSlabBytes : kArm;
+    constexpr int kBwdLds = 2 * (2 + 2 * NT) * G::kSlabBytes > kArm ? 2 * (2 + 2 * NT) * G::kSlabBytes : kArm;
     if (!bwd) {
-        hipLaunchKernelGGL((tri_att_fwd_kernel<T, D, HG, NT>), dim3(grid), dim3(G::kThreads),
-                           (1 + 2 * NT) * G::kSlabBytes, st, a);
+        static const int pf = getenv("TGT_TRI_FWD_PF") ? atoi(getenv("TGT_TRI_FWD_PF")) : 1;
+        if (NT == 1 && pf == 2)
+            hipLaunchKernelGGL((tri_att_fwd_kernel<T, D, HG, NT, (NT == 1 ? 2 : 1)>), dim3(grid), dim3(G::kThreads),
+                               kFwdLds, st, a);
+        else
+            hipLaunchKernelGGL((tri_att_fwd_kernel<T, D, HG, NT, 1>), dim3(grid), dim3(G::kThreads),
+                               kFwdLds, st, a);
     } else {
-        hipLaunchKernelGGL((tri_att_bwd_kernel<T, D, HG, NT>), dim3(grid), dim3(G::kThreads),
-                           (2 + 2 * NT) * G::kSlabBytes, st, a);
+        // experiment knob: TGT_TRI_BWD_OCC=2 caps registers for 2 waves/SIMD (NT == 1 only)
+        static const int occ = getenv("TGT_TRI_BWD_OCC") ? atoi(getenv("TGT_TRI_BWD_OCC")) : 2;
+        if (NT == 1 && occ == 2)
+            hipLaunchKernelGGL((tri_att_bwd_kernel<T, D, HG, NT, (NT == 1 ? 2 : 1)>), dim3(grid), dim3(G::kThreads),
+                               kBwdLds, st, a);
+        else
+            hipLaunchKernelGGL((tri_att_bwd_kernel<T, D, HG, NT, 1>), dim3(grid), dim3(G::kThreads),
+                               kBwdLds, st, a);
     }
     return check_launch(bwd ? "tri_att_bwd_kernel" : "tri_att_fwd_kernel");
 }

@@ -229,4 +229,107 @@ __device__ __forceinline__ void store_third_arm_grad(const ThirdArm& ta, void* d
     }
 }
 
+// ---------------------------------------------------------------------------
+// Staged third arm.  The per-lane gathers above touch one cache line per lane
+// per value (48 instructions x 64 lines per wave).  Instead the WORKGROUP pulls
+// the E/G columns of its HG heads and the mask for the pair region of one
+// query-tile pass through LDS (8 pairs per wave instruction), and each wave
+// then picks its head's tile in accumulator layout from LDS; the backward
+// scatters dE/dG back the same way.  The staging area aliases the slab
+// buffers (used strictly before / after the walk over j).
+//   region of pass i0: inward  x in [i0,i0+32), y in [0,32NT)
+//                      outward x in [0,32NT),   y in [i0,i0+32)
+// row pitch + 4 bytes: lanes that differ in x hit different banks.
+// ---------------------------------------------------------------------------
+template <typename T, int HG, int NT>
+struct ArmStage {
+    static constexpr int kVals = 2 * HG;
+    static constexpr int kPairBytes = kVals * (int)sizeof(T);
+    static constexpr int kOffM = ((32 * NT * 32 * kPairBytes + 4 * 32 * NT + 15) / 16) * 16;
+    static constexpr int kBytes = kOffM + 32 * NT * 32 * 4 + 4 * 32 * NT;
+    __device__ static __forceinline__ int nx(int dir) { return dir == 0 ? 32 : 32 * NT; }
+    __device__ static __forceinline__ int ny(int dir) { return dir == 0 ? 32 * NT : 32; }
+    __device__ static __forceinline__ int pitch(int dir) { return ny(dir) * kPairBytes + 4; }
+    __device__ static __forceinline__ int mpitch(int dir) { return ny(dir) * 4 + 4; }
+};
+
+template <typename T, int HG, int NT>
+__device__ __forceinline__ void arm_stage_load(const ThirdArm& ta, int b, int dir, int g, int N, int i0, char* lds,
+                                               int tid) {
+    using A = ArmStage<T, HG, NT>;
+    const int nx = A::nx(dir), ny = A::ny(dir), x0 = dir == 0 ? i0 : 0, y0 = dir == 0 ? 0 : i0;
+    const int pitch = A::pitch(dir), mpitch = A::mpitch(dir);
+    const T* eg = reinterpret_cast<const T*>(ta.eg);
+    for (int idx = tid; idx < nx * ny * A::kVals; idx += HG * 64) {
+        const int v = idx % A::kVals, p = idx / A::kVals, yy = p % ny, xx = p / ny;
+        const int x = x0 + xx, y = y0 + yy;
+        T val = from_f32<T>(0.f);
+        if (x < N && y < N) {
+            const bool is_e = v < HG;
+            if (is_e ? ta.biased : ta.gated)
+                val = eg[(((int64_t)b * N + x) * N + y) * ta.ld + (is_e ? ta.e_off + g * HG + v : ta.g_off + g * HG + v - HG)];
+        }
+        *reinterpret_cast<T*>(lds + xx * pitch + yy * A::kPairBytes + v * (int)sizeof(T)) = val;
+    }
+    for (int idx = tid; idx < nx * ny; idx += HG * 64) {
+        const int yy = idx % ny, xx = idx / ny, x = x0 + xx, y = y0 + yy;
+        float m = 0.f;
+        if (x < N && y < N && ta.mask) m = ta.mask[((int64_t)b * N + x) * N + y];
+        *reinterpret_cast<float*>(lds + A::kOffM + xx * mpitch + yy * 4) = m;
+    }
+}
+
+// tile (query tile at i0, key tile kt) of head `hh` of the group, accumulator layout
+template <typename T, int HG, int NT, bool PAD_COLS_NEG_INF>
+__device__ __forceinline__ void arm_stage_read(const ThirdArm& ta, const char* lds, int dir, int hh, int N, int r, int hi,
+                                               int i0, int kt, float (&biasM)[16], float (&gate)[16]) {
+    using A = ArmStage<T, HG, NT>;
+    const int pitch = A::pitch(dir), mpitch = A::mpitch(dir);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int kl = 32 * kt + acc_row(q, hi), k = kl, i = i0 + r;
+        const bool valid = i < N && k < N;
+        const int xx = dir == 0 ? r : kl, yy = dir == 0 ? kl : r;
+        const char* pp = lds + xx * pitch + yy * A::kPairBytes;
+        const float e = to_f32(*reinterpret_cast<const T*>(pp + hh * (int)sizeof(T)));
+        const float gl = to_f32(*reinterpret_cast<const T*>(pp + (HG + hh) * (int)sizeof(T)));
+        const float m = *reinterpret_cast<const float*>(lds + A::kOffM + xx * mpitch + yy * 4);
+        biasM[q] = (k < N && (!PAD_COLS_NEG_INF || i < N)) ? e + m : -INFINITY;
+        gate[q] = valid ? (ta.gated ? fast_sigmoid(gl + m) : 1.f) : 0.f;
+    }
+}
+
+template <typename T, int HG, int NT>
+__device__ __forceinline__ void arm_stage_put_grad(char* lds, int dir, int hh, int r, int hi, int kt,
+                                                   const float (&dE)[16], const float (&dG)[16]) {
+    using A = ArmStage<T, HG, NT>;
+    const int pitch = A::pitch(dir);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int kl = 32 * kt + acc_row(q, hi);
+        const int xx = dir == 0 ? r : kl, yy = dir == 0 ? kl : r;
+        char* pp = lds + xx * pitch + yy * A::kPairBytes;
+        *reinterpret_cast<T*>(pp + hh * (int)sizeof(T)) = from_f32<T>(dE[q]);
+        *reinterpret_cast<T*>(pp + (HG + hh) * (int)sizeof(T)) = from_f32<T>(dG[q]);
+    }
+}
+
+template <typename T, int HG, int NT>
+__device__ __forceinline__ void arm_stage_store_grad(const ThirdArm& ta, void* d_eg, int b, int dir, int g, int N,
+                                                     int i0, const char* lds, int tid) {
+    using A = ArmStage<T, HG, NT>;
+    if (!(ta.biased || ta.gated)) return;
+    const int nx = A::nx(dir), ny = A::ny(dir), x0 = dir == 0 ? i0 : 0, y0 = dir == 0 ? 0 : i0;
+    const int pitch = A::pitch(dir);
+    T* deg = reinterpret_cast<T*>(d_eg);
+    for (int idx = tid; idx < nx * ny * A::kVals; idx += HG * 64) {
+        const int v = idx % A::kVals, p = idx / A::kVals, yy = p % ny, xx = p / ny;
+        const int x = x0 + xx, y = y0 + yy;
+        const bool is_e = v < HG;
+        if (x < N && y < N && (is_e ? ta.biased : ta.gated))
+            deg[(((int64_t)b * N + x) * N + y) * ta.ld + (is_e ? ta.e_off + g * HG + v : ta.g_off + g * HG + v - HG)] =
+                *reinterpret_cast<const T*>(lds + xx * pitch + yy * A::kPairBytes + v * (int)sizeof(T));
+    }
+}
+
 }  // namespace tgt

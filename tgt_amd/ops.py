@@ -326,3 +326,113 @@ def adam_step_(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), e
     _lib.check(_lib.lib().tgt_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq),
                                         param.numel(), lr, betas[0], betas[1], eps, weight_decay,
                                         int(step), grad_scale, _stream()), 'tgt_adam_step')
+
+
+# ---------------------------------------------------------------------------
+# LayerNorm (reads x in its storage dtype, writes the consumer's dtype)
+# ---------------------------------------------------------------------------
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype):
+        _dev(x, weight, bias)
+        x = x.contiguous()
+        C_ = x.shape[-1]
+        rows = x.numel() // C_
+        w = weight.detach().float().contiguous()
+        b = bias.detach().float().contiguous()
+        y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        L = _lib.lib()
+        s, e = _prof_begin()
+        _lib.check(L.tgt_layer_norm_fwd(_ptr(x), _DT[x.dtype], _ptr(w), _ptr(b), _ptr(y), _DT[out_dtype],
+                                        _ptr(mean), _ptr(rstd), rows, C_, float(eps), _stream()), 'tgt_layer_norm_fwd')
+        _prof_end('tgt_layer_norm_fwd', s, e)
+        ctx.save_for_backward(x, w, mean, rstd)
+        ctx.wdtype = weight.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        C_ = x.shape[-1]
+        rows = x.numel() // C_
+        L = _lib.lib()
+        dx = torch.empty_like(x)
+        dgb = torch.empty(2, C_, dtype=torch.float32, device=x.device)
+        partial = torch.empty(L.tgt_layer_norm_parts() * 2 * C_, dtype=torch.float32, device=x.device)
+        s, e = _prof_begin()
+        _lib.check(L.tgt_layer_norm_bwd(_ptr(dy), _DT[dy.dtype], _ptr(x), _DT[x.dtype], _ptr(w), _ptr(mean), _ptr(rstd),
+                                        _ptr(dx), _DT[dx.dtype], _ptr(dgb[0]), _ptr(dgb[1]), _ptr(partial),
+                                        rows, C_, _stream()), 'tgt_layer_norm_bwd')
+        _prof_end('tgt_layer_norm_bwd', s, e)
+        return dx, dgb[0].to(ctx.wdtype), dgb[1].to(ctx.wdtype), None, None
+
+
+def _prof_begin():
+    if _PROFILE is None:
+        return None, None
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    return s, e
+
+
+def _prof_end(name, s, e):
+    if s is not None:
+        e.record()
+        _PROFILE.setdefault(name, []).append((s, e))
+
+
+def layer_norm(x, weight, bias, eps=1e-5, out_dtype=None):
+    """LayerNorm over the last axis.  out_dtype defaults to the autocast dtype when
+    autocast is on (what the consuming GEMM would cast to anyway), else x.dtype."""
+    if out_dtype is None:
+        out_dtype = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled('cuda') else x.dtype
+    return _LayerNorm.apply(x, weight, bias, eps, out_dtype)
+
+
+# ---------------------------------------------------------------------------
+# glue that is a single device op each
+# ---------------------------------------------------------------------------
+def drop_path_add_(x, residual, drop_prob, training):
+    """residual + DropPath(x)  (reference lib/tgt/layers/layers.py:169-174 followed by
+    the in-place add_ of :270-290) in ONE pass over the tensors."""
+    if drop_prob > 0 and training:
+        keep = 1.0 - drop_prob
+        scale = torch.empty([x.size(0)] + [1] * (x.ndim - 1), dtype=x.dtype, device=x.device)
+        scale.bernoulli_(keep).div_(keep)
+        return torch.addcmul(residual.to(x.dtype) if residual.dtype != x.dtype else residual, x, scale)
+    return x.add_(residual)
+
+
+class _MultiHotEmbed(torch.autograd.Function):
+    """sum_f W[idx[..., f]]  as  counts(idx) @ W: both directions are small GEMMs
+    instead of a gather and a sort-based scatter (the ATen embedding backward spends
+    ~5 ms per call on these few-hundred-row tables).  Row `padding_idx` gets no
+    gradient, like nn.Embedding(padding_idx=...)."""
+
+    @staticmethod
+    def forward(ctx, idx, weight, padding_idx, out_dtype):
+        lead, V = idx.shape[:-1], weight.shape[0]
+        flat = idx.reshape(-1, idx.shape[-1])
+        counts = torch.zeros(flat.shape[0], V, dtype=out_dtype, device=weight.device)
+        counts.scatter_add_(1, flat, torch.ones_like(flat, dtype=out_dtype))
+        ctx.save_for_backward(counts)
+        ctx.padding_idx, ctx.wdtype = padding_idx, weight.dtype
+        return (counts @ weight.to(out_dtype)).view(*lead, weight.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        counts, = ctx.saved_tensors
+        gw = counts.t() @ g.reshape(counts.shape[0], -1).to(counts.dtype)
+        if ctx.padding_idx is not None:
+            gw[ctx.padding_idx] = 0
+        return None, gw.to(ctx.wdtype), None, None
+
+
+def multi_hot_embed(idx, weight, padding_idx=None, out_dtype=None):
+    """idx: (..., F) long with values < weight.shape[0]; returns (..., C) = sum over F of rows."""
+    if out_dtype is None:
+        out_dtype = torch.get_autocast_dtype('cuda') if (weight.is_cuda and torch.is_autocast_enabled('cuda')) else weight.dtype
+    return _MultiHotEmbed.apply(idx, weight, padding_idx, out_dtype)

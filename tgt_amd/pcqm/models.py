@@ -10,7 +10,9 @@ import torch
 from torch import nn
 import torch.nn.functional as F
 
+from .. import ops
 from ..tgt import TGT_Encoder, Graph
+from ..tgt.layers.layers import LayerNorm
 
 NODE_FEATURES_OFFSET = 128      # reference lib/models/pcqm/consts.py:1-7
 NUM_NODE_FEATURES = 9
@@ -35,9 +37,20 @@ class GaussianLayer(nn.Module):
         nn.init.constant_(self.bias.weight, 0)
         nn.init.constant_(self.mul.weight, 1)
 
-    def forward(self, x, edge_types):
-        mul = self.mul(edge_types).sum(dim=-2)
-        bias = self.bias(edge_types).sum(dim=-2)
+    def pair_affine(self, type_i, type_j):
+        """mul/bias summed over the (i-type, j-type) pair, built from PER-NODE gathers and a
+        broadcast add: same value as embedding the (B,N,N,2) pair tensor, N times fewer
+        indices through the embedding backward."""
+        mul = self.mul(type_i).unsqueeze(2) + self.mul(type_j).unsqueeze(1)        # (B,N,N,1)
+        bias = self.bias(type_i).unsqueeze(2) + self.bias(type_j).unsqueeze(1)
+        return mul, bias
+
+    def forward(self, x, edge_types=None, affine=None):
+        if affine is None:
+            mul = self.mul(edge_types).sum(dim=-2)
+            bias = self.bias(edge_types).sum(dim=-2)
+        else:
+            mul, bias = affine
         x = (mul * x.unsqueeze(-1) + bias).float()
         mean = self.means.weight.float().view(-1)
         std = self.stds.weight.float().view(-1).abs() + 1e-2
@@ -64,7 +77,9 @@ class Gaussian3DEmbed(nn.Module):
         self.gbf = GaussianLayer(num_kernel, num_edges)
         self.gbf_proj = NonLinear(num_kernel, num_heads)
 
-    def forward(self, dist, node_type_edge):
+    def forward(self, dist, node_type_edge=None, node_types=None):
+        if node_types is not None:          # (type_i, type_j) per node: the fast path
+            return self.gbf_proj(self.gbf(dist, affine=self.gbf.pair_affine(*node_types)))
         return self.gbf_proj(self.gbf(dist, node_type_edge.long()))
 
 
@@ -105,15 +120,16 @@ class EmbedInput(nn.Module):
     def forward(self, inputs):
         g = Graph(inputs)
         nodef = g.node_features.long()
-        h = self.nodef_embed(nodef).sum(dim=2)
         hops = g.distance_matrix.long().clamp(max=self.upto_hop + 1)
-        e = self.dist_embed(hops) + self.featm_embed(g.feature_matrix.long()).sum(dim=-2)
+        # sums of embedding rows as count-matrix GEMMs (forward AND backward)
+        h = ops.multi_hot_embed(nodef, self.nodef_embed.weight, padding_idx=0)
+        n_hop = self.dist_embed.weight.shape[0]
+        pair_idx = torch.cat([hops.unsqueeze(-1), g.feature_matrix.long() + n_hop], dim=-1)
+        pair_w = torch.cat([self.dist_embed.weight, self.featm_embed.weight], dim=0)
+        e = ops.multi_hot_embed(pair_idx, pair_w, padding_idx=n_hop)
         if self.embed_3d_type == 'gaussian':
-            n = nodef.size(1)
             atom = nodef[:, :, 0]
-            pair = torch.stack([atom.unsqueeze(2).expand(-1, -1, n),
-                                (atom + NODE_FEATURES_OFFSET).unsqueeze(1).expand(-1, n, -1)], dim=-1)
-            e = e + self.m3d_embed(g.dist_input, pair)
+            e = e + self.m3d_embed(g.dist_input, node_types=(atom, atom + NODE_FEATURES_OFFSET))
         elif self.embed_3d_type == 'fourier':
             e = e + self.m3d_embed(g.dist_input)
         edge_mask = g.edge_mask.unsqueeze(-1).to(e.dtype)
@@ -138,12 +154,12 @@ class _Task(nn.Module):
                                       upto_hop=upto_hop, embed_3d_type=embed_3d_type,
                                       num_3d_kernels=num_3d_kernels)
         if self._node_ended:
-            self.final_ln_node = nn.LayerNorm(self.node_width)
+            self.final_ln_node = LayerNorm(self.node_width)
             self.pred = nn.Linear(self.node_width, 1)
             nn.init.constant_(self.pred.bias, HL_MEAN)
         if self._edge_ended:
             self.num_dist_bins = num_dist_bins
-            self.final_ln_edge = nn.LayerNorm(self.edge_width)
+            self.final_ln_edge = LayerNorm(self.edge_width)
             self.dist_pred = nn.Linear(self.edge_width, num_dist_bins)
 
     def _gap_head(self, g):

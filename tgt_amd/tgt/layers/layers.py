@@ -9,6 +9,14 @@ from .activations import get_activation
 from .triplet import get_triplet_layer
 
 
+class LayerNorm(nn.LayerNorm):
+    """nn.LayerNorm parameters / state_dict keys, HIP forward+backward: reads the
+    residual stream in its storage dtype and emits the consuming GEMM's dtype."""
+
+    def forward(self, x):
+        return ops.layer_norm(x, self.weight, self.bias, self.eps)
+
+
 class EGT_Attention(nn.Module):
     """Node attention biased and gated by edge channels.
     Reference lib/tgt/layers/layers.py:15-84."""
@@ -26,8 +34,8 @@ class EGT_Attention(nn.Module):
         self._dot_dim = node_width // num_heads
         self._scale_factor = self._dot_dim ** -0.5
 
-        self.mha_ln_h = nn.LayerNorm(node_width)
-        self.mha_ln_e = nn.LayerNorm(edge_width)
+        self.mha_ln_h = LayerNorm(node_width)
+        self.mha_ln_e = LayerNorm(edge_width)
         self.lin_QKV = nn.Linear(node_width, node_width * 3)
         self.lin_EG = nn.Linear(edge_width, num_heads * 2)
         self.lin_O_h = nn.Linear(node_width, node_width)
@@ -64,8 +72,8 @@ class EdgeUpdate(nn.Module):
         assert not (node_width % num_heads), 'node_width must be divisible by num_heads'
         self._dot_dim = node_width // num_heads
         self._scale_factor = self._dot_dim ** -0.5
-        self.mha_ln_h = nn.LayerNorm(node_width)
-        self.mha_ln_e = nn.LayerNorm(edge_width)
+        self.mha_ln_h = LayerNorm(node_width)
+        self.mha_ln_e = LayerNorm(edge_width)
         self.lin_QK = nn.Linear(node_width, node_width * 2)
         self.lin_E = nn.Linear(edge_width, num_heads)
         self.lin_O_e = nn.Linear(num_heads, edge_width)
@@ -87,7 +95,7 @@ class FFN(nn.Module):
         self.activation = activation
         self.ffn_fn, self.act_mul = get_activation(activation)
         inner_dim = round(width * multiplier)
-        self.ffn_ln = nn.LayerNorm(width)
+        self.ffn_ln = LayerNorm(width)
         self.lin_W1 = nn.Linear(width, inner_dim * self.act_mul)
         self.lin_W2 = nn.Linear(inner_dim, width)
         self.dropout = nn.Dropout(act_dropout)
@@ -167,14 +175,15 @@ class TGT_Layer(nn.Module):
         h, e, mask = g.h, g.e, g.mask
         h_in, e_in = h, e
         h, e = self.update(h, e, mask)
+        dp, tr = self.drop_path.drop_path, self.training
         if self.node_update:
-            h = self.drop_path(h).add_(h_in)
-            h = self.drop_path(self.node_ffn(h)).add_(h)
+            h = ops.drop_path_add_(h, h_in, dp, tr)
+            h = ops.drop_path_add_(self.node_ffn(h), h, dp, tr)
         if self.edge_update:
-            e = self.drop_path(e).add_(e_in)
+            e = ops.drop_path_add_(e, e_in, dp, tr)
             if self._triplet_update:
-                e = self.drop_path(self.tria(e, mask)).add_(e)
-            e = self.drop_path(self.edge_ffn(e)).add_(e)
+                e = ops.drop_path_add_(self.tria(e, mask), e, dp, tr)
+            e = ops.drop_path_add_(self.edge_ffn(e), e, dp, tr)
         g = g.copy()
         g.h, g.e = h, e
         return g

@@ -20,6 +20,13 @@ import torch.nn.functional as F
 from ... import layout, ops
 
 
+class LayerNorm(nn.LayerNorm):
+    """nn.LayerNorm parameters, HIP kernels (see layers.LayerNorm)."""
+
+    def forward(self, x):
+        return ops.layer_norm(x, self.weight, self.bias, self.eps)
+
+
 def _no_attention_dropout(mod):
     if mod.attention_dropout > 0 and mod.training:
         raise NotImplementedError(
@@ -59,7 +66,7 @@ class TripletAttention(_TripletBase):
         self._scale_factor = self._dot_dim ** -0.5
         nb = num_heads * (2 if self.gated else 1)
         bias_name = 'lin_EG' if self.gated else 'lin_E'
-        self.tri_ln_e = nn.LayerNorm(edge_width)
+        self.tri_ln_e = LayerNorm(edge_width)
         self.lin_QKV_in = nn.Linear(edge_width, edge_width * 3)
         if self.biased:
             setattr(self, bias_name + '_in', nn.Linear(edge_width, nb))
@@ -114,7 +121,7 @@ class TripletAggregate(_TripletBase):
         assert not (edge_width % num_heads), 'edge_width must be divisible by num_heads'
         self._dot_dim = edge_width // num_heads
         self._scale_factor = self._dot_dim ** -0.5
-        self.tri_ln_e = nn.LayerNorm(edge_width)
+        self.tri_ln_e = LayerNorm(edge_width)
         self.lin_V = nn.Linear(edge_width, edge_width * 2)
         if self.gated:
             self.lin_EG = nn.Linear(edge_width, num_heads * 4)
@@ -152,7 +159,7 @@ class TriangularUpdate(_TripletBase):
 
     def __init__(self, edge_width, num_heads, attention_dropout=0):
         super().__init__(edge_width, num_heads, attention_dropout)
-        self.tri_ln_e = nn.LayerNorm(edge_width)
+        self.tri_ln_e = LayerNorm(edge_width)
         self.lin_V = nn.Linear(edge_width, num_heads * 4)
         self.lin_E = nn.Linear(edge_width, num_heads * 4)
         self.lin_O = nn.Linear(num_heads * 2, edge_width * 2)

@@ -1,0 +1,100 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the hand-written kernels at the BASELINE shapes
+(B=256, N=32, C=256, Ht=16; W=768, Hn=64), HIP events on the launch stream.
+Prints algorithmic GB/s per kernel (bytes as in DESIGN.md §4)."""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tgt_amd import ops  # noqa: E402
+
+
+def timeit(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--B', type=int, default=256)
+    ap.add_argument('--N', type=int, default=32)
+    ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--dtype', default='bf16')
+    ap.add_argument('--only', default='')
+    a = ap.parse_args()
+    dt = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[a.dtype]
+    esz = 4 if a.dtype == 'fp32' else 2
+    B, N, C, Ht, W, Hn = a.B, a.N, 256, 16, 768, 64
+    dev = 'cuda'
+    torch.manual_seed(0)
+    mask = torch.zeros(B, N, N, device=dev)
+    out = {}
+    n2 = N * N
+
+    if not a.only or 'tri' in a.only:
+        L = ops.TripletLayout(C, Ht)
+        fused = torch.randn(B, N, N, L.width, device=dev, dtype=dt).requires_grad_(True)
+        va = ops.triplet_attention(fused, mask, L)
+        g = torch.randn_like(va)
+        fb = B * (2 * (4 * n2 * C + 2 * n2 * Ht) * esz + n2 * 4)
+        bb = B * (2 * (7 * n2 * C + 4 * n2 * Ht) * esz + n2 * 4)
+        t = timeit(lambda: ops.triplet_attention(fused, mask, L), a.iters)
+        out['tri_att_fwd'] = dict(ms=round(t, 4), GBs=round(fb / t / 1e6, 1))
+        t2 = timeit(lambda: torch.autograd.grad(ops.triplet_attention(fused, mask, L), fused, g), a.iters)
+        out['tri_att_bwd'] = dict(ms=round(t2 - t, 4), GBs=round(bb / (t2 - t) / 1e6, 1))
+        del fused, va, g
+
+    if not a.only or 'agg' in a.only:
+        L = ops.AggregateLayout(C, Ht)
+        fused = torch.randn(B, N, N, L.width, device=dev, dtype=dt).requires_grad_(True)
+        g = torch.randn(B, N, N, 2 * C, device=dev, dtype=dt)
+        fb = B * (2 * (2 * n2 * C + 2 * n2 * Ht) * esz + n2 * 4)
+        t = timeit(lambda: ops.triplet_aggregate(fused, mask, L), a.iters)
+        out['tri_agg_fwd'] = dict(ms=round(t, 4), GBs=round(fb / t / 1e6, 1))
+        t2 = timeit(lambda: torch.autograd.grad(ops.triplet_aggregate(fused, mask, L), fused, g), a.iters)
+        bb = B * (2 * (3 * n2 * C + 4 * n2 * Ht) * esz + n2 * 4)
+        out['tri_agg_bwd'] = dict(ms=round(t2 - t, 4), GBs=round(bb / (t2 - t) / 1e6, 1))
+        del fused, g
+
+    if not a.only or 'node' in a.only:
+        qkv = torch.randn(B, N, 3 * W, device=dev, dtype=dt).requires_grad_(True)
+        eg = torch.randn(B, N, N, 2 * Hn, device=dev, dtype=dt).requires_grad_(True)
+        gv = torch.randn(B, N, W, device=dev, dtype=dt)
+        gh = torch.randn(B, N, N, Hn, device=dev, dtype=dt)
+        fb = B * ((4 * N * W + 3 * n2 * Hn) * esz + n2 * 4)
+        bb = B * ((7 * N * W + 5 * n2 * Hn) * esz + n2 * 4)
+        t = timeit(lambda: ops.node_attention(qkv, eg, mask, Hn), a.iters)
+        out['node_att_fwd'] = dict(ms=round(t, 4), GBs=round(fb / t / 1e6, 1))
+
+        def fb_():
+            v, h = ops.node_attention(qkv, eg, mask, Hn)
+            torch.autograd.grad([v, h], [qkv, eg], [gv, gh])
+        t2 = timeit(fb_, a.iters)
+        out['node_att_bwd'] = dict(ms=round(t2 - t, 4), GBs=round(bb / (t2 - t) / 1e6, 1))
+        del qkv, eg
+
+    if not a.only or 'ln' in a.only:
+        x = torch.randn(B * n2, C, device=dev, dtype=dt).requires_grad_(True)
+        w, b = torch.ones(C, device=dev, requires_grad=True), torch.zeros(C, device=dev, requires_grad=True)
+        g = torch.randn(B * n2, C, device=dev, dtype=dt)
+        t = timeit(lambda: ops.layer_norm(x, w, b, 1e-5, dt), a.iters)
+        out['ln_fwd_edge'] = dict(ms=round(t, 4), GBs=round(2 * x.numel() * esz / t / 1e6, 1))
+        t2 = timeit(lambda: torch.autograd.grad(ops.layer_norm(x, w, b, 1e-5, dt), [x, w, b], g), a.iters)
+        out['ln_bwd_edge'] = dict(ms=round(t2 - t, 4), GBs=round(3 * x.numel() * esz / (t2 - t) / 1e6, 1))
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()
