@@ -91,6 +91,8 @@ def main():
     ap.add_argument('--nodes', type=int, default=32)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp16', 'fp32'])
+    ap.add_argument('--no-gemm-tuning', action='store_true', help='library default GEMM heuristics')
+    ap.add_argument('--write-gemm-tuning', default='', help='tune online and write the TunableOp file here')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -110,6 +112,13 @@ def main():
     from tgt_amd.training.configs import tgt_at_24l
     from tgt_amd.training.step import Trainer, StepConfig, preprocess_batch
     from tgt_amd.training.synthetic import make_batch, batch_seed
+
+    if not args.no_gemm_tuning:
+        from tgt_amd.training.gemm_tuning import enable_gemm_tuning
+        if args.write_gemm_tuning:
+            enable_gemm_tuning(online=True, filename=args.write_gemm_tuning, max_ms=150, max_iters=50)
+        else:
+            enable_gemm_tuning(online=True)
 
     mcfg = tgt_at_24l()
     torch.manual_seed(0)

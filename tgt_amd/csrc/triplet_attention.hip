@@ -472,6 +472,10 @@ static int launch_tri(const tgt_triplet_attention_args& a, bool bwd, hipStream_t
 
 template <typename T, int D>
 static int dispatch_hg(const tgt_triplet_attention_args& a, bool bwd, hipStream_t st) {
+    static const int hg = getenv("TGT_TRI_HG") ? atoi(getenv("TGT_TRI_HG")) : 8;     // 8 heads/workgroup: 256-byte row pieces
+    if constexpr (D == 16 && sizeof(T) == 2) {
+        if (hg == 8 && a.H % 8 == 0 && a.N <= 32) return launch_tri_nt<T, D, 8, 1>(a, bwd, st);
+    }
     if (a.H % 4 == 0) return launch_tri<T, D, 4>(a, bwd, st);
     if constexpr (D * sizeof(T) >= 16) return launch_tri<T, D, 1>(a, bwd, st);
     return set_error(TGT_ERR_UNSUPPORTED, "triplet attention: H=%d not a multiple of 4 with D=%d", a.H, D);

@@ -436,3 +436,72 @@ def multi_hot_embed(idx, weight, padding_idx=None, out_dtype=None):
     if out_dtype is None:
         out_dtype = torch.get_autocast_dtype('cuda') if (weight.is_cuda and torch.is_autocast_enabled('cuda')) else weight.dtype
     return _MultiHotEmbed.apply(idx, weight, padding_idx, out_dtype)
+
+
+# ---------------------------------------------------------------------------
+# Linear with a split-M weight gradient
+# ---------------------------------------------------------------------------
+def _wgrad_chunks(M):
+    """number of row chunks for dW = sum_c dY_c^T X_c (rows per chunk >= 1024, <= 128 chunks)"""
+    for P in (128, 64, 32, 16, 8, 4, 2):
+        if M % P == 0 and M // P >= 1024:
+            return P
+    return 1
+
+
+class _Linear(torch.autograd.Function):
+    """y = x W^T + b on the library GEMM, with the weight gradient computed as a BATCHED
+    GEMM over row chunks + an fp32 sum.  dW = dY^T X contracts over M = B*N*N = 262144 rows
+    into a tiny (out,in) result; as one GEMM the library runs it on a handful of
+    workgroups (0.4-0.8 ms), as 64-128 independent chunk products it is HBM-bound
+    (57 us for 256x256, measured; tools/wgrad_probe.py)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cd):
+        xs = x.shape
+        x2 = x.reshape(-1, xs[-1])
+        if x2.dtype != cd:
+            x2 = x2.to(cd)
+        w = weight if weight.dtype == cd else weight.to(cd)
+        b = None if bias is None else (bias if bias.dtype == cd else bias.to(cd))
+        # the result must own its storage (not be a view): the layer adds the residual in place
+        y = torch.empty(*xs[:-1], weight.shape[0], dtype=cd, device=x.device)
+        y2 = y.view(-1, weight.shape[0])
+        if b is None:
+            torch.mm(x2, w.t(), out=y2)
+        else:
+            torch.addmm(b, x2, w.t(), out=y2)
+        ctx.save_for_backward(x2, w)
+        ctx.meta = (xs, x.dtype, weight.dtype, None if bias is None else bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        xs, xdt, wdt, bdt = ctx.meta
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if dy2.dtype != w.dtype:
+            dy2 = dy2.to(w.dtype)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = (dy2 @ w).view(xs).to(xdt)
+        if ctx.needs_input_grad[1]:
+            M = x2.shape[0]
+            P = _wgrad_chunks(M)
+            if P > 1:
+                part = torch.bmm(dy2.view(P, M // P, -1).transpose(1, 2), x2.view(P, M // P, -1),
+                                 out_dtype=torch.float32) if dy2.dtype != torch.float32 else \
+                    torch.bmm(dy2.view(P, M // P, -1).transpose(1, 2), x2.view(P, M // P, -1))
+                dw = part.sum(0).to(wdt)
+            else:
+                dw = (dy2.t() @ x2).to(wdt)
+        if bdt is not None and ctx.needs_input_grad[2]:
+            db = dy2.sum(0, dtype=torch.float32).to(bdt)
+        return dx, dw, db, None
+
+
+def linear(x, weight, bias=None):
+    """F.linear replacement for the TGT modules (autocast-aware: computes in the autocast
+    dtype when autocast is on, else in x.dtype)."""
+    cd = torch.get_autocast_dtype('cuda') if (x.is_cuda and torch.is_autocast_enabled('cuda')) else x.dtype
+    return _Linear.apply(x, weight, bias, cd)

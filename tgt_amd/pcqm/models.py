@@ -12,7 +12,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..tgt import TGT_Encoder, Graph
-from ..tgt.layers.layers import LayerNorm
+from ..tgt.layers.layers import LayerNorm, Linear
 
 NODE_FEATURES_OFFSET = 128      # reference lib/models/pcqm/consts.py:1-7
 NUM_NODE_FEATURES = 9
@@ -160,7 +160,7 @@ class _Task(nn.Module):
         if self._edge_ended:
             self.num_dist_bins = num_dist_bins
             self.final_ln_edge = LayerNorm(self.edge_width)
-            self.dist_pred = nn.Linear(self.edge_width, num_dist_bins)
+            self.dist_pred = Linear(self.edge_width, num_dist_bins)
 
     def _gap_head(self, g):
         h = self.final_ln_node(g.h)

@@ -17,6 +17,13 @@ class LayerNorm(nn.LayerNorm):
         return ops.layer_norm(x, self.weight, self.bias, self.eps)
 
 
+class Linear(nn.Linear):
+    """nn.Linear parameters / state_dict keys; GEMMs through ops.linear (split-M weight gradient)."""
+
+    def forward(self, x):
+        return ops.linear(x, self.weight, self.bias)
+
+
 class EGT_Attention(nn.Module):
     """Node attention biased and gated by edge channels.
     Reference lib/tgt/layers/layers.py:15-84."""
@@ -36,11 +43,11 @@ class EGT_Attention(nn.Module):
 
         self.mha_ln_h = LayerNorm(node_width)
         self.mha_ln_e = LayerNorm(edge_width)
-        self.lin_QKV = nn.Linear(node_width, node_width * 3)
-        self.lin_EG = nn.Linear(edge_width, num_heads * 2)
-        self.lin_O_h = nn.Linear(node_width, node_width)
+        self.lin_QKV = Linear(node_width, node_width * 3)
+        self.lin_EG = Linear(edge_width, num_heads * 2)
+        self.lin_O_h = Linear(node_width, node_width)
         if edge_update:
-            self.lin_O_e = nn.Linear(num_heads, edge_width)
+            self.lin_O_e = Linear(num_heads, edge_width)
 
     def forward(self, h, e, mask):
         B, N = h.shape[0], h.shape[1]
@@ -74,9 +81,9 @@ class EdgeUpdate(nn.Module):
         self._scale_factor = self._dot_dim ** -0.5
         self.mha_ln_h = LayerNorm(node_width)
         self.mha_ln_e = LayerNorm(edge_width)
-        self.lin_QK = nn.Linear(node_width, node_width * 2)
-        self.lin_E = nn.Linear(edge_width, num_heads)
-        self.lin_O_e = nn.Linear(num_heads, edge_width)
+        self.lin_QK = Linear(node_width, node_width * 2)
+        self.lin_E = Linear(edge_width, num_heads)
+        self.lin_O_e = Linear(num_heads, edge_width)
 
     def forward(self, h, e, mask):
         qk = self.lin_QK(self.mha_ln_h(h))
@@ -96,8 +103,8 @@ class FFN(nn.Module):
         self.ffn_fn, self.act_mul = get_activation(activation)
         inner_dim = round(width * multiplier)
         self.ffn_ln = LayerNorm(width)
-        self.lin_W1 = nn.Linear(width, inner_dim * self.act_mul)
-        self.lin_W2 = nn.Linear(inner_dim, width)
+        self.lin_W1 = Linear(width, inner_dim * self.act_mul)
+        self.lin_W2 = Linear(inner_dim, width)
         self.dropout = nn.Dropout(act_dropout)
 
     def forward(self, x):

@@ -20,6 +20,13 @@ import torch.nn.functional as F
 from ... import layout, ops
 
 
+class Linear(nn.Linear):
+    """nn.Linear parameters; GEMMs through ops.linear (see layers.Linear)."""
+
+    def forward(self, x):
+        return ops.linear(x, self.weight, self.bias)
+
+
 class LayerNorm(nn.LayerNorm):
     """nn.LayerNorm parameters, HIP kernels (see layers.LayerNorm)."""
 
@@ -52,7 +59,7 @@ class _TripletBase(nn.Module):
         """lin_O on the kernel's [dir][h][d] channel order (reference order is
         d*2H + dir*H + h, triplet.py:248)."""
         cols = self._index('va', lambda: layout.va_cols_head_major(self.edge_width, self.num_heads), va.device)
-        return F.linear(va, self.lin_O.weight[:, cols], self.lin_O.bias)
+        return ops.linear(va, self.lin_O.weight[:, cols], self.lin_O.bias)
 
 
 class TripletAttention(_TripletBase):
@@ -67,13 +74,13 @@ class TripletAttention(_TripletBase):
         nb = num_heads * (2 if self.gated else 1)
         bias_name = 'lin_EG' if self.gated else 'lin_E'
         self.tri_ln_e = LayerNorm(edge_width)
-        self.lin_QKV_in = nn.Linear(edge_width, edge_width * 3)
+        self.lin_QKV_in = Linear(edge_width, edge_width * 3)
         if self.biased:
-            setattr(self, bias_name + '_in', nn.Linear(edge_width, nb))
-        self.lin_QKV_out = nn.Linear(edge_width, edge_width * 3)
+            setattr(self, bias_name + '_in', Linear(edge_width, nb))
+        self.lin_QKV_out = Linear(edge_width, edge_width * 3)
         if self.biased:
-            setattr(self, bias_name + '_out', nn.Linear(edge_width, nb))
-        self.lin_O = nn.Linear(edge_width * 2, edge_width)
+            setattr(self, bias_name + '_out', Linear(edge_width, nb))
+        self.lin_O = Linear(edge_width * 2, edge_width)
         self._bias_name = bias_name
         self._layout = ops.TripletLayout(edge_width, num_heads, gated=self.gated, biased=self.biased)
 
@@ -97,7 +104,7 @@ class TripletAttention(_TripletBase):
         B, N = e.shape[0], e.shape[1]
         x = self.tri_ln_e(e)
         w, b = self._fused_projection(e.device)
-        fused = F.linear(x, w, b)
+        fused = ops.linear(x, w, b)
         va = ops.triplet_attention(fused, ops.as_mask3(mask, B, N), self._layout)
         return self._out_proj(va)
 
@@ -122,12 +129,12 @@ class TripletAggregate(_TripletBase):
         self._dot_dim = edge_width // num_heads
         self._scale_factor = self._dot_dim ** -0.5
         self.tri_ln_e = LayerNorm(edge_width)
-        self.lin_V = nn.Linear(edge_width, edge_width * 2)
+        self.lin_V = Linear(edge_width, edge_width * 2)
         if self.gated:
-            self.lin_EG = nn.Linear(edge_width, num_heads * 4)
+            self.lin_EG = Linear(edge_width, num_heads * 4)
         else:
-            self.lin_E = nn.Linear(edge_width, num_heads * 2)
-        self.lin_O = nn.Linear(edge_width * 2, edge_width)
+            self.lin_E = Linear(edge_width, num_heads * 2)
+        self.lin_O = Linear(edge_width * 2, edge_width)
         self._layout = ops.AggregateLayout(edge_width, num_heads, gated=self.gated)
 
     def forward(self, e, mask):
@@ -141,7 +148,7 @@ class TripletAggregate(_TripletBase):
         if pad:
             ws.append(ws[0].new_zeros(pad, self.edge_width))
             bs.append(bs[0].new_zeros(pad))
-        fused = F.linear(x, torch.cat(ws, 0), torch.cat(bs, 0))
+        fused = ops.linear(x, torch.cat(ws, 0), torch.cat(bs, 0))
         va = ops.triplet_aggregate(fused, ops.as_mask3(mask, B, N), self._layout)
         return self._out_proj(va)
 
@@ -160,9 +167,9 @@ class TriangularUpdate(_TripletBase):
     def __init__(self, edge_width, num_heads, attention_dropout=0):
         super().__init__(edge_width, num_heads, attention_dropout)
         self.tri_ln_e = LayerNorm(edge_width)
-        self.lin_V = nn.Linear(edge_width, num_heads * 4)
-        self.lin_E = nn.Linear(edge_width, num_heads * 4)
-        self.lin_O = nn.Linear(num_heads * 2, edge_width * 2)
+        self.lin_V = Linear(edge_width, num_heads * 4)
+        self.lin_E = Linear(edge_width, num_heads * 4)
+        self.lin_O = Linear(num_heads * 2, edge_width * 2)
 
     def forward(self, e, mask):
         raise NotImplementedError("triplet_type 'tiangular_update' has no HIP kernel yet")
