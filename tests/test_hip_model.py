@@ -177,3 +177,72 @@ def test_trainer_step_runs_and_matches_torch_adam():
     p1 = torch.cat([p.detach().reshape(-1) for p in m1.parameters()])
     p2 = torch.cat([p.detach().reshape(-1) for p in m2.parameters()])
     assert rel(p1, p2) < 1e-4
+
+
+def test_cfg4_two_node_tiles_model_step():
+    """BASELINE cfg 4 shape class: N up to 48 (two node tiles), Gaussian 3-D embedding,
+    ragged batch; fp32 HIP path vs the oracle (outputs, loss, a few gradients)."""
+    from tgt_amd.pcqm import TGT_Multi
+    from tgt_amd.training.step import pretrain_loss, StepConfig
+    kwargs = dict(gu.MODEL_CASES['multi_at_tiny'][1])
+    geom = dict(B=3, N=48, num_nodes=[48, 33, 40])
+    model = gu.fill_params(TGT_Multi(**kwargs), seed=21).cuda().train()
+    ref = gu.fill_params(om.TGT_Multi(**kwargs), seed=21).train()
+    cpu = gu.model_batch(geom, seed=22)
+    batch = {k: v.cuda() for k, v in cpu.items()}
+    cfg = StepConfig(num_dist_bins=kwargs['num_dist_bins'], mixed_precision=None)
+    out = model(batch)
+    loss = pretrain_loss(out, batch, cfg)
+    loss.backward()
+    g_ref, l_ref = ref(cpu)
+    loss_ref = torch.nn.functional.l1_loss(g_ref, cpu['target']) + 0.1 * core.binned_distance_xent(
+        l_ref, core.pairwise_dist(cpu['dft_coords']), cpu['edge_mask'], kwargs['num_dist_bins'], 8)
+    loss_ref.backward()
+    assert rel(out[0], g_ref) < 1e-3 and rel(out[1], l_ref) < 1e-3
+    assert abs(float(loss) - float(loss_ref)) < 1e-4 * abs(float(loss_ref))
+    pm, pr = dict(model.named_parameters()), dict(ref.named_parameters())
+    for k in gu.GRAD_PROBE_KEYS:
+        if k in pm and pr[k].grad is not None:
+            assert rel(pm[k].grad, pr[k].grad) < 5e-3, (k, rel(pm[k].grad, pr[k].grad))
+
+
+def test_cfg5_two_stage_fp16_inference():
+    """BASELINE cfg 5 shape class: TGT-Agx2 (shared-weight x2, aggregate) distance predictor ->
+    argmax bins -> bins2dist -> gap predictor under fp16 autocast (the reference's
+    `mixed_precision: true`), eval mode; vs the fp32 oracle."""
+    from tgt_amd.pcqm import TGT_Distance, TGT_Gap
+    dk = dict(gu.MODEL_CASES['dist_agx2_tiny'][1])
+    gk = dict(gu.MODEL_CASES['gap_at_tiny'][1])
+    gk.update(embed_3d_type='gaussian', triplet_type='aggregate', layer_multiplier=2)
+    geom = dict(B=4, N=9, num_nodes=[9, 6, 9, 4])
+    cpu = gu.model_batch(geom, seed=31)
+    batch = {k: v.cuda() for k, v in cpu.items()}
+
+    def run(dist_model, gap_model, b, half):
+        with torch.no_grad():
+            logits = dist_model(b)
+            bins = logits.float().argmax(-1)
+            bins = torch.triu(bins, 1)
+            dist = core.bins_to_dist(bins, 8 / (dk['num_dist_bins'] - 1)).to(b['dist_input'].dtype)
+            b2 = dict(b)
+            b2['dist_input'] = dist
+            return logits, gap_model(b2)
+
+    d_ref = gu.fill_params(om.TGT_Distance(**dk), seed=32).eval()
+    g_ref = gu.fill_params(om.TGT_Gap(**gk), seed=33).eval()
+    l_ref, gap_ref = run(d_ref, g_ref, cpu, False)
+    d_hip = gu.fill_params(TGT_Distance(**dk), seed=32).cuda().eval()
+    g_hip = gu.fill_params(TGT_Gap(**gk), seed=33).cuda().eval()
+    hb = batch
+    with torch.autocast('cuda', dtype=torch.float16):
+        l_hip, gap_hip = run(d_hip, g_hip, hb, True)
+    assert l_hip.dtype == torch.float16 and torch.isfinite(l_hip).all() and torch.isfinite(gap_hip).all()
+    assert rel(l_hip, l_ref) < 2e-2, rel(l_hip, l_ref)
+    # the gap stage sees the hip model's own predicted bins; feed it the oracle's to isolate it
+    with torch.no_grad():
+        bins = torch.triu(l_ref.argmax(-1), 1)
+        b2 = dict(hb)
+        b2['dist_input'] = core.bins_to_dist(bins, 8 / (dk['num_dist_bins'] - 1)).cuda()
+        with torch.autocast('cuda', dtype=torch.float16):
+            gap_iso = g_hip(b2)
+    assert (gap_iso.float().cpu() - gap_ref).abs().max() < 3e-2 * gap_ref.abs().max()
