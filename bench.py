@@ -46,20 +46,19 @@ def algorithmic_bytes(kind, B, N, C, Ht, esz=2):
     return B * per_graph
 
 
-def cpu_baseline(batch_graphs=8, nodes=32, budget_s=12.0, max_steps=3):
-    """The oracle's TGT-At 24L training step on the host CPU (fp32), micro-batch
-    of `batch_graphs` graphs of the same synthetic workload."""
+def cpu_baseline_worker(threads, batch_graphs=8, nodes=32, budget_s=10.0, max_steps=3):
+    """(runs in a subprocess) the oracle's TGT-At 24L training step on the host CPU (fp32),
+    micro-batch of `batch_graphs` graphs of the same synthetic workload."""
     from oracle import modules as om, core
     from tgt_amd.training.configs import tgt_at_24l
     from tgt_amd.training.synthetic import make_batch, batch_seed
-    threads = os.cpu_count() or 1
     torch.set_num_threads(threads)
     torch.manual_seed(0)
     model = om.TGT_Multi(**tgt_at_24l()).train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
 
-    def one_step(step):
-        b = make_batch(batch_graphs, nodes, batch_seed(step))
+    def one_step(step, graphs):
+        b = make_batch(graphs, nodes, batch_seed(step))
         nm = b['node_mask']
         b['edge_mask'] = nm.unsqueeze(-1) * nm.unsqueeze(-2)
         coords = core.smoothed_coord_noise(b['dft_coords'], b['edge_mask'], 0.2, 1.0)
@@ -71,15 +70,35 @@ def cpu_baseline(batch_graphs=8, nodes=32, budget_s=12.0, max_steps=3):
         loss.backward()
         opt.step()
 
-    one_step(0)                                   # untimed warm-up (allocator, thread pool)
+    one_step(0, 2)                                # untimed warm-up (allocator, thread pool)
     t0, n = time.perf_counter(), 0
     while n < max_steps and (n == 0 or time.perf_counter() - t0 < budget_s):
-        one_step(1 + n)
+        one_step(1 + n, batch_graphs)
         n += 1
     dt = time.perf_counter() - t0
-    return dict(value=round(batch_graphs * n / dt, 3), unit='graphs/s', cores=threads, kind='port',
-                sample=f'oracle TGT-At 24L train step (fwd+loss+bwd+Adam), fp32, {n} step(s) of '
-                       f'{batch_graphs} synthetic N={nodes} graphs, dropouts on')
+    print(json.dumps(dict(value=round(batch_graphs * n / dt, 3), unit='graphs/s', cores=threads, kind='port',
+                          sample=f'oracle TGT-At 24L train step (fwd+loss+bwd+Adam), fp32, {n} step(s) of '
+                                 f'{batch_graphs} synthetic N={nodes} graphs, dropouts on, {threads} threads')),
+          flush=True)
+
+
+def cpu_baseline(timeout_s=240):
+    """Bounded: a subprocess with a hard timeout, a capped thread count (256 oversubscribed
+    OpenMP threads on the GPU box's host make the eager CPU path ~100x slower)."""
+    import subprocess
+    threads = max(1, min(32, os.cpu_count() or 1))
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', str(threads)]
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES='')
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
+        line = [l for l in out.stdout.splitlines() if l.startswith('{')]
+        if line:
+            return json.loads(line[-1])
+        return dict(value=None, unit='graphs/s', cores=threads, kind='port',
+                    sample='cpu baseline worker failed: ' + out.stderr[-200:])
+    except subprocess.TimeoutExpired:
+        return dict(value=None, unit='graphs/s', cores=threads, kind='port',
+                    sample=f'cpu baseline exceeded its {timeout_s}s bound (one 8-graph oracle step did not finish)')
 
 
 def main():
@@ -90,10 +109,14 @@ def main():
     ap.add_argument('--batch', type=int, default=256, help='graphs per GPU')
     ap.add_argument('--nodes', type=int, default=32)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-worker', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp16', 'fp32'])
     ap.add_argument('--no-gemm-tuning', action='store_true', help='library default GEMM heuristics')
     ap.add_argument('--write-gemm-tuning', default='', help='tune online and write the TunableOp file here')
     args = ap.parse_args()
+    if args.cpu_baseline_worker:
+        cpu_baseline_worker(args.cpu_baseline_worker)
+        return
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))

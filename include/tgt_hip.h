@@ -160,10 +160,13 @@ int tgt_node_attention_bwd(const tgt_node_attention_args* a, void* stream);
  *   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g
  *   p -= lr * (m/(1-b1^t)) / (sqrt(v/(1-b2^t)) + eps)   [+ lr*wd*p decoupled]
  * grad_scale multiplies g first (1/world_size or AMP unscale).
+ * shadow (may be NULL): n-element bf16/f16 buffer that receives the updated
+ * parameters in the same pass (the GEMM-dtype copy the next step reads).
  * ---------------------------------------------------------------------- */
 int tgt_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                   int64_t n, float lr, float beta1, float beta2, float eps,
-                  float weight_decay, int32_t step, float grad_scale, void* stream);
+                  float weight_decay, int32_t step, float grad_scale,
+                  void* shadow, int32_t shadow_dtype, void* stream);
 
 /* ------------------------------------------------------------------------
  * LayerNorm over the last axis (the five per-layer norms of the TGT layer:

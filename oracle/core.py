@@ -48,13 +48,13 @@ def egt_attention_core(qkv, eg, mask, num_heads, scale_degree=True,
     q, k, v = (heads_minor(t, num_heads) for t in qkv.split(W, dim=-1))
     e_bias, g_logit = eg.split(num_heads, dim=-1)
     # H_hat[b,l,m,h] = s * sum_d Q[b,l,d,h] K[b,m,d,h] + E[b,l,m,h]   (:66,:69)
-    h_hat = (q.unsqueeze(2) * k.unsqueeze(1)).sum(dim=3) * (D ** -0.5) + e_bias
+    h_hat = torch.einsum('bldh,bmdh->blmh', q, k) * (D ** -0.5) + e_bias
     if not want_nodes:
         return None, h_hat
     gates = torch.sigmoid(g_logit + mask)                              # :68
     att = torch.softmax(h_hat + mask, dim=2) * gates                   # :70
     # V_att[b,l,d,h] = sum_m att[b,l,m,h] V[b,m,d,h]                    # :71
-    v_att = (att.unsqueeze(3) * v.unsqueeze(1)).sum(dim=2)
+    v_att = torch.einsum('blmh,bmdh->bldh', att, v)
     if scale_degree:                                                   # :73-75
         v_att = v_att * degree_scaler(gates)
     return v_att.reshape(B, N, W), h_hat
@@ -66,7 +66,7 @@ def edge_update_core(qk, e_bias, num_heads):
     W = W2 // 2
     D = W // num_heads
     q, k = (heads_minor(t, num_heads) for t in qk.split(W, dim=-1))
-    return (q.unsqueeze(2) * k.unsqueeze(1)).sum(dim=3) * (D ** -0.5) + e_bias
+    return torch.einsum('bldh,bmdh->blmh', q, k) * (D ** -0.5) + e_bias
 
 
 def _triplet_dir(q, k, v, bias, gate_logit, mask, inward):

@@ -317,15 +317,18 @@ def edge_logits(qk, e_bias, num_heads):
 # flat Adam
 # ---------------------------------------------------------------------------
 def adam_step_(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8,
-               weight_decay=0.0, grad_scale=1.0):
+               weight_decay=0.0, grad_scale=1.0, shadow=None):
     """In-place Adam on flat float32 buffers (replaces apex FusedAdam,
     reference lib/training/training.py:159-171)."""
     _dev(param, grad, exp_avg, exp_avg_sq)
     for t in (param, grad, exp_avg, exp_avg_sq):
         assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == param.numel()
+    if shadow is not None:
+        assert shadow.is_cuda and shadow.numel() == param.numel() and shadow.dtype in (torch.bfloat16, torch.float16)
     _lib.check(_lib.lib().tgt_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq),
                                         param.numel(), lr, betas[0], betas[1], eps, weight_decay,
-                                        int(step), grad_scale, _stream()), 'tgt_adam_step')
+                                        int(step), grad_scale, _ptr(shadow),
+                                        0 if shadow is None else _DT[shadow.dtype], _stream()), 'tgt_adam_step')
 
 
 # ---------------------------------------------------------------------------
@@ -449,6 +452,17 @@ def _wgrad_chunks(M):
     return 1
 
 
+def _as_dtype(p, cd):
+    """p in dtype cd; a Trainer-maintained low-precision shadow (`p._lp`, refreshed by the Adam
+    kernel) is used instead of a cast kernel when it matches."""
+    if p.dtype == cd:
+        return p
+    lp = getattr(p, '_lp', None)
+    if lp is not None and lp.dtype == cd:
+        return lp
+    return p.to(cd)
+
+
 class _Linear(torch.autograd.Function):
     """y = x W^T + b on the library GEMM, with the weight gradient computed as a BATCHED
     GEMM over row chunks + an fp32 sum.  dW = dY^T X contracts over M = B*N*N = 262144 rows
@@ -462,8 +476,8 @@ class _Linear(torch.autograd.Function):
         x2 = x.reshape(-1, xs[-1])
         if x2.dtype != cd:
             x2 = x2.to(cd)
-        w = weight if weight.dtype == cd else weight.to(cd)
-        b = None if bias is None else (bias if bias.dtype == cd else bias.to(cd))
+        w = _as_dtype(weight, cd)
+        b = None if bias is None else _as_dtype(bias, cd)
         # the result must own its storage (not be a view): the layer adds the residual in place
         y = torch.empty(*xs[:-1], weight.shape[0], dtype=cd, device=x.device)
         y2 = y.view(-1, weight.shape[0])

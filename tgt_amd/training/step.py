@@ -119,15 +119,45 @@ class FlatState:
         self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(off, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad_views = []
         for p, o in zip(self.params, self.offsets):
             self.param[o:o + p.numel()].view_as(p).copy_(p.data)
             p.data = self.param[o:o + p.numel()].view_as(p)
-            p.grad = self.grad[o:o + p.numel()].view_as(p)
+            self.grad_views.append(self.grad[o:o + p.numel()].view_as(p))
+            p.grad = None
+        self.shadow = None
 
-    def rebind_grads(self):
+    def make_shadow(self, dtype):
+        """16-bit copy of all parameters (views hung on each parameter as `_lp`); the Adam
+        kernel keeps it current, so the step has no per-tensor weight casts."""
+        self.shadow = self.param.to(dtype)
         for p, o in zip(self.params, self.offsets):
-            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
-                p.grad = self.grad[o:o + p.numel()].view_as(p)
+            p._lp = self.shadow[o:o + p.numel()].view_as(p)
+
+    def drop_shadow(self):
+        self.shadow = None
+        for p in self.params:
+            if hasattr(p, '_lp'):
+                del p._lp
+
+    def clear_grads(self):
+        for p in self.params:
+            p.grad = None
+
+    def collect_grads(self, indices=None):
+        """autograd's per-tensor gradients -> the flat buffer (one multi-tensor copy instead of
+        883 accumulate kernels); parameters without a gradient contribute zeros."""
+        idx = range(len(self.params)) if indices is None else indices
+        src, dst = [], []
+        for i in idx:
+            g = self.params[i].grad
+            if g is None:
+                self.grad_views[i].zero_()
+            else:
+                src.append(g if g.dtype == torch.float32 else g.float())
+                dst.append(self.grad_views[i])
+        if src:
+            torch._foreach_copy_(dst, src)
 
 
 class Trainer:
@@ -146,25 +176,27 @@ class Trainer:
             # replicas start from rank 0's parameters (DDP's broadcast at wrap, training.py:152)
             dist.broadcast(self.flat.param, src=0, group=self.pg)
             self._setup_buckets()
+        if self.cfg.mixed_precision in ('bf16', 'fp16') and self.flat.param.is_cuda:
+            self.flat.make_shadow(torch.bfloat16 if self.cfg.mixed_precision == 'bf16' else torch.float16)
 
     # ---- data-parallel gradient exchange ---------------------------------
     def _setup_buckets(self):
         f, limit = self.flat, self.cfg.bucket_mbytes * (1 << 20) // 4
         shared = getattr(self.model, 'layer_multiplier', 1) > 1 or \
             getattr(getattr(self.model, 'encoder', None), 'layer_multiplier', 1) > 1
-        self.buckets = []          # [start, end, n_params_pending]
+        self.buckets = []          # [start, end, n_params, first_param_index]
         self._bucket_of = {}
         if shared:                 # weight-shared repeats accumulate several times: reduce after backward
             self.buckets = None
             return
-        start, count = 0, 0
+        start, count, first = 0, 0, 0
         ends = [o + (-(-p.numel() // 64) * 64) for p, o in zip(f.params, f.offsets)]
         for i, (p, o) in enumerate(zip(f.params, f.offsets)):
             self._bucket_of[id(p)] = len(self.buckets)
             count += 1
             if ends[i] - start >= limit or i == len(f.params) - 1:
-                self.buckets.append([start, ends[i], count])
-                start, count = ends[i], 0
+                self.buckets.append([start, ends[i], count, first])
+                start, count, first = ends[i], 0, i + 1
         self._pending = [b[2] for b in self.buckets]
         for p in f.params:
             p.register_post_accumulate_grad_hook(self._grad_ready)
@@ -175,24 +207,34 @@ class Trainer:
         k = self._bucket_of[id(p)]
         self._pending[k] -= 1
         if self._pending[k] == 0:
-            s, e, _ = self.buckets[k]
-            self._handles.append(dist.all_reduce(self.flat.grad[s:e], group=self.pg, async_op=True))
+            self._reduce_bucket(k)
+
+    def _reduce_bucket(self, k):
+        s, e, n, first = self.buckets[k]
+        self.flat.collect_grads(range(first, first + n))
+        self._handles.append(dist.all_reduce(self.flat.grad[s:e], group=self.pg, async_op=True))
 
     def _finish_reduce(self):
         if not self.distributed:
+            self.flat.collect_grads()
             return
         if self.buckets is None:
+            self.flat.collect_grads()
             dist.all_reduce(self.flat.grad, group=self.pg)
             return
         # parameters that received no gradient this step never fire their hook
         for k, left in enumerate(self._pending):
             if left > 0:
-                s, e, _ = self.buckets[k]
-                self._handles.append(dist.all_reduce(self.flat.grad[s:e], group=self.pg, async_op=True))
+                self._reduce_bucket(k)
         for h in self._handles:
             h.wait()
         self._handles.clear()
         self._pending = [b[2] for b in self.buckets]
+
+    def refresh_shadow(self):
+        """call after changing parameters outside the trainer (e.g. load_state_dict)"""
+        if self.flat.shadow is not None:
+            self.flat.shadow.copy_(self.flat.param)
 
     # ---- one step ----------------------------------------------------------
     def autocast(self):
@@ -205,8 +247,7 @@ class Trainer:
         """zero grads -> autocast forward + loss -> backward (+ overlapped RCCL
         all-reduce of gradient buckets).  Leaves SUMMED gradients in flat.grad."""
         cfg, f = self.cfg, self.flat
-        f.grad.zero_()
-        f.rebind_grads()
+        f.clear_grads()
         self._armed = True
         with self.autocast():
             outputs = self.model(batch)
@@ -230,7 +271,8 @@ class Trainer:
             if self._good_steps >= 2000:
                 self.loss_scale, self._good_steps = self.loss_scale * 2, 0
         ops.adam_step_(f.param, f.grad, f.exp_avg, f.exp_avg_sq, self.global_step, lr,
-                       betas=cfg.betas, eps=cfg.eps, weight_decay=cfg.weight_decay, grad_scale=grad_scale)
+                       betas=cfg.betas, eps=cfg.eps, weight_decay=cfg.weight_decay, grad_scale=grad_scale,
+                       shadow=f.shadow)
         return True
 
     def training_step(self, batch):
