@@ -190,13 +190,19 @@ def main():
             if name in times and times[name]:
                 avg_ms = sum(times[name]) / len(times[name])
                 cand[name] = (sum(times[name]), avg_ms, algorithmic_bytes(kind, args.batch, args.nodes, C, Ht, esz))
+        # HBM bytes per launch from the PMC passes (collected offline with rocprofv3 --pmc, see
+        # profiles/README.md); only valid for the shape they were measured at
+        traffic = {}
+        tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+        if os.path.exists(tpath) and args.batch == 256 and args.nodes == 32 and args.precision == 'bf16':
+            traffic = json.load(open(tpath))
         roofline = None
         if cand:
             name = max(cand, key=lambda k: cand[k][0])
             tot, avg_ms, nbytes = cand[name]
             ach = nbytes / (avg_ms * 1e-3) / 1e9
             roofline = dict(bound='hbm', kernel=name, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
-                            frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
+                            frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic.get(name, {}).get('traffic_bytes'),
                             avg_launch_ms=round(avg_ms, 4), launches=len(times[name]),
                             algorithmic_bytes_per_launch=nbytes,
                             share_of_step=round(tot / (dt * 1e3), 4),
