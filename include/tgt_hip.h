@@ -182,6 +182,11 @@ int tgt_layer_norm_parts(void);
 int tgt_layer_norm_fwd(const void* x, int32_t x_dtype, const float* gamma, const float* beta,
                        void* y, int32_t y_dtype, float* mean, float* rstd,
                        int64_t rows, int32_t C, float eps, void* stream);
+/* Column sums of a (rows, C) tensor into float32 (C): the bias gradient of a Linear layer
+ * (the `grad_output.sum(0)` ATen reduction behind nn.Linear, e.g. reference
+ * lib/tgt/layers/triplet.py:198-203).  partial: tgt_layer_norm_parts()*C floats of scratch. */
+int tgt_colsum(const void* x, int32_t x_dtype, int64_t rows, int32_t C, float* out, float* partial, void* stream);
+
 int tgt_layer_norm_bwd(const void* dy, int32_t dy_dtype, const void* x, int32_t x_dtype,
                        const float* gamma, const float* mean, const float* rstd,
                        void* dx, int32_t dx_dtype, float* dgamma, float* dbeta, float* partial,

@@ -276,3 +276,15 @@ def test_drop_path_add():
     f = per[:, 0]
     assert bool(((f.abs() < 1e-5) | ((f - 1 / 0.75).abs() < 1e-4)).all())
     assert 0 < int((f.abs() < 1e-5).sum()) < 64
+
+
+@pytest.mark.parametrize('shape,dtype', [((8192, 256), torch.bfloat16), ((5000, 1600), torch.bfloat16),
+                                         ((4096, 64), torch.float32), ((6000, 768), torch.float16)])
+def test_column_sum(shape, dtype):
+    from tgt_amd import ops
+    rng = np.random.default_rng(shape[1])
+    x = rnd(rng, *shape).to(dtype)
+    ref = x.double().sum(0)
+    out = ops.column_sum(x.cuda())
+    assert out.dtype == torch.float32
+    assert rel(out, ref) < 1e-5

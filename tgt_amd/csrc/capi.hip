@@ -26,6 +26,7 @@ int triplet_attention_run(const tgt_triplet_attention_args* a, bool bwd, hipStre
 int triplet_aggregate_run(const tgt_triplet_aggregate_args* a, bool bwd, hipStream_t st);
 int node_attention_run(const tgt_node_attention_args* a, bool bwd, hipStream_t st);
 int layer_norm_parts();
+int colsum_run(const void* x, int x_dtype, int64_t rows, int C, float* out, float* partial, hipStream_t st);
 int layer_norm_fwd_run(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
                        float* mean, float* rstd, int64_t rows, int C, float eps, hipStream_t st);
 int layer_norm_bwd_run(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, const float* mean,
@@ -94,7 +95,7 @@ using namespace tgt;
 extern "C" {
 
 const char* tgt_last_error(void) { return g_err; }
-int tgt_abi_version(void) { return 3; }
+int tgt_abi_version(void) { return 4; }
 
 int tgt_triplet_attention_fwd(const tgt_triplet_attention_args* a, void* stream) {
     return triplet_attention_run(a, false, reinterpret_cast<hipStream_t>(stream));
@@ -116,6 +117,9 @@ int tgt_node_attention_bwd(const tgt_node_attention_args* a, void* stream) {
 }
 
 int tgt_layer_norm_parts(void) { return layer_norm_parts(); }
+int tgt_colsum(const void* x, int32_t x_dtype, int64_t rows, int32_t C, float* out, float* partial, void* stream) {
+    return colsum_run(x, x_dtype, rows, C, out, partial, reinterpret_cast<hipStream_t>(stream));
+}
 int tgt_layer_norm_fwd(const void* x, int32_t x_dtype, const float* gamma, const float* beta, void* y, int32_t y_dtype,
                        float* mean, float* rstd, int64_t rows, int32_t C, float eps, void* stream) {
     return layer_norm_fwd_run(x, x_dtype, gamma, beta, y, y_dtype, mean, rstd, rows, C, eps,

@@ -212,23 +212,73 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const LnArgs a) {
     }
 }
 
-// sum the (parts, 2C) partials: block = 16 columns x 16 part-slices, fixed order
-__global__ void __launch_bounds__(256) ln_bwd_finalize_kernel(const float* partial, int parts, int C, float* dgamma,
-                                                              float* dbeta) {
-    __shared__ float red[16][17];
-    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int idx = blockIdx.x * 16 + cl;
+// sum a (parts, W) fp32 partial buffer over parts: block = 8 columns x 32 part-slices, fixed order.
+// out0 gets columns [0,split), out1 columns [split,W).
+__global__ void __launch_bounds__(256) partial_sum_kernel(const float* partial, int parts, int W, int split, float* out0,
+                                                          float* out1) {
+    __shared__ float red[32][9];
+    const int cl = threadIdx.x & 7, sl = threadIdx.x >> 3;
+    const int idx = blockIdx.x * 8 + cl;
     float s = 0.f;
-    if (idx < 2 * C)
-        for (int p = sl; p < parts; p += 16) s += partial[(int64_t)p * 2 * C + idx];
+    if (idx < W) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int p = sl;
+        for (; p + 96 < parts; p += 128) {
+            s0 += partial[(int64_t)p * W + idx];
+            s1 += partial[(int64_t)(p + 32) * W + idx];
+            s2 += partial[(int64_t)(p + 64) * W + idx];
+            s3 += partial[(int64_t)(p + 96) * W + idx];
+        }
+        for (; p < parts; p += 32) s0 += partial[(int64_t)p * W + idx];
+        s = (s0 + s1) + (s2 + s3);
+    }
     red[sl][cl] = s;
     __syncthreads();
-    if (sl == 0 && idx < 2 * C) {
+    if (sl == 0 && idx < W) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) t += red[k][cl];
-        if (idx < C) dgamma[idx] = t;
-        else dbeta[idx - C] = t;
+        for (int k = 0; k < 32; ++k) t += red[k][cl];
+        if (idx < split) out0[idx] = t;
+        else out1[idx - split] = t;
+    }
+}
+
+// column sums of a (rows, C) tensor (bias gradients of the Linear layers): same lane<->column
+// ownership and two-stage deterministic reduction as the LayerNorm backward.
+template <int LPR, int VPL>
+__global__ void __launch_bounds__(256) colsum_kernel(const void* x, int x_dtype, int64_t rows, int C, float* partial) {
+    constexpr int RPW = 64 / LPR;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);        // [4 waves][RPW][VPL*LPR*8]
+    const int lane = threadIdx.x & 63, sub = lane / LPR, gl = lane % LPR, w = threadIdx.x >> 6;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + w, nwaves = (int64_t)gridDim.x * 4;
+    float acc[VPL][8];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[v][i] = 0.f;
+    for (int64_t row = wave * RPW + sub; row < rows; row += nwaves * RPW) {
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            const int col = (v * LPR + gl) * 8;
+            if (col < C) {
+                float t[8];
+                ln_load8(x, x_dtype, row * C + col, t);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[v][i] += t[i];
+            }
+        }
+    }
+    constexpr int CW = VPL * LPR * 8;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[(w * RPW + sub) * CW + (v * LPR + gl) * 8 + i] = acc[v][i];
+    __syncthreads();
+    for (int col = threadIdx.x; col < C; col += 256) {
+        float s = 0.f;
+        for (int g = 0; g < 4 * RPW; ++g) s += red[g * CW + col];
+        partial[(int64_t)blockIdx.x * C + col] = s;
     }
 }
 
@@ -245,9 +295,9 @@ static int ln_launch(const LnArgs& a, bool bwd, float* dgamma, float* dbeta, hip
     const size_t lds = (size_t)4 * RPW * 2 * VPL * LPR * 8 * sizeof(float);
     hipLaunchKernelGGL((ln_bwd_kernel<LPR, VPL>), dim3(parts), dim3(256), lds, st, a);
     if (int e = check_launch("ln_bwd_kernel")) return e;
-    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((2 * a.C + 15) / 16), dim3(256), 0, st, a.partial, parts, a.C,
+    hipLaunchKernelGGL(partial_sum_kernel, dim3((2 * a.C + 7) / 8), dim3(256), 0, st, a.partial, parts, 2 * a.C, a.C,
                        dgamma, dbeta);
-    return check_launch("ln_bwd_finalize_kernel");
+    return check_launch("partial_sum_kernel");
 }
 
 static int ln_dispatch(const LnArgs& a, bool bwd, float* dgamma, float* dbeta, hipStream_t st) {
@@ -290,5 +340,30 @@ int layer_norm_bwd_run(const void* dy, int dy_dtype, const void* x, int x_dtype,
 }
 
 int layer_norm_parts() { return kLnParts; }
+
+template <int LPR, int VPL>
+static int colsum_launch(const void* x, int dt, int64_t rows, int C, float* out, float* partial, hipStream_t st) {
+    constexpr int RPW = 64 / LPR;
+    const size_t lds = (size_t)4 * RPW * VPL * LPR * 8 * sizeof(float);
+    hipLaunchKernelGGL((colsum_kernel<LPR, VPL>), dim3(kLnParts), dim3(256), lds, st, x, dt, rows, C, partial);
+    if (int e = check_launch("colsum_kernel")) return e;
+    hipLaunchKernelGGL(partial_sum_kernel, dim3((C + 7) / 8), dim3(256), 0, st, partial, kLnParts, C, C, out, out);
+    return check_launch("partial_sum_kernel");
+}
+
+int colsum_run(const void* x, int x_dtype, int64_t rows, int C, float* out, float* partial, hipStream_t st) {
+    if (!x || !out || !partial || rows < 0) return set_error(TGT_ERR_INVALID, "colsum: null tensor");
+    if (bad_dtype(x_dtype)) return set_error(TGT_ERR_INVALID, "colsum: bad dtype");
+    if (C % 8 || C <= 0 || C > 2048) return set_error(TGT_ERR_UNSUPPORTED, "colsum: C=%d must be a multiple of 8, <= 2048", C);
+    if ((uintptr_t)x % 16) return set_error(TGT_ERR_INVALID, "colsum: x must be 16-byte aligned");
+    const int v8 = C / 8;
+    if (v8 <= 4) return colsum_launch<4, 1>(x, x_dtype, rows, C, out, partial, st);
+    if (v8 <= 8) return colsum_launch<8, 1>(x, x_dtype, rows, C, out, partial, st);
+    if (v8 <= 16) return colsum_launch<16, 1>(x, x_dtype, rows, C, out, partial, st);
+    if (v8 <= 32) return colsum_launch<32, 1>(x, x_dtype, rows, C, out, partial, st);
+    if (v8 <= 64) return colsum_launch<64, 1>(x, x_dtype, rows, C, out, partial, st);
+    if (v8 <= 128) return colsum_launch<64, 2>(x, x_dtype, rows, C, out, partial, st);
+    return colsum_launch<64, 4>(x, x_dtype, rows, C, out, partial, st);
+}
 
 }  // namespace tgt

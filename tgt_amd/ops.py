@@ -444,6 +444,21 @@ def multi_hot_embed(idx, weight, padding_idx=None, out_dtype=None):
 # ---------------------------------------------------------------------------
 # Linear with a split-M weight gradient
 # ---------------------------------------------------------------------------
+def column_sum(x2):
+    """float32 column sums of a contiguous (rows, C) tensor (bias gradients): HIP kernel when the
+    shape qualifies (device tensor, C a multiple of 8, <= 2048), else the library reduction."""
+    rows, C_ = x2.shape
+    if not (x2.is_cuda and x2.is_contiguous() and C_ % 8 == 0 and C_ <= 2048 and x2.dtype in _DT and rows >= 4096):
+        return x2.sum(0, dtype=torch.float32)
+    L = _lib.lib()
+    out = torch.empty(C_, dtype=torch.float32, device=x2.device)
+    partial = torch.empty(L.tgt_layer_norm_parts() * C_, dtype=torch.float32, device=x2.device)
+    s, e = _prof_begin()
+    _lib.check(L.tgt_colsum(_ptr(x2), _DT[x2.dtype], rows, C_, _ptr(out), _ptr(partial), _stream()), 'tgt_colsum')
+    _prof_end('tgt_colsum', s, e)
+    return out
+
+
 def _wgrad_chunks(M):
     """number of row chunks for dW = sum_c dY_c^T X_c (rows per chunk >= 1024, <= 128 chunks)"""
     for P in (128, 64, 32, 16, 8, 4, 2):
@@ -510,7 +525,7 @@ class _Linear(torch.autograd.Function):
             else:
                 dw = (dy2.t() @ x2).to(wdt)
         if bdt is not None and ctx.needs_input_grad[2]:
-            db = dy2.sum(0, dtype=torch.float32).to(bdt)
+            db = column_sum(dy2).to(bdt)
         return dx, dw, db, None
 
 
