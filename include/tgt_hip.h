@@ -115,6 +115,18 @@ int tgt_triplet_aggregate_fwd(const tgt_triplet_aggregate_args* a, void* stream)
 int tgt_triplet_aggregate_bwd(const tgt_triplet_aggregate_args* a, void* stream);
 
 /* ------------------------------------------------------------------------
+ * TriangularUpdate core (reference lib/tgt/layers/triplet.py:156-172: the four
+ * "siglin" gates and the two einsums 'bikh,bjkh->bijh' / 'bkih,bkjh->bijh').
+ * e4, v4: (B,N,N,4H) = [in_gate | in_lin | out_gate | out_lin] (lin_E / lin_V outputs);
+ * mask (B,N,N) float32; out (B,N,N,2H) = [O_in | O_out].  Backward writes d_e4, d_v4 fully.
+ * ---------------------------------------------------------------------- */
+int tgt_triangular_update_fwd(const void* e4, const void* v4, const float* mask, void* out,
+                              int32_t B, int32_t N, int32_t H, int32_t dtype, void* stream);
+int tgt_triangular_update_bwd(const void* e4, const void* v4, const float* mask, const void* d_out,
+                              void* d_e4, void* d_v4, int32_t B, int32_t N, int32_t H, int32_t dtype,
+                              void* stream);
+
+/* ------------------------------------------------------------------------
  * Node attention with edge bias + gate (EGT_Attention) and the logits-only
  * EdgeUpdate.  Replaces reference lib/tgt/layers/layers.py:62-77 (and
  * :120-124 for EdgeUpdate) and its autograd backward.

@@ -31,7 +31,7 @@ def product_class(name):
     raise KeyError(name)
 
 
-SMALL_OPS = [k for k, v in gu.OP_CASES.items() if v[2] is gu.SMALL and v[0] != 'TriangularUpdate']
+SMALL_OPS = [k for k, v in gu.OP_CASES.items() if v[2] is gu.SMALL]
 
 
 @pytest.mark.parametrize('name', SMALL_OPS)

@@ -288,3 +288,23 @@ def test_column_sum(shape, dtype):
     out = ops.column_sum(x.cuda())
     assert out.dtype == torch.float32
     assert rel(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', [(2, 6, [6, 4], 4), (2, 20, [20, 13], 16), (1, 40, [33], 3)])
+def test_triangular_update(case, dtype):
+    from tgt_amd import ops
+    B, N, nn_, H = case
+    rng = np.random.default_rng(N + H)
+    e4, v4 = rnd(rng, B, N, N, 4 * H).to(dtype), rnd(rng, B, N, N, 4 * H).to(dtype)
+    d_out = rnd(rng, B, N, N, 2 * H).to(dtype)
+    mask = gu.additive_mask(nn_, N, torch.float32)
+    e64, v64 = e4.double().requires_grad_(True), v4.double().requires_grad_(True)
+    ref = core.triangular_update_core(v64, e64, mask.double(), H)
+    ref.backward(d_out.double())
+    ex, vx = e4.cuda().requires_grad_(True), v4.cuda().requires_grad_(True)
+    out = ops.triangular_update(ex, vx, mask.reshape(B, N, N).cuda(), H)
+    out.backward(d_out.cuda())
+    tol = TOL[dtype]
+    assert rel(out, ref) < tol
+    assert rel(ex.grad, e64.grad) < 2 * tol and rel(vx.grad, v64.grad) < 2 * tol

@@ -26,6 +26,8 @@ int triplet_attention_run(const tgt_triplet_attention_args* a, bool bwd, hipStre
 int triplet_aggregate_run(const tgt_triplet_aggregate_args* a, bool bwd, hipStream_t st);
 int node_attention_run(const tgt_node_attention_args* a, bool bwd, hipStream_t st);
 int layer_norm_parts();
+int triangular_update_run(const void* e4, const void* v4, const float* mask, void* out, const void* d_out, void* d_e4,
+                          void* d_v4, int B, int N, int H, int dtype, bool bwd, hipStream_t st);
 int colsum_run(const void* x, int x_dtype, int64_t rows, int C, float* out, float* partial, hipStream_t st);
 int layer_norm_fwd_run(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
                        float* mean, float* rstd, int64_t rows, int C, float eps, hipStream_t st);
@@ -95,7 +97,7 @@ using namespace tgt;
 extern "C" {
 
 const char* tgt_last_error(void) { return g_err; }
-int tgt_abi_version(void) { return 4; }
+int tgt_abi_version(void) { return 5; }
 
 int tgt_triplet_attention_fwd(const tgt_triplet_attention_args* a, void* stream) {
     return triplet_attention_run(a, false, reinterpret_cast<hipStream_t>(stream));
@@ -116,6 +118,16 @@ int tgt_node_attention_bwd(const tgt_node_attention_args* a, void* stream) {
     return node_attention_run(a, true, reinterpret_cast<hipStream_t>(stream));
 }
 
+int tgt_triangular_update_fwd(const void* e4, const void* v4, const float* mask, void* out, int32_t B, int32_t N,
+                              int32_t H, int32_t dtype, void* stream) {
+    return triangular_update_run(e4, v4, mask, out, nullptr, nullptr, nullptr, B, N, H, dtype, false,
+                                 reinterpret_cast<hipStream_t>(stream));
+}
+int tgt_triangular_update_bwd(const void* e4, const void* v4, const float* mask, const void* d_out, void* d_e4,
+                              void* d_v4, int32_t B, int32_t N, int32_t H, int32_t dtype, void* stream) {
+    return triangular_update_run(e4, v4, mask, nullptr, d_out, d_e4, d_v4, B, N, H, dtype, true,
+                                 reinterpret_cast<hipStream_t>(stream));
+}
 int tgt_layer_norm_parts(void) { return layer_norm_parts(); }
 int tgt_colsum(const void* x, int32_t x_dtype, int64_t rows, int32_t C, float* out, float* partial, void* stream) {
     return colsum_run(x, x_dtype, rows, C, out, partial, reinterpret_cast<hipStream_t>(stream));

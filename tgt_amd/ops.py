@@ -221,6 +221,41 @@ def triplet_aggregate(fused, mask3, layout):
 
 
 # ---------------------------------------------------------------------------
+# triangular update
+# ---------------------------------------------------------------------------
+class _TriangularUpdate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, e4, v4, mask3, H):
+        _dev(e4, v4, mask3)
+        e4, v4 = e4.contiguous(), v4.contiguous()
+        B, N = e4.shape[0], e4.shape[1]
+        out = torch.empty(B, N, N, 2 * H, dtype=e4.dtype, device=e4.device)
+        _lib.check(_lib.lib().tgt_triangular_update_fwd(_ptr(e4), _ptr(v4), _ptr(mask3), _ptr(out), B, N, H,
+                                                        _DT[e4.dtype], _stream()), 'tgt_triangular_update_fwd')
+        ctx.save_for_backward(e4, v4, mask3)
+        ctx.H = H
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        e4, v4, mask3 = ctx.saved_tensors
+        d_out = d_out.contiguous()
+        B, N = e4.shape[0], e4.shape[1]
+        d_e4, d_v4 = torch.empty_like(e4), torch.empty_like(v4)
+        _lib.check(_lib.lib().tgt_triangular_update_bwd(_ptr(e4), _ptr(v4), _ptr(mask3), _ptr(d_out), _ptr(d_e4),
+                                                        _ptr(d_v4), B, N, ctx.H, _DT[e4.dtype], _stream()),
+                   'tgt_triangular_update_bwd')
+        return d_e4, d_v4, None, None
+
+
+def triangular_update(e4, v4, mask3, num_heads):
+    """e4, v4: (B,N,N,4H) lin_E / lin_V outputs -> (B,N,N,2H).  Reference lib/tgt/layers/triplet.py:156-172."""
+    if v4.dtype != e4.dtype:
+        v4 = v4.to(e4.dtype)
+    return _TriangularUpdate.apply(e4, v4, mask3, num_heads)
+
+
+# ---------------------------------------------------------------------------
 # node attention (EGT_Attention core) and EdgeUpdate logits
 # ---------------------------------------------------------------------------
 def _node_args(qkv, eg, mask3, H, scale_degree, logits_only):

@@ -159,10 +159,8 @@ class TripletAggregateUngated(TripletAggregate):
 
 
 class TriangularUpdate(_TripletBase):
-    """Reference lib/tgt/layers/triplet.py:134-176.  Parameters and state_dict
-    keys are kept; no HIP kernel exists for its scalar-value contraction yet
-    (no shipped config selects it), so forward() refuses to run rather than
-    fall back to eager ops."""
+    """Reference lib/tgt/layers/triplet.py:134-176 (scalar values per head, sigmoid-gated
+    linear units instead of softmax)."""
 
     def __init__(self, edge_width, num_heads, attention_dropout=0):
         super().__init__(edge_width, num_heads, attention_dropout)
@@ -172,7 +170,11 @@ class TriangularUpdate(_TripletBase):
         self.lin_O = Linear(num_heads * 2, edge_width * 2)
 
     def forward(self, e, mask):
-        raise NotImplementedError("triplet_type 'tiangular_update' has no HIP kernel yet")
+        B, N = e.shape[0], e.shape[1]
+        x = self.tri_ln_e(e)
+        va = ops.triangular_update(self.lin_E(x), self.lin_V(x), ops.as_mask3(mask, B, N), self.num_heads)
+        gate, lin = self.lin_O(va).chunk(2, dim=-1)
+        return torch.sigmoid(gate) * lin
 
 
 _LAYERS = {
