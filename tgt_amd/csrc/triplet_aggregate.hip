@@ -45,12 +45,16 @@ __device__ __forceinline__ AggCtx agg_ctx(const tgt_triplet_aggregate_args& a, i
 }
 
 // weights of query tile it / key tile kt in (lane = i) layout: softmax over ALL key tiles
-template <typename T, int NT, bool PAD>
-__device__ __forceinline__ void agg_weights(const AggCtx& c, int N, int r, int hi, int i0, float (&p)[NT][16],
-                                            float (&gate)[NT][16]) {
+// (the E/G/mask tiles come through the LDS stage: two barriers inside, `lds` aliases the slabs)
+template <typename T, int HG, int NT, bool PAD>
+__device__ __forceinline__ void agg_weights(const AggCtx& c, int N, int wave, int tid, int r, int hi, int i0, char* lds,
+                                            float (&p)[NT][16], float (&gate)[NT][16]) {
+    arm_stage_load<T, HG, NT>(c.ta, c.b, c.dir, c.g, N, i0, lds, tid);
+    __syncthreads();
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
-        load_third_arm<T, PAD>(c.ta, c.b, c.dir, c.h, N, r, hi, p[kt], gate[kt], i0, 32 * kt);
+        arm_stage_read<T, HG, NT, PAD>(c.ta, lds, c.dir, wave, N, r, hi, i0, kt, p[kt], gate[kt]);
+    __syncthreads();
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
@@ -98,7 +102,7 @@ __global__ void __launch_bounds__(HG * 64) tri_agg_fwd_kernel(const tgt_triplet_
         F pa[NT][2];
         {
             float p[NT][16], gate[NT][16];
-            agg_weights<T, NT, false>(c, N, r, hi, i0, p, gate);
+            agg_weights<T, HG, NT, false>(c, N, wave, tid, r, hi, i0, smem, p, gate);
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt) {
                 f32x16 w;
@@ -163,7 +167,7 @@ __global__ void __launch_bounds__(HG * 64) tri_agg_bwd_kernel(const tgt_triplet_
         F a2f[NT][2];
         {
             float p[NT][16], gate[NT][16];
-            agg_weights<T, NT, true>(c, N, r, hi, i0, p, gate);
+            agg_weights<T, HG, NT, true>(c, N, wave, tid, r, hi, i0, smem, p, gate);
             F ident_k[2];
             make_ident_k<T>(ident_k, r, hi);
 #pragma unroll
@@ -241,7 +245,7 @@ __global__ void __launch_bounds__(HG * 64) tri_agg_bwd_kernel(const tgt_triplet_
 
         // softmax*gate backward on the accumulated dA (recompute P, g)
         float p[NT][16], gate[NT][16];
-        agg_weights<T, NT, true>(c, N, r, hi, i0, p, gate);
+        agg_weights<T, HG, NT, true>(c, N, wave, tid, r, hi, i0, smem, p, gate);
         float delta = 0.f;
         float dG[NT][16];
 #pragma unroll
@@ -258,8 +262,11 @@ __global__ void __launch_bounds__(HG * 64) tri_agg_bwd_kernel(const tgt_triplet_
             float dE[16];
 #pragma unroll
             for (int q = 0; q < 16; ++q) dE[q] = p[kt][q] * (dacc[kt][q] - delta);
-            store_third_arm_grad<T>(c.ta, a.d_eg[c.dir], c.b, c.dir, c.h, N, r, hi, dE, dG[kt], i0, 32 * kt);
+            arm_stage_put_grad<T, HG, NT>(smem, c.dir, wave, r, hi, kt, dE, dG[kt]);
         }
+        __syncthreads();
+        arm_stage_store_grad<T, HG, NT>(c.ta, a.d_eg[c.dir], c.b, c.dir, c.g, N, i0, smem, tid);
+        __syncthreads();
     }
 }
 
@@ -267,8 +274,10 @@ template <typename T, int D, int HG, int NT>
 static int launch_agg_nt(const tgt_triplet_aggregate_args& a, bool bwd, hipStream_t st) {
     using G = TriGeo<T, D, HG>;
     const int grid = a.B * 2 * (a.H / HG);
-    if (!bwd) hipLaunchKernelGGL((tri_agg_fwd_kernel<T, D, HG, NT>), dim3(grid), dim3(G::kThreads), (NT + 1) * G::kSlabBytes, st, a);
-    else      hipLaunchKernelGGL((tri_agg_bwd_kernel<T, D, HG, NT>), dim3(grid), dim3(G::kThreads), (NT + 1) * G::kSlabBytes, st, a);
+    constexpr int kArm = ArmStage<T, HG, NT>::kBytes;
+    constexpr int kLds = (NT + 1) * G::kSlabBytes > kArm ? (NT + 1) * G::kSlabBytes : kArm;
+    if (!bwd) hipLaunchKernelGGL((tri_agg_fwd_kernel<T, D, HG, NT>), dim3(grid), dim3(G::kThreads), kLds, st, a);
+    else      hipLaunchKernelGGL((tri_agg_bwd_kernel<T, D, HG, NT>), dim3(grid), dim3(G::kThreads), kLds, st, a);
     return check_launch(bwd ? "tri_agg_bwd_kernel" : "tri_agg_fwd_kernel");
 }
 template <typename T, int D, int HG>
@@ -278,6 +287,9 @@ static int launch_agg(const tgt_triplet_aggregate_args& a, bool bwd, hipStream_t
 }
 template <typename T, int D>
 static int agg_dispatch_hg(const tgt_triplet_aggregate_args& a, bool bwd, hipStream_t st) {
+    if constexpr (D == 16 && sizeof(T) == 2) {
+        if (a.H % 8 == 0 && a.N <= 32) return launch_agg_nt<T, D, 8, 1>(a, bwd, st);     // 256-byte row pieces
+    }
     if (a.H % 4 == 0) return launch_agg<T, D, 4>(a, bwd, st);
     if constexpr (D * sizeof(T) >= 16) return launch_agg<T, D, 1>(a, bwd, st);
     return set_error(TGT_ERR_UNSUPPORTED, "triplet aggregate: H=%d not a multiple of 4 with D=%d", a.H, D);
