@@ -139,7 +139,7 @@ int tgt_triangular_update_bwd(const void* e4, const void* v4, const float* mask,
  * vatt : (B,N,W=D*H) head-minor;  hhat: (B,N,N,H) (may be NULL: no edge update)
  * lse  : (B,N,H) float32;  gsum: (B,N,H) float32 (sum_m gate)   [saved for bwd]
  * logits_only != 0: EdgeUpdate -- only hhat is produced (V, G, mask, vatt unused).
- * Backward: d_vatt (B,N,W), d_hhat (B,N,N,H, may be NULL) -> d_qkv (B,N,ld_qkv;
+ * Backward: the forward's vatt/lse/gsum, d_vatt (B,N,W), d_hhat (B,N,N,H, may be NULL) -> d_qkv (B,N,ld_qkv;
  * Q,K,V columns written), d_eg (B,N,N,ld_eg; E,G columns written).
  * Supported: any N, D <= 32, any H.
  * ---------------------------------------------------------------------- */

@@ -198,28 +198,17 @@ __global__ void __launch_bounds__(256) node_att_bwd_row_kernel(const tgt_node_at
             vu[t][d] = 0.f;
         }
     }
-    // pass 1: unscaled V_att (needed for delta and for d(log(1+gsum)))
-    for (int m = 0; m < N; ++m) {
-        const int64_t row_m = row0 + m;
-        float kk[D], vv[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            kk[d] = ld(qkv, row_m * a.ld_qkv + a.k_off + d * H + h);
-            vv[d] = ld(qkv, row_m * a.ld_qkv + a.v_off + d * H + h);
-        }
+    // unscaled V_att (needed for delta and for d(log(1+gsum))) from the saved forward output:
+    // V_att = vu * log(1+gsum); a zero scaler means every gate of the row was 0, i.e. vu = 0.
+    {
+        const T* va = reinterpret_cast<const T*>(a.vatt);
 #pragma unroll
         for (int t = 0; t < RL; ++t) {
-            if (!live[t]) continue;
-            const int64_t lm = (row0 + n.x0 + t) * N + m;
-            float dot = 0.f;
+            const int64_t rl = row0 + (live[t] ? n.x0 + t : n.x0);
+            const float dsc = a.scale_degree ? __logf(1.f + gsum[t]) : 1.f;
+            const float inv = dsc != 0.f ? __frcp_rn(dsc) : 0.f;
 #pragma unroll
-            for (int d = 0; d < D; ++d) dot += q[t][d] * kk[d];
-            const float mk = a.mask[lm];
-            const float p = fast_exp(dot + ld(eg, lm * a.ld_eg + a.e_off + h) + mk - lse[t]);
-            const float g = fast_sigmoid(ld(eg, lm * a.ld_eg + a.g_off + h) + mk);
-            const float w = p * g;
-#pragma unroll
-            for (int d = 0; d < D; ++d) vu[t][d] += w * vv[d];
+            for (int d = 0; d < D; ++d) vu[t][d] = ld(va, rl * (int64_t)(D * H) + d * H + h) * inv;
         }
     }
     float delta[RL], dgsum[RL];
@@ -402,7 +391,7 @@ int node_attention_run(const tgt_node_attention_args* a, bool bwd, hipStream_t s
     if (!a->qkv || !a->eg) return set_error(TGT_ERR_INVALID, "node attention: null qkv/eg");
     if (a->logits_only) {
         if (!bwd && !a->hhat) return set_error(TGT_ERR_INVALID, "node attention: logits_only needs hhat");
-    } else if (!a->mask || !a->lse || !a->gsum || (!bwd && !a->vatt)) {
+    } else if (!a->mask || !a->lse || !a->gsum || !a->vatt) {
         return set_error(TGT_ERR_INVALID, "node attention: null mask/vatt/lse/gsum");
     }
     if (bwd) {

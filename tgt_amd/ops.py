@@ -288,7 +288,7 @@ class _NodeAttention(torch.autograd.Function):
         gsum = torch.empty(B, N, H, dtype=torch.float32, device=qkv.device)
         a.vatt, a.hhat, a.lse, a.gsum = vatt.data_ptr(), _ptr(hhat), lse.data_ptr(), gsum.data_ptr()
         _call('tgt_node_attention_fwd', _lib.lib().tgt_node_attention_fwd, a)
-        ctx.save_for_backward(qkv, eg, mask3, lse, gsum)
+        ctx.save_for_backward(qkv, eg, mask3, lse, gsum, vatt)
         ctx.cfg = (H, scale_degree, want_edges)
         if want_edges:
             return vatt, hhat
@@ -296,14 +296,14 @@ class _NodeAttention(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_vatt, d_hhat):
-        qkv, eg, mask3, lse, gsum = ctx.saved_tensors
+        qkv, eg, mask3, lse, gsum, vatt = ctx.saved_tensors
         H, scale_degree, want_edges = ctx.cfg
         a, W = _node_args(qkv, eg, mask3, H, scale_degree, False)
         d_vatt = torch.zeros_like(qkv[..., :W]).contiguous() if d_vatt is None else d_vatt.contiguous()
         if d_hhat is not None:
             d_hhat = d_hhat.contiguous()
         d_qkv, d_eg = torch.empty_like(qkv), torch.empty_like(eg)
-        a.lse, a.gsum = lse.data_ptr(), gsum.data_ptr()
+        a.lse, a.gsum, a.vatt = lse.data_ptr(), gsum.data_ptr(), vatt.data_ptr()
         a.d_vatt, a.d_hhat, a.d_qkv, a.d_eg = d_vatt.data_ptr(), _ptr(d_hhat), d_qkv.data_ptr(), d_eg.data_ptr()
         _call('tgt_node_attention_bwd', _lib.lib().tgt_node_attention_bwd, a)
         return d_qkv, d_eg, None, None, None, None
