@@ -194,6 +194,14 @@ int tgt_layer_norm_parts(void);
 int tgt_layer_norm_fwd(const void* x, int32_t x_dtype, const float* gamma, const float* beta,
                        void* y, int32_t y_dtype, float* mean, float* rstd,
                        int64_t rows, int32_t C, float eps, void* stream);
+/* Fused GELU (erf form) + dropout: the middle of the FFN block (reference
+ * lib/tgt/layers/layers.py:157-158).  y = keep(i) ? gelu(x)/(1-p) : 0, where keep(i) is a
+ * counter-based hash of (seed, i); the backward recomputes it from the same seed, so no
+ * mask is stored.  p = 0: plain GELU.  n elements of `dtype`. */
+int tgt_gelu_dropout_fwd(const void* x, void* y, int64_t n, int32_t dtype, float p, uint64_t seed, void* stream);
+int tgt_gelu_dropout_bwd(const void* x, const void* dy, void* dx, int64_t n, int32_t dtype, float p,
+                         uint64_t seed, void* stream);
+
 /* Column sums of a (rows, C) tensor into float32 (C): the bias gradient of a Linear layer
  * (the `grad_output.sum(0)` ATen reduction behind nn.Linear, e.g. reference
  * lib/tgt/layers/triplet.py:198-203).  partial: tgt_layer_norm_parts()*C floats of scratch. */

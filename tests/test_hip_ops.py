@@ -308,3 +308,36 @@ def test_triangular_update(case, dtype):
     tol = TOL[dtype]
     assert rel(out, ref) < tol
     assert rel(ex.grad, e64.grad) < 2 * tol and rel(vx.grad, v64.grad) < 2 * tol
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+def test_gelu_dropout(dtype):
+    from tgt_amd import ops
+    rng = np.random.default_rng(9)
+    x = (rnd(rng, 1000, 257) * 2).to(dtype)            # odd count: exercises the tail path
+    dy = rnd(rng, 1000, 257).to(dtype)
+    x64 = x.double().requires_grad_(True)
+    ref = torch.nn.functional.gelu(x64)
+    ref.backward(dy.double())
+    xg = x.cuda().requires_grad_(True)
+    y = ops.gelu_dropout(xg, 0.25, training=False)     # eval: plain GELU
+    y.backward(dy.cuda())
+    tol = TOL[dtype]
+    assert rel(y, ref) < tol and rel(xg.grad, x64.grad) < 2 * tol
+    # training: same mask forward and backward, keep rate ~ 1-p, kept values scaled by 1/(1-p)
+    torch.manual_seed(3)
+    xg2 = x.cuda().requires_grad_(True)
+    y2 = ops.gelu_dropout(xg2, 0.25, training=True)
+    y2.backward(dy.cuda())
+    g = torch.nn.functional.gelu(x.cuda().float())
+    nz = g.abs() > 1e-3
+    kept = (y2.float().abs() > 0) & nz
+    rate = float(kept.sum() / nz.sum())
+    assert abs(rate - 0.75) < 0.01, rate
+    assert rel(y2.float()[kept], g[kept] / 0.75) < tol
+    gref = x64.grad.float().cuda() / 0.75
+    assert rel(xg2.grad.float()[kept], gref[kept]) < 2 * tol
+    assert float(xg2.grad.float()[~kept & nz].abs().max()) == 0
+    # a different call draws a different pattern
+    y3 = ops.gelu_dropout(x.cuda(), 0.25, training=True)
+    assert ((y3.float().abs() > 0) != (y2.float().abs() > 0)).any()

@@ -26,6 +26,8 @@ int triplet_attention_run(const tgt_triplet_attention_args* a, bool bwd, hipStre
 int triplet_aggregate_run(const tgt_triplet_aggregate_args* a, bool bwd, hipStream_t st);
 int node_attention_run(const tgt_node_attention_args* a, bool bwd, hipStream_t st);
 int layer_norm_parts();
+int gelu_dropout_run(const void* x, const void* dy, void* out, int64_t n, int dtype, float p, uint64_t seed, bool bwd,
+                     hipStream_t st);
 int triangular_update_run(const void* e4, const void* v4, const float* mask, void* out, const void* d_out, void* d_e4,
                           void* d_v4, int B, int N, int H, int dtype, bool bwd, hipStream_t st);
 int colsum_run(const void* x, int x_dtype, int64_t rows, int C, float* out, float* partial, hipStream_t st);
@@ -97,7 +99,7 @@ using namespace tgt;
 extern "C" {
 
 const char* tgt_last_error(void) { return g_err; }
-int tgt_abi_version(void) { return 5; }
+int tgt_abi_version(void) { return 6; }
 
 int tgt_triplet_attention_fwd(const tgt_triplet_attention_args* a, void* stream) {
     return triplet_attention_run(a, false, reinterpret_cast<hipStream_t>(stream));
@@ -127,6 +129,13 @@ int tgt_triangular_update_bwd(const void* e4, const void* v4, const float* mask,
                               void* d_v4, int32_t B, int32_t N, int32_t H, int32_t dtype, void* stream) {
     return triangular_update_run(e4, v4, mask, nullptr, d_out, d_e4, d_v4, B, N, H, dtype, true,
                                  reinterpret_cast<hipStream_t>(stream));
+}
+int tgt_gelu_dropout_fwd(const void* x, void* y, int64_t n, int32_t dtype, float p, uint64_t seed, void* stream) {
+    return gelu_dropout_run(x, nullptr, y, n, dtype, p, seed, false, reinterpret_cast<hipStream_t>(stream));
+}
+int tgt_gelu_dropout_bwd(const void* x, const void* dy, void* dx, int64_t n, int32_t dtype, float p, uint64_t seed,
+                         void* stream) {
+    return gelu_dropout_run(x, dy, dx, n, dtype, p, seed, true, reinterpret_cast<hipStream_t>(stream));
 }
 int tgt_layer_norm_parts(void) { return layer_norm_parts(); }
 int tgt_colsum(const void* x, int32_t x_dtype, int64_t rows, int32_t C, float* out, float* partial, void* stream) {

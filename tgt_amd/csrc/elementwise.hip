@@ -1,0 +1,97 @@
+// Fused GELU + dropout (the middle of the FFN block, reference
+// lib/tgt/layers/layers.py:157-158: `x = gelu(lin_W1(x)); x = dropout(x)`) for gfx950.
+//
+// Pure streaming: one read + one write forward, two reads + one write backward, instead
+// of four passes + a mask tensor each way.  The keep/drop decision of element i is a
+// counter-based hash of (seed, i), recomputed in the backward -- no mask is stored.
+//   y  = keep(i) ? gelu(x) / (1-p) : 0          gelu(x) = x * 0.5 * (1 + erf(x / sqrt2))
+//   dx = keep(i) ? dy * gelu'(x) / (1-p) : 0    gelu'(x) = 0.5 (1 + erf(x/sqrt2)) + x exp(-x^2/2)/sqrt(2 pi)
+#include "common.hpp"
+
+namespace tgt {
+
+__device__ __forceinline__ uint32_t mix32(uint32_t h) {      // "lowbias32" integer finalizer
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ bool keep_elem(uint64_t seed, int64_t i, uint32_t thresh) {
+    const uint32_t lo = (uint32_t)i, hi = (uint32_t)((uint64_t)i >> 32);
+    const uint32_t h = mix32(lo ^ (uint32_t)seed) ^ mix32(hi + (uint32_t)(seed >> 32) + 0x9e3779b9u);
+    return mix32(h) >= thresh;                                // P(keep) = 1 - thresh / 2^32
+}
+
+template <typename T, bool BWD>
+__global__ void __launch_bounds__(256) gelu_dropout_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                          T* __restrict__ out, int64_t n, uint64_t seed,
+                                                          uint32_t thresh, float inv_keep) {
+    constexpr int V = 16 / (int)sizeof(T);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * V;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * V; i < n; i += stride) {
+        T xv[V], gv[V], ov[V];
+        if (i + V <= n) {
+            uint4 raw = *reinterpret_cast<const uint4*>(x + i);
+            __builtin_memcpy(xv, &raw, 16);
+            if (BWD) {
+                uint4 rg = *reinterpret_cast<const uint4*>(dy + i);
+                __builtin_memcpy(gv, &rg, 16);
+            }
+        } else {
+            for (int t = 0; t < V; ++t) {
+                xv[t] = i + t < n ? x[i + t] : from_f32<T>(0.f);
+                if (BWD) gv[t] = i + t < n ? dy[i + t] : from_f32<T>(0.f);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < V; ++t) {
+            const float v = to_f32(xv[t]);
+            const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
+            float r;
+            if (!BWD) r = v * cdf;
+            else r = to_f32(gv[t]) * (cdf + v * 0.3989422804014327f * __expf(-0.5f * v * v));
+            const bool keep = thresh == 0u || keep_elem(seed, i + t, thresh);
+            ov[t] = from_f32<T>(keep ? r * inv_keep : 0.f);
+        }
+        if (i + V <= n) {
+            uint4 raw;
+            __builtin_memcpy(&raw, ov, 16);
+            *reinterpret_cast<uint4*>(out + i) = raw;
+        } else {
+            for (int t = 0; t < V && i + t < n; ++t) out[i + t] = ov[t];
+        }
+    }
+}
+
+template <typename T>
+static int gd_launch(const void* x, const void* dy, void* out, int64_t n, float p, uint64_t seed, bool bwd,
+                     hipStream_t st) {
+    const uint32_t thresh = p <= 0.f ? 0u : (uint32_t)fmin(4294967295.0, (double)p * 4294967296.0);
+    const float inv_keep = p <= 0.f ? 1.f : 1.f / (1.f - p);
+    constexpr int V = 16 / (int)sizeof(T);
+    int64_t blocks = (n / V + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    if (!bwd)
+        hipLaunchKernelGGL((gelu_dropout_kernel<T, false>), dim3((unsigned)blocks), dim3(256), 0, st,
+                           reinterpret_cast<const T*>(x), nullptr, reinterpret_cast<T*>(out), n, seed, thresh, inv_keep);
+    else
+        hipLaunchKernelGGL((gelu_dropout_kernel<T, true>), dim3((unsigned)blocks), dim3(256), 0, st,
+                           reinterpret_cast<const T*>(x), reinterpret_cast<const T*>(dy), reinterpret_cast<T*>(out), n,
+                           seed, thresh, inv_keep);
+    return check_launch(bwd ? "gelu_dropout_bwd_kernel" : "gelu_dropout_fwd_kernel");
+}
+
+int gelu_dropout_run(const void* x, const void* dy, void* out, int64_t n, int dtype, float p, uint64_t seed, bool bwd,
+                     hipStream_t st) {
+    if (!x || !out || n < 0 || (bwd && !dy)) return set_error(TGT_ERR_INVALID, "gelu_dropout: null tensor");
+    if (p < 0.f || p >= 1.f) return set_error(TGT_ERR_INVALID, "gelu_dropout: p=%f outside [0,1)", p);
+    if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)dy) % 16) return set_error(TGT_ERR_INVALID, "gelu_dropout: tensors must be 16-byte aligned");
+    if (n == 0) return TGT_OK;
+    switch (dtype) {
+        case TGT_F32: return gd_launch<float>(x, dy, out, n, p, seed, bwd, st);
+        case TGT_BF16: return gd_launch<bf16_t>(x, dy, out, n, p, seed, bwd, st);
+        case TGT_F16: return gd_launch<f16_t>(x, dy, out, n, p, seed, bwd, st);
+        default: return set_error(TGT_ERR_INVALID, "gelu_dropout: bad dtype %d", dtype);
+    }
+}
+
+}  // namespace tgt

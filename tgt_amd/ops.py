@@ -444,6 +444,40 @@ def drop_path_add_(x, residual, drop_prob, training):
     return x.add_(residual)
 
 
+class _GeluDropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        _dev(x)
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        s, e = _prof_begin()
+        _lib.check(_lib.lib().tgt_gelu_dropout_fwd(_ptr(x), _ptr(y), x.numel(), _DT[x.dtype], float(p), seed, _stream()),
+                   'tgt_gelu_dropout_fwd')
+        _prof_end('tgt_gelu_dropout_fwd', s, e)
+        ctx.save_for_backward(x)
+        ctx.p, ctx.seed = float(p), seed
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        s, e = _prof_begin()
+        _lib.check(_lib.lib().tgt_gelu_dropout_bwd(_ptr(x), _ptr(dy), _ptr(dx), x.numel(), _DT[x.dtype], ctx.p, ctx.seed,
+                                                   _stream()), 'tgt_gelu_dropout_bwd')
+        _prof_end('tgt_gelu_dropout_bwd', s, e)
+        return dx, None, None
+
+
+def gelu_dropout(x, p, training):
+    """dropout(gelu(x), p) in one pass each way (reference FFN, lib/tgt/layers/layers.py:157-158).
+    The drop pattern comes from a per-call seed drawn from torch's CPU generator (no device sync)."""
+    p = float(p) if training else 0.0
+    seed = int(torch.empty((), dtype=torch.int64).random_().item()) if p > 0 else 0
+    return _GeluDropout.apply(x, p, seed)
+
+
 class _MultiHotEmbed(torch.autograd.Function):
     """sum_f W[idx[..., f]]  as  counts(idx) @ W: both directions are small GEMMs
     instead of a gather and a sort-based scatter (the ATen embedding backward spends

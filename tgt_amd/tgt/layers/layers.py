@@ -108,8 +108,12 @@ class FFN(nn.Module):
         self.dropout = nn.Dropout(act_dropout)
 
     def forward(self, x):
-        x = self.ffn_fn(self.lin_W1(self.ffn_ln(x)))
-        return self.lin_W2(self.dropout(x))
+        x = self.lin_W1(self.ffn_ln(x))
+        if self.activation == 'gelu' and x.dtype in (torch.float32, torch.bfloat16, torch.float16):
+            x = ops.gelu_dropout(x, self.act_dropout, self.training)      # one pass each way, no mask tensor
+        else:
+            x = self.dropout(self.ffn_fn(x))
+        return self.lin_W2(x)
 
 
 class DropPath(nn.Module):
