@@ -341,3 +341,33 @@ def test_gelu_dropout(dtype):
     # a different call draws a different pattern
     y3 = ops.gelu_dropout(x.cuda(), 0.25, training=True)
     assert ((y3.float().abs() > 0) != (y2.float().abs() > 0)).any()
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('with_scale', [False, True])
+def test_add_layer_norm(dtype, with_scale):
+    from tgt_amd import ops
+    rng = np.random.default_rng(17)
+    B, N, C = 4, 9, 256
+    x, res = rnd(rng, B, N, N, C).to(dtype), rnd(rng, B, N, N, C).to(dtype)
+    w, b = (1 + 0.2 * rnd(rng, C)).float(), (0.1 * rnd(rng, C)).float()
+    ds, dy = rnd(rng, B, N, N, C).to(dtype), rnd(rng, B, N, N, C).to(dtype)
+    scale = torch.tensor([0.0, 1.25, 1.25, 0.0]) if with_scale else None
+    x64, r64 = x.double().requires_grad_(True), res.double().requires_grad_(True)
+    w64, b64 = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    s_ref = r64 + (x64 * scale.double().view(B, 1, 1, 1) if with_scale else x64)
+    if dtype != torch.float32:
+        s_q = s_ref + (s_ref.detach().to(dtype).double() - s_ref.detach())     # LN sees the stored (rounded) stream
+    else:
+        s_q = s_ref
+    y_ref = torch.nn.functional.layer_norm(s_q, (C,), w64, b64, 1e-5)
+    (s_ref * ds.double()).sum().backward(retain_graph=True)
+    (y_ref * dy.double()).sum().backward()
+    xg, rg = x.cuda().requires_grad_(True), res.cuda().requires_grad_(True)
+    wg, bg = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    s, y = ops.add_layer_norm(xg, rg, None if scale is None else scale.cuda(), wg, bg, 1e-5, out_dtype=dtype)
+    ((s.float() * ds.cuda().float()).sum() + (y.float() * dy.cuda().float()).sum()).backward()
+    tol = TOL[dtype]
+    assert rel(s, s_ref) < tol and rel(y, y_ref) < 2 * tol
+    assert rel(rg.grad, r64.grad) < 2 * tol and rel(xg.grad, x64.grad) < 2 * tol
+    assert rel(wg.grad, w64.grad) < 2 * tol and rel(bg.grad, b64.grad) < 2 * tol

@@ -77,6 +77,12 @@ struct LnArgs {
     float* mean; float* rstd; float* partial;
     int64_t rows; int C; float eps;
     int x_dtype, y_dtype, dy_dtype, dx_dtype;
+    // fused residual entry (all optional):
+    //   forward : s = res + x * scale[row / rows_per_sample]  -> s_out (x_dtype); y = LN(s)
+    //   backward: d_total = ds_in + LN_bwd(dy)  -> dx;  dx2 = d_total * scale[...]
+    const void* res; int res_dtype; void* s_out;
+    const float* scale; int64_t rows_per_sample;
+    const void* ds_in; int ds_dtype; void* dx2;
 };
 
 template <int LPR, int VPL>
@@ -101,8 +107,25 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const LnArgs a) {
 #pragma unroll
         for (int v = 0; v < VPL; ++v) {
             const int col = (v * LPR + gl) * 8;
-            if (col < a.C) ln_load8(a.x, a.x_dtype, row * a.C + col, x[v]);
-            else {
+            if (col < a.C) {
+                ln_load8(a.x, a.x_dtype, row * a.C + col, x[v]);
+                if (a.res) {
+                    float rr[8];
+                    ln_load8(a.res, a.res_dtype, row * a.C + col, rr);
+                    const float sc = a.scale ? a.scale[row / a.rows_per_sample] : 1.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) x[v][i] = rr[i] + x[v][i] * sc;
+                    ln_store8(a.s_out, a.x_dtype, row * a.C + col, x[v]);
+                    // LN sees the stream value as stored (rounded to its storage dtype)
+                    if (a.x_dtype == TGT_BF16) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) x[v][i] = to_f32(from_f32<bf16_t>(x[v][i]));
+                    } else if (a.x_dtype == TGT_F16) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) x[v][i] = to_f32(from_f32<f16_t>(x[v][i]));
+                    }
+                }
+            } else {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) x[v][i] = 0.f;
             }
@@ -189,7 +212,19 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const LnArgs a) {
                 float dx[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) dx[i] = rstd * (g[v][i] - c1 - xh[v][i] * c2);
+                if (a.ds_in) {
+                    float dd[8];
+                    ln_load8(a.ds_in, a.ds_dtype, row * a.C + col, dd);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) dx[i] += dd[i];
+                }
                 ln_store8(a.dx, a.dx_dtype, row * a.C + col, dx);
+                if (a.dx2) {
+                    const float sc = a.scale ? a.scale[row / a.rows_per_sample] : 1.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) dx[i] *= sc;
+                    ln_store8(a.dx2, a.dx_dtype, row * a.C + col, dx);
+                }
             }
         }
     }
@@ -336,6 +371,40 @@ int layer_norm_bwd_run(const void* dy, int dy_dtype, const void* x, int x_dtype,
     LnArgs a = {};
     a.x = x; a.dy = dy; a.dx = dx; a.gamma = gamma; a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd);
     a.partial = partial; a.rows = rows; a.C = C; a.x_dtype = x_dtype; a.dy_dtype = dy_dtype; a.dx_dtype = dx_dtype;
+    return ln_dispatch(a, true, dgamma, dbeta, st);
+}
+
+int add_layer_norm_fwd_run(const void* x, int x_dtype, const void* res, int res_dtype, const float* scale,
+                           int64_t rows_per_sample, void* s_out, const float* gamma, const float* beta, void* y,
+                           int y_dtype, float* mean, float* rstd, int64_t rows, int C, float eps, hipStream_t st) {
+    if (!x || !res || !s_out || !gamma || !beta || !y || !mean || !rstd || rows < 0)
+        return set_error(TGT_ERR_INVALID, "add_layer_norm fwd: null tensor");
+    if (bad_dtype(x_dtype) || bad_dtype(y_dtype) || bad_dtype(res_dtype)) return set_error(TGT_ERR_INVALID, "add_layer_norm fwd: bad dtype");
+    if (scale && rows_per_sample <= 0) return set_error(TGT_ERR_INVALID, "add_layer_norm fwd: rows_per_sample");
+    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)res | (uintptr_t)s_out) % 16) return set_error(TGT_ERR_INVALID, "add_layer_norm fwd: tensors must be 16-byte aligned");
+    if (rows == 0) return TGT_OK;
+    LnArgs a = {};
+    a.x = x; a.y = y; a.gamma = gamma; a.beta = beta; a.mean = mean; a.rstd = rstd;
+    a.rows = rows; a.C = C; a.eps = eps; a.x_dtype = x_dtype; a.y_dtype = y_dtype;
+    a.res = res; a.res_dtype = res_dtype; a.s_out = s_out; a.scale = scale; a.rows_per_sample = rows_per_sample;
+    return ln_dispatch(a, false, nullptr, nullptr, st);
+}
+
+int add_layer_norm_bwd_run(const void* dy, int dy_dtype, const void* s, int s_dtype, const void* ds_in, int ds_dtype,
+                           const float* scale, int64_t rows_per_sample, const float* gamma, const float* mean,
+                           const float* rstd, void* d_res, void* d_x, int d_dtype, float* dgamma, float* dbeta,
+                           float* partial, int64_t rows, int C, hipStream_t st) {
+    if (!dy || !s || !gamma || !mean || !rstd || !d_res || !dgamma || !dbeta || !partial || rows < 0)
+        return set_error(TGT_ERR_INVALID, "add_layer_norm bwd: null tensor");
+    if (bad_dtype(s_dtype) || bad_dtype(dy_dtype) || bad_dtype(d_dtype) || (ds_in && bad_dtype(ds_dtype)))
+        return set_error(TGT_ERR_INVALID, "add_layer_norm bwd: bad dtype");
+    if (scale && (rows_per_sample <= 0 || !d_x)) return set_error(TGT_ERR_INVALID, "add_layer_norm bwd: scale needs d_x and rows_per_sample");
+    if (((uintptr_t)s | (uintptr_t)dy | (uintptr_t)d_res | (uintptr_t)d_x | (uintptr_t)ds_in) % 16)
+        return set_error(TGT_ERR_INVALID, "add_layer_norm bwd: tensors must be 16-byte aligned");
+    LnArgs a = {};
+    a.x = s; a.dy = dy; a.dx = d_res; a.gamma = gamma; a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd);
+    a.partial = partial; a.rows = rows; a.C = C; a.x_dtype = s_dtype; a.dy_dtype = dy_dtype; a.dx_dtype = d_dtype;
+    a.ds_in = ds_in; a.ds_dtype = ds_dtype; a.dx2 = d_x; a.scale = scale; a.rows_per_sample = rows_per_sample;
     return ln_dispatch(a, true, dgamma, dbeta, st);
 }
 

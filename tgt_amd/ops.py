@@ -603,3 +603,73 @@ def linear(x, weight, bias=None):
     dtype when autocast is on, else in x.dtype)."""
     cd = torch.get_autocast_dtype('cuda') if (x.is_cuda and torch.is_autocast_enabled('cuda')) else x.dtype
     return _Linear.apply(x, weight, bias, cd)
+
+
+# ---------------------------------------------------------------------------
+# residual entry of a pre-norm block: s = res + x*scale ; y = LN(s)   (one pass each way)
+# ---------------------------------------------------------------------------
+class _AddLayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, res, scale, weight, bias, eps, out_dtype):
+        _dev(x, res, weight, bias)
+        x, res = x.contiguous(), res.contiguous()
+        C_ = x.shape[-1]
+        rows = x.numel() // C_
+        w, b = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        s = torch.empty_like(x)
+        y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rps = rows // x.shape[0]
+        L = _lib.lib()
+        p0, p1 = _prof_begin()
+        _lib.check(L.tgt_add_layer_norm_fwd(_ptr(x), _DT[x.dtype], _ptr(res), _DT[res.dtype], _ptr(scale), rps, _ptr(s),
+                                            _ptr(w), _ptr(b), _ptr(y), _DT[out_dtype], _ptr(mean), _ptr(rstd),
+                                            rows, C_, float(eps), _stream()), 'tgt_add_layer_norm_fwd')
+        _prof_end('tgt_add_layer_norm_fwd', p0, p1)
+        ctx.save_for_backward(s, w, mean, rstd, scale)
+        ctx.meta = (weight.dtype, res.dtype, rps)
+        return s, y
+
+    @staticmethod
+    def backward(ctx, ds, dy):
+        s, w, mean, rstd, scale = ctx.saved_tensors
+        wdt, rdt, rps = ctx.meta
+        C_ = s.shape[-1]
+        rows = s.numel() // C_
+        L = _lib.lib()
+        if dy is None:                                  # the LN branch was not used
+            d_res = ds
+            d_x = ds if scale is None else ds * scale.view(-1, *([1] * (ds.ndim - 1))).to(ds.dtype)
+            return d_x, d_res.to(rdt), None, None, None, None, None
+        dy = dy.contiguous()
+        ds = None if ds is None else ds.contiguous()
+        d_res = torch.empty_like(s)
+        d_x = torch.empty_like(s) if scale is not None else None
+        dgb = torch.empty(2, C_, dtype=torch.float32, device=s.device)
+        partial = torch.empty(L.tgt_layer_norm_parts() * 2 * C_, dtype=torch.float32, device=s.device)
+        p0, p1 = _prof_begin()
+        _lib.check(L.tgt_add_layer_norm_bwd(_ptr(dy), _DT[dy.dtype], _ptr(s), _DT[s.dtype], _ptr(ds),
+                                            0 if ds is None else _DT[ds.dtype], _ptr(scale), rps, _ptr(w), _ptr(mean),
+                                            _ptr(rstd), _ptr(d_res), _ptr(d_x), _DT[s.dtype], _ptr(dgb[0]), _ptr(dgb[1]),
+                                            _ptr(partial), rows, C_, _stream()), 'tgt_add_layer_norm_bwd')
+        _prof_end('tgt_add_layer_norm_bwd', p0, p1)
+        if d_x is None:
+            d_x = d_res
+        return d_x, (d_res if rdt == d_res.dtype else d_res.to(rdt)), None, dgb[0].to(wdt), dgb[1].to(wdt), None, None
+
+
+def drop_path_scale(x, drop_prob, training):
+    """per-sample DropPath factor (B,) float32 = Bernoulli(keep)/keep, or None when inactive
+    (reference lib/tgt/layers/layers.py:169-174)."""
+    if drop_prob > 0 and training:
+        keep = 1.0 - drop_prob
+        return torch.empty(x.size(0), dtype=torch.float32, device=x.device).bernoulli_(keep).div_(keep)
+    return None
+
+
+def add_layer_norm(x, res, scale, weight, bias, eps=1e-5, out_dtype=None):
+    """(s, y) with s = res + x*scale (per-sample scale or None), y = LayerNorm(s)."""
+    if out_dtype is None:
+        out_dtype = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled('cuda') else x.dtype
+    return _AddLayerNorm.apply(x, res, scale, weight, bias, eps, out_dtype)

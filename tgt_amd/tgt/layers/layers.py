@@ -108,7 +108,11 @@ class FFN(nn.Module):
         self.dropout = nn.Dropout(act_dropout)
 
     def forward(self, x):
-        x = self.lin_W1(self.ffn_ln(x))
+        return self.forward_normed(self.ffn_ln(x))
+
+    def forward_normed(self, x):
+        """the block after ffn_ln (TGT_Layer fuses that LayerNorm with the residual add before it)"""
+        x = self.lin_W1(x)
         if self.activation == 'gelu' and x.dtype in (torch.float32, torch.bfloat16, torch.float16):
             x = ops.gelu_dropout(x, self.act_dropout, self.training)      # one pass each way, no mask tensor
         else:
@@ -186,15 +190,23 @@ class TGT_Layer(nn.Module):
         h, e, mask = g.h, g.e, g.mask
         h_in, e_in = h, e
         h, e = self.update(h, e, mask)
+        # Each residual add is fused with the LayerNorm that opens the next sub-block
+        # (s = res + DropPath(x); y = LN(s) in one pass, and one pass in the backward).
         dp, tr = self.drop_path.drop_path, self.training
+
+        def enter(x, res, ln):
+            return ops.add_layer_norm(x, res, ops.drop_path_scale(x, dp, tr), ln.weight, ln.bias, ln.eps)
+
         if self.node_update:
-            h = ops.drop_path_add_(h, h_in, dp, tr)
-            h = ops.drop_path_add_(self.node_ffn(h), h, dp, tr)
+            h, x = enter(h, h_in, self.node_ffn.ffn_ln)
+            h = ops.drop_path_add_(self.node_ffn.forward_normed(x), h, dp, tr)
         if self.edge_update:
-            e = ops.drop_path_add_(e, e_in, dp, tr)
             if self._triplet_update:
-                e = ops.drop_path_add_(self.tria(e, mask), e, dp, tr)
-            e = ops.drop_path_add_(self.edge_ffn(e), e, dp, tr)
+                e, x = enter(e, e_in, self.tria.tri_ln_e)
+                e, x = enter(self.tria.forward_normed(x, mask), e, self.edge_ffn.ffn_ln)
+            else:
+                e, x = enter(e, e_in, self.edge_ffn.ffn_ln)
+            e = ops.drop_path_add_(self.edge_ffn.forward_normed(x), e, dp, tr)
         g = g.copy()
         g.h, g.e = h, e
         return g

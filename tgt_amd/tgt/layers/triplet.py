@@ -100,10 +100,13 @@ class TripletAttention(_TripletBase):
         return torch.cat(ws, 0), torch.cat(bs, 0)
 
     def forward(self, e, mask):
+        return self.forward_normed(self.tri_ln_e(e), mask)
+
+    def forward_normed(self, x, mask):
+        """the block after tri_ln_e (TGT_Layer fuses that LayerNorm with the residual add before it)"""
         _no_attention_dropout(self)
-        B, N = e.shape[0], e.shape[1]
-        x = self.tri_ln_e(e)
-        w, b = self._fused_projection(e.device)
+        B, N = x.shape[0], x.shape[1]
+        w, b = self._fused_projection(x.device)
         fused = ops.linear(x, w, b)
         va = ops.triplet_attention(fused, ops.as_mask3(mask, B, N), self._layout)
         return self._out_proj(va)
@@ -138,10 +141,12 @@ class TripletAggregate(_TripletBase):
         self._layout = ops.AggregateLayout(edge_width, num_heads, gated=self.gated)
 
     def forward(self, e, mask):
+        return self.forward_normed(self.tri_ln_e(e), mask)
+
+    def forward_normed(self, x, mask):
         _no_attention_dropout(self)
-        B, N = e.shape[0], e.shape[1]
-        x = self.tri_ln_e(e)
-        rows = self._index('v', lambda: layout.qkv_rows_head_major(self.edge_width, self.num_heads, parts=2), e.device)
+        B, N = x.shape[0], x.shape[1]
+        rows = self._index('v', lambda: layout.qkv_rows_head_major(self.edge_width, self.num_heads, parts=2), x.device)
         lin_b = self.lin_EG if self.gated else self.lin_E
         ws, bs = [self.lin_V.weight[rows], lin_b.weight], [self.lin_V.bias[rows], lin_b.bias]
         pad = self._layout.width - self._layout.used
@@ -170,8 +175,10 @@ class TriangularUpdate(_TripletBase):
         self.lin_O = Linear(num_heads * 2, edge_width * 2)
 
     def forward(self, e, mask):
-        B, N = e.shape[0], e.shape[1]
-        x = self.tri_ln_e(e)
+        return self.forward_normed(self.tri_ln_e(e), mask)
+
+    def forward_normed(self, x, mask):
+        B, N = x.shape[0], x.shape[1]
         va = ops.triangular_update(self.lin_E(x), self.lin_V(x), ops.as_mask3(mask, B, N), self.num_heads)
         gate, lin = self.lin_O(va).chunk(2, dim=-1)
         return torch.sigmoid(gate) * lin
