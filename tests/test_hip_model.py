@@ -23,7 +23,7 @@ def load_gold(name):
 
 
 def product_class(name):
-    from tgt_amd.tgt.layers import layers as L, triplet as T
+    from tgt_amd.tgt.layers import blocks as L, triplet as T
     from tgt_amd import pcqm
     for mod in (L, T, pcqm):
         if hasattr(mod, name):

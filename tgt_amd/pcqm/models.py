@@ -12,7 +12,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..tgt import TGT_Encoder, Graph
-from ..tgt.layers.layers import LayerNorm, Linear
+from ..tgt.layers.blocks import LayerNorm, Linear
 
 NODE_FEATURES_OFFSET = 128      # reference lib/models/pcqm/consts.py:1-7
 NUM_NODE_FEATURES = 9

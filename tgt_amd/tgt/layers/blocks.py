@@ -1,12 +1,19 @@
-"""TGT layer modules on the HIP kernels.  API / state_dict = reference
-lib/tgt/layers/layers.py; the attention arithmetic is libtgt_hip.so."""
+"""The blocks of one TGT layer on the HIP kernels: node attention with edge bias/gate,
+logits-only edge update, FFN, DropPath and the layer wiring.  Class names, constructor
+keywords and state_dict keys follow the reference (lib/tgt/layers/layers.py,
+lib/tgt/layers/activations.py); the arithmetic is libtgt_hip.so plus library GEMMs."""
 import torch
 from torch import nn
 import torch.nn.functional as F
 
 from ... import ops
-from .activations import get_activation
 from .triplet import get_triplet_layer
+
+
+def _keep(module, **kw):
+    """constructor keywords stay readable as attributes, as on the reference modules"""
+    for k, v in kw.items():
+        setattr(module, k, v)
 
 
 class LayerNorm(nn.LayerNorm):
@@ -31,14 +38,10 @@ class EGT_Attention(nn.Module):
     def __init__(self, node_width, edge_width, num_heads, source_dropout=0,
                  scale_degree=True, edge_update=True):
         super().__init__()
-        self.node_width = node_width
-        self.edge_width = edge_width
-        self.num_heads = num_heads
-        self.source_dropout = source_dropout
-        self.scale_degree = scale_degree
-        self.edge_update = edge_update
-        assert not (node_width % num_heads), 'node_width must be divisible by num_heads'
-        self._dot_dim = node_width // num_heads
+        _keep(self, node_width=node_width, edge_width=edge_width, num_heads=num_heads,
+              source_dropout=source_dropout, scale_degree=scale_degree, edge_update=edge_update)
+        self._dot_dim, rem = divmod(node_width, num_heads)
+        assert rem == 0, 'node_width must be divisible by num_heads'
         self._scale_factor = self._dot_dim ** -0.5
 
         self.mha_ln_h = LayerNorm(node_width)
@@ -73,11 +76,9 @@ class EdgeUpdate(nn.Module):
 
     def __init__(self, node_width, edge_width, num_heads):
         super().__init__()
-        self.node_width = node_width
-        self.edge_width = edge_width
-        self.num_heads = num_heads
-        assert not (node_width % num_heads), 'node_width must be divisible by num_heads'
-        self._dot_dim = node_width // num_heads
+        _keep(self, node_width=node_width, edge_width=edge_width, num_heads=num_heads)
+        self._dot_dim, rem = divmod(node_width, num_heads)
+        assert rem == 0, 'node_width must be divisible by num_heads'
         self._scale_factor = self._dot_dim ** -0.5
         self.mha_ln_h = LayerNorm(node_width)
         self.mha_ln_e = LayerNorm(edge_width)
@@ -91,20 +92,39 @@ class EdgeUpdate(nn.Module):
         return h, self.lin_O_e(ops.edge_logits(qk, bias, self.num_heads))
 
 
+_GLU_GATES = {            # name -> gate nonlinearity g(.) of  lin * g(gate)  (reference activations.py:4-17)
+    'geglu': F.gelu,
+    'glu': torch.sigmoid,
+    'swiglu': F.silu,
+}
+
+
+def get_activation(activation):
+    """(callable, width multiplier of lin_W1): GLU-family names split the projection into
+    (gate, linear) halves, anything else is looked up in torch.nn.functional
+    (reference lib/tgt/layers/activations.py:21-25)."""
+    gate_fn = _GLU_GATES.get(activation)
+    if gate_fn is None:
+        return getattr(F, activation), 1
+
+    def gated(x):
+        gate, lin = x.chunk(2, dim=-1)
+        return lin * gate_fn(gate)
+    return gated, 2
+
+
 class FFN(nn.Module):
-    """Reference lib/tgt/layers/layers.py:134-160."""
+    """Pre-norm MLP block: ffn_ln -> lin_W1 -> activation -> dropout -> lin_W2
+    (reference lib/tgt/layers/layers.py:134-160)."""
 
     def __init__(self, width, multiplier=1., act_dropout=0., activation='gelu'):
         super().__init__()
-        self.width = width
-        self.multiplier = multiplier
-        self.act_dropout = act_dropout
-        self.activation = activation
+        _keep(self, width=width, multiplier=multiplier, act_dropout=act_dropout, activation=activation)
         self.ffn_fn, self.act_mul = get_activation(activation)
-        inner_dim = round(width * multiplier)
+        hidden = round(width * multiplier)
         self.ffn_ln = LayerNorm(width)
-        self.lin_W1 = Linear(width, inner_dim * self.act_mul)
-        self.lin_W2 = Linear(inner_dim, width)
+        self.lin_W1 = Linear(width, hidden * self.act_mul)
+        self.lin_W2 = Linear(hidden, width)
         self.dropout = nn.Dropout(act_dropout)
 
     def forward(self, x):
@@ -121,7 +141,9 @@ class FFN(nn.Module):
 
 
 class DropPath(nn.Module):
-    """Per-sample stochastic depth.  Reference lib/tgt/layers/layers.py:163-177."""
+    """Stochastic depth per graph of the batch (reference lib/tgt/layers/layers.py:163-177).
+    Inside TGT_Layer the factor is folded into the fused residual kernels
+    (`ops.drop_path_scale`); this module form exists for API parity."""
 
     def __init__(self, drop_path=0.):
         super().__init__()
@@ -129,14 +151,13 @@ class DropPath(nn.Module):
         self._keep_prob = 1 - drop_path
 
     def forward(self, x):
-        if self.drop_path > 0 and self.training:
-            shape = [x.size(0)] + [1] * (x.ndim - 1)
-            keep = x.new_empty(shape).bernoulli_(self._keep_prob)
-            x = x.div(self._keep_prob) * keep
-        return x
+        scale = ops.drop_path_scale(x, self.drop_path, self.training)
+        if scale is None:
+            return x
+        return x * scale.view(-1, *([1] * (x.ndim - 1))).to(x.dtype)
 
-    def __repr__(self):
-        return f'{self.__class__.__name__}(drop_path={self.drop_path})'
+    def extra_repr(self):
+        return f'drop_path={self.drop_path}'
 
 
 class TGT_Layer(nn.Module):
@@ -148,35 +169,23 @@ class TGT_Layer(nn.Module):
                  node_ffn_multiplier=1., edge_ffn_multiplier=1., source_dropout=0,
                  drop_path=0, node_act_dropout=0, edge_act_dropout=0):
         super().__init__()
-        self.node_width = node_width
-        self.edge_width = edge_width
-        self.num_heads = num_heads
-        self.activation = activation
-        self.node_ffn_multiplier = node_ffn_multiplier
-        self.edge_ffn_multiplier = edge_ffn_multiplier
-        self.node_act_dropout = node_act_dropout
-        self.edge_act_dropout = edge_act_dropout
-        self.source_dropout = source_dropout
-        self.scale_degree = scale_degree
-        self.node_update = node_update
-        self.edge_update = edge_update
-        self.triplet_heads = triplet_heads
-        self.triplet_type = triplet_type
-        self.triplet_dropout = triplet_dropout
+        _keep(self, node_width=node_width, edge_width=edge_width, num_heads=num_heads, activation=activation,
+              scale_degree=scale_degree, node_update=node_update, edge_update=edge_update,
+              triplet_heads=triplet_heads, triplet_type=triplet_type, triplet_dropout=triplet_dropout,
+              node_ffn_multiplier=node_ffn_multiplier, edge_ffn_multiplier=edge_ffn_multiplier,
+              source_dropout=source_dropout, node_act_dropout=node_act_dropout, edge_act_dropout=edge_act_dropout)
         self._triplet_update = triplet_heads > 0
+        if not (node_update or edge_update):
+            raise ValueError('At least one of node_update and edge_update must be True')
 
         if node_update:
             self.update = EGT_Attention(node_width=node_width, edge_width=edge_width,
                                         num_heads=num_heads, source_dropout=source_dropout,
                                         scale_degree=scale_degree, edge_update=edge_update)
-        elif edge_update:
-            self.update = EdgeUpdate(node_width=node_width, edge_width=edge_width, num_heads=num_heads)
-        else:
-            raise ValueError('At least one of node_update and edge_update must be True')
-
-        if node_update:
             self.node_ffn = FFN(width=node_width, multiplier=node_ffn_multiplier,
                                 act_dropout=node_act_dropout, activation=activation)
+        else:                       # last layer of an edge-ended model: logits-only edge update
+            self.update = EdgeUpdate(node_width=node_width, edge_width=edge_width, num_heads=num_heads)
         if edge_update:
             if self._triplet_update:
                 self.tria = get_triplet_layer(triplet_type)(edge_width=edge_width,
@@ -211,6 +220,5 @@ class TGT_Layer(nn.Module):
         g.h, g.e = h, e
         return g
 
-    def __repr__(self):
-        rep = super().__repr__()
-        return rep + f' (activation: {self.activation}, source_dropout: {self.source_dropout})'
+    def extra_repr(self):
+        return f'activation={self.activation}, source_dropout={self.source_dropout}'
