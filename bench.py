@@ -146,6 +146,7 @@ def main():
     mcfg = tgt_at_24l()
     torch.manual_seed(0)
     model = TGT_Multi(**mcfg).to(dev).train()
+    torch.manual_seed(4321 + rank)           # same initial weights on every rank, different dropout streams
     cfg = StepConfig(mixed_precision=None if args.precision == 'fp32' else args.precision)
     trainer = Trainer(model, cfg)
 

@@ -371,3 +371,35 @@ def test_add_layer_norm(dtype, with_scale):
     assert rel(s, s_ref) < tol and rel(y, y_ref) < 2 * tol
     assert rel(rg.grad, r64.grad) < 2 * tol and rel(xg.grad, x64.grad) < 2 * tol
     assert rel(wg.grad, w64.grad) < 2 * tol and rel(bg.grad, b64.grad) < 2 * tol
+
+
+@pytest.mark.parametrize('N', [1, 2])
+def test_tiny_graphs(N):
+    """single-node and two-node graphs through every kernel (degenerate softmax rows)"""
+    from tgt_amd import ops, layout
+    B, C, H, W, Hn = 3, 32, 4, 48, 4
+    rng = np.random.default_rng(N)
+    mask = gu.additive_mask([N] * B, N, torch.float32)
+    L = ops.TripletLayout(C, H)
+    fused = rnd(rng, B, N, N, L.width).float()
+    f64 = fused.double()
+    idx, oidx = layout.head_major_index(C, H), layout.va_cols_head_major(C, H)
+    blk = lambda lo: torch.cat([to_ref(f64[..., lo + p * C: lo + (p + 1) * C], idx) for p in range(3)], -1)
+    ref = core.triplet_attention_core(blk(0), f64[..., 6 * C:6 * C + 2 * H], blk(3 * C),
+                                      f64[..., 6 * C + 2 * H:6 * C + 4 * H], mask.double(), H)
+    out = ops.triplet_attention(fused.cuda(), mask.reshape(B, N, N).cuda(), L)
+    assert rel(out, from_ref(ref, oidx)) < 2e-5
+    qkv, eg = rnd(rng, B, N, 3 * W).float(), rnd(rng, B, N, N, 2 * Hn).float()
+    v_ref, h_ref = core.egt_attention_core(qkv.double(), eg.double(), mask.double(), Hn)
+    v, hh = ops.node_attention(qkv.cuda(), eg.cuda(), mask.reshape(B, N, N).cuda(), Hn)
+    assert rel(v, v_ref) < 2e-5 and rel(hh, h_ref) < 2e-5
+
+
+def test_empty_batch_is_a_no_op():
+    from tgt_amd import ops
+    L = ops.TripletLayout(32, 4)
+    out = ops.triplet_attention(torch.zeros(0, 5, 5, L.width, device='cuda'), torch.zeros(0, 5, 5, device='cuda'), L)
+    assert out.shape == (0, 5, 5, 64)
+    v, hh = ops.node_attention(torch.zeros(0, 5, 144, device='cuda'), torch.zeros(0, 5, 5, 8, device='cuda'),
+                               torch.zeros(0, 5, 5, device='cuda'), 4)
+    assert v.shape == (0, 5, 48) and hh.shape == (0, 5, 5, 4)

@@ -387,7 +387,8 @@ static int dispatch_node_d(const tgt_node_attention_args& a, bool bwd, hipStream
 
 int node_attention_run(const tgt_node_attention_args* a, bool bwd, hipStream_t st) {
     if (!a) return set_error(TGT_ERR_INVALID, "node attention: null args");
-    if (a->B <= 0 || a->N <= 0 || a->H <= 0) return set_error(TGT_ERR_INVALID, "node attention: bad sizes B=%d N=%d H=%d", a->B, a->N, a->H);
+    if (a->B < 0 || a->N < 0 || a->H <= 0) return set_error(TGT_ERR_INVALID, "node attention: bad sizes B=%d N=%d H=%d", a->B, a->N, a->H);
+    if (a->B == 0 || a->N == 0) return TGT_OK;
     if (!a->qkv || !a->eg) return set_error(TGT_ERR_INVALID, "node attention: null qkv/eg");
     if (a->logits_only) {
         if (!bwd && !a->hhat) return set_error(TGT_ERR_INVALID, "node attention: logits_only needs hhat");

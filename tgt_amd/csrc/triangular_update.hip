@@ -108,7 +108,9 @@ static int tri_upd_launch(const TriUpdArgs& a, bool bwd, hipStream_t st) {
 
 int triangular_update_run(const void* e4, const void* v4, const float* mask, void* out, const void* d_out, void* d_e4,
                           void* d_v4, int B, int N, int H, int dtype, bool bwd, hipStream_t st) {
-    if (!e4 || !v4 || !mask || B <= 0 || N <= 0 || H <= 0) return set_error(TGT_ERR_INVALID, "triangular update: null tensor / bad size");
+    if (B < 0 || N < 0 || H <= 0) return set_error(TGT_ERR_INVALID, "triangular update: bad size");
+    if (B == 0 || N == 0) return TGT_OK;
+    if (!e4 || !v4 || !mask) return set_error(TGT_ERR_INVALID, "triangular update: null tensor");
     if (!bwd && !out) return set_error(TGT_ERR_INVALID, "triangular update: null out");
     if (bwd && (!d_out || !d_e4 || !d_v4)) return set_error(TGT_ERR_INVALID, "triangular update bwd: null gradient tensor");
     TriUpdArgs a = {e4, v4, mask, out, d_out, d_e4, d_v4, B, N, H, dtype};

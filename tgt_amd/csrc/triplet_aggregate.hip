@@ -306,7 +306,8 @@ static int agg_dispatch_d(const tgt_triplet_aggregate_args& a, bool bwd, hipStre
 
 int triplet_aggregate_run(const tgt_triplet_aggregate_args* a, bool bwd, hipStream_t st) {
     if (!a) return set_error(TGT_ERR_INVALID, "triplet aggregate: null args");
-    if (a->B <= 0 || a->N <= 0 || a->H <= 0) return set_error(TGT_ERR_INVALID, "triplet aggregate: bad sizes");
+    if (a->B < 0 || a->N < 0 || a->H <= 0) return set_error(TGT_ERR_INVALID, "triplet aggregate: bad sizes");
+    if (a->B == 0 || a->N == 0) return TGT_OK;
     if (a->N > 64) return set_error(TGT_ERR_UNSUPPORTED, "triplet aggregate: N=%d > 64 not supported", a->N);
     const int64_t esz = a->dtype == TGT_F32 ? 4 : 2;
     for (int dir = 0; dir < 2; ++dir) {

@@ -493,7 +493,8 @@ static int dispatch_d(const tgt_triplet_attention_args& a, bool bwd, hipStream_t
 
 int triplet_attention_run(const tgt_triplet_attention_args* a, bool bwd, hipStream_t st) {
     if (!a) return set_error(TGT_ERR_INVALID, "triplet attention: null args");
-    if (a->B <= 0 || a->N <= 0 || a->H <= 0) return set_error(TGT_ERR_INVALID, "triplet attention: bad sizes B=%d N=%d H=%d", a->B, a->N, a->H);
+    if (a->B < 0 || a->N < 0 || a->H <= 0) return set_error(TGT_ERR_INVALID, "triplet attention: bad sizes B=%d N=%d H=%d", a->B, a->N, a->H);
+    if (a->B == 0 || a->N == 0) return TGT_OK;                 // empty batch: nothing to do
     if (a->N > 64) return set_error(TGT_ERR_UNSUPPORTED, "triplet attention: N=%d > 64 not supported", a->N);
     const int64_t esz = a->dtype == TGT_F32 ? 4 : 2;
     for (int dir = 0; dir < 2; ++dir) {
