@@ -21,124 +21,163 @@
 
 namespace tgt {
 
-// One lane owns head h of RL consecutive nodes x0..x0+RL-1 (queries in the forward
-// and row pass, keys in the column pass): every K/V (or Q/dV_att) value a lane
-// loads is reused RL times from registers, which divides the vector-memory
-// instruction count -- the real limiter of this kernel -- by ~RL.
+// One lane owns HV adjacent heads of one node (a query in the forward and row pass, a key in
+// the column pass).  HV = 4 turns every access into an 8-byte (bf16) / 16-byte (fp32) vector:
+// this kernel is bound by vector-memory INSTRUCTIONS (2-byte accesses fill 128 B per wave
+// instruction), not by bytes, so wider lanes are the lever.  64 / (H/HV) nodes share a wave;
+// they read the same K/V rows, which the memory pipeline serves once per instruction.
 struct NodeLane {
     bool active;
-    int b, x0, h;
+    int b, x, h;          // graph, node, first head of this lane
 };
 
-// lanes per node block: smallest power of two >= min(H,64); blocks per wave = 64/that
-__host__ __device__ inline int node_lpr(int H) {
+// lanes per node = smallest power of two >= min(H/HV, 64)
+__host__ __device__ inline int node_lpr(int H, int HV) {
     int l = 1;
-    while (l < H && l < 64) l <<= 1;
+    while (l < (H + HV - 1) / HV && l < 64) l <<= 1;
     return l;
 }
 
-template <int RL>
+template <int HV>
 __device__ __forceinline__ NodeLane node_lane(const tgt_node_attention_args& a) {
-    const int lpr = node_lpr(a.H), rpw = 64 / lpr, hb_count = (a.H + 63) / 64;
-    const int nblk = (a.N + RL - 1) / RL;
+    const int lpr = node_lpr(a.H, HV), rpw = 64 / lpr, hb_count = (a.H + 64 * HV - 1) / (64 * HV);
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int64_t unit = wave * rpw + lane / lpr;          // (b, node block, hb)
-    const int64_t total = (int64_t)a.B * nblk * hb_count;
+    const int64_t unit = wave * rpw + lane / lpr;          // (b, node, head block)
+    const int64_t total = (int64_t)a.B * a.N * hb_count;
     NodeLane n;
     const int hb = (int)(unit % hb_count);
     const int64_t bx = unit / hb_count;
-    n.h = hb * 64 + lane % lpr;
-    n.x0 = (int)(bx % nblk) * RL;
-    n.b = (int)(bx / nblk);
+    n.h = (hb * 64 + lane % lpr) * HV;
+    n.x = (int)(bx % a.N);
+    n.b = (int)(bx / a.N);
     n.active = unit < total && n.h < a.H;
     return n;
 }
 
-template <typename T>
-__device__ __forceinline__ float ld(const T* p, int64_t i) { return to_f32(p[i]); }
+// HV contiguous elements (HV*sizeof(T)-byte aligned) <-> floats
+template <typename T, int HV>
+__device__ __forceinline__ void ldv(const T* p, int64_t i, float (&o)[HV]) {
+    T t[HV];
+    if constexpr (HV * sizeof(T) == 16) { uint4 r = *reinterpret_cast<const uint4*>(p + i); __builtin_memcpy(t, &r, 16); }
+    else if constexpr (HV * sizeof(T) == 8) { uint2 r = *reinterpret_cast<const uint2*>(p + i); __builtin_memcpy(t, &r, 8); }
+    else if constexpr (HV * sizeof(T) == 4) { uint32_t r = *reinterpret_cast<const uint32_t*>(p + i); __builtin_memcpy(t, &r, 4); }
+    else { t[0] = p[i]; }
+#pragma unroll
+    for (int k = 0; k < HV; ++k) o[k] = to_f32(t[k]);
+}
+template <typename T, int HV>
+__device__ __forceinline__ void stv(T* p, int64_t i, const float (&v)[HV]) {
+    T t[HV];
+#pragma unroll
+    for (int k = 0; k < HV; ++k) t[k] = from_f32<T>(v[k]);
+    if constexpr (HV * sizeof(T) == 16) { uint4 r; __builtin_memcpy(&r, t, 16); *reinterpret_cast<uint4*>(p + i) = r; }
+    else if constexpr (HV * sizeof(T) == 8) { uint2 r; __builtin_memcpy(&r, t, 8); *reinterpret_cast<uint2*>(p + i) = r; }
+    else if constexpr (HV * sizeof(T) == 4) { uint32_t r; __builtin_memcpy(&r, t, 4); *reinterpret_cast<uint32_t*>(p + i) = r; }
+    else { p[i] = t[0]; }
+}
+template <int HV>
+__device__ __forceinline__ void ldf(const float* p, int64_t i, float (&o)[HV]) {
+#pragma unroll
+    for (int k = 0; k < HV; ++k) o[k] = p[i + k];
+}
 
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
-template <typename T, int D, int RL>
+template <typename T, int D, int HV>
 __global__ void __launch_bounds__(256) node_att_fwd_kernel(const tgt_node_attention_args a) {
-    const NodeLane n = node_lane<RL>(a);
+    const NodeLane n = node_lane<HV>(a);
     if (!n.active) return;
     const int N = a.N, H = a.H, h = n.h;
     const T* qkv = reinterpret_cast<const T*>(a.qkv);
     const T* eg = reinterpret_cast<const T*>(a.eg);
     T* hhat = reinterpret_cast<T*>(a.hhat);
-    const int64_t row0 = (int64_t)n.b * N;
+    const int64_t row0 = (int64_t)n.b * N, row_l = row0 + n.x;
 
-    float q[RL][D], acc[RL][D], mx[RL], sum[RL], gsum[RL];
-    bool live[RL];
+    float q[D][HV], acc[D][HV], mx[HV], sum[HV], gsum[HV];
 #pragma unroll
-    for (int t = 0; t < RL; ++t) {
-        live[t] = n.x0 + t < N;
-        const int64_t rl = row0 + (live[t] ? n.x0 + t : n.x0);
+    for (int d = 0; d < D; ++d) {
+        ldv<T, HV>(qkv, row_l * a.ld_qkv + a.q_off + d * H + h, q[d]);
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            q[t][d] = ld(qkv, rl * a.ld_qkv + a.q_off + d * H + h) * a.scale;
-            acc[t][d] = 0.f;
+        for (int k = 0; k < HV; ++k) {
+            q[d][k] *= a.scale;
+            acc[d][k] = 0.f;
         }
-        mx[t] = -INFINITY;
-        sum[t] = gsum[t] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < HV; ++k) {
+        mx[k] = -INFINITY;
+        sum[k] = gsum[k] = 0.f;
     }
     for (int m = 0; m < N; ++m) {
-        const int64_t row_m = row0 + m;
-        float kk[D], vv[D];
+        const int64_t row_m = row0 + m, lm = row_l * N + m;
+        float e[HV], g[HV], s[HV];
+        ldv<T, HV>(eg, lm * a.ld_eg + a.e_off + h, e);
+        if (!a.logits_only) ldv<T, HV>(eg, lm * a.ld_eg + a.g_off + h, g);
 #pragma unroll
-        for (int d = 0; d < D; ++d) kk[d] = ld(qkv, row_m * a.ld_qkv + a.k_off + d * H + h);
-        if (!a.logits_only) {
+        for (int k = 0; k < HV; ++k) s[k] = e[k];
 #pragma unroll
-            for (int d = 0; d < D; ++d) vv[d] = ld(qkv, row_m * a.ld_qkv + a.v_off + d * H + h);
+        for (int d = 0; d < D; ++d) {
+            float kk[HV];
+            ldv<T, HV>(qkv, row_m * a.ld_qkv + a.k_off + d * H + h, kk);
+#pragma unroll
+            for (int k = 0; k < HV; ++k) s[k] += q[d][k] * kk[k];
+        }
+        if (hhat) stv<T, HV>(hhat, lm * H + h, s);
+        if (a.logits_only) continue;
+        const float mk = a.mask[lm];
+        float corr[HV], w[HV];
+#pragma unroll
+        for (int k = 0; k < HV; ++k) {
+            const float x = s[k] + mk;
+            const float gt = fast_sigmoid(g[k] + mk);
+            // online softmax; mref = 0 while everything seen so far is -inf
+            const float mnew = fmaxf(mx[k], x);
+            const float mref = mnew == -INFINITY ? 0.f : mnew;
+            corr[k] = fast_exp(mx[k] - mref);
+            const float p = fast_exp(x - mref);
+            sum[k] = sum[k] * corr[k] + p;
+            w[k] = p * gt;
+            gsum[k] += gt;
+            mx[k] = mnew;
         }
 #pragma unroll
-        for (int t = 0; t < RL; ++t) {
-            if (!live[t]) continue;
-            const int64_t lm = (row0 + n.x0 + t) * N + m;
-            float dot = 0.f;
+        for (int d = 0; d < D; ++d) {
+            float vv[HV];
+            ldv<T, HV>(qkv, row_m * a.ld_qkv + a.v_off + d * H + h, vv);
 #pragma unroll
-            for (int d = 0; d < D; ++d) dot += q[t][d] * kk[d];
-            const float s = dot + ld(eg, lm * a.ld_eg + a.e_off + h);
-            if (hhat) hhat[lm * H + h] = from_f32<T>(s);
-            if (a.logits_only) continue;
-            const float mk = a.mask[lm];
-            const float x = s + mk;
-            const float g = fast_sigmoid(ld(eg, lm * a.ld_eg + a.g_off + h) + mk);
-            // online softmax; mref = 0 while everything seen so far is -inf
-            const float mnew = fmaxf(mx[t], x);
-            const float mref = mnew == -INFINITY ? 0.f : mnew;
-            const float corr = fast_exp(mx[t] - mref), p = fast_exp(x - mref);
-            sum[t] = sum[t] * corr + p;
-            const float w = p * g;
-#pragma unroll
-            for (int d = 0; d < D; ++d) acc[t][d] = acc[t][d] * corr + w * vv[d];
-            gsum[t] += g;
-            mx[t] = mnew;
+            for (int k = 0; k < HV; ++k) acc[d][k] = acc[d][k] * corr[k] + w[k] * vv[k];
         }
     }
     if (a.logits_only) return;
     T* vatt = reinterpret_cast<T*>(a.vatt);
+    float f[HV], lse[HV];
 #pragma unroll
-    for (int t = 0; t < RL; ++t) {
-        if (!live[t]) continue;
-        const int64_t rl = row0 + n.x0 + t;
-        const float f = __frcp_rn(sum[t]) * (a.scale_degree ? __logf(1.f + gsum[t]) : 1.f);
+    for (int k = 0; k < HV; ++k) {
+        f[k] = __frcp_rn(sum[k]) * (a.scale_degree ? __logf(1.f + gsum[k]) : 1.f);
+        lse[k] = mx[k] + __logf(sum[k]);
+    }
 #pragma unroll
-        for (int d = 0; d < D; ++d) vatt[rl * (int64_t)(D * H) + d * H + h] = from_f32<T>(acc[t][d] * f);
-        a.lse[rl * H + h] = mx[t] + __logf(sum[t]);
-        a.gsum[rl * H + h] = gsum[t];
+    for (int d = 0; d < D; ++d) {
+        float o[HV];
+#pragma unroll
+        for (int k = 0; k < HV; ++k) o[k] = acc[d][k] * f[k];
+        stv<T, HV>(vatt, row_l * (int64_t)(D * H) + d * H + h, o);
+    }
+#pragma unroll
+    for (int k = 0; k < HV; ++k) {
+        a.lse[row_l * H + h + k] = lse[k];
+        a.gsum[row_l * H + h + k] = gsum[k];
     }
 }
 
 // ---------------------------------------------------------------------------
-// backward, row pass: lane = (RL queries, head h).  Writes dE, dG and dQ.
+// backward, row pass: lane = (query l, HV heads).  Writes dE, dG and dQ.
 // ---------------------------------------------------------------------------
-template <typename T, int D, int RL>
+template <typename T, int D, int HV>
 __global__ void __launch_bounds__(256) node_att_bwd_row_kernel(const tgt_node_attention_args a) {
-    const NodeLane n = node_lane<RL>(a);
+    const NodeLane n = node_lane<HV>(a);
     if (!n.active) return;
     const int N = a.N, H = a.H, h = n.h;
     const T* qkv = reinterpret_cast<const T*>(a.qkv);
@@ -146,230 +185,223 @@ __global__ void __launch_bounds__(256) node_att_bwd_row_kernel(const tgt_node_at
     const T* dhh = reinterpret_cast<const T*>(a.d_hhat);
     T* dqkv = reinterpret_cast<T*>(a.d_qkv);
     T* deg = reinterpret_cast<T*>(a.d_eg);
-    const int64_t row0 = (int64_t)n.b * N;
+    const int64_t row0 = (int64_t)n.b * N, row_l = row0 + n.x;
 
-    float q[RL][D], dq[RL][D];
-    bool live[RL];
+    float q[D][HV], dq[D][HV];
 #pragma unroll
-    for (int t = 0; t < RL; ++t) {
-        live[t] = n.x0 + t < N;
-        const int64_t rl = row0 + (live[t] ? n.x0 + t : n.x0);
+    for (int d = 0; d < D; ++d) {
+        ldv<T, HV>(qkv, row_l * a.ld_qkv + a.q_off + d * H + h, q[d]);
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            q[t][d] = ld(qkv, rl * a.ld_qkv + a.q_off + d * H + h) * a.scale;
-            dq[t][d] = 0.f;
+        for (int k = 0; k < HV; ++k) {
+            q[d][k] *= a.scale;
+            dq[d][k] = 0.f;
         }
     }
 
     if (a.logits_only) {
         for (int m = 0; m < N; ++m) {
-            float kk[D];
+            const int64_t lm = row_l * N + m;
+            float dH[HV];
 #pragma unroll
-            for (int d = 0; d < D; ++d) kk[d] = ld(qkv, (row0 + m) * a.ld_qkv + a.k_off + d * H + h);
-#pragma unroll
-            for (int t = 0; t < RL; ++t) {
-                if (!live[t]) continue;
-                const int64_t lm = (row0 + n.x0 + t) * N + m;
-                const float dH = dhh ? ld(dhh, lm * H + h) : 0.f;
-                deg[lm * a.ld_eg + a.e_off + h] = from_f32<T>(dH);
-#pragma unroll
-                for (int d = 0; d < D; ++d) dq[t][d] += dH * kk[d];
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < RL; ++t)
-            if (live[t])
-#pragma unroll
-                for (int d = 0; d < D; ++d)
-                    dqkv[(row0 + n.x0 + t) * a.ld_qkv + a.q_off + d * H + h] = from_f32<T>(dq[t][d] * a.scale);
-        return;
-    }
-
-    const T* dva = reinterpret_cast<const T*>(a.d_vatt);
-    float lse[RL], gsum[RL], dv_att[RL][D], vu[RL][D];
-#pragma unroll
-    for (int t = 0; t < RL; ++t) {
-        const int64_t rl = row0 + (live[t] ? n.x0 + t : n.x0);
-        lse[t] = a.lse[rl * H + h];
-        gsum[t] = a.gsum[rl * H + h];
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            dv_att[t][d] = ld(dva, rl * (int64_t)(D * H) + d * H + h);
-            vu[t][d] = 0.f;
-        }
-    }
-    // unscaled V_att (needed for delta and for d(log(1+gsum))) from the saved forward output:
-    // V_att = vu * log(1+gsum); a zero scaler means every gate of the row was 0, i.e. vu = 0.
-    {
-        const T* va = reinterpret_cast<const T*>(a.vatt);
-#pragma unroll
-        for (int t = 0; t < RL; ++t) {
-            const int64_t rl = row0 + (live[t] ? n.x0 + t : n.x0);
-            const float dsc = a.scale_degree ? __logf(1.f + gsum[t]) : 1.f;
-            const float inv = dsc != 0.f ? __frcp_rn(dsc) : 0.f;
-#pragma unroll
-            for (int d = 0; d < D; ++d) vu[t][d] = ld(va, rl * (int64_t)(D * H) + d * H + h) * inv;
-        }
-    }
-    float delta[RL], dgsum[RL];
-#pragma unroll
-    for (int t = 0; t < RL; ++t) {
-        const float dsc = a.scale_degree ? __logf(1.f + gsum[t]) : 1.f;
-        float d_dsc = 0.f;
-        delta[t] = 0.f;
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            d_dsc += dv_att[t][d] * vu[t][d];
-            dv_att[t][d] *= dsc;                 // gradient wrt the unscaled V_att
-            delta[t] += dv_att[t][d] * vu[t][d];
-        }
-        dgsum[t] = a.scale_degree ? d_dsc * __frcp_rn(1.f + gsum[t]) : 0.f;
-    }
-    // pass 2
-    for (int m = 0; m < N; ++m) {
-        const int64_t row_m = row0 + m;
-        float kk[D], vv[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            kk[d] = ld(qkv, row_m * a.ld_qkv + a.k_off + d * H + h);
-            vv[d] = ld(qkv, row_m * a.ld_qkv + a.v_off + d * H + h);
-        }
-#pragma unroll
-        for (int t = 0; t < RL; ++t) {
-            if (!live[t]) continue;
-            const int64_t lm = (row0 + n.x0 + t) * N + m;
-            float dot = 0.f, dA = 0.f;
+            for (int k = 0; k < HV; ++k) dH[k] = 0.f;
+            if (dhh) ldv<T, HV>(dhh, lm * H + h, dH);
+            stv<T, HV>(deg, lm * a.ld_eg + a.e_off + h, dH);
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                dot += q[t][d] * kk[d];
-                dA += dv_att[t][d] * vv[d];
+                float kk[HV];
+                ldv<T, HV>(qkv, (row0 + m) * a.ld_qkv + a.k_off + d * H + h, kk);
+#pragma unroll
+                for (int k = 0; k < HV; ++k) dq[d][k] += dH[k] * kk[k];
+            }
+        }
+    } else {
+        const T* dva = reinterpret_cast<const T*>(a.d_vatt);
+        const T* va = reinterpret_cast<const T*>(a.vatt);
+        float lse[HV], gsum[HV], dsc[HV], inv[HV], d_dsc[HV], delta[HV], dgsum[HV], dvu[D][HV];
+        ldf<HV>(a.lse, row_l * H + h, lse);
+        ldf<HV>(a.gsum, row_l * H + h, gsum);
+#pragma unroll
+        for (int k = 0; k < HV; ++k) {
+            dsc[k] = a.scale_degree ? __logf(1.f + gsum[k]) : 1.f;
+            inv[k] = dsc[k] != 0.f ? __frcp_rn(dsc[k]) : 0.f;     // zero scaler <=> every gate 0 <=> V_att 0
+            d_dsc[k] = delta[k] = 0.f;
+        }
+        // unscaled V_att from the saved forward output: V_att = vu * log(1+gsum)
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            float vu[HV];
+            ldv<T, HV>(dva, row_l * (int64_t)(D * H) + d * H + h, dvu[d]);
+            ldv<T, HV>(va, row_l * (int64_t)(D * H) + d * H + h, vu);
+#pragma unroll
+            for (int k = 0; k < HV; ++k) {
+                vu[k] *= inv[k];
+                d_dsc[k] += dvu[d][k] * vu[k];
+                dvu[d][k] *= dsc[k];                       // gradient wrt the unscaled V_att
+                delta[k] += dvu[d][k] * vu[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < HV; ++k) dgsum[k] = a.scale_degree ? d_dsc[k] * __frcp_rn(1.f + gsum[k]) : 0.f;
+        for (int m = 0; m < N; ++m) {
+            const int64_t row_m = row0 + m, lm = row_l * N + m;
+            float e[HV], g[HV], dot[HV], dA[HV], dH[HV], dGl[HV];
+            ldv<T, HV>(eg, lm * a.ld_eg + a.e_off + h, e);
+            ldv<T, HV>(eg, lm * a.ld_eg + a.g_off + h, g);
+#pragma unroll
+            for (int k = 0; k < HV; ++k) dH[k] = 0.f;
+            if (dhh) ldv<T, HV>(dhh, lm * H + h, dH);
+#pragma unroll
+            for (int k = 0; k < HV; ++k) dot[k] = dA[k] = 0.f;
+            float kk[D][HV];
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                float vv[HV];
+                ldv<T, HV>(qkv, row_m * a.ld_qkv + a.k_off + d * H + h, kk[d]);
+                ldv<T, HV>(qkv, row_m * a.ld_qkv + a.v_off + d * H + h, vv);
+#pragma unroll
+                for (int k = 0; k < HV; ++k) {
+                    dot[k] += q[d][k] * kk[d][k];
+                    dA[k] += dvu[d][k] * vv[k];
+                }
             }
             const float mk = a.mask[lm];
-            const float p = fast_exp(dot + ld(eg, lm * a.ld_eg + a.e_off + h) + mk - lse[t]);
-            const float g = fast_sigmoid(ld(eg, lm * a.ld_eg + a.g_off + h) + mk);
-            const float dS = p * (dA * g - delta[t]);
-            const float dGl = (dA * p + dgsum[t]) * g * (1.f - g);
-            const float dH = dS + (dhh ? ld(dhh, lm * H + h) : 0.f);
-            deg[lm * a.ld_eg + a.e_off + h] = from_f32<T>(dH);
-            deg[lm * a.ld_eg + a.g_off + h] = from_f32<T>(dGl);
 #pragma unroll
-            for (int d = 0; d < D; ++d) dq[t][d] += dH * kk[d];
+            for (int k = 0; k < HV; ++k) {
+                const float p = fast_exp(dot[k] + e[k] + mk - lse[k]);
+                const float gt = fast_sigmoid(g[k] + mk);
+                const float dS = p * (dA[k] * gt - delta[k]);
+                dGl[k] = (dA[k] * p + dgsum[k]) * gt * (1.f - gt);
+                dH[k] += dS;
+            }
+            stv<T, HV>(deg, lm * a.ld_eg + a.e_off + h, dH);
+            stv<T, HV>(deg, lm * a.ld_eg + a.g_off + h, dGl);
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+#pragma unroll
+                for (int k = 0; k < HV; ++k) dq[d][k] += dH[k] * kk[d][k];
         }
     }
 #pragma unroll
-    for (int t = 0; t < RL; ++t)
-        if (live[t])
+    for (int d = 0; d < D; ++d) {
 #pragma unroll
-            for (int d = 0; d < D; ++d)
-                dqkv[(row0 + n.x0 + t) * a.ld_qkv + a.q_off + d * H + h] = from_f32<T>(dq[t][d] * a.scale);
+        for (int k = 0; k < HV; ++k) dq[d][k] *= a.scale;
+        stv<T, HV>(dqkv, row_l * a.ld_qkv + a.q_off + d * H + h, dq[d]);
+    }
 }
 
 // ---------------------------------------------------------------------------
-// backward, column pass: lane = (RL keys m, head h).  dK and dV, reading the
+// backward, column pass: lane = (key m, HV heads).  dK and dV, reading the
 // dH = dE the row pass stored (same stream, so ordered).
 // ---------------------------------------------------------------------------
-template <typename T, int D, int RL>
+template <typename T, int D, int HV>
 __global__ void __launch_bounds__(256) node_att_bwd_col_kernel(const tgt_node_attention_args a) {
-    const NodeLane n = node_lane<RL>(a);
+    const NodeLane n = node_lane<HV>(a);
     if (!n.active) return;
-    const int N = a.N, H = a.H, h = n.h;
+    const int N = a.N, H = a.H, h = n.h, m = n.x;
     const T* qkv = reinterpret_cast<const T*>(a.qkv);
     const T* eg = reinterpret_cast<const T*>(a.eg);
     const T* deg = reinterpret_cast<const T*>(a.d_eg);
     const T* dva = reinterpret_cast<const T*>(a.d_vatt);
     T* dqkv = reinterpret_cast<T*>(a.d_qkv);
-    const int64_t row0 = (int64_t)n.b * N;
+    const int64_t row0 = (int64_t)n.b * N, row_m = row0 + m;
 
-    float k[RL][D], dk[RL][D], dv[RL][D];
-    bool live[RL];
+    float kv[D][HV], dk[D][HV], dv[D][HV];
 #pragma unroll
-    for (int t = 0; t < RL; ++t) {
-        live[t] = n.x0 + t < N;
-        const int64_t rm = row0 + (live[t] ? n.x0 + t : n.x0);
+    for (int d = 0; d < D; ++d) {
+        ldv<T, HV>(qkv, row_m * a.ld_qkv + a.k_off + d * H + h, kv[d]);
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            k[t][d] = ld(qkv, rm * a.ld_qkv + a.k_off + d * H + h);
-            dk[t][d] = dv[t][d] = 0.f;
-        }
+        for (int k = 0; k < HV; ++k) dk[d][k] = dv[d][k] = 0.f;
     }
     for (int l = 0; l < N; ++l) {
-        const int64_t row_l = row0 + l;
-        float ql[D], dvl[D];
+        const int64_t row_l = row0 + l, lm = row_l * N + m;
+        float dH[HV], dot[HV];
+        ldv<T, HV>(deg, lm * a.ld_eg + a.e_off + h, dH);
 #pragma unroll
-        for (int d = 0; d < D; ++d) ql[d] = ld(qkv, row_l * a.ld_qkv + a.q_off + d * H + h);
-        float lse_l = 0.f, dsc = 1.f;
-        if (!a.logits_only) {
-            lse_l = a.lse[row_l * H + h];
-            dsc = a.scale_degree ? __logf(1.f + a.gsum[row_l * H + h]) : 1.f;
+        for (int k = 0; k < HV; ++k) dot[k] = 0.f;
 #pragma unroll
-            for (int d = 0; d < D; ++d) dvl[d] = ld(dva, row_l * (int64_t)(D * H) + d * H + h) * dsc;
+        for (int d = 0; d < D; ++d) {
+            float ql[HV];
+            ldv<T, HV>(qkv, row_l * a.ld_qkv + a.q_off + d * H + h, ql);
+#pragma unroll
+            for (int k = 0; k < HV; ++k) {
+                dot[k] += ql[k] * kv[d][k];
+                dk[d][k] += dH[k] * ql[k];
+            }
+        }
+        if (a.logits_only) continue;
+        float e[HV], g[HV], lse[HV], gsum[HV], w[HV];
+        ldv<T, HV>(eg, lm * a.ld_eg + a.e_off + h, e);
+        ldv<T, HV>(eg, lm * a.ld_eg + a.g_off + h, g);
+        ldf<HV>(a.lse, row_l * H + h, lse);
+        ldf<HV>(a.gsum, row_l * H + h, gsum);
+        const float mk = a.mask[lm];
+#pragma unroll
+        for (int k = 0; k < HV; ++k) {
+            const float p = fast_exp(dot[k] * a.scale + e[k] + mk - lse[k]);
+            const float gt = fast_sigmoid(g[k] + mk);
+            w[k] = p * gt * (a.scale_degree ? __logf(1.f + gsum[k]) : 1.f);
         }
 #pragma unroll
-        for (int t = 0; t < RL; ++t) {
-            if (!live[t]) continue;
-            const int64_t lm = row_l * N + n.x0 + t;
-            const float dH = ld(deg, lm * a.ld_eg + a.e_off + h);
-            float dot = 0.f;
+        for (int d = 0; d < D; ++d) {
+            float dvl[HV];
+            ldv<T, HV>(dva, row_l * (int64_t)(D * H) + d * H + h, dvl);
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
-                dot += ql[d] * k[t][d];
-                dk[t][d] += dH * ql[d];
-            }
-            if (a.logits_only) continue;
-            const float mk = a.mask[lm];
-            const float p = fast_exp(dot * a.scale + ld(eg, lm * a.ld_eg + a.e_off + h) + mk - lse_l);
-            const float g = fast_sigmoid(ld(eg, lm * a.ld_eg + a.g_off + h) + mk);
-            const float w = p * g;
-#pragma unroll
-            for (int d = 0; d < D; ++d) dv[t][d] += w * dvl[d];
+            for (int k = 0; k < HV; ++k) dv[d][k] += w[k] * dvl[k];
         }
     }
 #pragma unroll
-    for (int t = 0; t < RL; ++t) {
-        if (!live[t]) continue;
-        const int64_t rm = row0 + n.x0 + t;
+    for (int d = 0; d < D; ++d) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            dqkv[rm * a.ld_qkv + a.k_off + d * H + h] = from_f32<T>(dk[t][d] * a.scale);
-            if (!a.logits_only) dqkv[rm * a.ld_qkv + a.v_off + d * H + h] = from_f32<T>(dv[t][d]);
-        }
+        for (int k = 0; k < HV; ++k) dk[d][k] *= a.scale;
+        stv<T, HV>(dqkv, row_m * a.ld_qkv + a.k_off + d * H + h, dk[d]);
+        if (!a.logits_only) stv<T, HV>(dqkv, row_m * a.ld_qkv + a.v_off + d * H + h, dv[d]);
     }
 }
 
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-static int node_grid(const tgt_node_attention_args& a, int rl) {
-    const int lpr = node_lpr(a.H), rpw = 64 / lpr, hb = (a.H + 63) / 64;
-    const int64_t units = (int64_t)a.B * ((a.N + rl - 1) / rl) * hb;
+static int node_grid(const tgt_node_attention_args& a, int hv) {
+    const int lpr = node_lpr(a.H, hv), rpw = 64 / lpr, hb = (a.H + 64 * hv - 1) / (64 * hv);
+    const int64_t units = (int64_t)a.B * a.N * hb;
     const int64_t waves = (units + rpw - 1) / rpw;
     return (int)((waves + 3) / 4);
 }
 
-template <typename T, int D, int RF, int RR, int RC>
-static int launch_node_r(const tgt_node_attention_args& a, bool bwd, hipStream_t st) {
-    if (!bwd) {
-        hipLaunchKernelGGL((node_att_fwd_kernel<T, D, RF>), dim3(node_grid(a, RF)), dim3(256), 0, st, a);
-        return check_launch("node_att_fwd_kernel");
+// heads per lane: the widest vector the layout allows (every offset / row length a multiple of it)
+static int node_vec(const tgt_node_attention_args& a, int esz, int want) {
+    for (int hv = want; hv > 1; hv >>= 1) {
+        const bool ok = a.H % hv == 0 && a.ld_qkv % hv == 0 && a.ld_eg % hv == 0 && a.q_off % hv == 0 &&
+                        a.k_off % hv == 0 && a.v_off % hv == 0 && a.e_off % hv == 0 && a.g_off % hv == 0 &&
+                        ((uintptr_t)a.qkv % (hv * esz)) == 0 && ((uintptr_t)a.eg % (hv * esz)) == 0;
+        if (ok) return hv;
     }
-    hipLaunchKernelGGL((node_att_bwd_row_kernel<T, D, RR>), dim3(node_grid(a, RR)), dim3(256), 0, st, a);
-    if (int e = check_launch("node_att_bwd_row_kernel")) return e;
-    hipLaunchKernelGGL((node_att_bwd_col_kernel<T, D, RC>), dim3(node_grid(a, RC)), dim3(256), 0, st, a);
-    return check_launch("node_att_bwd_col_kernel");
+    return 1;
 }
+
+static int env_int(const char* name, int dflt) { return getenv(name) ? atoi(getenv(name)) : dflt; }
+
+#define TGT_NODE_LAUNCH(KERNEL, NAME, WANT)                                                                       \
+    do {                                                                                                          \
+        const int hv = node_vec(a, (int)sizeof(T), (D <= 16) ? (WANT) : ((WANT) > 2 ? 2 : (WANT)));               \
+        if (hv == 4) { if constexpr (D <= 16) hipLaunchKernelGGL((KERNEL<T, D, 4>), dim3(node_grid(a, 4)), dim3(256), 0, st, a); } \
+        else if (hv == 2) hipLaunchKernelGGL((KERNEL<T, D, 2>), dim3(node_grid(a, 2)), dim3(256), 0, st, a);       \
+        else hipLaunchKernelGGL((KERNEL<T, D, 1>), dim3(node_grid(a, 1)), dim3(256), 0, st, a);                    \
+        if (int e = check_launch(NAME)) return e;                                                                 \
+    } while (0)
 
 template <typename T, int D>
 static int launch_node(const tgt_node_attention_args& a, bool bwd, hipStream_t st) {
-    // nodes per lane: registers hold RL x (q, acc) [fwd], RL x (q, dq, dV_att, V_att) [row], RL x (k, dk, dv) [col]
-    static const int knob = getenv("TGT_NODE_RL") ? atoi(getenv("TGT_NODE_RL")) : 0;     // experiment knob
-    if constexpr (D <= 16) {
-        if (knob == 1) return launch_node_r<T, D, 1, 1, 1>(a, bwd, st);
-        if (knob == 2) return launch_node_r<T, D, 2, 2, 2>(a, bwd, st);
-        if (knob == 4) return launch_node_r<T, D, 4, 4, 4>(a, bwd, st);
-        return launch_node_r<T, D, 4, 2, 2>(a, bwd, st);
-    } else {
-        return launch_node_r<T, D, 2, 1, 1>(a, bwd, st);
+    // measured on MI355X (B=256 N=32 H=64 D=12 bf16): forward best with 4 heads per lane, both
+    // backward passes with 2 (4 pushes them to one wave per SIMD); env knobs for experiments
+    static const int hv_f = env_int("TGT_NODE_HV_F", 4), hv_r = env_int("TGT_NODE_HV_R", 2), hv_c = env_int("TGT_NODE_HV_C", 2);
+    if (!bwd) {
+        TGT_NODE_LAUNCH(node_att_fwd_kernel, "node_att_fwd_kernel", hv_f);
+        return TGT_OK;
     }
+    TGT_NODE_LAUNCH(node_att_bwd_row_kernel, "node_att_bwd_row_kernel", hv_r);
+    TGT_NODE_LAUNCH(node_att_bwd_col_kernel, "node_att_bwd_col_kernel", hv_c);
+    return TGT_OK;
 }
 
 template <typename T>
