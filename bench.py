@@ -34,6 +34,15 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+def node_algorithmic_bytes(kind, B, N, W, Hn, esz=2):
+    """node attention (bias/softmax path), DESIGN.md §4.3: fwd reads Q,K,V (3NW), E,G (2N^2 Hn), writes
+    V_att (NW), H_hat (N^2 Hn); bwd reads Q,K,V,V_att,dV_att (5NW), E,G,dH_hat (3N^2 Hn), writes dQ,dK,dV (3NW),
+    dE,dG (2N^2 Hn); + mask."""
+    n2 = N * N
+    per_graph = ((4 * N * W + 3 * n2 * Hn) if kind == 'fwd' else (8 * N * W + 5 * n2 * Hn)) * esz + n2 * 4
+    return B * per_graph
+
+
 def algorithmic_bytes(kind, B, N, C, Ht, esz=2):
     """HBM bytes one launch must move (both directions), SURVEY §8(d):
     fwd: 2 dirs x (Q,K,V in + O out = 4 N^2 C, E,G = 2 N^2 Ht) elements + mask
@@ -210,6 +219,13 @@ def main():
                             other_kernels={k: dict(avg_launch_ms=round(v[1], 4),
                                                    achieved=round(v[2] / (v[1] * 1e-3) / 1e9, 1))
                                            for k, v in cand.items() if k != name})
+            # the bias/softmax path (node attention with edge bias and gate), same accounting
+            for kname, kind in (('tgt_node_attention_fwd', 'fwd'), ('tgt_node_attention_bwd', 'bwd')):
+                if times.get(kname):
+                    avg = sum(times[kname]) / len(times[kname])
+                    nb = node_algorithmic_bytes(kind, args.batch, args.nodes, mcfg['node_width'], mcfg['num_heads'], esz)
+                    roofline['other_kernels'][kname] = dict(avg_launch_ms=round(avg, 4),
+                                                            achieved=round(nb / (avg * 1e-3) / 1e9, 1))
         out = dict(
             metric='graphs/sec training step, TGT-At 24L PCQM batch 256',
             value=round(args.batch * world * args.steps / dt, 2), unit='graphs/s',
