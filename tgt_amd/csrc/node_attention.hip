@@ -173,6 +173,135 @@ __global__ void __launch_bounds__(256) node_att_fwd_kernel(const tgt_node_attent
 }
 
 // ---------------------------------------------------------------------------
+// forward, LDS variant (the fast path for 16-bit types): one workgroup owns QB query nodes of
+// ONE graph and stages that graph's K and V rows in LDS once (tiles of MT keys), so the walk
+// over keys issues only the streaming accesses to global memory -- E, G (read) and H_hat
+// (written), 8 bytes per lane -- and those run PD keys ahead in a register ring.
+//   lane = (query l, HV heads), lanes of the same wave that share heads read the same LDS words.
+// ---------------------------------------------------------------------------
+template <typename T, int D, int HV, int MT>
+__global__ void __launch_bounds__(512) node_att_fwd_lds_kernel(const tgt_node_attention_args a, int lpr, int qb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int N = a.N, H = a.H, W = D * H;
+    T* sK = reinterpret_cast<T*>(smem);
+    T* sV = sK + (size_t)MT * W;
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int nblk = (N + qb - 1) / qb;
+    const int b = blockIdx.x / nblk, l = (blockIdx.x % nblk) * qb + tid / lpr, h = (tid % lpr) * HV;
+    const bool active = l < N && h < H;
+    const T* qkv = reinterpret_cast<const T*>(a.qkv);
+    const T* eg = reinterpret_cast<const T*>(a.eg);
+    T* hhat = reinterpret_cast<T*>(a.hhat);
+    const int64_t row0 = (int64_t)b * N, row_l = row0 + (active ? l : 0);
+
+    float q[D][HV], acc[D][HV], mx[HV], sum[HV], gsum[HV];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        if (active) ldv<T, HV>(qkv, row_l * a.ld_qkv + a.q_off + d * H + h, q[d]);
+#pragma unroll
+        for (int k = 0; k < HV; ++k) {
+            q[d][k] = active ? q[d][k] * a.scale : 0.f;
+            acc[d][k] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < HV; ++k) {
+        mx[k] = -INFINITY;
+        sum[k] = gsum[k] = 0.f;
+    }
+
+    constexpr int PD = 8;
+    constexpr int VE = 16 / (int)sizeof(T);              // elements per 16-byte staging chunk
+    for (int mt0 = 0; mt0 < N; mt0 += MT) {
+        const int mt = min(MT, N - mt0);
+        __syncthreads();                                   // previous tile fully consumed
+        for (int c = tid; c < mt * (W / VE); c += nthreads) {
+            const int m = c / (W / VE), off = (c % (W / VE)) * VE;
+            const int64_t g = (row0 + mt0 + m) * a.ld_qkv;
+            *reinterpret_cast<uint4*>(sK + (size_t)m * W + off) = *reinterpret_cast<const uint4*>(qkv + g + a.k_off + off);
+            if (!a.logits_only)
+                *reinterpret_cast<uint4*>(sV + (size_t)m * W + off) = *reinterpret_cast<const uint4*>(qkv + g + a.v_off + off);
+        }
+        __syncthreads();
+        if (!active) continue;
+
+        float er[PD][HV], gr[PD][HV], mr[PD];
+        auto fetch = [&](int slot, int m) {
+            const int64_t lm = row_l * N + mt0 + m;
+            ldv<T, HV>(eg, lm * a.ld_eg + a.e_off + h, er[slot]);
+            if (!a.logits_only) {
+                ldv<T, HV>(eg, lm * a.ld_eg + a.g_off + h, gr[slot]);
+                mr[slot] = a.mask[lm];
+            }
+        };
+#pragma unroll
+        for (int k = 0; k < PD; ++k)
+            if (k < mt) fetch(k, k);
+        for (int m0 = 0; m0 < mt; m0 += PD) {
+#pragma unroll
+            for (int kk = 0; kk < PD; ++kk) {
+                const int m = m0 + kk;
+                if (m < mt) {
+                    const int64_t lm = row_l * N + mt0 + m;
+                    float s[HV];
+#pragma unroll
+                    for (int k = 0; k < HV; ++k) s[k] = er[kk][k];
+#pragma unroll
+                    for (int d = 0; d < D; ++d) {
+                        float kv[HV];
+                        ldv<T, HV>(sK, (int64_t)m * W + d * H + h, kv);
+#pragma unroll
+                        for (int k = 0; k < HV; ++k) s[k] += q[d][k] * kv[k];
+                    }
+                    if (hhat) stv<T, HV>(hhat, lm * H + h, s);
+                    if (!a.logits_only) {
+                        const float mk = mr[kk];
+                        float corr[HV], w[HV];
+#pragma unroll
+                        for (int k = 0; k < HV; ++k) {
+                            const float x = s[k] + mk;
+                            const float gt = fast_sigmoid(gr[kk][k] + mk);
+                            const float mnew = fmaxf(mx[k], x);
+                            const float mref = mnew == -INFINITY ? 0.f : mnew;
+                            corr[k] = fast_exp(mx[k] - mref);
+                            const float p = fast_exp(x - mref);
+                            sum[k] = sum[k] * corr[k] + p;
+                            w[k] = p * gt;
+                            gsum[k] += gt;
+                            mx[k] = mnew;
+                        }
+#pragma unroll
+                        for (int d = 0; d < D; ++d) {
+                            float vv[HV];
+                            ldv<T, HV>(sV, (int64_t)m * W + d * H + h, vv);
+#pragma unroll
+                            for (int k = 0; k < HV; ++k) acc[d][k] = acc[d][k] * corr[k] + w[k] * vv[k];
+                        }
+                    }
+                    if (m + PD < mt) fetch(kk, m + PD);
+                }
+            }
+        }
+    }
+    if (a.logits_only || !active) return;
+    T* vatt = reinterpret_cast<T*>(a.vatt);
+    float f[HV];
+#pragma unroll
+    for (int k = 0; k < HV; ++k) {
+        f[k] = __frcp_rn(sum[k]) * (a.scale_degree ? __logf(1.f + gsum[k]) : 1.f);
+        a.lse[row_l * H + h + k] = mx[k] + __logf(sum[k]);
+        a.gsum[row_l * H + h + k] = gsum[k];
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        float o[HV];
+#pragma unroll
+        for (int k = 0; k < HV; ++k) o[k] = acc[d][k] * f[k];
+        stv<T, HV>(vatt, row_l * (int64_t)(D * H) + d * H + h, o);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // backward, row pass: lane = (query l, HV heads).  Writes dE, dG and dQ.
 // ---------------------------------------------------------------------------
 template <typename T, int D, int HV>
@@ -396,6 +525,25 @@ static int launch_node(const tgt_node_attention_args& a, bool bwd, hipStream_t s
     // backward passes with 2 (4 pushes them to one wave per SIMD); env knobs for experiments
     static const int hv_f = env_int("TGT_NODE_HV_F", 4), hv_r = env_int("TGT_NODE_HV_R", 2), hv_c = env_int("TGT_NODE_HV_C", 2);
     if (!bwd) {
+        // LDS variant: 16-bit types, 4 heads per lane, K/V rows 16-byte aligned, one key tile of <= 32 keys
+        // fits the 160 KB LDS (2 * 32 * W * 2 bytes = 96 KB at W = 768)
+        static const int use_lds = env_int("TGT_NODE_LDS", 1);
+        if constexpr (sizeof(T) == 2 && D <= 16) {
+            constexpr int MT = 32;
+            const int W = D * a.H;
+            const size_t lds = (size_t)2 * MT * W * sizeof(T);
+            const int lpr = (a.H + 3) / 4;
+            if (use_lds && node_vec(a, 2, 4) == 4 && W % 8 == 0 && a.ld_qkv % 8 == 0 && a.k_off % 8 == 0 &&
+                a.v_off % 8 == 0 && lds <= 160 * 1024 && lpr <= 512 && a.H % 4 == 0) {
+                int qb = 512 / lpr;                        // query nodes per workgroup
+                if (qb > a.N) qb = a.N;
+                if (qb > 32) qb = 32;
+                const int threads = ((qb * lpr + 63) / 64) * 64;
+                const int grid = a.B * ((a.N + qb - 1) / qb);
+                hipLaunchKernelGGL((node_att_fwd_lds_kernel<T, D, 4, MT>), dim3(grid), dim3(threads), lds, st, a, lpr, qb);
+                return check_launch("node_att_fwd_lds_kernel");
+            }
+        }
         TGT_NODE_LAUNCH(node_att_fwd_kernel, "node_att_fwd_kernel", hv_f);
         return TGT_OK;
     }
