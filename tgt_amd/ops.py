@@ -433,14 +433,52 @@ def layer_norm(x, weight, bias, eps=1e-5, out_dtype=None):
 # ---------------------------------------------------------------------------
 # glue that is a single device op each
 # ---------------------------------------------------------------------------
+class _Permute(torch.autograd.Function):
+    """index_select along `dim` by a PERMUTATION; the backward is the gather by the inverse
+    permutation (one kernel) instead of the sort-based index_put of advanced indexing."""
+
+    @staticmethod
+    def forward(ctx, w, perm, inv, dim):
+        ctx.save_for_backward(inv)
+        ctx.dim = dim
+        return w.index_select(dim, perm)
+
+    @staticmethod
+    def backward(ctx, g):
+        inv, = ctx.saved_tensors
+        return g.index_select(ctx.dim, inv), None, None, None
+
+
+def permute(w, perm, inv, dim=0):
+    return _Permute.apply(w, perm, inv, dim)
+
+
+class _ScalePool:
+    """Per-sample DropPath factors drawn 64 vectors at a time (one Bernoulli launch per refill
+    instead of one per residual branch)."""
+
+    def __init__(self):
+        self.buf, self.cur, self.key = None, 0, None
+
+    def take(self, B, keep, device):
+        key = (B, keep, device)
+        if self.key != key or self.buf is None or self.cur >= self.buf.shape[0]:
+            self.buf = torch.empty(64, B, dtype=torch.float32, device=device).bernoulli_(keep).div_(keep)
+            self.cur, self.key = 0, key
+        out = self.buf[self.cur]
+        self.cur += 1
+        return out
+
+
+_scale_pool = _ScalePool()
+
+
 def drop_path_add_(x, residual, drop_prob, training):
     """residual + DropPath(x)  (reference lib/tgt/layers/layers.py:169-174 followed by
     the in-place add_ of :270-290) in ONE pass over the tensors."""
     if drop_prob > 0 and training:
-        keep = 1.0 - drop_prob
-        scale = torch.empty([x.size(0)] + [1] * (x.ndim - 1), dtype=x.dtype, device=x.device)
-        scale.bernoulli_(keep).div_(keep)
-        return torch.addcmul(residual.to(x.dtype) if residual.dtype != x.dtype else residual, x, scale)
+        scale = _scale_pool.take(x.size(0), 1.0 - drop_prob, x.device).view([x.size(0)] + [1] * (x.ndim - 1))
+        return torch.addcmul(residual.to(x.dtype) if residual.dtype != x.dtype else residual, x, scale.to(x.dtype))
     return x.add_(residual)
 
 
@@ -517,7 +555,7 @@ def column_sum(x2):
     """float32 column sums of a contiguous (rows, C) tensor (bias gradients): HIP kernel when the
     shape qualifies (device tensor, C a multiple of 8, <= 2048), else the library reduction."""
     rows, C_ = x2.shape
-    if not (x2.is_cuda and x2.is_contiguous() and C_ % 8 == 0 and C_ <= 2048 and x2.dtype in _DT and rows >= 4096):
+    if not (x2.is_cuda and x2.is_contiguous() and C_ % 8 == 0 and C_ <= 2048 and x2.dtype in _DT and rows >= 65536):
         return x2.sum(0, dtype=torch.float32)
     L = _lib.lib()
     out = torch.empty(C_, dtype=torch.float32, device=x2.device)
@@ -663,8 +701,7 @@ def drop_path_scale(x, drop_prob, training):
     """per-sample DropPath factor (B,) float32 = Bernoulli(keep)/keep, or None when inactive
     (reference lib/tgt/layers/layers.py:169-174)."""
     if drop_prob > 0 and training:
-        keep = 1.0 - drop_prob
-        return torch.empty(x.size(0), dtype=torch.float32, device=x.device).bernoulli_(keep).div_(keep)
+        return _scale_pool.take(x.size(0), 1.0 - drop_prob, x.device)
     return None
 
 

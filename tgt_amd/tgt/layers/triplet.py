@@ -50,16 +50,20 @@ class _TripletBase(nn.Module):
         self._idx = {}
 
     def _index(self, name, make, device):
+        """(permutation, inverse permutation) on `device`, cached"""
         key = (name, device)
         if key not in self._idx:
-            self._idx[key] = make().to(device)
+            perm = make()
+            inv = torch.empty_like(perm)
+            inv[perm] = torch.arange(perm.numel())
+            self._idx[key] = (perm.to(device), inv.to(device))
         return self._idx[key]
 
     def _out_proj(self, va):
         """lin_O on the kernel's [dir][h][d] channel order (reference order is
         d*2H + dir*H + h, triplet.py:248)."""
         cols = self._index('va', lambda: layout.va_cols_head_major(self.edge_width, self.num_heads), va.device)
-        return ops.linear(va, self.lin_O.weight[:, cols], self.lin_O.bias)
+        return ops.linear(va, ops.permute(self.lin_O.weight, *cols, dim=1), self.lin_O.bias)
 
 
 class TripletAttention(_TripletBase):
@@ -86,8 +90,8 @@ class TripletAttention(_TripletBase):
 
     def _fused_projection(self, device):
         rows = self._index('qkv', lambda: layout.qkv_rows_head_major(self.edge_width, self.num_heads), device)
-        ws = [self.lin_QKV_in.weight[rows], self.lin_QKV_out.weight[rows]]
-        bs = [self.lin_QKV_in.bias[rows], self.lin_QKV_out.bias[rows]]
+        ws = [ops.permute(self.lin_QKV_in.weight, *rows), ops.permute(self.lin_QKV_out.weight, *rows)]
+        bs = [ops.permute(self.lin_QKV_in.bias, *rows), ops.permute(self.lin_QKV_out.bias, *rows)]
         if self.biased:
             for which in ('_in', '_out'):
                 lin = getattr(self, self._bias_name + which)
@@ -148,7 +152,7 @@ class TripletAggregate(_TripletBase):
         B, N = x.shape[0], x.shape[1]
         rows = self._index('v', lambda: layout.qkv_rows_head_major(self.edge_width, self.num_heads, parts=2), x.device)
         lin_b = self.lin_EG if self.gated else self.lin_E
-        ws, bs = [self.lin_V.weight[rows], lin_b.weight], [self.lin_V.bias[rows], lin_b.bias]
+        ws, bs = [ops.permute(self.lin_V.weight, *rows), lin_b.weight], [ops.permute(self.lin_V.bias, *rows), lin_b.bias]
         pad = self._layout.width - self._layout.used
         if pad:
             ws.append(ws[0].new_zeros(pad, self.edge_width))
