@@ -398,7 +398,8 @@ class _LayerNorm(torch.autograd.Function):
         rows = x.numel() // C_
         L = _lib.lib()
         dx = torch.empty_like(x)
-        dgb = torch.empty(2, C_, dtype=torch.float32, device=x.device)
+        # separate tensors (not two views of one): autograd can then adopt them as .grad without a copy
+        dgb = (torch.empty(C_, dtype=torch.float32, device=x.device), torch.empty(C_, dtype=torch.float32, device=x.device))
         partial = torch.empty(L.tgt_layer_norm_parts() * 2 * C_, dtype=torch.float32, device=x.device)
         s, e = _prof_begin()
         _lib.check(L.tgt_layer_norm_bwd(_ptr(dy), _DT[dy.dtype], _ptr(x), _DT[x.dtype], _ptr(w), _ptr(mean), _ptr(rstd),
@@ -684,7 +685,7 @@ class _AddLayerNorm(torch.autograd.Function):
         ds = None if ds is None else ds.contiguous()
         d_res = torch.empty_like(s)
         d_x = torch.empty_like(s) if scale is not None else None
-        dgb = torch.empty(2, C_, dtype=torch.float32, device=s.device)
+        dgb = (torch.empty(C_, dtype=torch.float32, device=s.device), torch.empty(C_, dtype=torch.float32, device=s.device))
         partial = torch.empty(L.tgt_layer_norm_parts() * 2 * C_, dtype=torch.float32, device=s.device)
         p0, p1 = _prof_begin()
         _lib.check(L.tgt_add_layer_norm_bwd(_ptr(dy), _DT[dy.dtype], _ptr(s), _DT[s.dtype], _ptr(ds),
