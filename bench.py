@@ -227,7 +227,7 @@ def main():
                     roofline['other_kernels'][kname] = dict(avg_launch_ms=round(avg, 4),
                                                             achieved=round(nb / (avg * 1e-3) / 1e9, 1))
         out = dict(
-            metric='graphs/sec training step, TGT-At 24L PCQM batch 256',
+            metric='graphs/sec training step, TGT-At 24L PCQM batch 256, 1/2/4/8 MI355X',
             value=round(args.batch * world * args.steps / dt, 2), unit='graphs/s',
             n_gpus=world, steps=args.steps, warmup=args.warmup,
             ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling='weak',

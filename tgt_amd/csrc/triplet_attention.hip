@@ -309,22 +309,19 @@ __global__ void __launch_bounds__(HG * 64, OCC) tri_att_bwd_kernel(const tgt_tri
             read_frags<T, D, HG>(fq, sQ, wave, r, hi);
             read_frags<T, D, HG>(fo, sO, wave, r, hi);
 
-            f32x16 s[NT], da[NT], kT[NT];
+            f32x16 s[NT], da[NT];
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt) {
                 F fk[G::kDC], fv[G::kDC];
                 read_frags<T, D, HG>(fk, sK, wave, 32 * kt + r, hi);
                 read_frags<T, D, HG>(fv, sV, wave, 32 * kt + r, hi);
-                f32x16 z0 = {0}, z1 = {0}, z2 = {0};
+                f32x16 z0 = {0}, z1 = {0};
 #pragma unroll
                 for (int dc = 0; dc < G::kDC; ++dc) z0 = mma32(fk[dc], fq[dc], z0);         // S^T[k][i]
 #pragma unroll
                 for (int dc = 0; dc < G::kDC; ++dc) z1 = mma32(fv[dc], fo[dc], z1);         // dA^T[k][i]
-#pragma unroll
-                for (int dc = 0; dc < G::kDC; ++dc) z2 = mma32(fk[dc], ident_d[dc], z2);    // K^T
                 s[kt] = z0;
                 da[kt] = z1;
-                kT[kt] = z2;
             }
 
             // softmax statistics are recomputed (in-lane values + the partner lane); saving a
@@ -349,9 +346,8 @@ __global__ void __launch_bounds__(HG * 64, OCC) tri_att_bwd_kernel(const tgt_tri
                 }
             sum += xhalf(sum);
             const float inv = sum > 0.f ? __frcp_rn(sum) : 0.f;
-            // s -> P, then A;  da -> dS
+            // s -> P;  da -> dP = dA * g;  delta_i = sum_k P dP
             float delta = 0.f;
-            f32x16 att[NT];
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
@@ -359,31 +355,11 @@ __global__ void __launch_bounds__(HG * 64, OCC) tri_att_bwd_kernel(const tgt_tri
                     const float p = s[kt][q] * inv;
                     const float dp = da[kt][q] * gate[kt][q];
                     delta += p * dp;
-                    att[kt][q] = p * gate[kt][q];
+                    if (gated) dG[kt][q] += da[kt][q] * p * gate[kt][q] * (1.f - gate[kt][q]);
                     s[kt][q] = p;
-                    if (gated) dG[kt][q] += da[kt][q] * att[kt][q] * (1.f - gate[kt][q]);
                     da[kt][q] = dp;
                 }
             delta += xhalf(delta);
-            f32x16 dq = {0};
-            F dsf[NT][2], af[NT][2];
-#pragma unroll
-            for (int kt = 0; kt < NT; ++kt) {
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const float ds = s[kt][q] * (da[kt][q] - delta);
-                    if (biased) dE[kt][q] += ds;
-                    s[kt][q] = ds * a.scale;
-                }
-#pragma unroll
-                for (int cc = 0; cc < 2; ++cc) {
-                    dsf[kt][cc] = pack_chunk<T>(s[kt], cc);
-                    af[kt][cc] = pack_chunk<T>(att[kt], cc);
-                    // dQ^T[d][i] += sum_k K^T[d][k] dS^T[k][i]
-                    dq = mma32(pack_chunk<T>(kT[kt], cc), dsf[kt][cc], dq);
-                }
-            }
-            write_rows<T, D, HG>(sQ, dq, wave, r, hi);
 
             f32x16 qT = {0}, oT = {0};
 #pragma unroll
@@ -392,23 +368,54 @@ __global__ void __launch_bounds__(HG * 64, OCC) tri_att_bwd_kernel(const tgt_tri
             for (int dc = 0; dc < G::kDC; ++dc) oT = mma32(fo[dc], ident_d[dc], oT);   // dO^T
             F qTf[2] = {pack_chunk<T>(qT, 0), pack_chunk<T>(qT, 1)};
             F oTf[2] = {pack_chunk<T>(oT, 0), pack_chunk<T>(oT, 1)};
+
+            // one key tile at a time from here on (short live ranges): dS, A -> dQ partial, dK, dV
+            f32x16 dq = {0};
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt) {
+                F dsf[2], af[2];
+                {
+                    f32x16 att;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const float ds = s[kt][q] * (da[kt][q] - delta);
+                        if (biased) dE[kt][q] += ds;
+                        att[q] = s[kt][q] * gate[kt][q];
+                        s[kt][q] = ds * a.scale;
+                    }
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc) {
+                        dsf[cc] = pack_chunk<T>(s[kt], cc);
+                        af[cc] = pack_chunk<T>(att, cc);
+                    }
+                }
+                {   // dQ^T[d][i] += sum_k K^T[d][k] dS^T[k][i]   (K^T through the identity trick)
+                    F fk[G::kDC];
+                    read_frags<T, D, HG>(fk, sK, wave, 32 * kt + r, hi);
+                    f32x16 kT = {0};
+#pragma unroll
+                    for (int dc = 0; dc < G::kDC; ++dc) kT = mma32(fk[dc], ident_d[dc], kT);
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc) dq = mma32(pack_chunk<T>(kT, cc), dsf[cc], dq);
+                }
                 // re-layout dS, A to lane = k:  X[i][k] = sum_kk X^T-frag[i][kk] I[kk][k]
                 f32x16 ds2 = {0}, a2 = {0}, dk = {0}, dv = {0};
 #pragma unroll
                 for (int cc = 0; cc < 2; ++cc) {
-                    ds2 = mma32(dsf[kt][cc], ident_k[cc], ds2);
-                    a2 = mma32(af[kt][cc], ident_k[cc], a2);
+                    ds2 = mma32(dsf[cc], ident_k[cc], ds2);
+                    a2 = mma32(af[cc], ident_k[cc], a2);
                 }
 #pragma unroll
                 for (int cc = 0; cc < 2; ++cc) {
                     dk = mma32(qTf[cc], pack_chunk<T>(ds2, cc), dk);   // dK^T[d][k] = sum_i Q^T[d][i] dS[i][k]
                     dv = mma32(oTf[cc], pack_chunk<T>(a2, cc), dv);    // dV^T[d][k] = sum_i dO^T[d][i] A[i][k]
                 }
+                // NOTE: this wave still has to read the K fragments of the NEXT key tile from sK,
+                // and write_rows only touches the rows of THIS tile, so in-place is safe
                 write_rows<T, D, HG>(sK, dk, wave, 32 * kt + r, hi);
                 write_rows<T, D, HG>(sV, dv, wave, 32 * kt + r, hi);
             }
+            write_rows<T, D, HG>(sQ, dq, wave, r, hi);
             __syncthreads();
             slab_store<G, 32>(sQ, dq_base, c.q.row_stride, c.q.j_stride, j, i0, N, tid);
             bool plain = true;
