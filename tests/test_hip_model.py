@@ -246,3 +246,38 @@ def test_cfg5_two_stage_fp16_inference():
         with torch.autocast('cuda', dtype=torch.float16):
             gap_iso = g_hip(b2)
     assert (gap_iso.float().cpu() - gap_ref).abs().max() < 3e-2 * gap_ref.abs().max()
+
+
+def test_trainer_rccl_bucket_path_single_rank():
+    """The data-parallel code path on the GPU with RCCL (one rank: all-reduce is the identity):
+    autograd hooks -> bucket gather -> async all_reduce -> Adam must give the same parameters as
+    the plain path."""
+    import torch.distributed as dist
+    from tgt_amd.pcqm import TGT_Multi
+    from tgt_amd.training.step import Trainer, StepConfig, preprocess_batch
+    from tgt_amd.training.synthetic import make_batch
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+        created = True
+    try:
+        kwargs = gu.MODEL_CASES['multi_at_tiny'][1]
+        cfg = StepConfig(num_dist_bins=24, mixed_precision='bf16', coords_noise=0.0, bucket_mbytes=0,
+                         lr_warmup_steps=10, lr_total_steps=100)
+        m1 = gu.fill_params(TGT_Multi(**kwargs), seed=3).cuda()
+        m2 = gu.fill_params(TGT_Multi(**kwargs), seed=3).cuda()
+        t1 = Trainer(m1, cfg, force_distributed=True)
+        t2 = Trainer(m2, cfg)
+        assert t1.distributed and t1.buckets is not None and len(t1.buckets) > 10 and not t2.distributed
+        for step in range(3):
+            batch = preprocess_batch(make_batch(3, 7, seed=50 + step, ragged=True), 'cuda', cfg, training=False)
+            _, l1 = t1.training_step(batch)
+            _, l2 = t2.training_step(batch)
+            assert abs(float(l1) - float(l2)) < 1e-6 * abs(float(l2))
+        torch.cuda.synchronize()
+        assert rel(t1.flat.param, t2.flat.param) < 1e-6
+    finally:
+        if created:
+            dist.destroy_process_group()

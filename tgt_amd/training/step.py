@@ -161,11 +161,13 @@ class FlatState:
 
 
 class Trainer:
-    def __init__(self, model, cfg=None, loss_fn=pretrain_loss, process_group=None):
+    def __init__(self, model, cfg=None, loss_fn=pretrain_loss, process_group=None, force_distributed=False):
         self.model, self.cfg, self.loss_fn = model, (cfg or StepConfig()), loss_fn
         self.flat = FlatState(model)
         self.global_step = 0
-        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
+        # force_distributed: run the bucketed all-reduce path even with one rank (tests)
+        self.distributed = dist.is_available() and dist.is_initialized() and \
+            (dist.get_world_size(process_group) > 1 or force_distributed)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if self.distributed else 1
         self.loss_scale = 65536.0 if self.cfg.mixed_precision == 'fp16' else 1.0
