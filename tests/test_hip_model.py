@@ -281,3 +281,35 @@ def test_trainer_rccl_bucket_path_single_rank():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_full_width_24L_training_gradients_vs_oracle():
+    """TGT-At 24L at BASELINE widths: loss and parameter gradients of one training-step-equivalent
+    (dropouts off) on the HIP path, fp32 and bf16 autocast, against the oracle in fp32 on the CPU."""
+    from tgt_amd.pcqm import TGT_Multi
+    from tgt_amd.training.step import pretrain_loss, StepConfig
+    geom = dict(B=2, N=12, num_nodes=[12, 9])
+    cpu = gu.model_batch(geom, seed=911)
+    ref = gu.fill_params(om.TGT_Multi(**gu.FULL_AT_CFG), seed=910).train()
+    g_ref, l_ref = ref(cpu)
+    loss_ref = torch.nn.functional.l1_loss(g_ref, cpu['target']) + 0.1 * core.binned_distance_xent(
+        l_ref, core.pairwise_dist(cpu['dft_coords']), cpu['edge_mask'], 512, 8)
+    loss_ref.backward()
+    pr = dict(ref.named_parameters())
+    keys = ['encoder.TGT_layers.0.update.lin_QKV.weight', 'encoder.TGT_layers.0.tria.lin_QKV_in.weight',
+            'encoder.TGT_layers.5.tria.lin_EG_out.weight', 'encoder.TGT_layers.11.tria.tri_ln_e.weight',
+            'encoder.TGT_layers.17.edge_ffn.lin_W1.weight', 'encoder.TGT_layers.23.tria.lin_O.weight',
+            'encoder.TGT_layers.23.update.lin_O_e.bias', 'input_embed.dist_embed.weight', 'dist_pred.weight']
+    batch = {k: v.cuda() for k, v in cpu.items()}
+    cfg = StepConfig(num_dist_bins=512, mixed_precision=None)
+    for mode, tol_loss, tol_grad in (('fp32', 2e-5, 5e-3), ('bf16', 5e-3, 1.5e-1)):
+        model = gu.fill_params(TGT_Multi(**gu.FULL_AT_CFG), seed=910).cuda().train()
+        ctx = torch.autocast('cuda', dtype=torch.bfloat16) if mode == 'bf16' else torch.autocast('cuda', enabled=False)
+        with ctx:
+            loss = pretrain_loss(model(batch), batch, cfg)
+        loss.backward()
+        assert abs(float(loss.detach()) - float(loss_ref.detach())) < tol_loss * abs(float(loss_ref.detach())), mode
+        pm = dict(model.named_parameters())
+        for k in keys:
+            assert rel(pm[k].grad, pr[k].grad) < tol_grad, (mode, k, rel(pm[k].grad, pr[k].grad))
+        del model
