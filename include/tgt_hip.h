@@ -82,6 +82,13 @@ typedef struct tgt_triplet_attention_args {
     const void* d_out;
     void*   d_qkv[2];
     void*   d_eg[2];
+    /* backward, optional (both NULL or both set per direction): per-graph column sums of the
+     * gradient rows, i.e. the bias gradients of the projections that produced qkv / eg
+     * (`grad.sum(0)` of nn.Linear) before the sum over graphs.  d_qkv_colsum[dir] is (B, ld_qkv[dir])
+     * float32, d_eg_colsum[dir] (B, ld_eg[dir]); only the Q/K/V/E/G columns of `dir` are written
+     * (each exactly once), finish with tgt_sum_rows over B.  Saves a full pass over d_qkv. */
+    float*  d_qkv_colsum[2];
+    float*  d_eg_colsum[2];
 } tgt_triplet_attention_args;
 
 int tgt_triplet_attention_fwd(const tgt_triplet_attention_args* a, void* stream);
@@ -222,6 +229,10 @@ int tgt_gelu_dropout_bwd(const void* x, const void* dy, void* dx, int64_t n, int
  * (the `grad_output.sum(0)` ATen reduction behind nn.Linear, e.g. reference
  * lib/tgt/layers/triplet.py:198-203).  partial: tgt_layer_norm_parts()*C floats of scratch. */
 int tgt_colsum(const void* x, int32_t x_dtype, int64_t rows, int32_t C, float* out, float* partial, void* stream);
+
+/* out[c] = sum_r x[r*C + c] for a small float32 (rows, C) matrix, fixed summation order (the last
+ * stage of the two-stage reductions; finishes tgt_triplet_attention_args.d_*_colsum). */
+int tgt_sum_rows(const float* x, int32_t rows, int32_t C, float* out, void* stream);
 
 int tgt_layer_norm_bwd(const void* dy, int32_t dy_dtype, const void* x, int32_t x_dtype,
                        const float* gamma, const float* mean, const float* rstd,

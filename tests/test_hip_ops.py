@@ -90,6 +90,45 @@ def test_triplet_attention(case, dtype, variant):
         assert rel(g[..., 6 * C:L.used], gr[..., 6 * C:L.used]) < 2 * tol, ('deg', rel(g[..., 6 * C:L.used], gr[..., 6 * C:L.used]))
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', CASES)
+@pytest.mark.parametrize('variant', ['gated', 'ungated', 'axial'])
+def test_projected_triplet_attention_bias_gradient(case, dtype, variant):
+    """projection + core as one autograd node: the projection's bias gradient comes from the
+    column sums the backward kernel accumulates while it writes d_fused; it must equal the
+    column sums of d_fused itself, and every other gradient must be unchanged."""
+    from tgt_amd import ops
+    B, N, nn_, C, H = case
+    gated, biased = variant == 'gated', variant != 'axial'
+    L = ops.TripletLayout(C, H, gated=gated, biased=biased)
+    rng = np.random.default_rng(7 + hash((B, N, C, H)) % 1000)
+    x = rnd(rng, B, N, N, C).to(dtype).cuda()
+    w = (rnd(rng, L.width, C) * C ** -0.5).to(dtype).cuda()
+    b = (rnd(rng, L.width) * 0.1).to(dtype).cuda()
+    if L.width > L.used:
+        w[L.used:] = 0
+        b[L.used:] = 0
+    d_out = rnd(rng, B, N, N, 2 * C).to(dtype).cuda()
+    mask = gu.additive_mask(nn_, N, torch.float32).reshape(B, N, N).cuda()
+
+    ref_in = [t.clone().requires_grad_(True) for t in (x, w, b)]
+    fused = ops.linear(*ref_in)
+    fused.retain_grad()
+    ops.triplet_attention(fused, mask, L).backward(d_out)
+    new_in = [t.clone().requires_grad_(True) for t in (x, w, b)]
+    va = ops.projected_triplet_attention(*new_in, mask, L)
+    va.backward(d_out)
+    torch.cuda.synchronize()
+    for got, want, name in zip(new_in[:2], ref_in[:2], ('dx', 'dw')):
+        assert torch.equal(got.grad, want.grad), name
+    want_db = fused.grad.double().sum((0, 1, 2))[:L.used]
+    got_db = new_in[2].grad.double()[:L.used]
+    scale = float(fused.grad.double().abs().sum((0, 1, 2)).max()) + 1e-30      # sum of |terms|: the rounding scale
+    err = float((got_db - want_db).abs().max()) / scale
+    assert err < (1e-6 if dtype == torch.float32 else 4e-3), err
+    assert torch.isfinite(new_in[2].grad).all()
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('case', CASES)
 @pytest.mark.parametrize('gated', [True, False])

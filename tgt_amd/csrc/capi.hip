@@ -38,6 +38,7 @@ int gelu_dropout_run(const void* x, const void* dy, void* out, int64_t n, int dt
 int triangular_update_run(const void* e4, const void* v4, const float* mask, void* out, const void* d_out, void* d_e4,
                           void* d_v4, int B, int N, int H, int dtype, bool bwd, hipStream_t st);
 int colsum_run(const void* x, int x_dtype, int64_t rows, int C, float* out, float* partial, hipStream_t st);
+int sum_rows_run(const float* x, int rows, int C, float* out, hipStream_t st);
 int layer_norm_fwd_run(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
                        float* mean, float* rstd, int64_t rows, int C, float eps, hipStream_t st);
 int layer_norm_bwd_run(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, const float* mean,
@@ -106,7 +107,7 @@ using namespace tgt;
 extern "C" {
 
 const char* tgt_last_error(void) { return g_err; }
-int tgt_abi_version(void) { return 7; }
+int tgt_abi_version(void) { return 8; }
 
 int tgt_triplet_attention_fwd(const tgt_triplet_attention_args* a, void* stream) {
     return triplet_attention_run(a, false, reinterpret_cast<hipStream_t>(stream));
@@ -159,6 +160,9 @@ int tgt_add_layer_norm_bwd(const void* dy, int32_t dy_dtype, const void* s, int3
                                   reinterpret_cast<hipStream_t>(stream));
 }
 int tgt_layer_norm_parts(void) { return layer_norm_parts(); }
+int tgt_sum_rows(const float* x, int32_t rows, int32_t C, float* out, void* stream) {
+    return sum_rows_run(x, rows, C, out, reinterpret_cast<hipStream_t>(stream));
+}
 int tgt_colsum(const void* x, int32_t x_dtype, int64_t rows, int32_t C, float* out, float* partial, void* stream) {
     return colsum_run(x, x_dtype, rows, C, out, partial, reinterpret_cast<hipStream_t>(stream));
 }

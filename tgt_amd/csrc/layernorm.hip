@@ -420,6 +420,12 @@ static int colsum_launch(const void* x, int dt, int64_t rows, int C, float* out,
     return check_launch("partial_sum_kernel");
 }
 
+int sum_rows_run(const float* x, int rows, int C, float* out, hipStream_t st) {
+    if (!x || !out || rows < 0 || C <= 0) return set_error(TGT_ERR_INVALID, "sum_rows: bad arguments");
+    hipLaunchKernelGGL(partial_sum_kernel, dim3((C + 7) / 8), dim3(256), 0, st, x, rows, C, C, out, out);
+    return check_launch("partial_sum_kernel");
+}
+
 int colsum_run(const void* x, int x_dtype, int64_t rows, int C, float* out, float* partial, hipStream_t st) {
     if (!x || !out || !partial || rows < 0) return set_error(TGT_ERR_INVALID, "colsum: null tensor");
     if (bad_dtype(x_dtype)) return set_error(TGT_ERR_INVALID, "colsum: bad dtype");

@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(HG * 64, (NT == 1 && sizeof(T) == 2) ? 4 : 1) 
 // NT > 1: one pass per query tile; dK/dV sum over query tiles, so pass `it > 0`
 // adds its partial to what pass it-1 stored (same thread wrote that address).
 // ---------------------------------------------------------------------------
-template <typename T, int D, int HG, int NT, int OCC>
+template <typename T, int D, int HG, int NT, int OCC, bool CS>
 __global__ void __launch_bounds__(HG * 64, OCC) tri_att_bwd_kernel(const tgt_triplet_attention_args a) {
     using G = TriGeo<T, D, HG>;
     using F = frag_t<T>;
@@ -246,6 +246,14 @@ __global__ void __launch_bounds__(HG * 64, OCC) tri_att_bwd_kernel(const tgt_tri
     char* dq_base = const_cast<char*>(c.q.base) + shift;
     const SlabSrc dK = {c.k.base + shift, c.k.row_stride, c.k.j_stride};
     const SlabSrc dV = {c.v.base + shift, c.v.row_stride, c.v.j_stride};
+
+    // optional per-graph column sums of dQ/dK/dV and dE/dG (= bias gradients of the projection):
+    // per-thread fp32 accumulators (3 planes: dQ, dK, dV) in LDS behind the slab sets
+    constexpr int kPlane = slab_colsum_plane_floats<G, T>();
+    constexpr int kArmB = ArmStage<T, HG, NT>::kBytes;
+    float* cs = reinterpret_cast<float*>(smem + (2 * kSet > kArmB ? 2 * kSet : kArmB));
+    if constexpr (CS)
+        for (int t = tid; t < 3 * kPlane + HG * 64; t += HG * 64) cs[t] = 0.f;     // + one dE/dG partial per thread
 
     for (int it = 0; it < NT; ++it) {
         const int i0 = 32 * it;
@@ -417,18 +425,33 @@ __global__ void __launch_bounds__(HG * 64, OCC) tri_att_bwd_kernel(const tgt_tri
             }
             write_rows<T, D, HG>(sQ, dq, wave, r, hi);
             __syncthreads();
-            slab_store<G, 32>(sQ, dq_base, c.q.row_stride, c.q.j_stride, j, i0, N, tid);
             bool plain = true;
-            if constexpr (NT > 1) {
-                if (it > 0) {
-                    plain = false;
-                    slab_store_add<G, KR, T>(sK, curk, const_cast<char*>(dK.base), dK.row_stride, dK.j_stride, j, 0, N, tid);
-                    slab_store_add<G, KR, T>(sV, curv, const_cast<char*>(dV.base), dV.row_stride, dV.j_stride, j, 0, N, tid);
+            if constexpr (CS) {
+                slab_store_sum<G, 32, T, false>(sQ, pq, dq_base, c.q.row_stride, c.q.j_stride, j, i0, N, tid, cs);
+                if constexpr (NT > 1) {
+                    if (it > 0) {
+                        plain = false;
+                        slab_store_sum<G, KR, T, true>(sK, curk, const_cast<char*>(dK.base), dK.row_stride, dK.j_stride, j, 0, N, tid, cs + kPlane);
+                        slab_store_sum<G, KR, T, true>(sV, curv, const_cast<char*>(dV.base), dV.row_stride, dV.j_stride, j, 0, N, tid, cs + 2 * kPlane);
+                    }
                 }
-            }
-            if (plain) {
-                slab_store<G, KR>(sK, const_cast<char*>(dK.base), dK.row_stride, dK.j_stride, j, 0, N, tid);
-                slab_store<G, KR>(sV, const_cast<char*>(dV.base), dV.row_stride, dV.j_stride, j, 0, N, tid);
+                if (plain) {
+                    slab_store_sum<G, KR, T, false>(sK, pk, const_cast<char*>(dK.base), dK.row_stride, dK.j_stride, j, 0, N, tid, cs + kPlane);
+                    slab_store_sum<G, KR, T, false>(sV, pv, const_cast<char*>(dV.base), dV.row_stride, dV.j_stride, j, 0, N, tid, cs + 2 * kPlane);
+                }
+            } else {
+                slab_store<G, 32>(sQ, dq_base, c.q.row_stride, c.q.j_stride, j, i0, N, tid);
+                if constexpr (NT > 1) {
+                    if (it > 0) {
+                        plain = false;
+                        slab_store_add<G, KR, T>(sK, curk, const_cast<char*>(dK.base), dK.row_stride, dK.j_stride, j, 0, N, tid);
+                        slab_store_add<G, KR, T>(sV, curv, const_cast<char*>(dV.base), dV.row_stride, dV.j_stride, j, 0, N, tid);
+                    }
+                }
+                if (plain) {
+                    slab_store<G, KR>(sK, const_cast<char*>(dK.base), dK.row_stride, dK.j_stride, j, 0, N, tid);
+                    slab_store<G, KR>(sV, const_cast<char*>(dV.base), dV.row_stride, dV.j_stride, j, 0, N, tid);
+                }
             }
         }
         __syncthreads();      // the next query-tile pass re-fills both sets
@@ -436,8 +459,28 @@ __global__ void __launch_bounds__(HG * 64, OCC) tri_att_bwd_kernel(const tgt_tri
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) arm_stage_put_grad<T, HG, NT>(smem, c.dir, wave, r, hi, kt, dE[kt], dG[kt]);
         __syncthreads();
-        arm_stage_store_grad<T, HG, NT>(ta, a.d_eg[c.dir], c.b, c.dir, c.g, N, i0, smem, tid);
+        {
+            const float part = arm_stage_store_grad<T, HG, NT>(ta, a.d_eg[c.dir], c.b, c.dir, c.g, N, i0, smem, tid);
+            if constexpr (CS) cs[3 * kPlane + tid] += part;
+        }
         __syncthreads();
+    }
+    if constexpr (CS) {
+        // (the last barrier above also ordered every wave's accumulator updates)
+        float* row = a.d_qkv_colsum[c.dir] + (int64_t)c.b * a.ld_qkv[c.dir] + c.g * HG * D;
+        slab_colsum_finish<G, T>(cs, row + a.q_off[c.dir], tid);
+        slab_colsum_finish<G, T>(cs + kPlane, row + a.k_off[c.dir], tid);
+        slab_colsum_finish<G, T>(cs + 2 * kPlane, row + a.v_off[c.dir], tid);
+        if (biased || gated) {
+            constexpr int kVals = ArmStage<T, HG, NT>::kVals;      // E of the HG heads, then G
+            if (tid < kVals) {      // (the barrier that ended the last pass ordered the partials)
+                float v = 0.f;
+                for (int t = tid; t < HG * 64; t += kVals) v += cs[3 * kPlane + t];
+                float* erow = a.d_eg_colsum[c.dir] + (int64_t)c.b * a.ld_eg[c.dir];
+                if (tid < HG) { if (biased) erow[a.e_off[c.dir] + c.g * HG + tid] = v; }
+                else if (gated) erow[a.g_off[c.dir] + c.g * HG + tid - HG] = v;
+            }
+        }
     }
 }
 
@@ -450,6 +493,7 @@ static int launch_tri_nt(const tgt_triplet_attention_args& a, bool bwd, hipStrea
     const int grid = a.B * 2 * (a.H / HG);
     constexpr int kArm = ArmStage<T, HG, NT>::kBytes;
     constexpr int kFwdLds = 2 * (1 + 2 * NT) * G::kSlabBytes > kArm ? 2 * (1 + 2 * NT) * G::kSlabBytes : kArm;
+    // (+ the column-sum accumulators, 3 planes of 16/sizeof(T) fp32 per thread, when requested)
     constexpr int kBwdLds = 2 * (2 + 2 * NT) * G::kSlabBytes > kArm ? 2 * (2 + 2 * NT) * G::kSlabBytes : kArm;
     if (!bwd) {
         static const int pf = getenv("TGT_TRI_FWD_PF") ? atoi(getenv("TGT_TRI_FWD_PF")) : 1;
@@ -462,12 +506,23 @@ static int launch_tri_nt(const tgt_triplet_attention_args& a, bool bwd, hipStrea
     } else {
         // experiment knob: TGT_TRI_BWD_OCC=2 caps registers for 2 waves/SIMD (NT == 1 only)
         static const int occ = getenv("TGT_TRI_BWD_OCC") ? atoi(getenv("TGT_TRI_BWD_OCC")) : 2;
-        if (NT == 1 && occ == 2)
-            hipLaunchKernelGGL((tri_att_bwd_kernel<T, D, HG, NT, (NT == 1 ? 2 : 1)>), dim3(grid), dim3(G::kThreads),
-                               kBwdLds, st, a);
-        else
-            hipLaunchKernelGGL((tri_att_bwd_kernel<T, D, HG, NT, 1>), dim3(grid), dim3(G::kThreads),
-                               kBwdLds, st, a);
+        const bool cs = a.d_qkv_colsum[0] != nullptr;
+        constexpr int kCs = (3 * slab_colsum_plane_floats<G, T>() + G::kThreads) * 4;
+        if (NT == 1 && occ == 2) {
+            if (cs)
+                hipLaunchKernelGGL((tri_att_bwd_kernel<T, D, HG, NT, (NT == 1 ? 2 : 1), true>), dim3(grid),
+                                   dim3(G::kThreads), kBwdLds + kCs, st, a);
+            else
+                hipLaunchKernelGGL((tri_att_bwd_kernel<T, D, HG, NT, (NT == 1 ? 2 : 1), false>), dim3(grid),
+                                   dim3(G::kThreads), kBwdLds, st, a);
+        } else {
+            if (cs)
+                hipLaunchKernelGGL((tri_att_bwd_kernel<T, D, HG, NT, 1, true>), dim3(grid), dim3(G::kThreads),
+                                   kBwdLds + kCs, st, a);
+            else
+                hipLaunchKernelGGL((tri_att_bwd_kernel<T, D, HG, NT, 1, false>), dim3(grid), dim3(G::kThreads),
+                                   kBwdLds, st, a);
+        }
     }
     return check_launch(bwd ? "tri_att_bwd_kernel" : "tri_att_fwd_kernel");
 }
@@ -512,6 +567,9 @@ int triplet_attention_run(const tgt_triplet_attention_args* a, bool bwd, hipStre
             return set_error(TGT_ERR_INVALID, "triplet attention: rows/offsets must be 16-byte aligned");
         if ((a->flags & (TGT_TRI_BIASED | TGT_TRI_GATED)) && !a->eg[dir]) return set_error(TGT_ERR_INVALID, "triplet attention: eg missing");
         if (bwd) {
+            if ((a->d_qkv_colsum[dir] != nullptr) != (a->d_qkv_colsum[0] != nullptr) ||
+                ((a->flags & (TGT_TRI_BIASED | TGT_TRI_GATED)) && (a->d_eg_colsum[dir] != nullptr) != (a->d_qkv_colsum[0] != nullptr)))
+                return set_error(TGT_ERR_INVALID, "triplet attention bwd: d_qkv_colsum / d_eg_colsum must be all set or all NULL");
             if (!a->d_out || !a->d_qkv[dir] || ((uintptr_t)a->d_qkv[dir] % 16) || ((uintptr_t)a->d_out % 16))
                 return set_error(TGT_ERR_INVALID, "triplet attention bwd: null/misaligned gradient tensor");
             if ((a->flags & (TGT_TRI_BIASED | TGT_TRI_GATED)) && !a->d_eg[dir]) return set_error(TGT_ERR_INVALID, "triplet attention bwd: d_eg missing");

@@ -105,6 +105,66 @@ __device__ __forceinline__ void slab_store_add(const char* slab, const uint4 (&p
     }
 }
 
+// slab_store that also folds the stored values into column sums (the bias gradient of the
+// projection that produced the slab's tensor).  A thread always owns the same 16-byte column
+// chunk (slot = tid % kSlots), so it keeps E private fp32 accumulators -- in LDS, the register
+// file is full -- at cs[tid*E .. +E); the workgroup reduces them once at the end
+// (slab_colsum_finish).  Fixed order -> deterministic.  ADD: the stored value is slab + prior
+// (see slab_store_add) and only the increment is counted.
+template <typename G, int ROWS, typename T, bool ADD, int IT = SlabIO<G, ROWS>::kIters>
+__device__ __forceinline__ void slab_store_sum(const char* slab, const uint4 (&prior)[IT], char* dst_base,
+                                               int64_t row_stride, int64_t j_stride, int j, int row0, int N, int tid,
+                                               float* cs) {
+    constexpr int E = 16 / (int)sizeof(T);
+    static_assert(G::kThreads % G::kSlots == 0, "a thread must own one column chunk");
+    // (plain read-modify-write of this thread's own words: LDS float atomics were 5x slower)
+    float4* mine = reinterpret_cast<float4*>(cs + tid * E);
+    float acc[E];
+#pragma unroll
+    for (int t = 0; t < E / 4; ++t) *reinterpret_cast<float4*>(acc + 4 * t) = mine[t];
+#pragma unroll
+    for (int it = 0; it < SlabIO<G, ROWS>::kIters; ++it) {
+        const int c = it * G::kThreads + tid;
+        const int row = c / G::kSlots, slot = c % G::kSlots;
+        if (c < SlabIO<G, ROWS>::kChunks && row0 + row < N) {
+            uint4 a = *reinterpret_cast<const uint4*>(slab + G::lds_off(row, slot));
+            T xa[E];
+            __builtin_memcpy(xa, &a, 16);
+            if constexpr (ADD) {
+                T xb[E];
+                __builtin_memcpy(xb, &prior[it], 16);
+#pragma unroll
+                for (int t = 0; t < E; ++t) {
+                    const float old = to_f32(xb[t]);
+                    xa[t] = from_f32<T>(to_f32(xa[t]) + old);
+                    acc[t] += to_f32(xa[t]) - old;
+                }
+                __builtin_memcpy(&a, xa, 16);
+            } else {
+#pragma unroll
+                for (int t = 0; t < E; ++t) acc[t] += to_f32(xa[t]);
+            }
+            *reinterpret_cast<uint4*>(dst_base + j * j_stride + (row0 + row) * row_stride + slot * 16) = a;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < E / 4; ++t) mine[t] = *reinterpret_cast<const float4*>(acc + 4 * t);
+}
+// floats of one accumulator plane (one of dQ/dK/dV): E per thread
+template <typename G, typename T> constexpr int slab_colsum_plane_floats() { return G::kThreads * (16 / (int)sizeof(T)); }
+// sum the per-thread accumulators of plane `cs` over the threads that share a slot and write the
+// kSlots*E column sums to out[0 .. kSlots*E)
+template <typename G, typename T>
+__device__ __forceinline__ void slab_colsum_finish(const float* cs, float* out, int tid) {
+    constexpr int E = 16 / (int)sizeof(T), W = G::kSlots * E;
+    for (int col = tid; col < W; col += G::kThreads) {
+        const int slot = col / E, e = col % E;
+        float v = 0.f;
+        for (int t = slot; t < G::kThreads; t += G::kSlots) v += cs[t * E + e];
+        out[col] = v;
+    }
+}
+
 // operand fragments of head `wave` for slab row r: d in [16*dc + 8*hi, +8)
 template <typename T, int D, int HG>
 __device__ __forceinline__ void read_frags(frag_t<T> (&f)[(D + 15) / 16], const char* slab,
@@ -314,22 +374,30 @@ __device__ __forceinline__ void arm_stage_put_grad(char* lds, int dir, int hh, i
     }
 }
 
+// Returns this thread's sum of the values it stored: idx % kVals is fixed per thread
+// ((HG*64) % kVals == 0), i.e. a partial column sum of dE (v < HG) or dG of head g*HG + v % HG.
 template <typename T, int HG, int NT>
-__device__ __forceinline__ void arm_stage_store_grad(const ThirdArm& ta, void* d_eg, int b, int dir, int g, int N,
-                                                     int i0, const char* lds, int tid) {
+__device__ __forceinline__ float arm_stage_store_grad(const ThirdArm& ta, void* d_eg, int b, int dir, int g, int N,
+                                                      int i0, const char* lds, int tid) {
     using A = ArmStage<T, HG, NT>;
-    if (!(ta.biased || ta.gated)) return;
+    static_assert((HG * 64) % A::kVals == 0, "a thread must own one E/G column");
+    float part = 0.f;
+    if (!(ta.biased || ta.gated)) return part;
     const int nx = A::nx(dir), ny = A::ny(dir), x0 = dir == 0 ? i0 : 0, y0 = dir == 0 ? 0 : i0;
     const int pitch = A::pitch(dir);
     T* deg = reinterpret_cast<T*>(d_eg);
+#pragma nounroll
     for (int idx = tid; idx < nx * ny * A::kVals; idx += HG * 64) {
         const int v = idx % A::kVals, p = idx / A::kVals, yy = p % ny, xx = p / ny;
         const int x = x0 + xx, y = y0 + yy;
         const bool is_e = v < HG;
-        if (x < N && y < N && (is_e ? ta.biased : ta.gated))
-            deg[(((int64_t)b * N + x) * N + y) * ta.ld + (is_e ? ta.e_off + g * HG + v : ta.g_off + g * HG + v - HG)] =
-                *reinterpret_cast<const T*>(lds + xx * pitch + yy * A::kPairBytes + v * (int)sizeof(T));
+        if (x < N && y < N && (is_e ? ta.biased : ta.gated)) {
+            const T val = *reinterpret_cast<const T*>(lds + xx * pitch + yy * A::kPairBytes + v * (int)sizeof(T));
+            deg[(((int64_t)b * N + x) * N + y) * ta.ld + (is_e ? ta.e_off + g * HG + v : ta.g_off + g * HG + v - HG)] = val;
+            part += to_f32(val);
+        }
     }
+    return part;
 }
 
 }  // namespace tgt

@@ -5,6 +5,7 @@ arithmetic.  They require HIP device tensors and libtgt_hip.so; there is no
 eager / CPU fallback (a missing library or a CPU tensor raises).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -88,7 +89,7 @@ class TripletLayout:
         self.flags = (_lib.TRI_BIASED if biased else 0) | (_lib.TRI_GATED if gated else 0)
 
 
-def _tri_args(fused, mask3, out, L, d_out=None, d_fused=None):
+def _tri_args(fused, mask3, out, L, d_out=None, d_fused=None, colsum=None):
     B, N = fused.shape[0], fused.shape[1]
     a = _lib.TripletAttentionArgs()
     a.B, a.N, a.H, a.D = B, N, L.H, L.D
@@ -108,6 +109,11 @@ def _tri_args(fused, mask3, out, L, d_out=None, d_fused=None):
         dp = d_fused.data_ptr()
         a.d_qkv = _pair(C.c_void_p, dp, dp)
         a.d_eg = _pair(C.c_void_p, dp, dp)
+        if colsum is not None:            # (B, width) fp32: per-graph column sums of d_fused
+            cp = colsum.data_ptr()
+            a.d_qkv_colsum = _pair(C.c_void_p, cp, cp)
+            if L.biased:
+                a.d_eg_colsum = _pair(C.c_void_p, cp, cp)
     return a
 
 
@@ -142,6 +148,75 @@ def triplet_attention(fused, mask3, layout):
     (B,N,N) float32.  Returns Va (B,N,N,2C) with channel = dir*C + h*D + d.
     Reference arithmetic: lib/tgt/layers/triplet.py:213-246."""
     return _TripletAttention.apply(fused, mask3, layout)
+
+
+_colsum_ws = {}
+
+
+def _colsum_workspace(B, width, device):
+    """(B, width) fp32 scratch for the kernels' per-graph column sums; zero-filled once (columns a
+    kernel never writes -- row padding -- stay zero), reused by every layer: stream order makes
+    the consumer (sum_rows) finish before the next producer starts."""
+    key = (device, B, width)
+    ws = _colsum_ws.get(key)
+    if ws is None:
+        ws = _colsum_ws[key] = torch.zeros(B, width, dtype=torch.float32, device=device)
+    return ws
+
+
+def sum_rows(x):
+    """fp32 (rows, C) -> (C,) column sums, fixed order (tgt_sum_rows)."""
+    _dev(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
+    out = torch.empty(x.shape[1], dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().tgt_sum_rows(_ptr(x), x.shape[0], x.shape[1], _ptr(out), _stream()), 'tgt_sum_rows')
+    return out
+
+
+class _ProjectedTripletAttention(torch.autograd.Function):
+    """fused projection GEMM + triplet attention core as ONE autograd node, so that the backward
+    kernel can hand the projection its bias gradient (column sums of d_fused, accumulated while
+    the gradient rows are written) instead of a separate 0.84 GB reduction pass."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, mask3, L, cd):
+        _dev(x, mask3)
+        B, N = x.shape[0], x.shape[1]
+        x2, w, fused = _linear_forward(x, weight, bias, cd)
+        out = torch.empty(B, N, N, 2 * L.C, dtype=cd, device=x.device)
+        a = _tri_args(fused, mask3, out, L)
+        _call('tgt_triplet_attention_fwd', _lib.lib().tgt_triplet_attention_fwd, a)
+        ctx.save_for_backward(x2, w, fused, mask3, out)
+        ctx.L = L
+        ctx.meta = (x.shape, x.dtype, weight.dtype, bias.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x2, w, fused, mask3, out = ctx.saved_tensors
+        L = ctx.L
+        xs, xdt, wdt, bdt = ctx.meta
+        d_out = d_out.contiguous()
+        d_fused = torch.empty_like(fused)          # every used column is written by the kernel
+        if L.width > L.used:
+            d_fused[..., L.used:] = 0
+        colsum = _colsum_workspace(fused.shape[0], L.width, fused.device)
+        a = _tri_args(fused, mask3, out, L, d_out, d_fused, colsum)
+        _call('tgt_triplet_attention_bwd', _lib.lib().tgt_triplet_attention_bwd, a)
+        db = sum_rows(colsum).to(bdt) if ctx.needs_input_grad[2] else None
+        dx, dw, _ = _linear_backward(x2, w, d_fused.view(-1, L.width), xs, xdt, wdt, None,
+                                     ctx.needs_input_grad[0], ctx.needs_input_grad[1], False)
+        return dx, dw, db, None, None, None
+
+
+def projected_triplet_attention(x, weight, bias, mask3, layout):
+    """triplet_attention(linear(x, weight, bias), mask3, layout) with the bias gradient of the
+    projection produced inside the backward kernel.  weight/bias: the fused (layout.width, C)
+    projection in kernel order (see TripletLayout)."""
+    if os.environ.get('TGT_TRI_COLSUM', '1') == '0':          # A/B knob: separate bias-gradient pass
+        return triplet_attention(linear(x, weight, bias), mask3, layout)
+    cd = torch.get_autocast_dtype('cuda') if (x.is_cuda and torch.is_autocast_enabled('cuda')) else x.dtype
+    return _ProjectedTripletAttention.apply(x, weight, bias, mask3, layout, cd)
 
 
 # ---------------------------------------------------------------------------
@@ -567,9 +642,11 @@ def column_sum(x2):
     return out
 
 
-def _wgrad_chunks(M):
-    """number of row chunks for dW = sum_c dY_c^T X_c (rows per chunk >= 1024, <= 128 chunks)"""
-    for P in (128, 64, 32, 16, 8, 4, 2):
+def _wgrad_chunks(M, out_in=0):
+    """number of row chunks for dW = sum_c dY_c^T X_c (rows per chunk >= 1024, <= 128 chunks; 64
+    for the 1600x256 fused projection, whose fp32 partials are 1.6 MB each:
+    tools/wgrad_chunk_probe.py)"""
+    for P in ((64, 32, 16, 8, 4, 2) if out_in >= 262144 else (128, 64, 32, 16, 8, 4, 2)):
         if M % P == 0 and M // P >= 1024:
             return P
     return 1
@@ -586,54 +663,67 @@ def _as_dtype(p, cd):
     return p.to(cd)
 
 
+def _linear_forward(x, weight, bias, cd):
+    """(x2, w, y): the operands saved for the backward and y = x W^T + b in dtype cd"""
+    xs = x.shape
+    x2 = x.reshape(-1, xs[-1])
+    if x2.dtype != cd:
+        x2 = x2.to(cd)
+    w = _as_dtype(weight, cd)
+    b = None if bias is None else _as_dtype(bias, cd)
+    # the result must own its storage (not be a view): the layer adds the residual in place
+    y = torch.empty(*xs[:-1], weight.shape[0], dtype=cd, device=x.device)
+    y2 = y.view(-1, weight.shape[0])
+    if b is None:
+        torch.mm(x2, w.t(), out=y2)
+    else:
+        torch.addmm(b, x2, w.t(), out=y2)
+    return x2, w, y
+
+
+def _linear_backward(x2, w, dy2, xs, xdt, wdt, bdt, need_dx, need_dw, need_db):
+    """(dx, dW, db) of y = x W^T + b.  dW = dY^T X contracts over M = B*N*N = 262144 rows into a
+    tiny (out,in) result; as one GEMM the library runs it on a handful of workgroups
+    (0.4-0.8 ms), as 64-128 independent chunk products + an fp32 sum it is HBM-bound (57 us for
+    256x256, measured; tools/wgrad_probe.py)."""
+    if dy2.dtype != w.dtype:
+        dy2 = dy2.to(w.dtype)
+    dx = dw = db = None
+    if need_dx:
+        dx = (dy2 @ w).view(xs).to(xdt)
+    if need_dw:
+        M = x2.shape[0]
+        P = _wgrad_chunks(M, dy2.shape[1] * x2.shape[1])
+        if P > 1:
+            part = torch.bmm(dy2.view(P, M // P, -1).transpose(1, 2), x2.view(P, M // P, -1),
+                             out_dtype=torch.float32) if dy2.dtype != torch.float32 else \
+                torch.bmm(dy2.view(P, M // P, -1).transpose(1, 2), x2.view(P, M // P, -1))
+            dw = part.sum(0).to(wdt)
+        else:
+            dw = (dy2.t() @ x2).to(wdt)
+    if need_db:
+        db = column_sum(dy2).to(bdt)
+    return dx, dw, db
+
+
 class _Linear(torch.autograd.Function):
-    """y = x W^T + b on the library GEMM, with the weight gradient computed as a BATCHED
-    GEMM over row chunks + an fp32 sum.  dW = dY^T X contracts over M = B*N*N = 262144 rows
-    into a tiny (out,in) result; as one GEMM the library runs it on a handful of
-    workgroups (0.4-0.8 ms), as 64-128 independent chunk products it is HBM-bound
-    (57 us for 256x256, measured; tools/wgrad_probe.py)."""
+    """y = x W^T + b on the library GEMM, with the weight gradient computed as a BATCHED GEMM
+    over row chunks (see _linear_backward)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, cd):
-        xs = x.shape
-        x2 = x.reshape(-1, xs[-1])
-        if x2.dtype != cd:
-            x2 = x2.to(cd)
-        w = _as_dtype(weight, cd)
-        b = None if bias is None else _as_dtype(bias, cd)
-        # the result must own its storage (not be a view): the layer adds the residual in place
-        y = torch.empty(*xs[:-1], weight.shape[0], dtype=cd, device=x.device)
-        y2 = y.view(-1, weight.shape[0])
-        if b is None:
-            torch.mm(x2, w.t(), out=y2)
-        else:
-            torch.addmm(b, x2, w.t(), out=y2)
+        x2, w, y = _linear_forward(x, weight, bias, cd)
         ctx.save_for_backward(x2, w)
-        ctx.meta = (xs, x.dtype, weight.dtype, None if bias is None else bias.dtype)
+        ctx.meta = (x.shape, x.dtype, weight.dtype, None if bias is None else bias.dtype)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x2, w = ctx.saved_tensors
         xs, xdt, wdt, bdt = ctx.meta
-        dy2 = dy.reshape(-1, dy.shape[-1])
-        if dy2.dtype != w.dtype:
-            dy2 = dy2.to(w.dtype)
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = (dy2 @ w).view(xs).to(xdt)
-        if ctx.needs_input_grad[1]:
-            M = x2.shape[0]
-            P = _wgrad_chunks(M)
-            if P > 1:
-                part = torch.bmm(dy2.view(P, M // P, -1).transpose(1, 2), x2.view(P, M // P, -1),
-                                 out_dtype=torch.float32) if dy2.dtype != torch.float32 else \
-                    torch.bmm(dy2.view(P, M // P, -1).transpose(1, 2), x2.view(P, M // P, -1))
-                dw = part.sum(0).to(wdt)
-            else:
-                dw = (dy2.t() @ x2).to(wdt)
-        if bdt is not None and ctx.needs_input_grad[2]:
-            db = column_sum(dy2).to(bdt)
+        dx, dw, db = _linear_backward(x2, w, dy.reshape(-1, dy.shape[-1]), xs, xdt, wdt, bdt,
+                                      ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                      bdt is not None and ctx.needs_input_grad[2])
         return dx, dw, db, None
 
 

@@ -111,8 +111,7 @@ class TripletAttention(_TripletBase):
         _no_attention_dropout(self)
         B, N = x.shape[0], x.shape[1]
         w, b = self._fused_projection(x.device)
-        fused = ops.linear(x, w, b)
-        va = ops.triplet_attention(fused, ops.as_mask3(mask, B, N), self._layout)
+        va = ops.projected_triplet_attention(x, w, b, ops.as_mask3(mask, B, N), self._layout)
         return self._out_proj(va)
 
 
