@@ -179,6 +179,46 @@ def test_trainer_step_runs_and_matches_torch_adam():
     assert rel(p1, p2) < 1e-4
 
 
+def test_node_side_stream_gives_identical_gradients():
+    """the node FFN of every layer runs on a second HIP stream under the edge kernels: the
+    losses and all gradients must be bit-identical to the single-stream run (no race), also
+    through the bucketed gradient path that reads gradients inside autograd hooks."""
+    import torch.distributed as dist
+    from tgt_amd import ops
+    from tgt_amd.pcqm import TGT_Multi
+    from tgt_amd.training.step import Trainer, StepConfig, preprocess_batch
+    from tgt_amd.training.synthetic import make_batch
+    kwargs = dict(gu.MODEL_CASES['multi_at_tiny'][1])
+    kwargs.update(model_height=6)
+    cfg = StepConfig(num_dist_bins=24, mixed_precision='bf16', coords_noise=0.0, bucket_mbytes=0.05)
+    own_pg = not dist.is_initialized()
+    if own_pg:
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29517', rank=0, world_size=1)
+    try:
+        grads = {}
+        for enabled in (False, True, True):
+            ops.side_stream.enabled = enabled
+            model = gu.fill_params(TGT_Multi(**kwargs), seed=5).cuda()
+            tr = Trainer(model, cfg, force_distributed=True)
+            outs = []
+            for step in range(3):
+                batch = preprocess_batch(make_batch(16, 24, seed=70 + step, ragged=True), 'cuda', cfg, training=False)
+                model.eval()                               # dropouts off: runs are comparable bit for bit
+                loss = tr.compute_gradients(batch)[1]
+                outs.append((float(loss), tr.flat.grad.clone()))
+            torch.cuda.synchronize()
+            grads.setdefault(enabled, []).append(outs)
+        ref = grads[False][0]
+        for run in grads[True]:
+            for (l0, g0), (l1, g1) in zip(ref, run):
+                assert l0 == l1
+                assert torch.equal(g0, g1)
+    finally:
+        ops.side_stream.enabled = True
+        if own_pg:
+            dist.destroy_process_group()
+
+
 def test_cfg4_two_node_tiles_model_step():
     """BASELINE cfg 4 shape class: N up to 48 (two node tiles), Gaussian 3-D embedding,
     ragged batch; fp32 HIP path vs the oracle (outputs, loss, a few gradients)."""

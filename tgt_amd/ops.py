@@ -536,7 +536,7 @@ class _ScalePool:
     def __init__(self):
         self.buf, self.cur, self.key = None, 0, None
 
-    def take(self, B, keep, device):
+    def _take(self, B, keep, device):
         key = (B, keep, device)
         if self.key != key or self.buf is None or self.cur >= self.buf.shape[0]:
             self.buf = torch.empty(64, B, dtype=torch.float32, device=device).bernoulli_(keep).div_(keep)
@@ -545,8 +545,19 @@ class _ScalePool:
         self.cur += 1
         return out
 
+    _pools = {}
 
-_scale_pool = _ScalePool()
+    @classmethod
+    def take(cls, B, keep, device):
+        """one pool per stream: a refill and the reads of its rows stay on one stream"""
+        sid = torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0
+        pool = cls._pools.get(sid)
+        if pool is None:
+            pool = cls._pools[sid] = cls()
+        return pool._take(B, keep, device)
+
+
+_scale_pool = _ScalePool
 
 
 def drop_path_add_(x, residual, drop_prob, training):
@@ -786,6 +797,57 @@ class _AddLayerNorm(torch.autograd.Function):
         if d_x is None:
             d_x = d_res
         return d_x, (d_res if rdt == d_res.dtype else d_res.to(rdt)), None, dgb[0].to(wdt), dgb[1].to(wdt), None, None
+
+
+_side_streams = {}
+
+
+class side_stream:
+    """`with ops.side_stream(t):` runs the block on a second HIP stream that first waits for
+    the work queued so far on the current one; `.join()` makes the current stream wait for the
+    block.  Used to run the small node-channel kernels (8192 rows: latency-bound, a few
+    workgroups) under the edge-channel kernels of the same layer.  Autograd replays the block's
+    backward on the same side stream and inserts the cross-stream waits itself.
+    TGT_NODE_STREAM=0 disables it (everything stays on the current stream)."""
+    enabled = os.environ.get('TGT_NODE_STREAM', '1') != '0'
+
+    def __init__(self, *inputs):
+        self.active = self.enabled and len(inputs) > 0 and all(t.is_cuda for t in inputs)
+        if self.active:
+            dev = inputs[0].device
+            self.main = torch.cuda.current_stream(dev)
+            if dev not in _side_streams:
+                _side_streams[dev] = torch.cuda.Stream(dev)
+            self.side = _side_streams[dev]
+            self.inputs = inputs
+
+    def __enter__(self):
+        if self.active:
+            self.side.wait_stream(self.main)
+            for t in self.inputs:               # the allocator must not recycle them under the side stream
+                t.record_stream(self.side)
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.active:
+            self.ctx.__exit__(*exc)
+        return False
+
+    def join(self, *outputs):
+        if self.active:
+            self.main.wait_stream(self.side)
+            for t in outputs:
+                t.record_stream(self.main)
+
+
+def wait_side_streams(device=None):
+    """make the current stream wait for everything queued on the side streams (before reading
+    tensors -- e.g. gradients inside a hook -- that a side-stream block may have produced)"""
+    for dev, st in _side_streams.items():
+        if device is None or dev == device:
+            torch.cuda.current_stream(dev).wait_stream(st)
 
 
 def drop_path_scale(x, drop_prob, training):

@@ -206,9 +206,18 @@ class TGT_Layer(nn.Module):
         def enter(x, res, ln):
             return ops.add_layer_norm(x, res, ops.drop_path_scale(x, dp, tr), ln.weight, ln.bias, ln.eps)
 
+        node_side = None
         if self.node_update:
-            h, x = enter(h, h_in, self.node_ffn.ffn_ln)
-            h = ops.drop_path_add_(self.node_ffn.forward_normed(x), h, dp, tr)
+            # the node FFN (a dozen latency-bound launches on 8192 rows) runs under the edge
+            # kernels of this layer on a second stream; joined before the layer returns
+            node_side = ops.side_stream(h, h_in) if self.edge_update else None
+            if node_side is not None:
+                with node_side:
+                    h, x = enter(h, h_in, self.node_ffn.ffn_ln)
+                    h = ops.drop_path_add_(self.node_ffn.forward_normed(x), h, dp, tr)
+            else:
+                h, x = enter(h, h_in, self.node_ffn.ffn_ln)
+                h = ops.drop_path_add_(self.node_ffn.forward_normed(x), h, dp, tr)
         if self.edge_update:
             if self._triplet_update:
                 e, x = enter(e, e_in, self.tria.tri_ln_e)
@@ -216,6 +225,8 @@ class TGT_Layer(nn.Module):
             else:
                 e, x = enter(e, e_in, self.edge_ffn.ffn_ln)
             e = ops.drop_path_add_(self.edge_ffn.forward_normed(x), e, dp, tr)
+        if node_side is not None:
+            node_side.join(h)
         g = g.copy()
         g.h, g.e = h, e
         return g

@@ -148,6 +148,8 @@ class FlatState:
         """autograd's per-tensor gradients -> the flat buffer (one multi-tensor copy instead of
         883 accumulate kernels); parameters without a gradient contribute zeros."""
         idx = range(len(self.params)) if indices is None else indices
+        if self.param.is_cuda:
+            ops.wait_side_streams(self.param.device)       # node-FFN gradients come from a second stream
         src, dst = [], []
         for i in idx:
             g = self.params[i].grad
