@@ -560,6 +560,36 @@ class _ScalePool:
 _scale_pool = _ScalePool
 
 
+def scaled_add_(x, residual, scale):
+    """residual + x*scale with a per-sample scale (B,) float32 or None (then in place on x)"""
+    if scale is not None:
+        sc = scale.view([x.size(0)] + [1] * (x.ndim - 1))
+        return torch.addcmul(residual.to(x.dtype) if residual.dtype != x.dtype else residual, x, sc.to(x.dtype))
+    return x.add_(residual)
+
+
+class _DropMaskPool:
+    """Source-dropout masks (B,1,N) = Bernoulli(p)*finfo.min drawn 32 layers at a time per stream."""
+    _pools = {}
+
+    @classmethod
+    def take(cls, B, N, p, fill, device):
+        sid = torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0
+        key = (sid, B, N, p, fill, device)
+        st = cls._pools.get(key)
+        if st is None or st[1] >= st[0].shape[0]:
+            st = cls._pools[key] = [torch.empty(32, B, 1, N, dtype=torch.float32, device=device).bernoulli_(p).mul_(fill), 0]
+        out = st[0][st[1]]
+        st[1] += 1
+        return out
+
+
+def source_drop_mask(B, N, p, fill, device):
+    """additive per-key-node mask of EGT_Attention's source dropout (reference
+    lib/tgt/layers/layers.py:55-59): (B,1,N) float32, `fill` (finfo.min) where the key is dropped"""
+    return _DropMaskPool.take(B, N, float(p), float(fill), device)
+
+
 def drop_path_add_(x, residual, drop_prob, training):
     """residual + DropPath(x)  (reference lib/tgt/layers/layers.py:169-174 followed by
     the in-place add_ of :270-290) in ONE pass over the tensors."""

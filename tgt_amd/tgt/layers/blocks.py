@@ -31,6 +31,23 @@ class Linear(nn.Linear):
         return ops.linear(x, self.weight, self.bias)
 
 
+class PendingResidual:
+    """`res + DropPath(x)` not yet added: the edge residual that closes a layer is handed to the
+    next layer un-added, so that the add happens inside the LayerNorm pass that opens that layer
+    (one read/write of the edge tensor instead of two, and one fused pass in the backward).
+    Only TGT_Encoder asks layers for this (defer_edge=True) and resolves the last one."""
+
+    def __init__(self, x, res, scale):
+        self.x, self.res, self.scale = x, res, scale
+
+    def materialize(self):
+        return ops.scaled_add_(self.x, self.res, self.scale)
+
+    def enter(self, ln):
+        """(res + x*scale, LayerNorm of it)"""
+        return ops.add_layer_norm(self.x, self.res, self.scale, ln.weight, ln.bias, ln.eps)
+
+
 class EGT_Attention(nn.Module):
     """Node attention biased and gated by edge channels.
     Reference lib/tgt/layers/layers.py:15-84."""
@@ -53,16 +70,19 @@ class EGT_Attention(nn.Module):
             self.lin_O_e = Linear(num_heads, edge_width)
 
     def forward(self, h, e, mask):
+        return self.forward_normed(h, self.mha_ln_e(e), mask, e)
+
+    def forward_normed(self, h, e_hat, mask, e=None):
+        """the block with mha_ln_e already applied (TGT_Layer fuses that LayerNorm with the
+        residual add that closed the previous layer); e: returned as is without edge_update"""
         B, N = h.shape[0], h.shape[1]
         qkv = self.lin_QKV(self.mha_ln_h(h))
-        eg = self.lin_EG(self.mha_ln_e(e))
+        eg = self.lin_EG(e_hat)
         mask3 = ops.as_mask3(mask, B, N)
         if self.source_dropout > 0 and self.training:
             # per-key-node drop shared by all queries/heads (layers.py:55-59); the
             # caller's mask is left untouched (the triplet module sees it un-dropped)
-            drop = torch.empty(B, 1, N, dtype=torch.float32, device=h.device)
-            drop = drop.bernoulli_(self.source_dropout) * torch.finfo(mask.dtype).min
-            mask3 = mask3 + drop
+            mask3 = mask3 + ops.source_drop_mask(B, N, self.source_dropout, torch.finfo(mask.dtype).min, h.device)
         v_att, h_hat = ops.node_attention(qkv, eg, mask3, self.num_heads,
                                           self.scale_degree, self.edge_update)
         h = self.lin_O_h(v_att)
@@ -87,8 +107,11 @@ class EdgeUpdate(nn.Module):
         self.lin_O_e = Linear(num_heads, edge_width)
 
     def forward(self, h, e, mask):
+        return self.forward_normed(h, self.mha_ln_e(e), mask, e)
+
+    def forward_normed(self, h, e_hat, mask, e=None):
         qk = self.lin_QK(self.mha_ln_h(h))
-        bias = self.lin_E(self.mha_ln_e(e))
+        bias = self.lin_E(e_hat)
         return h, self.lin_O_e(ops.edge_logits(qk, bias, self.num_heads))
 
 
@@ -195,10 +218,16 @@ class TGT_Layer(nn.Module):
                                 act_dropout=edge_act_dropout, activation=activation)
         self.drop_path = DropPath(drop_path)
 
-    def forward(self, g):
+    def forward(self, g, defer_edge=False):
+        """defer_edge: leave the closing edge residual un-added in g.e (a PendingResidual) for
+        the next layer's opening LayerNorm; TGT_Encoder resolves the last one."""
         h, e, mask = g.h, g.e, g.mask
+        if isinstance(e, PendingResidual):
+            e, e_hat = e.enter(self.update.mha_ln_e)
+        else:
+            e_hat = self.update.mha_ln_e(e)
         h_in, e_in = h, e
-        h, e = self.update(h, e, mask)
+        h, e = self.update.forward_normed(h, e_hat, mask, e)
         # Each residual add is fused with the LayerNorm that opens the next sub-block
         # (s = res + DropPath(x); y = LN(s) in one pass, and one pass in the backward).
         dp, tr = self.drop_path.drop_path, self.training
@@ -224,7 +253,8 @@ class TGT_Layer(nn.Module):
                 e, x = enter(self.tria.forward_normed(x, mask), e, self.edge_ffn.ffn_ln)
             else:
                 e, x = enter(e, e_in, self.edge_ffn.ffn_ln)
-            e = ops.drop_path_add_(self.edge_ffn.forward_normed(x), e, dp, tr)
+            closing = PendingResidual(self.edge_ffn.forward_normed(x), e, ops.drop_path_scale(x, dp, tr))
+            e = closing if defer_edge else closing.materialize()
         if node_side is not None:
             node_side.join(h)
         g = g.copy()

@@ -1,9 +1,15 @@
 """The layer stack (`TGT_Encoder`) and the attribute-style batch container (`Graph`).
 Same public behaviour and state_dict prefixes (`TGT_layers.{i}.`) as the reference's
 lib/tgt/encoder.py."""
+import os
+
 from torch import nn
 
 from .layers import TGT_Layer
+from .layers.blocks import PendingResidual
+
+
+_DEFER_EDGE = os.environ.get('TGT_DEFER_EDGE', '1') != '0'      # A/B knob
 
 
 class Graph(dict):
@@ -56,13 +62,16 @@ class TGT_Encoder(nn.Module):
                       edge_update=not self.egt_simple and (self.edge_ended or not last))
         return kwargs
 
-    def apply_layer(self, layer_idx, graph):
+    def apply_layer(self, layer_idx, graph, defer_edge=False):
         for _ in range(self.layer_multiplier):
-            graph = self.TGT_layers[layer_idx](graph)
+            graph = self.TGT_layers[layer_idx](graph, defer_edge=defer_edge)
         return graph
 
     def forward(self, inputs):
         graph = Graph(inputs)
         for idx in range(self.model_height):
-            graph = self.apply_layer(idx, graph)
+            # between layers the closing edge residual travels un-added (layers.PendingResidual)
+            graph = self.apply_layer(idx, graph, defer_edge=_DEFER_EDGE)
+        if isinstance(graph.e, PendingResidual):
+            graph.e = graph.e.materialize()
         return graph
