@@ -230,6 +230,35 @@ int tgt_gelu_dropout_bwd(const void* x, const void* dy, void* dx, int64_t n, int
  * lib/tgt/layers/triplet.py:198-203).  partial: tgt_layer_norm_parts()*C floats of scratch. */
 int tgt_colsum(const void* x, int32_t x_dtype, int64_t rows, int32_t C, float* out, float* partial, void* stream);
 
+/* Kernel-order parameters of a triplet module in one launch.  The reference holds the
+ * projections as separate nn.Linear with head-minor channels (lib/tgt/layers/triplet.py:198-203,
+ * :23-43); tgt_triplet_*_args want one fused, head-major projection.
+ *   tgt_fuse_rows   : fused[r,:] = src[row_src[r]][row_idx[r],:]  (row_src < 0: a zero row), and
+ *                     the same for the bias vectors when fused_bias != NULL; values are converted
+ *                     src_dtype -> fused_dtype.
+ *   tgt_unfuse_rows : the inverse scatter (fused -> sources): the gradient path.  Source rows that
+ *                     no fused row references are left untouched.
+ * row_src/row_idx are device int32 (n_rows).  All matrices row-major contiguous, n_cols wide. */
+typedef struct tgt_fuse_rows_args {
+    int32_t n_rows, n_cols, n_src;
+    int32_t src_dtype, fused_dtype;
+    int32_t _pad0;
+    const int32_t* row_src;
+    const int32_t* row_idx;
+    void* src[8];
+    void* src_bias[8];
+    void* fused;
+    void* fused_bias;              /* NULL: weights only */
+} tgt_fuse_rows_args;
+int tgt_fuse_rows(const tgt_fuse_rows_args* a, void* stream);
+int tgt_unfuse_rows(const tgt_fuse_rows_args* a, void* stream);
+
+/* dst[r][c] = src[r][idx[c]] with dtype conversion: lin_O's input columns in the kernels'
+ * [dir][h][d] output order (reference order d*2H + dir*H + h, triplet.py:248); the gradient uses
+ * the inverse index.  idx: device int32 (cols). */
+int tgt_permute_cols(const void* src, int32_t src_dtype, const int32_t* idx, void* dst, int32_t dst_dtype,
+                     int32_t rows, int32_t cols, void* stream);
+
 /* out[c] = sum_r x[r*C + c] for a small float32 (rows, C) matrix, fixed summation order (the last
  * stage of the two-stage reductions; finishes tgt_triplet_attention_args.d_*_colsum). */
 int tgt_sum_rows(const float* x, int32_t rows, int32_t C, float* out, void* stream);

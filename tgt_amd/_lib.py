@@ -11,8 +11,8 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtgt_hip.so')
 CSRC = os.path.join(_HERE, 'csrc')
-SOURCES = ['capi.hip', 'triplet_attention.hip', 'triplet_aggregate.hip', 'node_attention.hip', 'layernorm.hip', 'triangular_update.hip', 'elementwise.hip']
-ABI_VERSION = 8
+SOURCES = ['capi.hip', 'params.hip', 'triplet_attention.hip', 'triplet_aggregate.hip', 'node_attention.hip', 'layernorm.hip', 'triangular_update.hip', 'elementwise.hip']
+ABI_VERSION = 9
 
 TGT_F32, TGT_BF16, TGT_F16 = 0, 1, 2
 TRI_BIASED, TRI_GATED, TRI_MASK_OUT = 1, 2, 4
@@ -58,6 +58,13 @@ class NodeAttentionArgs(C.Structure):
     ]
 
 
+class FuseRowsArgs(C.Structure):
+    _fields_ = [
+        ('n_rows', _i32), ('n_cols', _i32), ('n_src', _i32), ('src_dtype', _i32), ('fused_dtype', _i32), ('_pad0', _i32),
+        ('row_src', _vp), ('row_idx', _vp), ('src', _vp * 8), ('src_bias', _vp * 8), ('fused', _vp), ('fused_bias', _vp),
+    ]
+
+
 # symbol -> (restype, argtypes); every symbol include/tgt_hip.h declares
 SYMBOLS = {
     'tgt_last_error': (C.c_char_p, []),
@@ -77,6 +84,9 @@ SYMBOLS = {
     'tgt_layer_norm_parts': (C.c_int, []),
     'tgt_colsum': (C.c_int, [_vp, _i32, _i64, _i32, _vp, _vp, _vp]),
     'tgt_sum_rows': (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
+    'tgt_fuse_rows': (C.c_int, [C.POINTER(FuseRowsArgs), _vp]),
+    'tgt_unfuse_rows': (C.c_int, [C.POINTER(FuseRowsArgs), _vp]),
+    'tgt_permute_cols': (C.c_int, [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
     'tgt_layer_norm_fwd': (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _f32, _vp]),
     'tgt_layer_norm_bwd': (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp]),
     'tgt_adam_step': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp, _i32, _vp]),

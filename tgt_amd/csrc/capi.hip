@@ -39,6 +39,8 @@ int triangular_update_run(const void* e4, const void* v4, const float* mask, voi
                           void* d_v4, int B, int N, int H, int dtype, bool bwd, hipStream_t st);
 int colsum_run(const void* x, int x_dtype, int64_t rows, int C, float* out, float* partial, hipStream_t st);
 int sum_rows_run(const float* x, int rows, int C, float* out, hipStream_t st);
+int fuse_rows_run(const tgt_fuse_rows_args* a, bool scatter, hipStream_t st);
+int permute_cols_run(const void* src, int sd, const int32_t* idx, void* dst, int dd, int rows, int cols, hipStream_t st);
 int layer_norm_fwd_run(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
                        float* mean, float* rstd, int64_t rows, int C, float eps, hipStream_t st);
 int layer_norm_bwd_run(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, const float* mean,
@@ -107,7 +109,7 @@ using namespace tgt;
 extern "C" {
 
 const char* tgt_last_error(void) { return g_err; }
-int tgt_abi_version(void) { return 8; }
+int tgt_abi_version(void) { return 9; }
 
 int tgt_triplet_attention_fwd(const tgt_triplet_attention_args* a, void* stream) {
     return triplet_attention_run(a, false, reinterpret_cast<hipStream_t>(stream));
@@ -160,6 +162,12 @@ int tgt_add_layer_norm_bwd(const void* dy, int32_t dy_dtype, const void* s, int3
                                   reinterpret_cast<hipStream_t>(stream));
 }
 int tgt_layer_norm_parts(void) { return layer_norm_parts(); }
+int tgt_fuse_rows(const tgt_fuse_rows_args* a, void* stream) { return fuse_rows_run(a, false, reinterpret_cast<hipStream_t>(stream)); }
+int tgt_unfuse_rows(const tgt_fuse_rows_args* a, void* stream) { return fuse_rows_run(a, true, reinterpret_cast<hipStream_t>(stream)); }
+int tgt_permute_cols(const void* src, int32_t src_dtype, const int32_t* idx, void* dst, int32_t dst_dtype, int32_t rows,
+                     int32_t cols, void* stream) {
+    return permute_cols_run(src, src_dtype, idx, dst, dst_dtype, rows, cols, reinterpret_cast<hipStream_t>(stream));
+}
 int tgt_sum_rows(const float* x, int32_t rows, int32_t C, float* out, void* stream) {
     return sum_rows_run(x, rows, C, out, reinterpret_cast<hipStream_t>(stream));
 }

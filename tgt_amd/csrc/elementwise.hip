@@ -14,10 +14,28 @@ __device__ __forceinline__ uint32_t mix32(uint32_t h) {      // "lowbias32" inte
     h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
     return h;
 }
-__device__ __forceinline__ bool keep_elem(uint64_t seed, int64_t i, uint32_t thresh) {
-    const uint32_t lo = (uint32_t)i, hi = (uint32_t)((uint64_t)i >> 32);
-    const uint32_t h = mix32(lo ^ (uint32_t)seed) ^ mix32(hi + (uint32_t)(seed >> 32) + 0x9e3779b9u);
-    return mix32(h) >= thresh;                                // P(keep) = 1 - thresh / 2^32
+// keep/drop of the V consecutive elements of vector `vec` (= first element index / V): one hash
+// of (seed, vec), then one 32-bit word per TWO elements, 16 bits each;
+// P(keep) = 1 - thresh16 / 65536.
+template <int V>
+__device__ __forceinline__ void keep_vector(uint64_t seed, int64_t vec, uint32_t thresh16, bool (&keep)[V]) {
+    const uint32_t lo = (uint32_t)vec, hi = (uint32_t)((uint64_t)vec >> 32);
+    const uint32_t base = mix32(lo ^ (uint32_t)seed) ^ mix32(hi + (uint32_t)(seed >> 32) + 0x9e3779b9u);
+#pragma unroll
+    for (int w = 0; w < V / 2; ++w) {
+        const uint32_t r = mix32(base + (uint32_t)(w + 1) * 0x9e3779b9u);
+        keep[2 * w] = (r & 0xffffu) >= thresh16;
+        keep[2 * w + 1] = (r >> 16) >= thresh16;
+    }
+}
+// Phi(v) = 0.5 (1 + erf(v / sqrt2)) and exp(-v^2/2): erf by Abramowitz & Stegun 7.1.26
+// (|error| <= 1.5e-7, below fp32 parity tolerance); the kernel is otherwise ALU-bound on erff.
+__device__ __forceinline__ float gelu_cdf(float v, float& e) {
+    const float ax = fabsf(v) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * ax);
+    e = __expf(-ax * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    return 0.5f + copysignf(0.5f - 0.5f * poly * e, v);
 }
 
 template <typename T, bool BWD>
@@ -41,15 +59,17 @@ __global__ void __launch_bounds__(256) gelu_dropout_kernel(const T* __restrict__
                 if (BWD) gv[t] = i + t < n ? dy[i + t] : from_f32<T>(0.f);
             }
         }
+        bool keep[V];
+        if (thresh != 0u) keep_vector<V>(seed, i / V, thresh, keep);
 #pragma unroll
         for (int t = 0; t < V; ++t) {
             const float v = to_f32(xv[t]);
-            const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
+            float e;
+            const float cdf = gelu_cdf(v, e);
             float r;
             if (!BWD) r = v * cdf;
-            else r = to_f32(gv[t]) * (cdf + v * 0.3989422804014327f * __expf(-0.5f * v * v));
-            const bool keep = thresh == 0u || keep_elem(seed, i + t, thresh);
-            ov[t] = from_f32<T>(keep ? r * inv_keep : 0.f);
+            else r = to_f32(gv[t]) * (cdf + v * 0.3989422804014327f * e);
+            ov[t] = from_f32<T>((thresh == 0u || keep[t]) ? r * inv_keep : 0.f);
         }
         if (i + V <= n) {
             uint4 raw;
@@ -64,7 +84,7 @@ __global__ void __launch_bounds__(256) gelu_dropout_kernel(const T* __restrict__
 template <typename T>
 static int gd_launch(const void* x, const void* dy, void* out, int64_t n, float p, uint64_t seed, bool bwd,
                      hipStream_t st) {
-    const uint32_t thresh = p <= 0.f ? 0u : (uint32_t)fmin(4294967295.0, (double)p * 4294967296.0);
+    const uint32_t thresh = p <= 0.f ? 0u : (uint32_t)fmin(65535.0, fmax(1.0, nearbyint((double)p * 65536.0)));   // 16-bit
     const float inv_keep = p <= 0.f ? 1.f : 1.f / (1.f - p);
     constexpr int V = 16 / (int)sizeof(T);
     int64_t blocks = (n / V + 255) / 256;

@@ -1,0 +1,102 @@
+// Assembling the kernel-order projection parameters of a triplet module for gfx950.
+//
+// The reference keeps lin_QKV_in / lin_EG_in / lin_QKV_out / lin_EG_out as four nn.Linear
+// (lib/tgt/layers/triplet.py:198-202) with head-MINOR output channels; the kernels consume ONE
+// fused projection whose rows are head-major (include/tgt_hip.h).  Instead of a dozen
+// gather / cat / cast launches per layer and step, one launch gathers the rows of up to 8 source
+// matrices (+ their bias vectors) into the fused matrix, casting on the way, and one launch
+// scatters the fused gradient back to per-parameter gradients.  Pure data movement (a few
+// hundred KB); the point is the launch count.
+#include "common.hpp"
+
+namespace tgt {
+
+template <typename S, typename D>
+__global__ void __launch_bounds__(128) fuse_rows_kernel(const tgt_fuse_rows_args a, bool scatter) {
+    const int r = blockIdx.x;
+    const int sid = a.row_src[r], sr = a.row_idx[r];
+    // gather: fused (type D) <- source (type S);  scatter: source (type S) <- fused (type D)
+    D* frow = reinterpret_cast<D*>(a.fused) + (int64_t)r * a.n_cols;
+    if (sid < 0) {
+        if (!scatter) {
+            for (int c = threadIdx.x; c < a.n_cols; c += blockDim.x) frow[c] = from_f32<D>(0.f);
+            if (a.fused_bias && threadIdx.x == 0) reinterpret_cast<D*>(a.fused_bias)[r] = from_f32<D>(0.f);
+        }
+        return;
+    }
+    S* srow = reinterpret_cast<S*>(a.src[sid]) + (int64_t)sr * a.n_cols;
+    if (!scatter) {
+        for (int c = threadIdx.x; c < a.n_cols; c += blockDim.x) frow[c] = from_f32<D>(to_f32(srow[c]));
+        if (a.fused_bias && threadIdx.x == 0)
+            reinterpret_cast<D*>(a.fused_bias)[r] = from_f32<D>(to_f32(reinterpret_cast<const S*>(a.src_bias[sid])[sr]));
+    } else {
+        for (int c = threadIdx.x; c < a.n_cols; c += blockDim.x) srow[c] = from_f32<S>(to_f32(frow[c]));
+        if (a.fused_bias && threadIdx.x == 0)
+            reinterpret_cast<S*>(a.src_bias[sid])[sr] = from_f32<S>(to_f32(reinterpret_cast<const D*>(a.fused_bias)[r]));
+    }
+}
+
+// dst[r][c] = src[r][idx[c]]  (lin_O's input columns in the kernel's [dir][h][d] order; the
+// gradient goes back through the same kernel with the inverse index)
+template <typename S, typename D>
+__global__ void __launch_bounds__(256) permute_cols_kernel(const S* src, const int32_t* idx, D* dst, int rows, int cols) {
+    const int64_t n = (int64_t)rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / cols), c = (int)(i % cols);
+        dst[i] = from_f32<D>(to_f32(src[(int64_t)r * cols + idx[c]]));
+    }
+}
+
+template <typename S>
+static int fuse_rows_d(const tgt_fuse_rows_args& a, bool scatter, hipStream_t st) {
+    switch (a.fused_dtype) {
+        case TGT_F32: hipLaunchKernelGGL((fuse_rows_kernel<S, float>), dim3(a.n_rows), dim3(128), 0, st, a, scatter); break;
+        case TGT_BF16: hipLaunchKernelGGL((fuse_rows_kernel<S, bf16_t>), dim3(a.n_rows), dim3(128), 0, st, a, scatter); break;
+        case TGT_F16: hipLaunchKernelGGL((fuse_rows_kernel<S, f16_t>), dim3(a.n_rows), dim3(128), 0, st, a, scatter); break;
+        default: return set_error(TGT_ERR_INVALID, "fuse_rows: bad fused dtype %d", a.fused_dtype);
+    }
+    return check_launch("fuse_rows_kernel");
+}
+
+int fuse_rows_run(const tgt_fuse_rows_args* a, bool scatter, hipStream_t st) {
+    if (!a) return set_error(TGT_ERR_INVALID, "fuse_rows: null args");
+    if (a->n_rows < 0 || a->n_cols <= 0 || a->n_src <= 0 || a->n_src > 8)
+        return set_error(TGT_ERR_INVALID, "fuse_rows: bad sizes rows=%d cols=%d sources=%d", a->n_rows, a->n_cols, a->n_src);
+    if (!a->row_src || !a->row_idx || !a->fused) return set_error(TGT_ERR_INVALID, "fuse_rows: null tensor");
+    for (int i = 0; i < a->n_src; ++i)
+        if (!a->src[i] || (a->fused_bias && !a->src_bias[i])) return set_error(TGT_ERR_INVALID, "fuse_rows: null source %d", i);
+    if (a->n_rows == 0) return TGT_OK;
+    switch (a->src_dtype) {
+        case TGT_F32: return fuse_rows_d<float>(*a, scatter, st);
+        case TGT_BF16: return fuse_rows_d<bf16_t>(*a, scatter, st);
+        case TGT_F16: return fuse_rows_d<f16_t>(*a, scatter, st);
+        default: return set_error(TGT_ERR_INVALID, "fuse_rows: bad source dtype %d", a->src_dtype);
+    }
+}
+
+template <typename S>
+static int permute_cols_d(const void* src, const int32_t* idx, void* dst, int dd, int rows, int cols, hipStream_t st) {
+    const int64_t n = (int64_t)rows * cols;
+    const unsigned grid = (unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+    const S* s = reinterpret_cast<const S*>(src);
+    switch (dd) {
+        case TGT_F32: hipLaunchKernelGGL((permute_cols_kernel<S, float>), dim3(grid), dim3(256), 0, st, s, idx, reinterpret_cast<float*>(dst), rows, cols); break;
+        case TGT_BF16: hipLaunchKernelGGL((permute_cols_kernel<S, bf16_t>), dim3(grid), dim3(256), 0, st, s, idx, reinterpret_cast<bf16_t*>(dst), rows, cols); break;
+        case TGT_F16: hipLaunchKernelGGL((permute_cols_kernel<S, f16_t>), dim3(grid), dim3(256), 0, st, s, idx, reinterpret_cast<f16_t*>(dst), rows, cols); break;
+        default: return set_error(TGT_ERR_INVALID, "permute_cols: bad dst dtype %d", dd);
+    }
+    return check_launch("permute_cols_kernel");
+}
+
+int permute_cols_run(const void* src, int sd, const int32_t* idx, void* dst, int dd, int rows, int cols, hipStream_t st) {
+    if (!src || !idx || !dst || rows < 0 || cols <= 0) return set_error(TGT_ERR_INVALID, "permute_cols: bad arguments");
+    if (rows == 0) return TGT_OK;
+    switch (sd) {
+        case TGT_F32: return permute_cols_d<float>(src, idx, dst, dd, rows, cols, st);
+        case TGT_BF16: return permute_cols_d<bf16_t>(src, idx, dst, dd, rows, cols, st);
+        case TGT_F16: return permute_cols_d<f16_t>(src, idx, dst, dd, rows, cols, st);
+        default: return set_error(TGT_ERR_INVALID, "permute_cols: bad src dtype %d", sd);
+    }
+}
+
+}  // namespace tgt

@@ -173,28 +173,86 @@ def sum_rows(x):
     return out
 
 
+class ParamTable:
+    """Which source parameter row feeds each row of a fused kernel-order projection
+    (tgt_fuse_rows_args.row_src / row_idx); device copies are made once per device."""
+
+    def __init__(self, row_src, row_idx, n_cols, n_src):
+        self.row_src = torch.as_tensor(row_src, dtype=torch.int32).contiguous()
+        self.row_idx = torch.as_tensor(row_idx, dtype=torch.int32).contiguous()
+        self.n_rows, self.n_cols, self.n_src = int(self.row_src.numel()), int(n_cols), int(n_src)
+        self._dev = {}
+
+    def on(self, device):
+        t = self._dev.get(device)
+        if t is None:
+            t = self._dev[device] = (self.row_src.to(device), self.row_idx.to(device))
+        return t
+
+
+def _fuse_args(table, ws, bs, fused_w, fused_b):
+    a = _lib.FuseRowsArgs()
+    a.n_rows, a.n_cols, a.n_src = table.n_rows, table.n_cols, table.n_src
+    a.src_dtype, a.fused_dtype = _DT[ws[0].dtype], _DT[fused_w.dtype]
+    rs, ri = table.on(fused_w.device)
+    a.row_src, a.row_idx = rs.data_ptr(), ri.data_ptr()
+    for i, (w, b) in enumerate(zip(ws, bs)):
+        assert w.is_contiguous() and b.is_contiguous() and w.dtype == ws[0].dtype and b.dtype == ws[0].dtype
+        a.src[i], a.src_bias[i] = w.data_ptr(), b.data_ptr()
+    a.fused, a.fused_bias = fused_w.data_ptr(), fused_b.data_ptr()
+    return a
+
+
+def _fuse_params(table, params, cd):
+    """(weight, bias) of the fused projection in dtype cd from the module's nn.Linear parameters
+    (w0, b0, w1, b1, ...) in ONE launch; reads the 16-bit shadows when the Trainer keeps them."""
+    _dev(*params)
+    srcs = [_as_dtype_view(p, cd) for p in params]
+    if any(t.dtype != srcs[0].dtype for t in srcs):
+        srcs = [p.detach() for p in params]
+    w = torch.empty(table.n_rows, table.n_cols, dtype=cd, device=params[0].device)
+    b = torch.empty(table.n_rows, dtype=cd, device=params[0].device)
+    a = _fuse_args(table, srcs[0::2], srcs[1::2], w, b)
+    _lib.check(_lib.lib().tgt_fuse_rows(C.byref(a), _stream()), 'tgt_fuse_rows')
+    return w, b
+
+
+def _unfuse_grads(table, params, dW, db):
+    """per-parameter gradients (dtype of each parameter) from the fused projection's fp32
+    gradients in ONE launch"""
+    grads = [torch.empty_like(p) for p in params]
+    dW, db = dW.contiguous(), db.to(dW.dtype).contiguous()
+    a = _fuse_args(table, grads[0::2], grads[1::2], dW, db)
+    _lib.check(_lib.lib().tgt_unfuse_rows(C.byref(a), _stream()), 'tgt_unfuse_rows')
+    return grads
+
+
 class _ProjectedTripletAttention(torch.autograd.Function):
     """fused projection GEMM + triplet attention core as ONE autograd node, so that the backward
     kernel can hand the projection its bias gradient (column sums of d_fused, accumulated while
-    the gradient rows are written) instead of a separate 0.84 GB reduction pass."""
+    the gradient rows are written) instead of a separate 0.84 GB reduction pass.
+    wb: the pre-fused (weight, bias), or -- with a ParamTable -- the module's nn.Linear
+    parameters (w0, b0, w1, b1, ...), fused/unfused here with one launch each way."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, mask3, L, cd):
+    def forward(ctx, x, mask3, L, cd, table, *wb):
         _dev(x, mask3)
         B, N = x.shape[0], x.shape[1]
+        weight, bias = wb if table is None else _fuse_params(table, wb, cd)
         x2, w, fused = _linear_forward(x, weight, bias, cd)
         out = torch.empty(B, N, N, 2 * L.C, dtype=cd, device=x.device)
         a = _tri_args(fused, mask3, out, L)
         _call('tgt_triplet_attention_fwd', _lib.lib().tgt_triplet_attention_fwd, a)
-        ctx.save_for_backward(x2, w, fused, mask3, out)
-        ctx.L = L
+        ctx.save_for_backward(x2, w, fused, mask3, out, *(wb if table is not None else ()))
+        ctx.L, ctx.table = L, table
         ctx.meta = (x.shape, x.dtype, weight.dtype, bias.dtype)
         return out
 
     @staticmethod
     def backward(ctx, d_out):
-        x2, w, fused, mask3, out = ctx.saved_tensors
-        L = ctx.L
+        x2, w, fused, mask3, out = ctx.saved_tensors[:5]
+        params = ctx.saved_tensors[5:]
+        L, table = ctx.L, ctx.table
         xs, xdt, wdt, bdt = ctx.meta
         d_out = d_out.contiguous()
         d_fused = torch.empty_like(fused)          # every used column is written by the kernel
@@ -203,20 +261,27 @@ class _ProjectedTripletAttention(torch.autograd.Function):
         colsum = _colsum_workspace(fused.shape[0], L.width, fused.device)
         a = _tri_args(fused, mask3, out, L, d_out, d_fused, colsum)
         _call('tgt_triplet_attention_bwd', _lib.lib().tgt_triplet_attention_bwd, a)
-        db = sum_rows(colsum).to(bdt) if ctx.needs_input_grad[2] else None
-        dx, dw, _ = _linear_backward(x2, w, d_fused.view(-1, L.width), xs, xdt, wdt, None,
-                                     ctx.needs_input_grad[0], ctx.needs_input_grad[1], False)
-        return dx, dw, db, None, None, None
+        need_p = any(ctx.needs_input_grad[5:])
+        db = sum_rows(colsum) if need_p else None
+        dx, dw, _ = _linear_backward(x2, w, d_fused.view(-1, L.width), xs, xdt, torch.float32, None,
+                                     ctx.needs_input_grad[0], need_p, False)
+        if not need_p:
+            return (dx, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 5)
+        if table is None:
+            return dx, None, None, None, None, dw.to(wdt), db.to(bdt)
+        return (dx, None, None, None, None, *_unfuse_grads(table, params, dw, db))
 
 
-def projected_triplet_attention(x, weight, bias, mask3, layout):
+def projected_triplet_attention(x, weight, bias, mask3, layout, table=None):
     """triplet_attention(linear(x, weight, bias), mask3, layout) with the bias gradient of the
     projection produced inside the backward kernel.  weight/bias: the fused (layout.width, C)
-    projection in kernel order (see TripletLayout)."""
-    if os.environ.get('TGT_TRI_COLSUM', '1') == '0':          # A/B knob: separate bias-gradient pass
+    projection in kernel order (see TripletLayout) -- or, with a ParamTable, `weight` is the
+    tuple of the module's nn.Linear parameters (w0, b0, w1, b1, ...) and bias is None."""
+    if os.environ.get('TGT_TRI_COLSUM', '1') == '0' and table is None:      # A/B knob: separate bias-gradient pass
         return triplet_attention(linear(x, weight, bias), mask3, layout)
     cd = torch.get_autocast_dtype('cuda') if (x.is_cuda and torch.is_autocast_enabled('cuda')) else x.dtype
-    return _ProjectedTripletAttention.apply(x, weight, bias, mask3, layout, cd)
+    wb = (weight, bias) if table is None else tuple(weight)
+    return _ProjectedTripletAttention.apply(x, mask3, layout, cd, table, *wb)
 
 
 # ---------------------------------------------------------------------------
@@ -704,6 +769,13 @@ def _as_dtype(p, cd):
     return p.to(cd)
 
 
+def _as_dtype_view(p, cd):
+    """the tensor to READ parameter p from when a kernel converts to cd itself: the 16-bit shadow
+    when it is there and matches, else the parameter"""
+    lp = getattr(p, '_lp', None)
+    return lp if (lp is not None and lp.dtype == cd and p.dtype != cd) else p.detach()
+
+
 def _linear_forward(x, weight, bias, cd):
     """(x2, w, y): the operands saved for the backward and y = x W^T + b in dtype cd"""
     xs = x.shape
@@ -766,6 +838,75 @@ class _Linear(torch.autograd.Function):
                                       ctx.needs_input_grad[0], ctx.needs_input_grad[1],
                                       bdt is not None and ctx.needs_input_grad[2])
         return dx, dw, db, None
+
+
+def _permute_cols(src, idx, dtype):
+    out = torch.empty(src.shape, dtype=dtype, device=src.device)
+    _lib.check(_lib.lib().tgt_permute_cols(_ptr(src), _DT[src.dtype], _ptr(idx), _ptr(out), _DT[dtype],
+                                           src.shape[0], src.shape[1], _stream()), 'tgt_permute_cols')
+    return out
+
+
+class _LinearPermutedCols(torch.autograd.Function):
+    """y = x W[:, idx]^T + b: the weight's input columns re-ordered (and cast) by one launch,
+    the weight gradient re-ordered back by one launch (lin_O of the triplet modules)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cd, idx, inv):
+        _dev(x, weight)
+        w = _permute_cols(_as_dtype_view(weight, cd).contiguous(), idx, cd)
+        x2, w, y = _linear_forward(x, w, bias, cd)
+        ctx.save_for_backward(x2, w, inv)
+        ctx.meta = (x.shape, x.dtype, weight.dtype, None if bias is None else bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, inv = ctx.saved_tensors
+        xs, xdt, wdt, bdt = ctx.meta
+        dx, dw, db = _linear_backward(x2, w, dy.reshape(-1, dy.shape[-1]), xs, xdt, torch.float32, bdt,
+                                      ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                      bdt is not None and ctx.needs_input_grad[2])
+        if dw is not None:
+            dw = _permute_cols(dw.contiguous(), inv, wdt)
+        return dx, dw, db, None, None, None
+
+
+def linear_permuted_cols(x, weight, bias, idx, inv):
+    """linear(x, weight[:, idx], bias); idx / inv: int32 device tensors (a permutation and its inverse)"""
+    cd = torch.get_autocast_dtype('cuda') if (x.is_cuda and torch.is_autocast_enabled('cuda')) else x.dtype
+    return _LinearPermutedCols.apply(x, weight, bias, cd, idx, inv)
+
+
+class _FusedLinear(torch.autograd.Function):
+    """y = x W^T + b where (W, b) are rows gathered from several nn.Linear (ParamTable): fuse,
+    GEMM / dgrad, wgrad, unfuse -- one launch each for the parameter plumbing."""
+
+    @staticmethod
+    def forward(ctx, x, cd, table, *params):
+        _dev(x)
+        weight, bias = _fuse_params(table, params, cd)
+        x2, w, y = _linear_forward(x, weight, bias, cd)
+        ctx.save_for_backward(x2, w, *params)
+        ctx.table, ctx.meta = table, (x.shape, x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors[:2]
+        params = ctx.saved_tensors[2:]
+        xs, xdt = ctx.meta
+        need_p = any(ctx.needs_input_grad[3:])
+        dx, dw, db = _linear_backward(x2, w, dy.reshape(-1, dy.shape[-1]), xs, xdt, torch.float32, torch.float32,
+                                      ctx.needs_input_grad[0], need_p, need_p)
+        grads = _unfuse_grads(ctx.table, params, dw, db) if need_p else (None,) * len(params)
+        return (dx, None, None, *grads)
+
+
+def fused_linear(x, table, params):
+    """linear(x, W, b) with (W, b) assembled from `params` = (w0, b0, w1, b1, ...) by `table`"""
+    cd = torch.get_autocast_dtype('cuda') if (x.is_cuda and torch.is_autocast_enabled('cuda')) else x.dtype
+    return _FusedLinear.apply(x, cd, table, *params)
 
 
 def linear(x, weight, bias=None):

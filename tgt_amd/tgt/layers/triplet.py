@@ -61,9 +61,23 @@ class _TripletBase(nn.Module):
 
     def _out_proj(self, va):
         """lin_O on the kernel's [dir][h][d] channel order (reference order is
-        d*2H + dir*H + h, triplet.py:248)."""
-        cols = self._index('va', lambda: layout.va_cols_head_major(self.edge_width, self.num_heads), va.device)
-        return ops.linear(va, ops.permute(self.lin_O.weight, *cols, dim=1), self.lin_O.bias)
+        d*2H + dir*H + h, triplet.py:248): the weight's input columns are re-ordered, one launch"""
+        key = ('va32', va.device)
+        if key not in self._idx:
+            perm, inv = self._index('va', lambda: layout.va_cols_head_major(self.edge_width, self.num_heads), va.device)
+            self._idx[key] = (perm.int(), inv.int())
+        return ops.linear_permuted_cols(va, self.lin_O.weight, self.lin_O.bias, *self._idx[key])
+
+    def _param_table(self, blocks, width):
+        """ops.ParamTable of a fused projection: blocks = [(source id, row index tensor)], in
+        fused-row order; rows past the blocks (alignment padding) are zero rows"""
+        src = torch.cat([torch.full((len(idx),), sid, dtype=torch.int32) for sid, idx in blocks])
+        row = torch.cat([idx.to(torch.int32) for _, idx in blocks])
+        pad = width - src.numel()
+        if pad:
+            src = torch.cat([src, torch.full((pad,), -1, dtype=torch.int32)])
+            row = torch.cat([row, torch.zeros(pad, dtype=torch.int32)])
+        return ops.ParamTable(src, row, self.edge_width, 1 + max(sid for sid, _ in blocks))
 
 
 class TripletAttention(_TripletBase):
@@ -87,21 +101,18 @@ class TripletAttention(_TripletBase):
         self.lin_O = Linear(edge_width * 2, edge_width)
         self._bias_name = bias_name
         self._layout = ops.TripletLayout(edge_width, num_heads, gated=self.gated, biased=self.biased)
-
-    def _fused_projection(self, device):
-        rows = self._index('qkv', lambda: layout.qkv_rows_head_major(self.edge_width, self.num_heads), device)
-        ws = [ops.permute(self.lin_QKV_in.weight, *rows), ops.permute(self.lin_QKV_out.weight, *rows)]
-        bs = [ops.permute(self.lin_QKV_in.bias, *rows), ops.permute(self.lin_QKV_out.bias, *rows)]
+        # fused projection rows: [QKV_in (head-major) | QKV_out (head-major) | E(G)_in | E(G)_out | pad]
+        rows = layout.qkv_rows_head_major(edge_width, num_heads)
+        blocks = [(0, rows), (1, rows)]
         if self.biased:
-            for which in ('_in', '_out'):
-                lin = getattr(self, self._bias_name + which)
-                ws.append(lin.weight)
-                bs.append(lin.bias)
-        pad = self._layout.width - self._layout.used
-        if pad:
-            ws.append(ws[0].new_zeros(pad, self.edge_width))
-            bs.append(bs[0].new_zeros(pad))
-        return torch.cat(ws, 0), torch.cat(bs, 0)
+            blocks += [(2, torch.arange(nb)), (3, torch.arange(nb))]
+        self._table = self._param_table(blocks, self._layout.width)
+
+    def _projection_params(self):
+        lins = [self.lin_QKV_in, self.lin_QKV_out]
+        if self.biased:
+            lins += [getattr(self, self._bias_name + '_in'), getattr(self, self._bias_name + '_out')]
+        return tuple(t for lin in lins for t in (lin.weight, lin.bias))
 
     def forward(self, e, mask):
         return self.forward_normed(self.tri_ln_e(e), mask)
@@ -110,8 +121,8 @@ class TripletAttention(_TripletBase):
         """the block after tri_ln_e (TGT_Layer fuses that LayerNorm with the residual add before it)"""
         _no_attention_dropout(self)
         B, N = x.shape[0], x.shape[1]
-        w, b = self._fused_projection(x.device)
-        va = ops.projected_triplet_attention(x, w, b, ops.as_mask3(mask, B, N), self._layout)
+        va = ops.projected_triplet_attention(x, self._projection_params(), None, ops.as_mask3(mask, B, N),
+                                             self._layout, table=self._table)
         return self._out_proj(va)
 
 
@@ -142,6 +153,9 @@ class TripletAggregate(_TripletBase):
             self.lin_E = Linear(edge_width, num_heads * 2)
         self.lin_O = Linear(edge_width * 2, edge_width)
         self._layout = ops.AggregateLayout(edge_width, num_heads, gated=self.gated)
+        # fused projection rows: [V_in | V_out (head-major) | E(G) | pad]
+        self._table = self._param_table([(0, layout.qkv_rows_head_major(edge_width, num_heads, parts=2)),
+                                         (1, torch.arange(num_heads * (4 if self.gated else 2)))], self._layout.width)
 
     def forward(self, e, mask):
         return self.forward_normed(self.tri_ln_e(e), mask)
@@ -149,14 +163,8 @@ class TripletAggregate(_TripletBase):
     def forward_normed(self, x, mask):
         _no_attention_dropout(self)
         B, N = x.shape[0], x.shape[1]
-        rows = self._index('v', lambda: layout.qkv_rows_head_major(self.edge_width, self.num_heads, parts=2), x.device)
         lin_b = self.lin_EG if self.gated else self.lin_E
-        ws, bs = [ops.permute(self.lin_V.weight, *rows), lin_b.weight], [ops.permute(self.lin_V.bias, *rows), lin_b.bias]
-        pad = self._layout.width - self._layout.used
-        if pad:
-            ws.append(ws[0].new_zeros(pad, self.edge_width))
-            bs.append(bs[0].new_zeros(pad))
-        fused = ops.linear(x, torch.cat(ws, 0), torch.cat(bs, 0))
+        fused = ops.fused_linear(x, self._table, (self.lin_V.weight, self.lin_V.bias, lin_b.weight, lin_b.bias))
         va = ops.triplet_aggregate(fused, ops.as_mask3(mask, B, N), self._layout)
         return self._out_proj(va)
 
