@@ -207,7 +207,10 @@ int tgt_layer_norm_fwd(const void* x, int32_t x_dtype, const float* gamma, const
  *   y = LayerNorm(s) -> y (y_dtype);  mean/rstd saved.
  * Backward: d_total = ds_in (gradient reaching s from the residual path; may be NULL) + LN_bwd(dy);
  *   d_res = d_total (d_dtype);  d_x = d_total * scale (written only when scale != NULL, else d_x may be NULL
- *   and d_res doubles as d_x);  dgamma/dbeta as tgt_layer_norm_bwd. */
+ *   and d_res doubles as d_x);  dgamma/dbeta as tgt_layer_norm_bwd.
+ *   d_x_colsum (optional, float32 C, must be dbeta + C: one 2C buffer): column sums of d_x, i.e. the
+ *   bias gradient of the Linear that produced x, for free in the same pass; `partial` then needs
+ *   tgt_layer_norm_parts()*3*C floats instead of *2*C. */
 int tgt_add_layer_norm_fwd(const void* x, int32_t x_dtype, const void* res, int32_t res_dtype, const float* scale,
                            int64_t rows_per_sample, void* s_out, const float* gamma, const float* beta,
                            void* y, int32_t y_dtype, float* mean, float* rstd, int64_t rows, int32_t C,
@@ -215,7 +218,8 @@ int tgt_add_layer_norm_fwd(const void* x, int32_t x_dtype, const void* res, int3
 int tgt_add_layer_norm_bwd(const void* dy, int32_t dy_dtype, const void* s, int32_t s_dtype, const void* ds_in,
                            int32_t ds_dtype, const float* scale, int64_t rows_per_sample, const float* gamma,
                            const float* mean, const float* rstd, void* d_res, void* d_x, int32_t d_dtype,
-                           float* dgamma, float* dbeta, float* partial, int64_t rows, int32_t C, void* stream);
+                           float* dgamma, float* dbeta, float* d_x_colsum, float* partial, int64_t rows, int32_t C,
+                           void* stream);
 
 /* Fused GELU (erf form) + dropout: the middle of the FFN block (reference
  * lib/tgt/layers/layers.py:157-158).  y = keep(i) ? gelu(x)/(1-p) : 0, where keep(i) is a

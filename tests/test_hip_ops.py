@@ -318,7 +318,10 @@ def test_drop_path_add():
 
 
 @pytest.mark.parametrize('shape,dtype', [((8192, 256), torch.bfloat16), ((5000, 1600), torch.bfloat16),
-                                         ((4096, 64), torch.float32), ((6000, 768), torch.float16)])
+                                         ((4096, 64), torch.float32), ((6000, 768), torch.float16),
+                                         ((8192, 2304), torch.bfloat16), ((70001, 1600), torch.bfloat16),
+                                         ((1500, 3072), torch.float32), ((1027, 8), torch.float32),
+                                         ((300, 24), torch.bfloat16)])
 def test_column_sum(shape, dtype):
     from tgt_amd import ops
     rng = np.random.default_rng(shape[1])
@@ -410,6 +413,53 @@ def test_add_layer_norm(dtype, with_scale):
     assert rel(s, s_ref) < tol and rel(y, y_ref) < 2 * tol
     assert rel(rg.grad, r64.grad) < 2 * tol and rel(xg.grad, x64.grad) < 2 * tol
     assert rel(wg.grad, w64.grad) < 2 * tol and rel(bg.grad, b64.grad) < 2 * tol
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('with_scale', [False, True])
+@pytest.mark.parametrize('permuted', [False, True])
+def test_linear_bias_gradient_from_layer_norm_backward(dtype, with_scale, permuted):
+    """Linear -> (residual add + LayerNorm): the LayerNorm backward accumulates the column sums of
+    the gradient it writes for the Linear's output and the Linear takes them as its bias
+    gradient (no separate reduction pass).  Same numbers as the separate reduction, and the
+    hand-over must actually happen."""
+    from tgt_amd import ops
+    rng = np.random.default_rng(23)
+    B, N, K, C = 4, 9, 64, 256
+    inp, res = rnd(rng, B, N, N, K).to(dtype).cuda(), rnd(rng, B, N, N, C).to(dtype).cuda()
+    W, b = (rnd(rng, C, K) * K ** -0.5).float().cuda(), (0.1 * rnd(rng, C)).float().cuda()
+    g, beta = (1 + 0.2 * rnd(rng, C)).float().cuda(), (0.1 * rnd(rng, C)).float().cuda()
+    ds, dy = rnd(rng, B, N, N, C).to(dtype).cuda(), rnd(rng, B, N, N, C).to(dtype).cuda()
+    scale = torch.tensor([0.0, 1.25, 1.25, 0.0]).cuda() if with_scale else None
+    perm = torch.randperm(K, generator=torch.Generator().manual_seed(1))
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(K)
+    idx = (perm.int().cuda(), inv.int().cuda())
+
+    def run(handoff):
+        Wp, bp = W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        lin = ops.linear_permuted_cols(inp, Wp, bp, *idx) if permuted else ops.linear(inp, Wp, bp)
+        lin.retain_grad()
+        s, y = ops.add_layer_norm(lin, res, scale, g, beta, 1e-5, out_dtype=dtype)
+        before = list(ops._colsum_handoffs)
+        if not handoff:
+            real, ops._hand_colsum = ops._hand_colsum, lambda *a: None
+        try:
+            ((s.float() * ds.float()).sum() + (y.float() * dy.float()).sum()).backward()
+        finally:
+            if not handoff:
+                ops._hand_colsum = real
+        used = ops._colsum_handoffs[1] - before[1]
+        return Wp.grad, bp.grad, lin.grad, used
+
+    w0, b0, d0, used0 = run(False)
+    w1, b1, d1, used1 = run(True)
+    assert used0 == 0 and used1 == 1
+    assert torch.equal(w0, w1) and torch.equal(d0, d1)
+    scale_ = float(d0.double().abs().sum((0, 1, 2)).max()) + 1e-30
+    assert float((b1.double() - b0.double()).abs().max()) / scale_ < (1e-6 if dtype == torch.float32 else 4e-3)
+    want = d0.double().sum((0, 1, 2))
+    assert float((b1.double() - want).abs().max()) / scale_ < (1e-6 if dtype == torch.float32 else 4e-3)
 
 
 @pytest.mark.parametrize('N', [1, 2])

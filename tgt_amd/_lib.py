@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtgt_hip.so')
 CSRC = os.path.join(_HERE, 'csrc')
 SOURCES = ['capi.hip', 'params.hip', 'triplet_attention.hip', 'triplet_aggregate.hip', 'node_attention.hip', 'layernorm.hip', 'triangular_update.hip', 'elementwise.hip']
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 TGT_F32, TGT_BF16, TGT_F16 = 0, 1, 2
 TRI_BIASED, TRI_GATED, TRI_MASK_OUT = 1, 2, 4
@@ -80,7 +80,7 @@ SYMBOLS = {
     'tgt_gelu_dropout_fwd': (C.c_int, [_vp, _vp, _i64, _i32, _f32, C.c_uint64, _vp]),
     'tgt_gelu_dropout_bwd': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, C.c_uint64, _vp]),
     'tgt_add_layer_norm_fwd': (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _f32, _vp]),
-    'tgt_add_layer_norm_bwd': (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp]),
+    'tgt_add_layer_norm_bwd': (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     'tgt_layer_norm_parts': (C.c_int, []),
     'tgt_colsum': (C.c_int, [_vp, _i32, _i64, _i32, _vp, _vp, _vp]),
     'tgt_sum_rows': (C.c_int, [_vp, _i32, _i32, _vp, _vp]),

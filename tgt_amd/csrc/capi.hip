@@ -32,7 +32,7 @@ int add_layer_norm_fwd_run(const void* x, int x_dtype, const void* res, int res_
 int add_layer_norm_bwd_run(const void* dy, int dy_dtype, const void* s, int s_dtype, const void* ds_in, int ds_dtype,
                            const float* scale, int64_t rows_per_sample, const float* gamma, const float* mean,
                            const float* rstd, void* d_res, void* d_x, int d_dtype, float* dgamma, float* dbeta,
-                           float* partial, int64_t rows, int C, hipStream_t st);
+                           float* d_x_colsum, float* partial, int64_t rows, int C, hipStream_t st);
 int gelu_dropout_run(const void* x, const void* dy, void* out, int64_t n, int dtype, float p, uint64_t seed, bool bwd,
                      hipStream_t st);
 int triangular_update_run(const void* e4, const void* v4, const float* mask, void* out, const void* d_out, void* d_e4,
@@ -109,7 +109,7 @@ using namespace tgt;
 extern "C" {
 
 const char* tgt_last_error(void) { return g_err; }
-int tgt_abi_version(void) { return 9; }
+int tgt_abi_version(void) { return 10; }
 
 int tgt_triplet_attention_fwd(const tgt_triplet_attention_args* a, void* stream) {
     return triplet_attention_run(a, false, reinterpret_cast<hipStream_t>(stream));
@@ -156,9 +156,9 @@ int tgt_add_layer_norm_fwd(const void* x, int32_t x_dtype, const void* res, int3
 int tgt_add_layer_norm_bwd(const void* dy, int32_t dy_dtype, const void* s, int32_t s_dtype, const void* ds_in,
                            int32_t ds_dtype, const float* scale, int64_t rows_per_sample, const float* gamma,
                            const float* mean, const float* rstd, void* d_res, void* d_x, int32_t d_dtype, float* dgamma,
-                           float* dbeta, float* partial, int64_t rows, int32_t C, void* stream) {
+                           float* dbeta, float* d_x_colsum, float* partial, int64_t rows, int32_t C, void* stream) {
     return add_layer_norm_bwd_run(dy, dy_dtype, s, s_dtype, ds_in, ds_dtype, scale, rows_per_sample, gamma, mean, rstd,
-                                  d_res, d_x, d_dtype, dgamma, dbeta, partial, rows, C,
+                                  d_res, d_x, d_dtype, dgamma, dbeta, d_x_colsum, partial, rows, C,
                                   reinterpret_cast<hipStream_t>(stream));
 }
 int tgt_layer_norm_parts(void) { return layer_norm_parts(); }

@@ -83,6 +83,7 @@ struct LnArgs {
     const void* res; int res_dtype; void* s_out;
     const float* scale; int64_t rows_per_sample;
     const void* ds_in; int ds_dtype; void* dx2;
+    float* x_colsum;     // backward, optional: column sums of the x-branch gradient
 };
 
 template <int LPR, int VPL>
@@ -161,15 +162,17 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const LnArgs a) {
     }
 }
 
-template <int LPR, int VPL>
+// CS: also accumulate the column sums of the x-branch gradient (d_total * scale) -- the bias
+// gradient of the Linear that produced x -- as a third column plane of the partial buffer.
+template <int LPR, int VPL, bool CS>
 __global__ void __launch_bounds__(256) ln_bwd_kernel(const LnArgs a) {
-    constexpr int RPW = 64 / LPR;
+    constexpr int RPW = 64 / LPR, NP = CS ? 3 : 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* red = reinterpret_cast<float*>(smem);        // [4 waves][RPW][2][VPL*LPR*8]
+    float* red = reinterpret_cast<float*>(smem);        // [4 waves][RPW][NP][VPL*LPR*8]
     const int lane = threadIdx.x & 63, sub = lane / LPR, gl = lane % LPR, w = threadIdx.x >> 6;
     const int64_t wave = (int64_t)blockIdx.x * 4 + w, nwaves = (int64_t)gridDim.x * 4;
     const float invC = 1.f / a.C;
-    float gam[VPL][8], dgam[VPL][8], dbet[VPL][8];
+    float gam[VPL][8], dgam[VPL][8], dbet[VPL][8], dxs[CS ? VPL : 1][8];
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
         const int col = (v * LPR + gl) * 8;
@@ -177,6 +180,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const LnArgs a) {
         for (int i = 0; i < 8; ++i) {
             gam[v][i] = col < a.C ? a.gamma[col + i] : 0.f;
             dgam[v][i] = dbet[v][i] = 0.f;
+            if constexpr (CS) dxs[v][i] = 0.f;
         }
     }
     for (int64_t row = wave * RPW + sub; row < a.rows; row += nwaves * RPW) {
@@ -225,6 +229,10 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const LnArgs a) {
                     for (int i = 0; i < 8; ++i) dx[i] *= sc;
                     ln_store8(a.dx2, a.dx_dtype, row * a.C + col, dx);
                 }
+                if constexpr (CS) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) dxs[v][i] += dx[i];
+                }
             }
         }
     }
@@ -235,15 +243,16 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const LnArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int col = (v * LPR + gl) * 8 + i;
-            red[((w * RPW + sub) * 2 + 0) * CW + col] = dgam[v][i];
-            red[((w * RPW + sub) * 2 + 1) * CW + col] = dbet[v][i];
+            red[((w * RPW + sub) * NP + 0) * CW + col] = dgam[v][i];
+            red[((w * RPW + sub) * NP + 1) * CW + col] = dbet[v][i];
+            if constexpr (CS) red[((w * RPW + sub) * NP + 2) * CW + col] = dxs[v][i];
         }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < 2 * a.C; idx += 256) {
+    for (int idx = threadIdx.x; idx < NP * a.C; idx += 256) {
         const int which = idx / a.C, col = idx % a.C;
         float s = 0.f;
-        for (int gidx = 0; gidx < 4 * RPW; ++gidx) s += red[(gidx * 2 + which) * CW + col];
-        a.partial[(int64_t)blockIdx.x * 2 * a.C + idx] = s;
+        for (int gidx = 0; gidx < 4 * RPW; ++gidx) s += red[(gidx * NP + which) * CW + col];
+        a.partial[(int64_t)blockIdx.x * NP * a.C + idx] = s;
     }
 }
 
@@ -327,10 +336,13 @@ static int ln_launch(const LnArgs& a, bool bwd, float* dgamma, float* dbeta, hip
         return check_launch("ln_fwd_kernel");
     }
     const int parts = kLnParts;          // fixed grid: the partial buffer has exactly kLnParts rows
-    const size_t lds = (size_t)4 * RPW * 2 * VPL * LPR * 8 * sizeof(float);
-    hipLaunchKernelGGL((ln_bwd_kernel<LPR, VPL>), dim3(parts), dim3(256), lds, st, a);
+    const bool cs = a.x_colsum != nullptr;     // then dbeta and x_colsum are ONE buffer [dbeta | x_colsum] (checked by the caller)
+    const int np = cs ? 3 : 2;
+    const size_t lds = (size_t)4 * RPW * np * VPL * LPR * 8 * sizeof(float);
+    if (cs) hipLaunchKernelGGL((ln_bwd_kernel<LPR, VPL, true>), dim3(parts), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((ln_bwd_kernel<LPR, VPL, false>), dim3(parts), dim3(256), lds, st, a);
     if (int e = check_launch("ln_bwd_kernel")) return e;
-    hipLaunchKernelGGL(partial_sum_kernel, dim3((2 * a.C + 7) / 8), dim3(256), 0, st, a.partial, parts, 2 * a.C, a.C,
+    hipLaunchKernelGGL(partial_sum_kernel, dim3((np * a.C + 7) / 8), dim3(256), 0, st, a.partial, parts, np * a.C, a.C,
                        dgamma, dbeta);
     return check_launch("partial_sum_kernel");
 }
@@ -393,18 +405,21 @@ int add_layer_norm_fwd_run(const void* x, int x_dtype, const void* res, int res_
 int add_layer_norm_bwd_run(const void* dy, int dy_dtype, const void* s, int s_dtype, const void* ds_in, int ds_dtype,
                            const float* scale, int64_t rows_per_sample, const float* gamma, const float* mean,
                            const float* rstd, void* d_res, void* d_x, int d_dtype, float* dgamma, float* dbeta,
-                           float* partial, int64_t rows, int C, hipStream_t st) {
+                           float* d_x_colsum, float* partial, int64_t rows, int C, hipStream_t st) {
     if (!dy || !s || !gamma || !mean || !rstd || !d_res || !dgamma || !dbeta || !partial || rows < 0)
         return set_error(TGT_ERR_INVALID, "add_layer_norm bwd: null tensor");
     if (bad_dtype(s_dtype) || bad_dtype(dy_dtype) || bad_dtype(d_dtype) || (ds_in && bad_dtype(ds_dtype)))
         return set_error(TGT_ERR_INVALID, "add_layer_norm bwd: bad dtype");
     if (scale && (rows_per_sample <= 0 || !d_x)) return set_error(TGT_ERR_INVALID, "add_layer_norm bwd: scale needs d_x and rows_per_sample");
+    if (d_x_colsum && d_x_colsum != dbeta + C)
+        return set_error(TGT_ERR_INVALID, "add_layer_norm bwd: d_x_colsum must directly follow dbeta (one 2C buffer)");
     if (((uintptr_t)s | (uintptr_t)dy | (uintptr_t)d_res | (uintptr_t)d_x | (uintptr_t)ds_in) % 16)
         return set_error(TGT_ERR_INVALID, "add_layer_norm bwd: tensors must be 16-byte aligned");
     LnArgs a = {};
     a.x = s; a.dy = dy; a.dx = d_res; a.gamma = gamma; a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd);
     a.partial = partial; a.rows = rows; a.C = C; a.x_dtype = s_dtype; a.dy_dtype = dy_dtype; a.dx_dtype = d_dtype;
     a.ds_in = ds_in; a.ds_dtype = ds_dtype; a.dx2 = d_x; a.scale = scale; a.rows_per_sample = rows_per_sample;
+    a.x_colsum = d_x_colsum;
     return ln_dispatch(a, true, dgamma, dbeta, st);
 }
 
@@ -414,9 +429,11 @@ template <int LPR, int VPL>
 static int colsum_launch(const void* x, int dt, int64_t rows, int C, float* out, float* partial, hipStream_t st) {
     constexpr int RPW = 64 / LPR;
     const size_t lds = (size_t)4 * RPW * VPL * LPR * 8 * sizeof(float);
-    hipLaunchKernelGGL((colsum_kernel<LPR, VPL>), dim3(kLnParts), dim3(256), lds, st, x, dt, rows, C, partial);
+    int64_t parts = (rows + 4 * RPW - 1) / (4 * RPW);        // node-sized inputs: fewer, still full, blocks
+    parts = parts < 1 ? 1 : (parts > kLnParts ? kLnParts : parts);
+    hipLaunchKernelGGL((colsum_kernel<LPR, VPL>), dim3((unsigned)parts), dim3(256), lds, st, x, dt, rows, C, partial);
     if (int e = check_launch("colsum_kernel")) return e;
-    hipLaunchKernelGGL(partial_sum_kernel, dim3((C + 7) / 8), dim3(256), 0, st, partial, kLnParts, C, C, out, out);
+    hipLaunchKernelGGL(partial_sum_kernel, dim3((C + 7) / 8), dim3(256), 0, st, partial, (int)parts, C, C, out, out);
     return check_launch("partial_sum_kernel");
 }
 
@@ -429,7 +446,7 @@ int sum_rows_run(const float* x, int rows, int C, float* out, hipStream_t st) {
 int colsum_run(const void* x, int x_dtype, int64_t rows, int C, float* out, float* partial, hipStream_t st) {
     if (!x || !out || !partial || rows < 0) return set_error(TGT_ERR_INVALID, "colsum: null tensor");
     if (bad_dtype(x_dtype)) return set_error(TGT_ERR_INVALID, "colsum: bad dtype");
-    if (C % 8 || C <= 0 || C > 2048) return set_error(TGT_ERR_UNSUPPORTED, "colsum: C=%d must be a multiple of 8, <= 2048", C);
+    if (C % 8 || C <= 0 || C > 4096) return set_error(TGT_ERR_UNSUPPORTED, "colsum: C=%d must be a multiple of 8, <= 4096", C);
     if ((uintptr_t)x % 16) return set_error(TGT_ERR_INVALID, "colsum: x must be 16-byte aligned");
     const int v8 = C / 8;
     if (v8 <= 4) return colsum_launch<4, 1>(x, x_dtype, rows, C, out, partial, st);
@@ -438,7 +455,8 @@ int colsum_run(const void* x, int x_dtype, int64_t rows, int C, float* out, floa
     if (v8 <= 32) return colsum_launch<32, 1>(x, x_dtype, rows, C, out, partial, st);
     if (v8 <= 64) return colsum_launch<64, 1>(x, x_dtype, rows, C, out, partial, st);
     if (v8 <= 128) return colsum_launch<64, 2>(x, x_dtype, rows, C, out, partial, st);
-    return colsum_launch<64, 4>(x, x_dtype, rows, C, out, partial, st);
+    if (v8 <= 256) return colsum_launch<64, 4>(x, x_dtype, rows, C, out, partial, st);
+    return colsum_launch<64, 8>(x, x_dtype, rows, C, out, partial, st);
 }
 
 }  // namespace tgt

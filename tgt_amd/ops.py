@@ -735,9 +735,9 @@ def multi_hot_embed(idx, weight, padding_idx=None, out_dtype=None):
 # ---------------------------------------------------------------------------
 def column_sum(x2):
     """float32 column sums of a contiguous (rows, C) tensor (bias gradients): HIP kernel when the
-    shape qualifies (device tensor, C a multiple of 8, <= 2048), else the library reduction."""
+    shape qualifies (device tensor, >= 1024 rows, C a multiple of 8, <= 4096), else the library reduction."""
     rows, C_ = x2.shape
-    if not (x2.is_cuda and x2.is_contiguous() and C_ % 8 == 0 and C_ <= 2048 and x2.dtype in _DT and rows >= 65536):
+    if not (x2.is_cuda and x2.is_contiguous() and C_ % 8 == 0 and C_ <= 4096 and x2.dtype in _DT and rows >= 1024):
         return x2.sum(0, dtype=torch.float32)
     L = _lib.lib()
     out = torch.empty(C_, dtype=torch.float32, device=x2.device)
@@ -746,6 +746,27 @@ def column_sum(x2):
     _lib.check(L.tgt_colsum(_ptr(x2), _DT[x2.dtype], rows, C_, _ptr(out), _ptr(partial), _stream()), 'tgt_colsum')
     _prof_end('tgt_colsum', s, e)
     return out
+
+
+# A kernel that writes a gradient tensor can accumulate its column sums on the way; the Linear
+# whose output that gradient belongs to needs exactly those as its bias gradient.  The sums ride
+# on the gradient tensor object (autograd hands the same object to the next node) together with
+# the tensor's version counter: any in-place change (e.g. autograd accumulating a second
+# gradient into it) or a new tensor object silently falls back to the separate reduction.
+_colsum_handoffs = [0, 0]            # [offered, used]  (tests / diagnostics)
+
+
+def _hand_colsum(grad, colsum):
+    grad._tgt_colsum = (colsum, grad._version)
+    _colsum_handoffs[0] += 1
+
+
+def _take_colsum(grad, C_):
+    tag = getattr(grad, '_tgt_colsum', None)
+    if tag is None or tag[1] != grad._version or tag[0].numel() != C_ or grad.shape[-1] != C_:
+        return None
+    _colsum_handoffs[1] += 1
+    return tag[0]
 
 
 def _wgrad_chunks(M, out_in=0):
@@ -834,9 +855,12 @@ class _Linear(torch.autograd.Function):
     def backward(ctx, dy):
         x2, w = ctx.saved_tensors
         xs, xdt, wdt, bdt = ctx.meta
+        need_db = bdt is not None and ctx.needs_input_grad[2]
+        cs = _take_colsum(dy, dy.shape[-1]) if need_db else None
         dx, dw, db = _linear_backward(x2, w, dy.reshape(-1, dy.shape[-1]), xs, xdt, wdt, bdt,
-                                      ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                      bdt is not None and ctx.needs_input_grad[2])
+                                      ctx.needs_input_grad[0], ctx.needs_input_grad[1], need_db and cs is None)
+        if cs is not None:
+            db = cs.to(bdt)
         return dx, dw, db, None
 
 
@@ -864,9 +888,12 @@ class _LinearPermutedCols(torch.autograd.Function):
     def backward(ctx, dy):
         x2, w, inv = ctx.saved_tensors
         xs, xdt, wdt, bdt = ctx.meta
+        need_db = bdt is not None and ctx.needs_input_grad[2]
+        cs = _take_colsum(dy, dy.shape[-1]) if need_db else None
         dx, dw, db = _linear_backward(x2, w, dy.reshape(-1, dy.shape[-1]), xs, xdt, torch.float32, bdt,
-                                      ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                      bdt is not None and ctx.needs_input_grad[2])
+                                      ctx.needs_input_grad[0], ctx.needs_input_grad[1], need_db and cs is None)
+        if cs is not None:
+            db = cs.to(bdt)
         if dw is not None:
             dw = _permute_cols(dw.contiguous(), inv, wdt)
         return dx, dw, db, None, None, None
@@ -957,17 +984,22 @@ class _AddLayerNorm(torch.autograd.Function):
         ds = None if ds is None else ds.contiguous()
         d_res = torch.empty_like(s)
         d_x = torch.empty_like(s) if scale is not None else None
-        dgb = (torch.empty(C_, dtype=torch.float32, device=s.device), torch.empty(C_, dtype=torch.float32, device=s.device))
-        partial = torch.empty(L.tgt_layer_norm_parts() * 2 * C_, dtype=torch.float32, device=s.device)
+        # [dbeta | column sums of d_x]: the second half is the bias gradient of the Linear that
+        # produced x (lin_O / lin_W2 / lin_O_e), handed over on the gradient tensor (see _hand_colsum)
+        dg = torch.empty(C_, dtype=torch.float32, device=s.device)
+        db_cs = torch.empty(2 * C_, dtype=torch.float32, device=s.device)
+        partial = torch.empty(L.tgt_layer_norm_parts() * 3 * C_, dtype=torch.float32, device=s.device)
         p0, p1 = _prof_begin()
         _lib.check(L.tgt_add_layer_norm_bwd(_ptr(dy), _DT[dy.dtype], _ptr(s), _DT[s.dtype], _ptr(ds),
                                             0 if ds is None else _DT[ds.dtype], _ptr(scale), rps, _ptr(w), _ptr(mean),
-                                            _ptr(rstd), _ptr(d_res), _ptr(d_x), _DT[s.dtype], _ptr(dgb[0]), _ptr(dgb[1]),
-                                            _ptr(partial), rows, C_, _stream()), 'tgt_add_layer_norm_bwd')
+                                            _ptr(rstd), _ptr(d_res), _ptr(d_x), _DT[s.dtype], _ptr(dg), _ptr(db_cs),
+                                            db_cs.data_ptr() + 4 * C_, _ptr(partial), rows, C_, _stream()),
+                   'tgt_add_layer_norm_bwd')
         _prof_end('tgt_add_layer_norm_bwd', p0, p1)
         if d_x is None:
             d_x = d_res
-        return d_x, (d_res if rdt == d_res.dtype else d_res.to(rdt)), None, dgb[0].to(wdt), dgb[1].to(wdt), None, None
+        _hand_colsum(d_x, db_cs[C_:])
+        return d_x, (d_res if rdt == d_res.dtype else d_res.to(rdt)), None, dg.to(wdt), db_cs[:C_].to(wdt), None, None
 
 
 _side_streams = {}
