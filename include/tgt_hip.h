@@ -234,6 +234,21 @@ int tgt_gelu_dropout_bwd(const void* x, const void* dy, void* dx, int64_t n, int
  * lib/tgt/layers/triplet.py:198-203).  partial: tgt_layer_norm_parts()*C floats of scratch. */
 int tgt_colsum(const void* x, int32_t x_dtype, int64_t rows, int32_t C, float* out, float* partial, void* stream);
 
+/* Triplet attention forward with the Q/K/V projection fused in: the workgroup that walks node j
+ * projects the edge rows it needs on the matrix cores (reference lib/tgt/layers/triplet.py:210-211
+ * and :229-230, `lin_QKV_in/out(e_ln)`) and feeds the attention core from registers.
+ *   x    : (B,N,N,C) layer-normed edge rows, dtype a->dtype, contiguous
+ *   w    : (>= 6*H*D, C) row-major weight whose ROW index is the output channel of a->qkv
+ *          (rows q_off/k_off/v_off[dir] + h*D + d), bias: same indexing
+ *   a    : as tgt_triplet_attention_fwd, but a->qkv[dir] is an OUTPUT here (the projected rows, for
+ *          the backward kernel); a->eg (E/G third arm) is still an input.
+ * Supported: N <= 32, D = 16, H % 8 == 0, bf16/fp16, C in {64,128,256}
+ * (tgt_triplet_attention_proj_supported() tells; otherwise project with a GEMM and call
+ * tgt_triplet_attention_fwd). */
+int tgt_triplet_attention_proj_supported(const tgt_triplet_attention_args* a, int32_t C);
+int tgt_triplet_attention_proj_fwd(const tgt_triplet_attention_args* a, const void* x, int32_t C, const void* w,
+                                   const void* bias, void* stream);
+
 /* Kernel-order parameters of a triplet module in one launch.  The reference holds the
  * projections as separate nn.Linear with head-minor channels (lib/tgt/layers/triplet.py:198-203,
  * :23-43); tgt_triplet_*_args want one fused, head-major projection.

@@ -90,10 +90,11 @@ def test_triplet_attention(case, dtype, variant):
         assert rel(g[..., 6 * C:L.used], gr[..., 6 * C:L.used]) < 2 * tol, ('deg', rel(g[..., 6 * C:L.used], gr[..., 6 * C:L.used]))
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('case', CASES)
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('case', CASES + [(2, 17, [17, 9], 128, 8), (2, 32, [32, 30], 128, 8)])
 @pytest.mark.parametrize('variant', ['gated', 'ungated', 'axial'])
-def test_projected_triplet_attention_bias_gradient(case, dtype, variant):
+@pytest.mark.parametrize('proj_kernel', [False, True])
+def test_projected_triplet_attention_bias_gradient(case, dtype, variant, proj_kernel, monkeypatch):
     """projection + core as one autograd node: the projection's bias gradient comes from the
     column sums the backward kernel accumulates while it writes d_fused; it must equal the
     column sums of d_fused itself, and every other gradient must be unchanged."""
@@ -101,6 +102,10 @@ def test_projected_triplet_attention_bias_gradient(case, dtype, variant):
     B, N, nn_, C, H = case
     gated, biased = variant == 'gated', variant != 'axial'
     L = ops.TripletLayout(C, H, gated=gated, biased=biased)
+    # proj_kernel: the Q/K/V projection runs INSIDE the attention forward kernel (opt-in path)
+    monkeypatch.setenv('TGT_TRI_PROJ', '1' if proj_kernel else '0')
+    if proj_kernel and not ops._proj_fused_ok(torch.empty(0), N, L, dtype):
+        pytest.skip('shape not covered by the projection-fused kernel')
     rng = np.random.default_rng(7 + hash((B, N, C, H)) % 1000)
     x = rnd(rng, B, N, N, C).to(dtype).cuda()
     w = (rnd(rng, L.width, C) * C ** -0.5).to(dtype).cuda()
@@ -119,13 +124,17 @@ def test_projected_triplet_attention_bias_gradient(case, dtype, variant):
     va = ops.projected_triplet_attention(*new_in, mask, L)
     va.backward(d_out)
     torch.cuda.synchronize()
+    # (N <= 32, D = 16, H % 8 == 0, 16-bit: the projection runs INSIDE the attention kernel, so
+    # Q/K/V round from a different summation order than the library GEMM's)
+    tol = TOL[dtype]
+    assert rel(va, ops.triplet_attention(ops.linear(x, w, b), mask, L)) < tol
     for got, want, name in zip(new_in[:2], ref_in[:2], ('dx', 'dw')):
-        assert torch.equal(got.grad, want.grad), name
+        assert rel(got.grad, want.grad) < 2 * tol, (name, rel(got.grad, want.grad))
     want_db = fused.grad.double().sum((0, 1, 2))[:L.used]
     got_db = new_in[2].grad.double()[:L.used]
     scale = float(fused.grad.double().abs().sum((0, 1, 2)).max()) + 1e-30      # sum of |terms|: the rounding scale
     err = float((got_db - want_db).abs().max()) / scale
-    assert err < (1e-6 if dtype == torch.float32 else 4e-3), err
+    assert err < (1e-6 if dtype == torch.float32 else 6e-3), err
     assert torch.isfinite(new_in[2].grad).all()
 
 

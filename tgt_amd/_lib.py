@@ -11,8 +11,8 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtgt_hip.so')
 CSRC = os.path.join(_HERE, 'csrc')
-SOURCES = ['capi.hip', 'params.hip', 'triplet_attention.hip', 'triplet_aggregate.hip', 'node_attention.hip', 'layernorm.hip', 'triangular_update.hip', 'elementwise.hip']
-ABI_VERSION = 10
+SOURCES = ['capi.hip', 'params.hip', 'triplet_attention_proj.hip', 'triplet_attention.hip', 'triplet_aggregate.hip', 'node_attention.hip', 'layernorm.hip', 'triangular_update.hip', 'elementwise.hip']
+ABI_VERSION = 11
 
 TGT_F32, TGT_BF16, TGT_F16 = 0, 1, 2
 TRI_BIASED, TRI_GATED, TRI_MASK_OUT = 1, 2, 4
@@ -71,6 +71,8 @@ SYMBOLS = {
     'tgt_abi_version': (C.c_int, []),
     'tgt_triplet_attention_fwd': (C.c_int, [C.POINTER(TripletAttentionArgs), _vp]),
     'tgt_triplet_attention_bwd': (C.c_int, [C.POINTER(TripletAttentionArgs), _vp]),
+    'tgt_triplet_attention_proj_supported': (C.c_int, [C.POINTER(TripletAttentionArgs), _i32]),
+    'tgt_triplet_attention_proj_fwd': (C.c_int, [C.POINTER(TripletAttentionArgs), _vp, _i32, _vp, _vp, _vp]),
     'tgt_triplet_aggregate_fwd': (C.c_int, [C.POINTER(TripletAggregateArgs), _vp]),
     'tgt_triplet_aggregate_bwd': (C.c_int, [C.POINTER(TripletAggregateArgs), _vp]),
     'tgt_node_attention_fwd': (C.c_int, [C.POINTER(NodeAttentionArgs), _vp]),

@@ -39,6 +39,9 @@ int triangular_update_run(const void* e4, const void* v4, const float* mask, voi
                           void* d_v4, int B, int N, int H, int dtype, bool bwd, hipStream_t st);
 int colsum_run(const void* x, int x_dtype, int64_t rows, int C, float* out, float* partial, hipStream_t st);
 int sum_rows_run(const float* x, int rows, int C, float* out, hipStream_t st);
+int triplet_attention_proj_supported(const tgt_triplet_attention_args* a, int C);
+int triplet_attention_proj_run(const tgt_triplet_attention_args* a, const void* x, int C, const void* w, const void* bias,
+                               hipStream_t st);
 int fuse_rows_run(const tgt_fuse_rows_args* a, bool scatter, hipStream_t st);
 int permute_cols_run(const void* src, int sd, const int32_t* idx, void* dst, int dd, int rows, int cols, hipStream_t st);
 int layer_norm_fwd_run(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
@@ -109,7 +112,7 @@ using namespace tgt;
 extern "C" {
 
 const char* tgt_last_error(void) { return g_err; }
-int tgt_abi_version(void) { return 10; }
+int tgt_abi_version(void) { return 11; }
 
 int tgt_triplet_attention_fwd(const tgt_triplet_attention_args* a, void* stream) {
     return triplet_attention_run(a, false, reinterpret_cast<hipStream_t>(stream));
@@ -162,6 +165,11 @@ int tgt_add_layer_norm_bwd(const void* dy, int32_t dy_dtype, const void* s, int3
                                   reinterpret_cast<hipStream_t>(stream));
 }
 int tgt_layer_norm_parts(void) { return layer_norm_parts(); }
+int tgt_triplet_attention_proj_supported(const tgt_triplet_attention_args* a, int32_t C) { return triplet_attention_proj_supported(a, C); }
+int tgt_triplet_attention_proj_fwd(const tgt_triplet_attention_args* a, const void* x, int32_t C, const void* w, const void* bias,
+                                   void* stream) {
+    return triplet_attention_proj_run(a, x, C, w, bias, reinterpret_cast<hipStream_t>(stream));
+}
 int tgt_fuse_rows(const tgt_fuse_rows_args* a, void* stream) { return fuse_rows_run(a, false, reinterpret_cast<hipStream_t>(stream)); }
 int tgt_unfuse_rows(const tgt_fuse_rows_args* a, void* stream) { return fuse_rows_run(a, true, reinterpret_cast<hipStream_t>(stream)); }
 int tgt_permute_cols(const void* src, int32_t src_dtype, const int32_t* idx, void* dst, int32_t dst_dtype, int32_t rows,

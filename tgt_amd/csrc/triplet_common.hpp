@@ -400,4 +400,41 @@ __device__ __forceinline__ float arm_stage_store_grad(const ThirdArm& ta, void* 
     return part;
 }
 
+// ---------------------------------------------------------------------------
+// workgroup coordinates and slab sources of the triplet-attention kernels
+// ---------------------------------------------------------------------------
+struct TriCtx {
+    int b, dir, g, h, N;
+    SlabSrc q, k, v;
+};
+
+template <typename T, int D, int HG>
+__device__ __forceinline__ TriCtx tri_ctx(const tgt_triplet_attention_args& a, int wave) {
+    TriCtx c;
+    const int ngroups = a.H / HG;
+    int bid = blockIdx.x;
+    c.g = bid % ngroups;
+    bid /= ngroups;
+    c.dir = bid & 1;
+    c.b = bid >> 1;
+    c.h = c.g * HG + wave;
+    c.N = a.N;
+    const int64_t N = a.N, ld = a.ld_qkv[c.dir], sz = sizeof(T);
+    const char* base = reinterpret_cast<const char*>(a.qkv[c.dir]) + ((int64_t)c.b * N * N * ld + c.g * HG * D) * sz;
+    c.q = {base + (int64_t)a.q_off[c.dir] * sz, N * ld * sz, ld * sz};
+    if (c.dir == 0) {   // partner rows (j,k): contiguous rows of graph row j
+        c.k = {base + (int64_t)a.k_off[c.dir] * sz, ld * sz, N * ld * sz};
+        c.v = {base + (int64_t)a.v_off[c.dir] * sz, ld * sz, N * ld * sz};
+    } else {            // partner rows (k,j): column j
+        c.k = {base + (int64_t)a.k_off[c.dir] * sz, N * ld * sz, ld * sz};
+        c.v = {base + (int64_t)a.v_off[c.dir] * sz, N * ld * sz, ld * sz};
+    }
+    return c;
+}
+
+__device__ __forceinline__ ThirdArm tri_third_arm(const tgt_triplet_attention_args& a, int dir) {
+    return ThirdArm{a.eg[dir], a.ld_eg[dir], a.e_off[dir], a.g_off[dir], a.mask,
+                    (a.flags & TGT_TRI_BIASED) != 0, (a.flags & TGT_TRI_GATED) != 0};
+}
+
 }  // namespace tgt

@@ -227,6 +227,14 @@ def _unfuse_grads(table, params, dW, db):
     return grads
 
 
+def _proj_fused_ok(x, N, L, cd):
+    """the projection-fused forward kernel (tgt_triplet_attention_proj_fwd): opt-in with
+    TGT_TRI_PROJ=1 -- correct, but in round 1 still slower than the library GEMM + attention
+    kernel pair it replaces (0.77 vs 0.63 ms at the BASELINE shape)"""
+    return (os.environ.get('TGT_TRI_PROJ', '0') == '1' and N <= 32 and L.D == 16 and L.H % 8 == 0 and
+            cd in (torch.bfloat16, torch.float16) and L.C in (64, 128, 256))
+
+
 class _ProjectedTripletAttention(torch.autograd.Function):
     """fused projection GEMM + triplet attention core as ONE autograd node, so that the backward
     kernel can hand the projection its bias gradient (column sums of d_fused, accumulated while
@@ -239,10 +247,26 @@ class _ProjectedTripletAttention(torch.autograd.Function):
         _dev(x, mask3)
         B, N = x.shape[0], x.shape[1]
         weight, bias = wb if table is None else _fuse_params(table, wb, cd)
-        x2, w, fused = _linear_forward(x, weight, bias, cd)
         out = torch.empty(B, N, N, 2 * L.C, dtype=cd, device=x.device)
-        a = _tri_args(fused, mask3, out, L)
-        _call('tgt_triplet_attention_fwd', _lib.lib().tgt_triplet_attention_fwd, a)
+        if _proj_fused_ok(x, N, L, cd):
+            # Q/K/V projected inside the attention kernel (it still writes them once, for the
+            # backward); only the narrow E/G third-arm projection stays a library GEMM, written
+            # straight into its columns of the fused row
+            x2 = x.reshape(-1, L.C)
+            x2 = (x2 if x2.dtype == cd else x2.to(cd)).contiguous()
+            w, b = _as_dtype(weight, cd).contiguous(), _as_dtype(bias, cd).contiguous()
+            fused = torch.empty(B, N, N, L.width, dtype=cd, device=x.device)
+            if L.biased:       # (a GEMM straight into the column slice fails under TunableOp: GEMM, then a strided copy)
+                fused.view(-1, L.width)[:, 6 * L.C:L.used].copy_(torch.addmm(b[6 * L.C:L.used], x2, w[6 * L.C:L.used].t()))
+            a = _tri_args(fused, mask3, out, L)
+            s0, s1 = _prof_begin()
+            _lib.check(_lib.lib().tgt_triplet_attention_proj_fwd(C.byref(a), _ptr(x2), L.C, _ptr(w), _ptr(b), _stream()),
+                       'tgt_triplet_attention_proj_fwd')
+            _prof_end('tgt_triplet_attention_fwd', s0, s1)
+        else:
+            x2, w, fused = _linear_forward(x, weight, bias, cd)
+            a = _tri_args(fused, mask3, out, L)
+            _call('tgt_triplet_attention_fwd', _lib.lib().tgt_triplet_attention_fwd, a)
         ctx.save_for_backward(x2, w, fused, mask3, out, *(wb if table is not None else ()))
         ctx.L, ctx.table = L, table
         ctx.meta = (x.shape, x.dtype, weight.dtype, bias.dtype)
