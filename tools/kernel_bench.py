@@ -56,6 +56,22 @@ def main():
         out['tri_att_bwd'] = dict(ms=round(t2 - t, 4), GBs=round(bb / (t2 - t) / 1e6, 1))
         del fused, va, g
 
+    if 'tricol' in a.only:
+        # the backward as the training step runs it: projection + attention as one autograd node,
+        # bias gradient accumulated inside the backward kernel (CS variant)
+        L = ops.TripletLayout(C, Ht)
+        x = torch.randn(B, N, N, C, device=dev, dtype=dt).requires_grad_(True)
+        w = (torch.randn(L.width, C, device=dev) * C ** -0.5).to(dt).requires_grad_(True)
+        bias = torch.randn(L.width, device=dev).to(dt).requires_grad_(True)
+        g = torch.randn(B, N, N, 2 * C, device=dev, dtype=dt)
+        prof = ops.profile_kernels(True)
+        for _ in range(a.iters):
+            torch.autograd.grad(ops.projected_triplet_attention(x, w, bias, mask, L), (x, w, bias), g)
+        torch.cuda.synchronize()
+        ops.profile_kernels(False)
+        out['tricol'] = {k: round(sum(v[1:]) / max(1, len(v) - 1), 4) for k, v in ops.kernel_times_ms(prof).items()}
+        del x, w, bias, g
+
     if 'proj' in a.only:
         import ctypes
         from tgt_amd import _lib
