@@ -84,7 +84,10 @@ __device__ __forceinline__ typename Frag<T>::type load_frag(const T* p) {
 }
 
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
-__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
+// v_rcp_f32 (1 ulp) -- __frcp_rn expands to the full IEEE division sequence (~10 VALU instructions)
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_sigmoid(float x) { return fast_rcp(1.f + __expf(-x)); }
 // exchange with the lane holding the other half of the same column (l ^ 32)
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
 

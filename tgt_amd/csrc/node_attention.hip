@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(256) node_att_fwd_kernel(const tgt_node_attent
     float f[HV], lse[HV];
 #pragma unroll
     for (int k = 0; k < HV; ++k) {
-        f[k] = __frcp_rn(sum[k]) * (a.scale_degree ? __logf(1.f + gsum[k]) : 1.f);
+        f[k] = fast_rcp(sum[k]) * (a.scale_degree ? __logf(1.f + gsum[k]) : 1.f);
         lse[k] = mx[k] + __logf(sum[k]);
     }
 #pragma unroll
@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(512) node_att_fwd_lds_kernel(const tgt_node_at
     float f[HV];
 #pragma unroll
     for (int k = 0; k < HV; ++k) {
-        f[k] = __frcp_rn(sum[k]) * (a.scale_degree ? __logf(1.f + gsum[k]) : 1.f);
+        f[k] = fast_rcp(sum[k]) * (a.scale_degree ? __logf(1.f + gsum[k]) : 1.f);
         a.lse[row_l * H + h + k] = mx[k] + __logf(sum[k]);
         a.gsum[row_l * H + h + k] = gsum[k];
     }
@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(256) node_att_bwd_row_kernel(const tgt_node_at
 #pragma unroll
         for (int k = 0; k < HV; ++k) {
             dsc[k] = a.scale_degree ? __logf(1.f + gsum[k]) : 1.f;
-            inv[k] = dsc[k] != 0.f ? __frcp_rn(dsc[k]) : 0.f;     // zero scaler <=> every gate 0 <=> V_att 0
+            inv[k] = dsc[k] != 0.f ? fast_rcp(dsc[k]) : 0.f;     // zero scaler <=> every gate 0 <=> V_att 0
             d_dsc[k] = delta[k] = 0.f;
         }
         // unscaled V_att from the saved forward output: V_att = vu * log(1+gsum)
@@ -370,7 +370,7 @@ __global__ void __launch_bounds__(256) node_att_bwd_row_kernel(const tgt_node_at
             }
         }
 #pragma unroll
-        for (int k = 0; k < HV; ++k) dgsum[k] = a.scale_degree ? d_dsc[k] * __frcp_rn(1.f + gsum[k]) : 0.f;
+        for (int k = 0; k < HV; ++k) dgsum[k] = a.scale_degree ? d_dsc[k] * fast_rcp(1.f + gsum[k]) : 0.f;
         for (int m = 0; m < N; ++m) {
             const int64_t row_m = row0 + m, lm = row_l * N + m;
             float e[HV], g[HV], dot[HV], dA[HV], dH[HV], dGl[HV];

@@ -71,7 +71,7 @@ __device__ __forceinline__ void agg_weights(const AggCtx& c, int N, int wave, in
             sum += p[kt][q];
         }
     sum += xhalf(sum);
-    const float inv = sum > 0.f ? __frcp_rn(sum) : 0.f;
+    const float inv = sum > 0.f ? fast_rcp(sum) : 0.f;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
 #pragma unroll

@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(HG * 64, (NT == 1 && sizeof(T) == 2) ? 4 : 1) 
                     sum += s[kt][q];
                 }
             sum += xhalf(sum);
-            const float inv = __frcp_rn(sum);
+            const float inv = fast_rcp(sum);
             f32x16 o = {0};
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt) {
@@ -185,7 +185,9 @@ __global__ void __launch_bounds__(HG * 64, (NT == 1 && sizeof(T) == 2) ? 4 : 1) 
 // NT > 1: one pass per query tile; dK/dV sum over query tiles, so pass `it > 0`
 // adds its partial to what pass it-1 stored (same thread wrote that address).
 // ---------------------------------------------------------------------------
-template <typename T, int D, int HG, int NT, int OCC, bool CS>
+// FL >= 0: the BIASED/GATED flags are compile-time (the hot gated+biased instantiation: no
+// per-element selects); FL < 0: read from the arguments.
+template <typename T, int D, int HG, int NT, int OCC, bool CS, int FL>
 __global__ void __launch_bounds__(HG * 64, OCC) tri_att_bwd_kernel(const tgt_triplet_attention_args a) {
     using G = TriGeo<T, D, HG>;
     using F = frag_t<T>;
@@ -198,7 +200,9 @@ __global__ void __launch_bounds__(HG * 64, OCC) tri_att_bwd_kernel(const tgt_tri
     const TriCtx c = tri_ctx<T, D, HG>(a, wave);
     const int N = c.N;
     const ThirdArm ta = tri_third_arm(a, c.dir);
-    const bool biased = ta.biased, gated = ta.gated;
+    const bool biased = FL >= 0 ? (FL & TGT_TRI_BIASED) != 0 : ta.biased, gated = FL >= 0 ? (FL & TGT_TRI_GATED) != 0 : ta.gated;
+    constexpr float kLog2e = 1.4426950408889634f;
+    const float scale2 = a.scale * kLog2e;          // logits in the log2 domain: exp2 without the per-element multiply
     F ident_d[G::kDC], ident_k[2];
     make_ident_d<T, G::kDC>(ident_d, r, hi);
     make_ident_k<T>(ident_k, r, hi);
@@ -231,7 +235,14 @@ __global__ void __launch_bounds__(HG * 64, OCC) tri_att_bwd_kernel(const tgt_tri
         for (int kt = 0; kt < NT; ++kt) {
             arm_stage_read<T, HG, NT, true>(ta, smem, c.dir, wave, N, r, hi, i0, kt, biasM[kt], gate[kt]);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) dE[kt][q] = dG[kt][q] = 0.f;
+            for (int q = 0; q < 16; ++q) {
+                // log2 domain.  A masked entry is finfo.min (-3.4e38): times log2(e) it would overflow to
+                // -inf and a fully masked row would lose its (reference) uniform softmax -- clamp it
+                // back to finfo.min; real -inf (padding past N) stays -inf.
+                const float bl = biasM[kt][q] * kLog2e;
+                biasM[kt][q] = (bl == -INFINITY && biasM[kt][q] != -INFINITY) ? -3.402823466e38f : bl;
+                dE[kt][q] = dG[kt][q] = 0.f;          // dG accumulates sum_j dA*P; the gate factor is applied once, after the walk
+            }
         }
         __syncthreads();
 
@@ -305,7 +316,7 @@ __global__ void __launch_bounds__(HG * 64, OCC) tri_att_bwd_kernel(const tgt_tri
             for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
-                    s[kt][q] = s[kt][q] * a.scale + biasM[kt][q];
+                    s[kt][q] = s[kt][q] * scale2 + biasM[kt][q];
                     mx = fmaxf(mx, s[kt][q]);
                 }
             mx = fmaxf(mx, xhalf(mx));
@@ -315,11 +326,11 @@ __global__ void __launch_bounds__(HG * 64, OCC) tri_att_bwd_kernel(const tgt_tri
             for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
-                    s[kt][q] = fast_exp(s[kt][q] - mx);
+                    s[kt][q] = fast_exp2(s[kt][q] - mx);
                     sum += s[kt][q];
                 }
             sum += xhalf(sum);
-            const float inv = sum > 0.f ? __frcp_rn(sum) : 0.f;
+            const float inv = sum > 0.f ? fast_rcp(sum) : 0.f;
             // s -> P;  da -> dP = dA * g;  delta_i = sum_k P dP
             float delta = 0.f;
 #pragma unroll
@@ -329,7 +340,7 @@ __global__ void __launch_bounds__(HG * 64, OCC) tri_att_bwd_kernel(const tgt_tri
                     const float p = s[kt][q] * inv;
                     const float dp = da[kt][q] * gate[kt][q];
                     delta += p * dp;
-                    if (gated) dG[kt][q] += da[kt][q] * p * gate[kt][q] * (1.f - gate[kt][q]);
+                    if (gated) dG[kt][q] += da[kt][q] * p;
                     s[kt][q] = p;
                     da[kt][q] = dp;
                 }
@@ -423,7 +434,13 @@ __global__ void __launch_bounds__(HG * 64, OCC) tri_att_bwd_kernel(const tgt_tri
         __syncthreads();      // the next query-tile pass re-fills both sets
         // third-arm gradients of this query tile (summed over j in registers) leave through LDS
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt) arm_stage_put_grad<T, HG, NT>(smem, c.dir, wave, r, hi, kt, dE[kt], dG[kt]);
+        for (int kt = 0; kt < NT; ++kt) {
+            if (gated) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) dG[kt][q] *= gate[kt][q] * (1.f - gate[kt][q]);      // d sigmoid, once per tile
+            }
+            arm_stage_put_grad<T, HG, NT>(smem, c.dir, wave, r, hi, kt, dE[kt], dG[kt]);
+        }
         __syncthreads();
         {
             const float part = arm_stage_store_grad<T, HG, NT>(ta, a.d_eg[c.dir], c.b, c.dir, c.g, N, i0, smem, tid);
@@ -475,18 +492,22 @@ static int launch_tri_nt(const tgt_triplet_attention_args& a, bool bwd, hipStrea
         const bool cs = a.d_qkv_colsum[0] != nullptr;
         constexpr int kCs = (3 * slab_colsum_plane_floats<G, T>() + G::kThreads) * 4;
         if (NT == 1 && occ == 2) {
-            if (cs)
-                hipLaunchKernelGGL((tri_att_bwd_kernel<T, D, HG, NT, (NT == 1 ? 2 : 1), true>), dim3(grid),
+            constexpr int kBG = TGT_TRI_BIASED | TGT_TRI_GATED;
+            if (cs && HG == 8 && (a.flags & kBG) == kBG)         // the training hot path: flags compiled in
+                hipLaunchKernelGGL((tri_att_bwd_kernel<T, D, HG, NT, (NT == 1 ? 2 : 1), true, (HG == 8 ? kBG : -1)>), dim3(grid),
+                                   dim3(G::kThreads), kBwdLds + kCs, st, a);
+            else if (cs)
+                hipLaunchKernelGGL((tri_att_bwd_kernel<T, D, HG, NT, (NT == 1 ? 2 : 1), true, -1>), dim3(grid),
                                    dim3(G::kThreads), kBwdLds + kCs, st, a);
             else
-                hipLaunchKernelGGL((tri_att_bwd_kernel<T, D, HG, NT, (NT == 1 ? 2 : 1), false>), dim3(grid),
+                hipLaunchKernelGGL((tri_att_bwd_kernel<T, D, HG, NT, (NT == 1 ? 2 : 1), false, -1>), dim3(grid),
                                    dim3(G::kThreads), kBwdLds, st, a);
         } else {
             if (cs)
-                hipLaunchKernelGGL((tri_att_bwd_kernel<T, D, HG, NT, 1, true>), dim3(grid), dim3(G::kThreads),
+                hipLaunchKernelGGL((tri_att_bwd_kernel<T, D, HG, NT, 1, true, -1>), dim3(grid), dim3(G::kThreads),
                                    kBwdLds + kCs, st, a);
             else
-                hipLaunchKernelGGL((tri_att_bwd_kernel<T, D, HG, NT, 1, false>), dim3(grid), dim3(G::kThreads),
+                hipLaunchKernelGGL((tri_att_bwd_kernel<T, D, HG, NT, 1, false, -1>), dim3(grid), dim3(G::kThreads),
                                    kBwdLds, st, a);
         }
     }

@@ -175,7 +175,7 @@ __device__ __forceinline__ void proj_walk(const tgt_triplet_attention_args& a, c
             sum += st[q];
         }
         sum += xhalf(sum);
-        const float inv = __frcp_rn(sum);
+        const float inv = fast_rcp(sum);
 #pragma unroll
         for (int q = 0; q < 16; ++q) st[q] = st[q] * inv * gate[q];
         f32x16 o = {0};
