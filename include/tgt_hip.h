@@ -89,6 +89,12 @@ typedef struct tgt_triplet_attention_args {
      * (each exactly once), finish with tgt_sum_rows over B.  Saves a full pass over d_qkv. */
     float*  d_qkv_colsum[2];
     float*  d_eg_colsum[2];
+    /* attention dropout on the gated weights (reference triplet.py:223-225, :242-244); 0 = off.
+     * Counter-based: the backward must be called with the forward's (p, seed).  Generator:
+     * csrc/triplet_common.hpp (tri_drop_bits), unit = ((b*2 + dir)*H + h)*N + j. */
+    float    dropout_p;
+    uint32_t _pad1;
+    uint64_t dropout_seed;
 } tgt_triplet_attention_args;
 
 int tgt_triplet_attention_fwd(const tgt_triplet_attention_args* a, void* stream);
@@ -116,6 +122,11 @@ typedef struct tgt_triplet_aggregate_args {
     const void* d_out;
     void*   d_v[2];
     void*   d_eg[2];
+    /* attention dropout on the gated weights (reference triplet.py:59-60, :66-67); 0 = off;
+     * unit = (b*2 + dir)*H + h, otherwise as tgt_triplet_attention_args. */
+    float    dropout_p;
+    uint32_t _pad1;
+    uint64_t dropout_seed;
 } tgt_triplet_aggregate_args;
 
 int tgt_triplet_aggregate_fwd(const tgt_triplet_aggregate_args* a, void* stream);

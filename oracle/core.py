@@ -69,7 +69,7 @@ def edge_update_core(qk, e_bias, num_heads):
     return torch.einsum('bldh,bmdh->blmh', q, k) * (D ** -0.5) + e_bias
 
 
-def _triplet_dir(q, k, v, bias, gate_logit, mask, inward):
+def _triplet_dir(q, k, v, bias, gate_logit, mask, inward, drop=None):
     """One direction of the triplet attention.  q,k,v: (B,N,N,D,H).
     bias/gate_logit: (B,N,N,H) or None.  mask: (B,N,N,1).
 
@@ -95,21 +95,27 @@ def _triplet_dir(q, k, v, bias, gate_logit, mask, inward):
     p = torch.softmax(s + mask.unsqueeze(2), dim=3)
     if gate_logit is not None:
         p = p * torch.sigmoid(gate_logit + mask).unsqueeze(2)
+    if drop is not None:            # F.dropout(A, p) with a GIVEN keep pattern (triplet.py:223-225, :242-244)
+        keep, scale = drop          # keep: (B,i,j,k,H) bool
+        p = p * keep.to(p.dtype) * scale
     return torch.einsum('bijkh,bjkdh->bijdh', p, v)
 
 
 def triplet_attention_core(qkv_in, eg_in, qkv_out, eg_out, mask, num_heads,
-                           gated=True, biased=True):
+                           gated=True, biased=True, dropout=None):
     """lib/tgt/layers/triplet.py:209-248 (and :276-320 ungated, :343-385 axial).
 
     qkv_* : (B,N,N,3C)   eg_*: (B,N,N,2H) gated | (B,N,N,H) ungated | None axial
     returns Va (B,N,N,2C) with channel = d*2H + dir*H + h  (triplet.py:248).
+    dropout: None, or (keep_in, keep_out, scale) with keep_* (B,i,j,k,H) bool: the attention dropout
+    with a given keep pattern (the tests pass the kernels' counter-based pattern).
     """
     B, N, _, C3 = qkv_in.shape
     C = C3 // 3
     D = C // num_heads
     outs = []
     for qkv, eg, inward in ((qkv_in, eg_in, True), (qkv_out, eg_out, False)):
+        drop = None if dropout is None else (dropout[0 if inward else 1], dropout[2])
         q, k, v = (heads_minor(t, num_heads) for t in qkv.split(C, dim=-1))
         q = q * (D ** -0.5)
         bias = gate = None
@@ -117,11 +123,11 @@ def triplet_attention_core(qkv_in, eg_in, qkv_out, eg_out, mask, num_heads,
             bias, gate = eg.split(num_heads, dim=-1)
         elif biased:
             bias = eg
-        outs.append(_triplet_dir(q, k, v, bias, gate, mask, inward))
+        outs.append(_triplet_dir(q, k, v, bias, gate, mask, inward, drop))
     return torch.cat(outs, dim=-1).reshape(B, N, N, 2 * C)
 
 
-def triplet_aggregate_core(v_both, eg, mask, num_heads, gated=True):
+def triplet_aggregate_core(v_both, eg, mask, num_heads, gated=True, dropout=None):
     """lib/tgt/layers/triplet.py:50-70 (gated; outward unmasked, quirk Q2) and
     :100-123 (ungated; both directions masked).
 
@@ -139,6 +145,9 @@ def triplet_aggregate_core(v_both, eg, mask, num_heads, gated=True):
         e_in, e_out = eg.split(num_heads, dim=-1)
         a_in = torch.softmax(e_in + mask, dim=2)
         a_out = torch.softmax(e_out + mask, dim=1)
+    if dropout is not None:         # (keep_in (B,i,k,H), keep_out (B,k,i,H), scale): given keep pattern (:59-60, :66-67)
+        a_in = a_in * dropout[0].to(a_in.dtype) * dropout[2]
+        a_out = a_out * dropout[1].to(a_out.dtype) * dropout[2]
     # o_in[b,i,j,d,h]  = sum_k a_in[b,i,k,h]  V_in[b,j,k,d,h]     (:61)
     # o_out[b,i,j,d,h] = sum_k a_out[b,k,i,h] V_out[b,k,j,d,h]    (:68)
     o_in = torch.einsum('bikh,bjkdh->bijdh', a_in, v_in)

@@ -202,3 +202,35 @@ GRAD_PROBE_KEYS = [
     'input_embed.dist_embed.weight',
     'input_embed.nodef_embed.weight',
 ]
+
+
+# ---------------------------------------------------------------------------
+# numpy restatement of the kernels' attention-dropout generator
+# (tgt_amd/csrc/triplet_common.hpp: tri_drop_bits) -- test infrastructure
+# ---------------------------------------------------------------------------
+def _mix32(h):
+    import numpy as np
+    h = h.astype(np.uint64) & 0xFFFFFFFF
+    h ^= h >> 16
+    h = (h * 0x7feb352d) & 0xFFFFFFFF
+    h ^= h >> 15
+    h = (h * 0x846ca68b) & 0xFFFFFFFF
+    h ^= h >> 16
+    return h
+
+
+def triplet_dropout_keep(seed, p, units, N):
+    """keep[u, i, k] (bool) and the scale 1/(1-p) for the given `unit` numbers (1-D int array):
+    attention: unit = ((b*2 + dir)*H + h)*N + j;  aggregate: unit = (b*2 + dir)*H + h"""
+    import numpy as np
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    lo, hi = seed & 0xFFFFFFFF, seed >> 32
+    thresh = int(min(65535, max(1, np.rint(np.float32(p) * np.float32(65536.0)))))
+    units = np.asarray(units, dtype=np.uint64)
+    base = (_mix32(np.uint64(lo) ^ _mix32(units)) + np.uint64(hi)) & 0xFFFFFFFF            # (U,)
+    i = np.arange(N, dtype=np.uint64)[:, None]
+    k = np.arange(N, dtype=np.uint64)[None, :]
+    word = (i * 64 + k) >> 1                                                                # (N, N)
+    r = _mix32((base[:, None, None] + word[None] * 0x9e3779b9) & 0xFFFFFFFF)                # (U, N, N)
+    bits = np.where((k & 1)[None] == 1, r >> 16, r & 0xFFFF)
+    return bits >= thresh, 1.0 / (1.0 - float(np.float32(p)))

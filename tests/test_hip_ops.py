@@ -138,6 +138,114 @@ def test_projected_triplet_attention_bias_gradient(case, dtype, variant, proj_ke
     assert torch.isfinite(new_in[2].grad).all()
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', [CASES[0], CASES[2], CASES[4], CASES[5]])
+@pytest.mark.parametrize('variant', ['gated', 'axial'])
+def test_triplet_attention_dropout(case, dtype, variant):
+    """attention dropout inside the kernels (reference triplet.py:223-225): forward and backward
+    against the oracle given the SAME keep pattern (numpy restatement of the counter-based
+    generator), plus the keep rate."""
+    from tgt_amd import ops, layout
+    B, N, nn_, C, H = case
+    gated, biased = variant == 'gated', variant != 'axial'
+    L = ops.TripletLayout(C, H, gated=gated, biased=biased)
+    rng = np.random.default_rng(11 + hash((B, N, C, H)) % 1000)
+    fused = rnd(rng, B, N, N, L.width).to(dtype)
+    d_out = rnd(rng, B, N, N, 2 * C).to(dtype)
+    mask = gu.additive_mask(nn_, N, torch.float32)
+    p_drop, seed = 0.3, 0x1234567890ABCDEF
+    units = (((np.arange(B)[:, None, None, None] * 2 + np.arange(2)[None, :, None, None]) * H +
+              np.arange(H)[None, None, :, None]) * N + np.arange(N)[None, None, None, :]).reshape(-1)
+    keep, scale = gu.triplet_dropout_keep(seed, p_drop, units, N)
+    keep = torch.from_numpy(keep.reshape(B, 2, H, N, N, N))            # (b, dir, h, j, i, k)
+    keep_dirs = [keep[:, d].permute(0, 3, 2, 4, 1).contiguous() for d in (0, 1)]      # (b, i, j, k, h)
+    rate = float(keep.float().mean())
+    assert abs(rate - (1 - p_drop)) < 0.02, rate
+
+    f64 = fused.double().requires_grad_(True)
+    idx, oidx = layout.head_major_index(C, H), layout.va_cols_head_major(C, H)
+    blk = lambda lo: torch.cat([to_ref(f64[..., lo + q * C: lo + (q + 1) * C], idx) for q in range(3)], -1)
+    nb = (2 if gated else 1) * H
+    eg_in = f64[..., 6 * C: 6 * C + nb] if biased else None
+    eg_out = f64[..., 6 * C + nb: 6 * C + 2 * nb] if biased else None
+    va_ref = core.triplet_attention_core(blk(0), eg_in, blk(3 * C), eg_out, mask.double(), H, gated, biased,
+                                         dropout=(keep_dirs[0], keep_dirs[1], scale))
+    va_ref_hm = from_ref(va_ref, oidx)
+    (va_ref_hm * d_out.double()).sum().backward()
+
+    fx = fused.cuda().requires_grad_(True)
+    va = ops.triplet_attention(fx, mask.reshape(B, N, N).cuda(), L, dropout=(p_drop, seed))
+    va.backward(d_out.cuda())
+    tol = TOL[dtype]
+    assert rel(va, va_ref_hm) < tol, ('fwd', rel(va, va_ref_hm))
+    assert rel(fx.grad[..., :L.used], f64.grad[..., :L.used]) < 2 * tol, rel(fx.grad[..., :L.used], f64.grad[..., :L.used])
+    # the projection + attention node takes the same path (and its in-kernel bias-gradient sums)
+    x = rnd(rng, B, N, N, C).to(dtype).cuda()
+    w = (rnd(rng, L.width, C) * C ** -0.5).to(dtype).cuda().requires_grad_(True)
+    b = (rnd(rng, L.width) * 0.1).to(dtype).cuda().requires_grad_(True)
+    m3 = mask.reshape(B, N, N).cuda()
+    y1 = ops.projected_triplet_attention(x, w, b, m3, L, dropout=(p_drop, seed))
+    g1 = torch.autograd.grad(y1, (w, b), d_out.cuda())
+    y0 = ops.triplet_attention(ops.linear(x, w, b), m3, L, dropout=(p_drop, seed))
+    g0 = torch.autograd.grad(y0, (w, b), d_out.cuda())
+    assert rel(y1, y0) < tol and rel(g1[0], g0[0]) < 2 * tol          # (different kernel instantiations: not bit-equal)
+    assert rel(g1[1][:L.used], g0[1][:L.used]) < (1e-5 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize('name', ['attention', 'attention_ungated', 'axial_attention', 'aggregate', 'aggregate_ungated'])
+def test_triplet_modules_take_attention_dropout(name):
+    """module API (reference triplet.py:23, :180: attention_dropout kwarg): active in training only,
+    a new pattern per call, finite gradients"""
+    from tgt_amd.tgt.layers import get_triplet_layer
+    torch.manual_seed(0)
+    mod = get_triplet_layer(name)(64, 4, attention_dropout=0.2).cuda()
+    e = torch.randn(2, 10, 10, 64, device='cuda', requires_grad=True)
+    mask = gu.additive_mask([10, 7], 10, torch.float32).cuda()
+    mod.eval()
+    y_eval = mod(e, mask)
+    assert torch.equal(y_eval, mod(e, mask))
+    mod.train()
+    y1, y2 = mod(e, mask), mod(e, mask)
+    assert not torch.equal(y1, y2) and not torch.equal(y1, y_eval)
+    y1.square().sum().backward()
+    assert torch.isfinite(e.grad).all() and all(torch.isfinite(p.grad).all() for p in mod.parameters())
+    assert 0.5 < float(y1.float().norm() / y_eval.float().norm()) < 2.0
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', [CASES[0], CASES[2], CASES[5]])
+@pytest.mark.parametrize('gated', [True, False])
+def test_triplet_aggregate_dropout(case, dtype, gated):
+    """attention dropout inside the aggregate kernels (reference triplet.py:59-60, :66-67)"""
+    from tgt_amd import ops, layout
+    B, N, nn_, C, H = case
+    L = ops.AggregateLayout(C, H, gated=gated)
+    rng = np.random.default_rng(13 + hash((B, N, C, H)) % 1000)
+    fused = rnd(rng, B, N, N, L.width).to(dtype)
+    d_out = rnd(rng, B, N, N, 2 * C).to(dtype)
+    mask = gu.additive_mask(nn_, N, torch.float32)
+    p_drop, seed = 0.25, 987654321
+    units = ((np.arange(B)[:, None, None] * 2 + np.arange(2)[None, :, None]) * H + np.arange(H)[None, None, :]).reshape(-1)
+    keep, scale = gu.triplet_dropout_keep(seed, p_drop, units, N)
+    keep = torch.from_numpy(keep.reshape(B, 2, H, N, N))                # (b, dir, h, i, k)
+    keep_in = keep[:, 0].permute(0, 2, 3, 1).contiguous()               # (b, i, k, h)
+    keep_out = keep[:, 1].permute(0, 3, 2, 1).contiguous()              # (b, k, i, h): the kernel's (i,k) is A_out[k,i]
+
+    f64 = fused.double().requires_grad_(True)
+    idx, oidx = layout.head_major_index(C, H), layout.va_cols_head_major(C, H)
+    v_both = torch.cat([to_ref(f64[..., q * C:(q + 1) * C], idx) for q in range(2)], -1)
+    eg = f64[..., 2 * C:L.used]
+    va_ref = core.triplet_aggregate_core(v_both, eg, mask.double(), H, gated, dropout=(keep_in, keep_out, scale))
+    va_ref_hm = from_ref(va_ref, oidx)
+    (va_ref_hm * d_out.double()).sum().backward()
+    fx = fused.cuda().requires_grad_(True)
+    va = ops.triplet_aggregate(fx, mask.reshape(B, N, N).cuda(), L, dropout=(p_drop, seed))
+    va.backward(d_out.cuda())
+    tol = TOL[dtype]
+    assert rel(va, va_ref_hm) < tol, ('fwd', rel(va, va_ref_hm))
+    assert rel(fx.grad[..., :L.used], f64.grad[..., :L.used]) < 2 * tol
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('case', CASES)
 @pytest.mark.parametrize('gated', [True, False])

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtgt_hip.so')
 CSRC = os.path.join(_HERE, 'csrc')
 SOURCES = ['capi.hip', 'params.hip', 'triplet_attention_proj.hip', 'triplet_attention.hip', 'triplet_aggregate.hip', 'node_attention.hip', 'layernorm.hip', 'triangular_update.hip', 'elementwise.hip']
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 TGT_F32, TGT_BF16, TGT_F16 = 0, 1, 2
 TRI_BIASED, TRI_GATED, TRI_MASK_OUT = 1, 2, 4
@@ -30,6 +30,7 @@ class TripletAttentionArgs(C.Structure):
         ('out', _vp), ('ld_out', _i64), ('o_off', _i32 * 2),
         ('d_out', _vp), ('d_qkv', _vp * 2), ('d_eg', _vp * 2),
         ('d_qkv_colsum', _vp * 2), ('d_eg_colsum', _vp * 2),
+        ('dropout_p', _f32), ('_pad1', C.c_uint32), ('dropout_seed', C.c_uint64),
     ]
 
 
@@ -42,6 +43,7 @@ class TripletAggregateArgs(C.Structure):
         ('mask', _vp),
         ('out', _vp), ('ld_out', _i64), ('o_off', _i32 * 2),
         ('d_out', _vp), ('d_v', _vp * 2), ('d_eg', _vp * 2),
+        ('dropout_p', _f32), ('_pad1', C.c_uint32), ('dropout_seed', C.c_uint64),
     ]
 
 

@@ -10,10 +10,6 @@
 
 namespace tgt {
 
-__device__ __forceinline__ uint32_t mix32(uint32_t h) {      // "lowbias32" integer finalizer
-    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
-    return h;
-}
 // keep/drop of the V consecutive elements of vector `vec` (= first element index / V): one hash
 // of (seed, vec), then one 32-bit word per TWO elements, 16 bits each;
 // P(keep) = 1 - thresh16 / 65536.

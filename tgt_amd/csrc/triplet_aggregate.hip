@@ -92,6 +92,8 @@ __global__ void __launch_bounds__(HG * 64) tri_agg_fwd_kernel(const tgt_triplet_
     const int N = c.N;
     F ident_d[G::kDC];
     make_ident_d<T, G::kDC>(ident_d, r, hi);
+    const TriDrop drop = tri_drop(a.dropout_p, a.dropout_seed);
+    const uint32_t drop_unit = (uint32_t)((c.b * 2 + c.dir) * a.H + c.h);
     const int64_t sz = sizeof(T);
     char* obase = reinterpret_cast<char*>(a.out) + ((int64_t)c.b * N * N * a.ld_out + a.o_off[c.dir] + c.g * HG * D) * sz;
     const int64_t o_row = (int64_t)N * a.ld_out * sz, o_j = a.ld_out * sz;
@@ -108,6 +110,11 @@ __global__ void __launch_bounds__(HG * 64) tri_agg_fwd_kernel(const tgt_triplet_
                 f32x16 w;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) w[q] = p[kt][q] * gate[kt][q];
+                if (drop.on) {
+                    const uint32_t keep = tri_drop_bits(drop, drop_unit, i0 + r, kt, hi);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) w[q] = (keep >> q) & 1u ? w[q] * drop.scale : 0.f;
+                }
                 pa[kt][0] = pack_chunk<T>(w, 0);
                 pa[kt][1] = pack_chunk<T>(w, 1);
             }
@@ -153,6 +160,8 @@ __global__ void __launch_bounds__(HG * 64) tri_agg_bwd_kernel(const tgt_triplet_
 
     F ident_d[G::kDC];
     make_ident_d<T, G::kDC>(ident_d, r, hi);
+    const TriDrop drop = tri_drop(a.dropout_p, a.dropout_seed);
+    const uint32_t drop_unit = (uint32_t)((c.b * 2 + c.dir) * a.H + c.h);
     const int64_t sz = sizeof(T), Nl = N;
     const SlabSrc dO = {reinterpret_cast<const char*>(a.d_out) +
                             ((int64_t)c.b * Nl * Nl * a.ld_out + a.o_off[c.dir] + c.g * HG * D) * sz,
@@ -175,6 +184,11 @@ __global__ void __launch_bounds__(HG * 64) tri_agg_bwd_kernel(const tgt_triplet_
                 f32x16 w, a2 = {0};
 #pragma unroll
                 for (int q = 0; q < 16; ++q) w[q] = p[kt][q] * gate[kt][q];
+                if (drop.on) {
+                    const uint32_t keep = tri_drop_bits(drop, drop_unit, i0 + r, kt, hi);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) w[q] = (keep >> q) & 1u ? w[q] * drop.scale : 0.f;
+                }
 #pragma unroll
                 for (int cc = 0; cc < 2; ++cc) a2 = mma32(pack_chunk<T>(w, cc), ident_k[cc], a2);
                 a2f[kt][0] = pack_chunk<T>(a2, 0);
@@ -248,6 +262,14 @@ __global__ void __launch_bounds__(HG * 64) tri_agg_bwd_kernel(const tgt_triplet_
         agg_weights<T, HG, NT, true>(c, N, wave, tid, r, hi, i0, smem, p, gate);
         float delta = 0.f;
         float dG[NT][16];
+        if (drop.on) {            // dacc is the gradient of the DROPPED weights
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                const uint32_t keep = tri_drop_bits(drop, drop_unit, i0 + r, kt, hi);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) dacc[kt][q] = (keep >> q) & 1u ? dacc[kt][q] * drop.scale : 0.f;
+            }
+        }
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll

@@ -256,7 +256,7 @@ static int dispatch_ks(const tgt_triplet_attention_args& a, int C, const void* x
 }
 
 int triplet_attention_proj_supported(const tgt_triplet_attention_args* a, int C) {
-    return a && a->N <= 32 && a->D == 16 && a->H % 8 == 0 && (a->dtype == TGT_BF16 || a->dtype == TGT_F16) &&
+    return a && a->dropout_p == 0.f && a->N <= 32 && a->D == 16 && a->H % 8 == 0 && (a->dtype == TGT_BF16 || a->dtype == TGT_F16) &&
            (C == 64 || C == 128 || C == 256);
 }
 

@@ -401,6 +401,46 @@ __device__ __forceinline__ float arm_stage_store_grad(const ThirdArm& ta, void* 
 }
 
 // ---------------------------------------------------------------------------
+// Attention dropout (reference lib/tgt/layers/triplet.py:223-225, :242-244, :59-60: F.dropout on
+// the gated weights).  Counter-based, so the backward recomputes the forward's pattern from the
+// seed and nothing is stored.  Element (unit, i, k): `unit` numbers the (graph, direction, head
+// [, shared node j]) the weights belong to; one hash word serves the pair (k even, k + 1):
+//   word = mix32( mix32(seed_lo ^ mix32(unit)) + seed_hi + ((i*64 + k) >> 1) * 0x9e3779b9 )
+//   keep(k even) = (word & 0xffff) >= thresh16,  keep(k odd) = (word >> 16) >= thresh16,
+//   thresh16 = clamp(round(p * 65536), 1, 65535); kept weights are scaled by 1/(1-p).
+// (tests/golden_util.py::triplet_dropout_keep restates it in numpy for the parity tests.)
+// Returns the keep bits of the 16 accumulator elements of one lane: bit q <-> k = 32*kt + acc_row(q,hi).
+// ---------------------------------------------------------------------------
+struct TriDrop {
+    uint32_t thresh16, seed_lo, seed_hi;
+    float scale;
+    bool on;
+};
+__device__ __forceinline__ TriDrop tri_drop(float p, uint64_t seed) {
+    TriDrop d;
+    d.on = p > 0.f;
+    float t = rintf(p * 65536.f);
+    t = t < 1.f ? 1.f : (t > 65535.f ? 65535.f : t);
+    d.thresh16 = (uint32_t)t;
+    d.seed_lo = (uint32_t)seed;
+    d.seed_hi = (uint32_t)(seed >> 32);
+    d.scale = d.on ? 1.f / (1.f - p) : 1.f;
+    return d;
+}
+__device__ __forceinline__ uint32_t tri_drop_bits(const TriDrop& d, uint32_t unit, int i, int kt, int hi) {
+    const uint32_t base = mix32(d.seed_lo ^ mix32(unit)) + d.seed_hi;
+    uint32_t bits = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        const int k = 32 * kt + acc_row(2 * w, hi);
+        const uint32_t r = mix32(base + (uint32_t)((i * 64 + k) >> 1) * 0x9e3779b9u);
+        bits |= ((r & 0xffffu) >= d.thresh16 ? 1u : 0u) << (2 * w);
+        bits |= ((r >> 16) >= d.thresh16 ? 1u : 0u) << (2 * w + 1);
+    }
+    return bits;
+}
+
+// ---------------------------------------------------------------------------
 // workgroup coordinates and slab sources of the triplet-attention kernels
 // ---------------------------------------------------------------------------
 struct TriCtx {

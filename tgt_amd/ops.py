@@ -89,7 +89,7 @@ class TripletLayout:
         self.flags = (_lib.TRI_BIASED if biased else 0) | (_lib.TRI_GATED if gated else 0)
 
 
-def _tri_args(fused, mask3, out, L, d_out=None, d_fused=None, colsum=None):
+def _tri_args(fused, mask3, out, L, d_out=None, d_fused=None, colsum=None, dropout=(0.0, 0)):
     B, N = fused.shape[0], fused.shape[1]
     a = _lib.TripletAttentionArgs()
     a.B, a.N, a.H, a.D = B, N, L.H, L.D
@@ -104,6 +104,7 @@ def _tri_args(fused, mask3, out, L, d_out=None, d_fused=None, colsum=None):
     a.mask = mask3.data_ptr()
     a.out, a.ld_out = out.data_ptr(), 2 * L.C
     a.o_off = _pair(C.c_int32, 0, L.C)
+    a.dropout_p, a.dropout_seed = float(dropout[0]), int(dropout[1]) & 0xFFFFFFFFFFFFFFFF
     if d_out is not None:
         a.d_out = d_out.data_ptr()
         dp = d_fused.data_ptr()
@@ -117,18 +118,25 @@ def _tri_args(fused, mask3, out, L, d_out=None, d_fused=None, colsum=None):
     return a
 
 
+def draw_dropout(p, training):
+    """(p, seed) of a counter-based in-kernel dropout: p forced to 0 outside training, the seed
+    drawn from torch's CPU generator (no device sync; torch.manual_seed makes it reproducible)"""
+    p = float(p) if training else 0.0
+    return (p, int(torch.empty((), dtype=torch.int64).random_().item()) if p > 0 else 0)
+
+
 class _TripletAttention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, fused, mask3, L):
+    def forward(ctx, fused, mask3, L, dropout=(0.0, 0)):
         _dev(fused, mask3)
         fused = fused.contiguous()
         B, N = fused.shape[0], fused.shape[1]
         assert fused.shape == (B, N, N, L.width), (fused.shape, L.width)
         out = torch.empty(B, N, N, 2 * L.C, dtype=fused.dtype, device=fused.device)
-        a = _tri_args(fused, mask3, out, L)
+        a = _tri_args(fused, mask3, out, L, dropout=dropout)
         _call('tgt_triplet_attention_fwd', _lib.lib().tgt_triplet_attention_fwd, a)
         ctx.save_for_backward(fused, mask3, out)
-        ctx.L = L
+        ctx.L, ctx.dropout = L, dropout
         return out
 
     @staticmethod
@@ -138,16 +146,20 @@ class _TripletAttention(torch.autograd.Function):
         d_fused = torch.empty_like(fused)          # every used column is written by the kernel
         if ctx.L.width > ctx.L.used:
             d_fused[..., ctx.L.used:] = 0
-        a = _tri_args(fused, mask3, out, ctx.L, d_out, d_fused)
+        a = _tri_args(fused, mask3, out, ctx.L, d_out, d_fused, dropout=ctx.dropout)
         _call('tgt_triplet_attention_bwd', _lib.lib().tgt_triplet_attention_bwd, a)
-        return d_fused, None, None
+        return d_fused, None, None, None
 
 
-def triplet_attention(fused, mask3, layout):
+def triplet_attention(fused, mask3, layout, dropout=(0.0, 0)):
     """fused: (B,N,N,layout.width) fused projections (head-major Q/K/V), mask3:
     (B,N,N) float32.  Returns Va (B,N,N,2C) with channel = dir*C + h*D + d.
+    dropout: (p, seed) of the attention dropout on the gated weights (draw_dropout).
     Reference arithmetic: lib/tgt/layers/triplet.py:213-246."""
-    return _TripletAttention.apply(fused, mask3, layout)
+    if dropout[0] > 0 and fused.shape[1] > 32 and fused.dtype == torch.bfloat16:
+        # the one combination the bf16 kernels refuse (two node tiles + dropout): fp32 rows for this call
+        return _TripletAttention.apply(fused.float(), mask3, layout, dropout).to(fused.dtype)
+    return _TripletAttention.apply(fused, mask3, layout, dropout)
 
 
 _colsum_ws = {}
@@ -235,6 +247,21 @@ def _proj_fused_ok(x, N, L, cd):
             cd in (torch.bfloat16, torch.float16) and L.C in (64, 128, 256))
 
 
+class _FuseRowsOnly(torch.autograd.Function):
+    """(weight, bias) of a fused projection as differentiable tensors (the rare paths that cannot
+    use the one-node projection + kernel functions)"""
+
+    @staticmethod
+    def forward(ctx, table, cd, *params):
+        ctx.save_for_backward(*params)
+        ctx.table = table
+        return _fuse_params(table, params, cd)
+
+    @staticmethod
+    def backward(ctx, dw, db):
+        return (None, None, *_unfuse_grads(ctx.table, ctx.saved_tensors, dw.float(), db.float()))
+
+
 class _ProjectedTripletAttention(torch.autograd.Function):
     """fused projection GEMM + triplet attention core as ONE autograd node, so that the backward
     kernel can hand the projection its bias gradient (column sums of d_fused, accumulated while
@@ -243,12 +270,12 @@ class _ProjectedTripletAttention(torch.autograd.Function):
     parameters (w0, b0, w1, b1, ...), fused/unfused here with one launch each way."""
 
     @staticmethod
-    def forward(ctx, x, mask3, L, cd, table, *wb):
+    def forward(ctx, x, mask3, L, cd, table, dropout, *wb):
         _dev(x, mask3)
         B, N = x.shape[0], x.shape[1]
         weight, bias = wb if table is None else _fuse_params(table, wb, cd)
         out = torch.empty(B, N, N, 2 * L.C, dtype=cd, device=x.device)
-        if _proj_fused_ok(x, N, L, cd):
+        if dropout[0] == 0 and _proj_fused_ok(x, N, L, cd):
             # Q/K/V projected inside the attention kernel (it still writes them once, for the
             # backward); only the narrow E/G third-arm projection stays a library GEMM, written
             # straight into its columns of the fused row
@@ -265,10 +292,10 @@ class _ProjectedTripletAttention(torch.autograd.Function):
             _prof_end('tgt_triplet_attention_fwd', s0, s1)
         else:
             x2, w, fused = _linear_forward(x, weight, bias, cd)
-            a = _tri_args(fused, mask3, out, L)
+            a = _tri_args(fused, mask3, out, L, dropout=dropout)
             _call('tgt_triplet_attention_fwd', _lib.lib().tgt_triplet_attention_fwd, a)
         ctx.save_for_backward(x2, w, fused, mask3, out, *(wb if table is not None else ()))
-        ctx.L, ctx.table = L, table
+        ctx.L, ctx.table, ctx.dropout = L, table, dropout
         ctx.meta = (x.shape, x.dtype, weight.dtype, bias.dtype)
         return out
 
@@ -283,29 +310,33 @@ class _ProjectedTripletAttention(torch.autograd.Function):
         if L.width > L.used:
             d_fused[..., L.used:] = 0
         colsum = _colsum_workspace(fused.shape[0], L.width, fused.device)
-        a = _tri_args(fused, mask3, out, L, d_out, d_fused, colsum)
+        a = _tri_args(fused, mask3, out, L, d_out, d_fused, colsum, dropout=ctx.dropout)
         _call('tgt_triplet_attention_bwd', _lib.lib().tgt_triplet_attention_bwd, a)
-        need_p = any(ctx.needs_input_grad[5:])
+        need_p = any(ctx.needs_input_grad[6:])
         db = sum_rows(colsum) if need_p else None
         dx, dw, _ = _linear_backward(x2, w, d_fused.view(-1, L.width), xs, xdt, torch.float32, None,
                                      ctx.needs_input_grad[0], need_p, False)
         if not need_p:
-            return (dx, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 5)
+            return (dx, None, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 6)
         if table is None:
-            return dx, None, None, None, None, dw.to(wdt), db.to(bdt)
-        return (dx, None, None, None, None, *_unfuse_grads(table, params, dw, db))
+            return dx, None, None, None, None, None, dw.to(wdt), db.to(bdt)
+        return (dx, None, None, None, None, None, *_unfuse_grads(table, params, dw, db))
 
 
-def projected_triplet_attention(x, weight, bias, mask3, layout, table=None):
+def projected_triplet_attention(x, weight, bias, mask3, layout, table=None, dropout=(0.0, 0)):
     """triplet_attention(linear(x, weight, bias), mask3, layout) with the bias gradient of the
     projection produced inside the backward kernel.  weight/bias: the fused (layout.width, C)
     projection in kernel order (see TripletLayout) -- or, with a ParamTable, `weight` is the
     tuple of the module's nn.Linear parameters (w0, b0, w1, b1, ...) and bias is None."""
     if os.environ.get('TGT_TRI_COLSUM', '1') == '0' and table is None:      # A/B knob: separate bias-gradient pass
-        return triplet_attention(linear(x, weight, bias), mask3, layout)
+        return triplet_attention(linear(x, weight, bias), mask3, layout, dropout)
     cd = torch.get_autocast_dtype('cuda') if (x.is_cuda and torch.is_autocast_enabled('cuda')) else x.dtype
+    if dropout[0] > 0 and x.shape[1] > 32 and cd == torch.bfloat16:          # see triplet_attention()
+        if table is not None:
+            weight, bias = _FuseRowsOnly.apply(table, cd, *weight)
+        return triplet_attention(linear(x, weight, bias), mask3, layout, dropout)
     wb = (weight, bias) if table is None else tuple(weight)
-    return _ProjectedTripletAttention.apply(x, mask3, layout, cd, table, *wb)
+    return _ProjectedTripletAttention.apply(x, mask3, layout, cd, table, dropout, *wb)
 
 
 # ---------------------------------------------------------------------------
@@ -330,7 +361,7 @@ class AggregateLayout:
         self.width = -(-self.used // 8) * 8
 
 
-def _agg_args(fused, mask3, out, L, d_out=None, d_fused=None):
+def _agg_args(fused, mask3, out, L, d_out=None, d_fused=None, dropout=(0.0, 0)):
     B, N = fused.shape[0], fused.shape[1]
     a = _lib.TripletAggregateArgs()
     a.B, a.N, a.H, a.D = B, N, L.H, L.D
@@ -345,6 +376,7 @@ def _agg_args(fused, mask3, out, L, d_out=None, d_fused=None):
     a.mask = mask3.data_ptr()
     a.out, a.ld_out = out.data_ptr(), 2 * L.C
     a.o_off = _pair(C.c_int32, 0, L.C)
+    a.dropout_p, a.dropout_seed = float(dropout[0]), int(dropout[1]) & 0xFFFFFFFFFFFFFFFF
     if d_out is not None:
         a.d_out = d_out.data_ptr()
         dp = d_fused.data_ptr()
@@ -355,16 +387,16 @@ def _agg_args(fused, mask3, out, L, d_out=None, d_fused=None):
 
 class _TripletAggregate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, fused, mask3, L):
+    def forward(ctx, fused, mask3, L, dropout=(0.0, 0)):
         _dev(fused, mask3)
         fused = fused.contiguous()
         B, N = fused.shape[0], fused.shape[1]
         assert fused.shape == (B, N, N, L.width), (fused.shape, L.width)
         out = torch.empty(B, N, N, 2 * L.C, dtype=fused.dtype, device=fused.device)
-        a = _agg_args(fused, mask3, out, L)
+        a = _agg_args(fused, mask3, out, L, dropout=dropout)
         _call('tgt_triplet_aggregate_fwd', _lib.lib().tgt_triplet_aggregate_fwd, a)
         ctx.save_for_backward(fused, mask3, out)
-        ctx.L = L
+        ctx.L, ctx.dropout = L, dropout
         return out
 
     @staticmethod
@@ -374,14 +406,14 @@ class _TripletAggregate(torch.autograd.Function):
         d_fused = torch.empty_like(fused)
         if ctx.L.width > ctx.L.used:
             d_fused[..., ctx.L.used:] = 0
-        a = _agg_args(fused, mask3, out, ctx.L, d_out, d_fused)
+        a = _agg_args(fused, mask3, out, ctx.L, d_out, d_fused, dropout=ctx.dropout)
         _call('tgt_triplet_aggregate_bwd', _lib.lib().tgt_triplet_aggregate_bwd, a)
-        return d_fused, None, None
+        return d_fused, None, None, None
 
 
-def triplet_aggregate(fused, mask3, layout):
-    """Reference arithmetic: lib/tgt/layers/triplet.py:56-70 / :107-123."""
-    return _TripletAggregate.apply(fused, mask3, layout)
+def triplet_aggregate(fused, mask3, layout, dropout=(0.0, 0)):
+    """Reference arithmetic: lib/tgt/layers/triplet.py:56-70 / :107-123; dropout as triplet_attention."""
+    return _TripletAggregate.apply(fused, mask3, layout, dropout)
 
 
 # ---------------------------------------------------------------------------

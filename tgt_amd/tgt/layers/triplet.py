@@ -34,13 +34,6 @@ class LayerNorm(nn.LayerNorm):
         return ops.layer_norm(x, self.weight, self.bias, self.eps)
 
 
-def _no_attention_dropout(mod):
-    if mod.attention_dropout > 0 and mod.training:
-        raise NotImplementedError(
-            'attention_dropout > 0 inside the fused triplet kernels is not implemented '
-            '(0 in every shipped config: lib/training_schemes/pcqm/tgt_training.py:35)')
-
-
 class _TripletBase(nn.Module):
     def __init__(self, edge_width, num_heads, attention_dropout=0):
         super().__init__()
@@ -119,10 +112,10 @@ class TripletAttention(_TripletBase):
 
     def forward_normed(self, x, mask):
         """the block after tri_ln_e (TGT_Layer fuses that LayerNorm with the residual add before it)"""
-        _no_attention_dropout(self)
         B, N = x.shape[0], x.shape[1]
         va = ops.projected_triplet_attention(x, self._projection_params(), None, ops.as_mask3(mask, B, N),
-                                             self._layout, table=self._table)
+                                             self._layout, table=self._table,
+                                             dropout=ops.draw_dropout(self.attention_dropout, self.training))
         return self._out_proj(va)
 
 
@@ -161,11 +154,11 @@ class TripletAggregate(_TripletBase):
         return self.forward_normed(self.tri_ln_e(e), mask)
 
     def forward_normed(self, x, mask):
-        _no_attention_dropout(self)
         B, N = x.shape[0], x.shape[1]
         lin_b = self.lin_EG if self.gated else self.lin_E
         fused = ops.fused_linear(x, self._table, (self.lin_V.weight, self.lin_V.bias, lin_b.weight, lin_b.bias))
-        va = ops.triplet_aggregate(fused, ops.as_mask3(mask, B, N), self._layout)
+        va = ops.triplet_aggregate(fused, ops.as_mask3(mask, B, N), self._layout,
+                                   ops.draw_dropout(self.attention_dropout, self.training))
         return self._out_proj(va)
 
 
