@@ -11,7 +11,10 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtgt_hip.so')
 CSRC = os.path.join(_HERE, 'csrc')
-SOURCES = ['capi.hip', 'params.hip', 'triplet_attention_proj.hip', 'triplet_attention.hip', 'triplet_aggregate.hip', 'node_attention.hip', 'layernorm.hip', 'triangular_update.hip', 'elementwise.hip']
+# (source, extra flags, object suffix): the triplet attention kernels compile one dtype per translation unit
+SOURCES = ['capi.hip', 'params.hip', 'triplet_attention_proj.hip',
+           ('triplet_attention.hip', ['-DTGT_TRI_INST=9'], '.f32'), ('triplet_attention.hip', ['-DTGT_TRI_INST=2'], '.bf16'),
+           ('triplet_attention.hip', ['-DTGT_TRI_INST=4'], '.f16'), 'triplet_aggregate.hip', 'node_attention.hip', 'layernorm.hip', 'triangular_update.hip', 'elementwise.hip']
 ABI_VERSION = 12
 
 TGT_F32, TGT_BF16, TGT_F16 = 0, 1, 2
@@ -101,7 +104,8 @@ _lib = None
 
 def build_library(force=False, verbose=False):
     """hipcc -> tgt_amd/libtgt_hip.so (gfx950).  Cross-compiles without a GPU."""
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    units = [(s, [], '') if isinstance(s, str) else s for s in SOURCES]
+    srcs = [os.path.join(CSRC, u[0]) for u in units]
     deps = srcs + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith('.hpp')] + \
         [os.path.join(os.path.dirname(_HERE), 'include', 'tgt_hip.h')]
     if not force and os.path.exists(LIB_PATH) and \
@@ -111,10 +115,10 @@ def build_library(force=False, verbose=False):
     objs = []
     procs = []
     os.makedirs(os.path.join(_HERE, 'build'), exist_ok=True)
-    for s in srcs:
-        o = os.path.join(_HERE, 'build', os.path.basename(s) + '.o')
+    for s, (_, flags, suffix) in zip(srcs, units):
+        o = os.path.join(_HERE, 'build', os.path.basename(s) + suffix + '.o')
         objs.append(o)
-        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', s, '-o', o]
+        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', *flags, '-c', s, '-o', o]
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for cmd, p in procs:
         out, _ = p.communicate()

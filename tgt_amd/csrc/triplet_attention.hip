@@ -571,6 +571,26 @@ static int dispatch_d(const tgt_triplet_attention_args& a, bool bwd, hipStream_t
     }
 }
 
+// The three dtypes are separate translation units in the build (TGT_TRI_INST: bit 0 fp32, bit 1
+// bf16, bit 2 fp16, bit 3 the argument checks + dispatch) so that they compile in parallel; one
+// TU with everything when the macro is not given.
+#ifndef TGT_TRI_INST
+#define TGT_TRI_INST 15
+#endif
+int tri_att_run_f32(const tgt_triplet_attention_args& a, bool bwd, hipStream_t st);
+int tri_att_run_bf16(const tgt_triplet_attention_args& a, bool bwd, hipStream_t st);
+int tri_att_run_f16(const tgt_triplet_attention_args& a, bool bwd, hipStream_t st);
+#if TGT_TRI_INST & 1
+int tri_att_run_f32(const tgt_triplet_attention_args& a, bool bwd, hipStream_t st) { return dispatch_d<float>(a, bwd, st); }
+#endif
+#if TGT_TRI_INST & 2
+int tri_att_run_bf16(const tgt_triplet_attention_args& a, bool bwd, hipStream_t st) { return dispatch_d<bf16_t>(a, bwd, st); }
+#endif
+#if TGT_TRI_INST & 4
+int tri_att_run_f16(const tgt_triplet_attention_args& a, bool bwd, hipStream_t st) { return dispatch_d<f16_t>(a, bwd, st); }
+#endif
+
+#if TGT_TRI_INST & 8
 int triplet_attention_run(const tgt_triplet_attention_args* a, bool bwd, hipStream_t st) {
     if (!a) return set_error(TGT_ERR_INVALID, "triplet attention: null args");
     if (a->B < 0 || a->N < 0 || a->H <= 0) return set_error(TGT_ERR_INVALID, "triplet attention: bad sizes B=%d N=%d H=%d", a->B, a->N, a->H);
@@ -599,11 +619,12 @@ int triplet_attention_run(const tgt_triplet_attention_args* a, bool bwd, hipStre
         }
     }
     switch (a->dtype) {
-        case TGT_F32: return dispatch_d<float>(*a, bwd, st);
-        case TGT_BF16: return dispatch_d<bf16_t>(*a, bwd, st);
-        case TGT_F16: return dispatch_d<f16_t>(*a, bwd, st);
+        case TGT_F32: return tri_att_run_f32(*a, bwd, st);
+        case TGT_BF16: return tri_att_run_bf16(*a, bwd, st);
+        case TGT_F16: return tri_att_run_f16(*a, bwd, st);
         default: return set_error(TGT_ERR_INVALID, "triplet attention: bad dtype %d", a->dtype);
     }
 }
+#endif
 
 }  // namespace tgt
