@@ -30,8 +30,8 @@
 // switching parts off: skeleton (core + LDS + barriers) 0.24, + projection MFMAs 0.35, + Q/K/V/O
 // stores 0.17, + tile loads 0.10 -- the phases add up instead of overlapping: the 128 VGPRs of
 // resident weights leave 2 waves/SIMD in ONE workgroup per CU, all meeting at the same
-// barrier.  Next: 4-head workgroups (two independent workgroups per CU, single-buffered tile),
-// or wave-specialised producer/consumer roles.  See DESIGN.md section 4.1a.
+// barrier.  4-head workgroups (two per CU, single-buffered tile) measured slower still (1.11 vs
+// 0.92 ms on one box).  Next: wave-specialised producer/consumer roles.  See DESIGN.md section 4.1a.
 #include <cstdlib>
 #include "triplet_common.hpp"
 
