@@ -15,6 +15,7 @@
 // visits (grid-stride); a workgroup folds its partials through LDS and writes
 // ONE row of a (parts, 2C) fp32 buffer; a second tiny kernel sums the parts in
 // a fixed order (deterministic, no atomics).
+#include <cstdlib>
 #include "common.hpp"
 
 namespace tgt {
@@ -331,7 +332,10 @@ static int ln_launch(const LnArgs& a, bool bwd, float* dgamma, float* dbeta, hip
     constexpr int RPW = 64 / LPR;
     int64_t blocks = (a.rows + 4 * RPW - 1) / (4 * RPW);
     if (!bwd) {
-        if (blocks > 4096) blocks = 4096;
+        // grid-stride over at most 4096 workgroups: swept 1024..32768 on MI355X (tools/kernel_bench.py --only ln);
+        // smaller grids lose parallelism, larger ones pay the per-workgroup gamma/beta loads (uncapped: 4x slower)
+        static const int64_t cap = getenv("TGT_LN_GRID_CAP") ? atoll(getenv("TGT_LN_GRID_CAP")) : 4096;
+        if (blocks > cap) blocks = cap;
         hipLaunchKernelGGL((ln_fwd_kernel<LPR, VPL>), dim3((unsigned)blocks), dim3(256), 0, st, a);
         return check_launch("ln_fwd_kernel");
     }

@@ -128,6 +128,13 @@ def main():
         out['ln_fwd_edge'] = dict(ms=round(t, 4), GBs=round(2 * x.numel() * esz / t / 1e6, 1))
         t2 = timeit(lambda: torch.autograd.grad(ops.layer_norm(x, w, b, 1e-5, dt), [x, w, b], g), a.iters)
         out['ln_bwd_edge'] = dict(ms=round(t2 - t, 4), GBs=round(3 * x.numel() * esz / (t2 - t) / 1e6, 1))
+        res = torch.randn(B, N, N, C, device=dev, dtype=dt)
+        x4 = x.detach().view(B, N, N, C)
+        sc = torch.ones(B, device=dev)
+        t = timeit(lambda: ops.add_layer_norm(x4, res, sc, w, b, 1e-5, dt), a.iters)
+        out['add_ln_fwd_edge'] = dict(ms=round(t, 4), GBs=round(4 * x.numel() * esz / t / 1e6, 1))
+        t = timeit(lambda: ops.gelu_dropout(x4, 0.1, True), a.iters)
+        out['gelu_dropout_fwd'] = dict(ms=round(t, 4), GBs=round(2 * x.numel() * esz / t / 1e6, 1))
     print(json.dumps(out))
 
 
