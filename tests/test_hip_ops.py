@@ -579,6 +579,59 @@ def test_linear_bias_gradient_from_layer_norm_backward(dtype, with_scale, permut
     assert float((b1.double() - want).abs().max()) / scale_ < (1e-6 if dtype == torch.float32 else 4e-3)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_fused_parameter_plumbing(dtype):
+    """tgt_fuse_rows / tgt_unfuse_rows / tgt_permute_cols against plain index arithmetic: the
+    kernel-order projection assembled from separate nn.Linear parameters, and the gradients sent
+    back to each of them (autocast-like: fp32 parameters, `dtype` compute)."""
+    from tgt_amd import ops
+    rng = np.random.default_rng(31)
+    K, rows = 64, (48, 40, 8, 8)
+    ws = [rnd(rng, r, K).float().cuda() for r in rows]
+    bs = [rnd(rng, r).float().cuda() for r in rows]
+    # fused row order: a permutation of source 0, source 1 reversed, sources 2 and 3 as they are, 3 zero rows
+    perm0 = torch.randperm(rows[0], generator=torch.Generator().manual_seed(2))
+    src = torch.cat([torch.full((rows[0],), 0), torch.full((rows[1],), 1), torch.full((rows[2],), 2), torch.full((rows[3],), 3),
+                     torch.full((3,), -1)]).int()
+    idx = torch.cat([perm0, torch.arange(rows[1] - 1, -1, -1), torch.arange(rows[2]), torch.arange(rows[3]), torch.zeros(3, dtype=torch.long)]).int()
+    table = ops.ParamTable(src, idx, K, 4)
+    x = rnd(rng, 5, 7, 7, K).to(dtype).cuda().requires_grad_(True)
+    dy = rnd(rng, 5, 7, 7, int(src.numel())).to(dtype).cuda()
+
+    def ref(params):
+        w = torch.cat([params[0][perm0.cuda()], params[2].flip(0), params[4], params[6], params[0].new_zeros(3, K)])
+        b = torch.cat([params[1][perm0.cuda()], params[3].flip(0), params[5], params[7], params[1].new_zeros(3)])
+        return torch.nn.functional.linear(x.float(), w, b)
+
+    p_ref = [t.clone().requires_grad_(True) for pair in zip(ws, bs) for t in pair]
+    p_hip = [t.clone().requires_grad_(True) for pair in zip(ws, bs) for t in pair]
+    y_ref = ref(p_ref)
+    g_ref = torch.autograd.grad(y_ref, [x] + p_ref, dy.float())
+    with torch.autocast('cuda', dtype=dtype, enabled=dtype != torch.float32):
+        y = ops.fused_linear(x, table, p_hip)
+    g = torch.autograd.grad(y, [x] + p_hip, dy)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert y.dtype == dtype and rel(y, y_ref) < tol
+    for a, b_, name in zip(g, g_ref, ['dx'] + [f'd{k}{i}' for i in range(4) for k in 'wb']):
+        assert a.dtype == (dtype if name == 'dx' else torch.float32), name
+        assert rel(a, b_) < 2 * tol, (name, rel(a, b_))
+
+    # column-permuted linear (lin_O on the kernels' [dir][h][d] channel order)
+    cperm = torch.randperm(K, generator=torch.Generator().manual_seed(3))
+    inv = torch.empty_like(cperm)
+    inv[cperm] = torch.arange(K)
+    W = rnd(rng, 24, K).float().cuda()
+    b2 = rnd(rng, 24).float().cuda()
+    Wr, Wh = W.clone().requires_grad_(True), W.clone().requires_grad_(True)
+    dy2 = rnd(rng, 5, 7, 7, 24).to(dtype).cuda()
+    y_ref = torch.nn.functional.linear(x.float(), Wr[:, cperm.cuda()], b2)
+    gw_ref, = torch.autograd.grad(y_ref, Wr, dy2.float())
+    with torch.autocast('cuda', dtype=dtype, enabled=dtype != torch.float32):
+        y = ops.linear_permuted_cols(x, Wh, b2, cperm.int().cuda(), inv.int().cuda())
+    gw, = torch.autograd.grad(y, Wh, dy2)
+    assert rel(y, y_ref) < tol and rel(gw, gw_ref) < 2 * tol and gw.dtype == torch.float32
+
+
 @pytest.mark.parametrize('N', [1, 2])
 def test_tiny_graphs(N):
     """single-node and two-node graphs through every kernel (degenerate softmax rows)"""
