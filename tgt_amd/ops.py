@@ -1059,6 +1059,7 @@ class _AddLayerNorm(torch.autograd.Function):
 
 
 _side_streams = {}
+_main_streams = {}          # the stream the side stream was last forked from, per device
 
 
 class side_stream:
@@ -1075,6 +1076,7 @@ class side_stream:
         if self.active:
             dev = inputs[0].device
             self.main = torch.cuda.current_stream(dev)
+            _main_streams[dev] = self.main
             if dev not in _side_streams:
                 _side_streams[dev] = torch.cuda.Stream(dev)
             self.side = _side_streams[dev]
@@ -1102,11 +1104,15 @@ class side_stream:
 
 
 def wait_side_streams(device=None):
-    """make the current stream wait for everything queued on the side streams (before reading
-    tensors -- e.g. gradients inside a hook -- that a side-stream block may have produced)"""
+    """make the current stream wait for everything queued on the side stream AND on the stream it
+    was forked from -- before reading tensors (e.g. gradients inside an autograd hook, which may
+    itself be running on either of the two) that blocks on both streams have produced"""
     for dev, st in _side_streams.items():
         if device is None or dev == device:
-            torch.cuda.current_stream(dev).wait_stream(st)
+            cur = torch.cuda.current_stream(dev)
+            for other in (st, _main_streams.get(dev)):
+                if other is not None and other != cur:
+                    cur.wait_stream(other)
 
 
 def drop_path_scale(x, drop_prob, training):
