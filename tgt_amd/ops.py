@@ -4,6 +4,7 @@ These functions are the only way the tgt_amd modules do the hot-path
 arithmetic.  They require HIP device tensors and libtgt_hip.so; there is no
 eager / CPU fallback (a missing library or a CPU tensor raises).
 """
+import contextlib
 import ctypes as C
 import os
 
@@ -1096,11 +1097,16 @@ class side_stream:
             self.ctx.__exit__(*exc)
         return False
 
+    def resume(self):
+        """context manager: more work on the side stream, ordered after what is already on it (no
+        new dependency on the current stream)"""
+        return torch.cuda.stream(self.side) if self.active else contextlib.nullcontext()
+
     def join(self, *outputs):
         if self.active:
-            self.main.wait_stream(self.side)
+            torch.cuda.current_stream(self.side.device).wait_stream(self.side)
             for t in outputs:
-                t.record_stream(self.main)
+                t.record_stream(torch.cuda.current_stream(self.side.device))
 
 
 def wait_side_streams(device=None):

@@ -2,12 +2,17 @@
 logits-only edge update, FFN, DropPath and the layer wiring.  Class names, constructor
 keywords and state_dict keys follow the reference (lib/tgt/layers/layers.py,
 lib/tgt/layers/activations.py); the arithmetic is libtgt_hip.so plus library GEMMs."""
+import contextlib
+
 import torch
 from torch import nn
 import torch.nn.functional as F
 
 from ... import ops
 from .triplet import get_triplet_layer
+
+
+_CHAIN_NODE_STREAM = __import__('os').environ.get('TGT_NODE_CHAIN', '1') != '0'      # A/B knob
 
 
 def _keep(module, **kw):
@@ -72,11 +77,24 @@ class EGT_Attention(nn.Module):
     def forward(self, h, e, mask):
         return self.forward_normed(h, self.mha_ln_e(e), mask, e)
 
-    def forward_normed(self, h, e_hat, mask, e=None):
+    def project_nodes(self, h):
+        """the node half of the block's input: lin_QKV(mha_ln_h(h)) (TGT_Layer runs it on the
+        node stream, right behind the previous layer's node FFN)"""
+        return self.lin_QKV(self.mha_ln_h(h))
+
+    def forward_normed(self, h, e_hat, mask, e=None, qkv=None):
         """the block with mha_ln_e already applied (TGT_Layer fuses that LayerNorm with the
-        residual add that closed the previous layer); e: returned as is without edge_update"""
+        residual add that closed the previous layer); e: returned as is without edge_update;
+        qkv: project_nodes(h) when the caller already has it"""
+        v_att, e = self.attend(h, e_hat, mask, e, qkv)
+        return self.lin_O_h(v_att), e
+
+    def attend(self, h, e_hat, mask, e=None, qkv=None):
+        """(V_att before lin_O_h, updated edge channels): forward_normed without the node output
+        projection, which TGT_Layer runs on the node stream together with the node FFN"""
         B, N = h.shape[0], h.shape[1]
-        qkv = self.lin_QKV(self.mha_ln_h(h))
+        if qkv is None:
+            qkv = self.project_nodes(h)
         eg = self.lin_EG(e_hat)
         mask3 = ops.as_mask3(mask, B, N)
         if self.source_dropout > 0 and self.training:
@@ -85,10 +103,9 @@ class EGT_Attention(nn.Module):
             mask3 = mask3 + ops.source_drop_mask(B, N, self.source_dropout, torch.finfo(mask.dtype).min, h.device)
         v_att, h_hat = ops.node_attention(qkv, eg, mask3, self.num_heads,
                                           self.scale_degree, self.edge_update)
-        h = self.lin_O_h(v_att)
         if self.edge_update:
             e = self.lin_O_e(h_hat)
-        return h, e
+        return v_att, e
 
 
 class EdgeUpdate(nn.Module):
@@ -109,8 +126,11 @@ class EdgeUpdate(nn.Module):
     def forward(self, h, e, mask):
         return self.forward_normed(h, self.mha_ln_e(e), mask, e)
 
-    def forward_normed(self, h, e_hat, mask, e=None):
-        qk = self.lin_QK(self.mha_ln_h(h))
+    def project_nodes(self, h):
+        return self.lin_QK(self.mha_ln_h(h))
+
+    def forward_normed(self, h, e_hat, mask, e=None, qkv=None):
+        qk = self.project_nodes(h) if qkv is None else qkv
         bias = self.lin_E(e_hat)
         return h, self.lin_O_e(ops.edge_logits(qk, bias, self.num_heads))
 
@@ -219,15 +239,27 @@ class TGT_Layer(nn.Module):
         self.drop_path = DropPath(drop_path)
 
     def forward(self, g, defer_edge=False):
-        """defer_edge: leave the closing edge residual un-added in g.e (a PendingResidual) for
-        the next layer's opening LayerNorm; TGT_Encoder resolves the last one."""
+        """defer_edge (TGT_Encoder only): leave the closing edge residual un-added in g.e (a
+        PendingResidual) for the next layer's opening LayerNorm, and leave the node stream
+        un-joined (g.node_side) so that the next layer's node projection follows this layer's node
+        FFN on it; TGT_Encoder resolves both after the last layer."""
         h, e, mask = g.h, g.e, g.mask
+        side = g.get('node_side')            # h was produced on the node stream and is not joined yet
+        qkv = None
+        if side is not None:
+            with side.resume():
+                qkv = self.update.project_nodes(h)
         if isinstance(e, PendingResidual):
             e, e_hat = e.enter(self.update.mha_ln_e)
         else:
             e_hat = self.update.mha_ln_e(e)
+        if side is not None:
+            side.join(h, qkv)
         h_in, e_in = h, e
-        h, e = self.update.forward_normed(h, e_hat, mask, e)
+        if self.node_update:
+            v_att, e = self.update.attend(h, e_hat, mask, e, qkv)      # lin_O_h follows on the node stream
+        else:
+            h, e = self.update.forward_normed(h, e_hat, mask, e, qkv)
         # Each residual add is fused with the LayerNorm that opens the next sub-block
         # (s = res + DropPath(x); y = LN(s) in one pass, and one pass in the backward).
         dp, tr = self.drop_path.drop_path, self.training
@@ -239,12 +271,9 @@ class TGT_Layer(nn.Module):
         if self.node_update:
             # the node FFN (a dozen latency-bound launches on 8192 rows) runs under the edge
             # kernels of this layer on a second stream; joined before the layer returns
-            node_side = ops.side_stream(h, h_in) if self.edge_update else None
-            if node_side is not None:
-                with node_side:
-                    h, x = enter(h, h_in, self.node_ffn.ffn_ln)
-                    h = ops.drop_path_add_(self.node_ffn.forward_normed(x), h, dp, tr)
-            else:
+            node_side = ops.side_stream(v_att, h_in) if self.edge_update else None
+            with (node_side if node_side is not None else contextlib.nullcontext()):
+                h = self.update.lin_O_h(v_att)
                 h, x = enter(h, h_in, self.node_ffn.ffn_ln)
                 h = ops.drop_path_add_(self.node_ffn.forward_normed(x), h, dp, tr)
         if self.edge_update:
@@ -255,9 +284,13 @@ class TGT_Layer(nn.Module):
                 e, x = enter(e, e_in, self.edge_ffn.ffn_ln)
             closing = PendingResidual(self.edge_ffn.forward_normed(x), e, ops.drop_path_scale(x, dp, tr))
             e = closing if defer_edge else closing.materialize()
-        if node_side is not None:
-            node_side.join(h)
         g = g.copy()
+        g.pop('node_side', None)
+        if node_side is not None:
+            if defer_edge and _CHAIN_NODE_STREAM:
+                g['node_side'] = node_side       # joined by the next layer (or TGT_Encoder)
+            else:
+                node_side.join(h)
         g.h, g.e = h, e
         return g
 

@@ -74,4 +74,7 @@ class TGT_Encoder(nn.Module):
             graph = self.apply_layer(idx, graph, defer_edge=_DEFER_EDGE)
         if isinstance(graph.e, PendingResidual):
             graph.e = graph.e.materialize()
+        side = graph.pop('node_side', None)
+        if side is not None:
+            side.join(graph.h)
         return graph
