@@ -95,6 +95,12 @@ typedef struct tgt_triplet_attention_args {
     float    dropout_p;
     uint32_t _pad1;
     uint64_t dropout_seed;
+    /* backward, optional: row length of the gradient buffers when it differs from the sources'
+     * (0 = ld_qkv / ld_eg).  d_qkv / d_eg then use the same channel offsets inside rows of this
+     * length, and d_qkv_colsum / d_eg_colsum are (B, ld_dqkv) / (B, ld_deg).  Lets the forward keep
+     * Q/K/V (1536 channels: six full 256-wide GEMM tile columns) and E/G in two tensors while the
+     * backward writes ONE fused gradient row for a single data/weight-gradient GEMM. */
+    int64_t  ld_dqkv[2], ld_deg[2];
 } tgt_triplet_attention_args;
 
 int tgt_triplet_attention_fwd(const tgt_triplet_attention_args* a, void* stream);

@@ -192,6 +192,38 @@ def test_triplet_attention_dropout(case, dtype, variant):
     assert rel(g1[1][:L.used], g0[1][:L.used]) < (1e-5 if dtype == torch.float32 else 2e-2)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', [CASES[1], CASES[2], CASES[5], CASES[7]])
+@pytest.mark.parametrize('variant', ['gated', 'ungated'])
+def test_split_projection_matches_fused(case, dtype, variant, monkeypatch):
+    """Q/K/V and E/G projected into two tensors by two GEMMs (what the training step does at
+    BASELINE size) with ONE fused gradient row in the backward (ld_dqkv / ld_deg): same outputs and
+    gradients as the single fused projection."""
+    from tgt_amd import ops
+    B, N, nn_, C, H = case
+    L = ops.TripletLayout(C, H, gated=variant == 'gated', biased=True)
+    if L.width != L.used or (L.used - 6 * C) % 8:
+        pytest.skip('layout not eligible for the split projection')
+    rng = np.random.default_rng(5 + hash((B, N, C, H)) % 1000)
+    x = rnd(rng, B, N, N, C).to(dtype).cuda()
+    w = (rnd(rng, L.width, C) * C ** -0.5).to(dtype).cuda()
+    b = (rnd(rng, L.width) * 0.1).to(dtype).cuda()
+    d_out = rnd(rng, B, N, N, 2 * C).to(dtype).cuda()
+    mask = gu.additive_mask(nn_, N, torch.float32).reshape(B, N, N).cuda()
+    res = {}
+    for split in (False, True):
+        monkeypatch.setattr(ops, '_SPLIT_MIN_ROWS', 0 if split else 1 << 60)
+        ins = [t.clone().requires_grad_(True) for t in (x, w, b)]
+        y = ops.projected_triplet_attention(*ins, mask, L)
+        assert ops._split_projection_ok(ins[0], L) == split
+        y.backward(d_out)
+        res[split] = (y, *[t.grad for t in ins])
+    tol = TOL[dtype]
+    for a_, b_, name in zip(res[True], res[False], ('y', 'dx', 'dw', 'db')):
+        assert torch.isfinite(a_).all(), name
+        assert rel(a_, b_) < 2 * tol, (name, rel(a_, b_))
+
+
 @pytest.mark.parametrize('name', ['attention', 'attention_ungated', 'axial_attention', 'aggregate', 'aggregate_ungated'])
 def test_triplet_modules_take_attention_dropout(name):
     """module API (reference triplet.py:23, :180: attention_dropout kwarg): active in training only,

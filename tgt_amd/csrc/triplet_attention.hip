@@ -220,11 +220,18 @@ __global__ void __launch_bounds__(HG * 64, OCC) tri_att_bwd_kernel(const tgt_tri
     const SlabSrc dO = {reinterpret_cast<const char*>(a.d_out) +
                             ((int64_t)c.b * Nl * Nl * a.ld_out + a.o_off[c.dir] + c.g * HG * D) * sz,
                         Nl * a.ld_out * sz, a.ld_out * sz};
-    // gradient slabs mirror the source slabs inside d_qkv
-    const int64_t shift = reinterpret_cast<const char*>(a.d_qkv[c.dir]) - reinterpret_cast<const char*>(a.qkv[c.dir]);
-    char* dq_base = const_cast<char*>(c.q.base) + shift;
-    const SlabSrc dK = {c.k.base + shift, c.k.row_stride, c.k.j_stride};
-    const SlabSrc dV = {c.v.base + shift, c.v.row_stride, c.v.j_stride};
+    // gradient slabs mirror the source slabs (same channel offsets) inside d_qkv, whose rows may be
+    // longer than the sources' (ld_dqkv: one fused gradient row for the projection's GEMMs)
+    const int64_t ldq = a.ld_dqkv[c.dir] ? a.ld_dqkv[c.dir] : a.ld_qkv[c.dir];
+    const int64_t lde = a.ld_deg[c.dir] ? a.ld_deg[c.dir] : a.ld_eg[c.dir];
+    char* dbase = reinterpret_cast<char*>(a.d_qkv[c.dir]) + ((int64_t)c.b * Nl * Nl * ldq + c.g * HG * D) * sz;
+    char* dq_base = dbase + (int64_t)a.q_off[c.dir] * sz;
+    const int64_t dq_row = Nl * ldq * sz, dq_j = ldq * sz;
+    const SlabSrc dK = {dbase + (int64_t)a.k_off[c.dir] * sz, c.dir == 0 ? ldq * sz : Nl * ldq * sz,
+                        c.dir == 0 ? Nl * ldq * sz : ldq * sz};
+    const SlabSrc dV = {dbase + (int64_t)a.v_off[c.dir] * sz, dK.row_stride, dK.j_stride};
+    ThirdArm dta = ta;                      // third-arm gradient rows
+    dta.ld = lde;
 
     // optional per-graph column sums of dQ/dK/dV and dE/dG (= bias gradients of the projection):
     // per-thread fp32 accumulators (3 planes: dQ, dK, dV) in LDS behind the slab sets
@@ -424,7 +431,7 @@ __global__ void __launch_bounds__(HG * 64, OCC) tri_att_bwd_kernel(const tgt_tri
             __syncthreads();
             bool plain = true;
             if constexpr (CS) {
-                slab_store_sum<G, 32, T, false>(sQ, pq, dq_base, c.q.row_stride, c.q.j_stride, j, i0, N, tid, cs);
+                slab_store_sum<G, 32, T, false>(sQ, pq, dq_base, dq_row, dq_j, j, i0, N, tid, cs);
                 if constexpr (NT > 1) {
                     if (it > 0) {
                         plain = false;
@@ -437,7 +444,7 @@ __global__ void __launch_bounds__(HG * 64, OCC) tri_att_bwd_kernel(const tgt_tri
                     slab_store_sum<G, KR, T, false>(sV, pv, const_cast<char*>(dV.base), dV.row_stride, dV.j_stride, j, 0, N, tid, cs + 2 * kPlane);
                 }
             } else {
-                slab_store<G, 32>(sQ, dq_base, c.q.row_stride, c.q.j_stride, j, i0, N, tid);
+                slab_store<G, 32>(sQ, dq_base, dq_row, dq_j, j, i0, N, tid);
                 if constexpr (NT > 1) {
                     if (it > 0) {
                         plain = false;
@@ -463,14 +470,14 @@ __global__ void __launch_bounds__(HG * 64, OCC) tri_att_bwd_kernel(const tgt_tri
         }
         __syncthreads();
         {
-            const float part = arm_stage_store_grad<T, HG, NT>(ta, a.d_eg[c.dir], c.b, c.dir, c.g, N, i0, smem, tid);
+            const float part = arm_stage_store_grad<T, HG, NT>(dta, a.d_eg[c.dir], c.b, c.dir, c.g, N, i0, smem, tid);
             if constexpr (CS) cs[3 * kPlane + tid] += part;
         }
         __syncthreads();
     }
     if constexpr (CS) {
         // (the last barrier above also ordered every wave's accumulator updates)
-        float* row = a.d_qkv_colsum[c.dir] + (int64_t)c.b * a.ld_qkv[c.dir] + c.g * HG * D;
+        float* row = a.d_qkv_colsum[c.dir] + (int64_t)c.b * ldq + c.g * HG * D;
         slab_colsum_finish<G, T>(cs, row + a.q_off[c.dir], tid);
         slab_colsum_finish<G, T>(cs + kPlane, row + a.k_off[c.dir], tid);
         slab_colsum_finish<G, T>(cs + 2 * kPlane, row + a.v_off[c.dir], tid);
@@ -479,7 +486,7 @@ __global__ void __launch_bounds__(HG * 64, OCC) tri_att_bwd_kernel(const tgt_tri
             if (tid < kVals) {      // (the barrier that ended the last pass ordered the partials)
                 float v = 0.f;
                 for (int t = tid; t < HG * 64; t += kVals) v += cs[3 * kPlane + t];
-                float* erow = a.d_eg_colsum[c.dir] + (int64_t)c.b * a.ld_eg[c.dir];
+                float* erow = a.d_eg_colsum[c.dir] + (int64_t)c.b * lde;
                 if (tid < HG) { if (biased) erow[a.e_off[c.dir] + c.g * HG + tid] = v; }
                 else if (gated) erow[a.g_off[c.dir] + c.g * HG + tid - HG] = v;
             }
@@ -613,6 +620,8 @@ int triplet_attention_run(const tgt_triplet_attention_args* a, bool bwd, hipStre
             if ((a->d_qkv_colsum[dir] != nullptr) != (a->d_qkv_colsum[0] != nullptr) ||
                 ((a->flags & (TGT_TRI_BIASED | TGT_TRI_GATED)) && (a->d_eg_colsum[dir] != nullptr) != (a->d_qkv_colsum[0] != nullptr)))
                 return set_error(TGT_ERR_INVALID, "triplet attention bwd: d_qkv_colsum / d_eg_colsum must be all set or all NULL");
+            if (a->ld_dqkv[dir] < 0 || a->ld_deg[dir] < 0 || (a->ld_dqkv[dir] * esz) % 16 || (a->ld_deg[dir] * esz) % 16)
+                return set_error(TGT_ERR_INVALID, "triplet attention bwd: ld_dqkv / ld_deg must be 0 or 16-byte-aligned row lengths");
             if (!a->d_out || !a->d_qkv[dir] || ((uintptr_t)a->d_qkv[dir] % 16) || ((uintptr_t)a->d_out % 16))
                 return set_error(TGT_ERR_INVALID, "triplet attention bwd: null/misaligned gradient tensor");
             if ((a->flags & (TGT_TRI_BIASED | TGT_TRI_GATED)) && !a->d_eg[dir]) return set_error(TGT_ERR_INVALID, "triplet attention bwd: d_eg missing");

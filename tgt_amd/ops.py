@@ -90,18 +90,24 @@ class TripletLayout:
         self.flags = (_lib.TRI_BIASED if biased else 0) | (_lib.TRI_GATED if gated else 0)
 
 
-def _tri_args(fused, mask3, out, L, d_out=None, d_fused=None, colsum=None, dropout=(0.0, 0)):
+def _tri_args(fused, mask3, out, L, d_out=None, d_fused=None, colsum=None, dropout=(0.0, 0), eg=None):
+    """eg given: `fused` holds only the Q/K/V channels (rows of 6C) and `eg` the third-arm E/G channels
+    (rows of L.used - 6C); d_fused / colsum stay ONE fused row of L.width (ld_dqkv / ld_deg)."""
     B, N = fused.shape[0], fused.shape[1]
     a = _lib.TripletAttentionArgs()
     a.B, a.N, a.H, a.D = B, N, L.H, L.D
     a.dtype, a.flags, a.scale = _DT[fused.dtype], L.flags, float(L.D) ** -0.5
     p = fused.data_ptr()
+    split = eg is not None
+    wq = 6 * L.C if split else L.width                    # row length of the Q/K/V tensor
+    we, eo = (L.used - 6 * L.C, 6 * L.C) if split else (L.width, 0)      # E/G rows, and where they start in a fused row
     a.qkv = _pair(C.c_void_p, p, p)
-    a.ld_qkv = _pair(C.c_int64, L.width, L.width)
+    a.ld_qkv = _pair(C.c_int64, wq, wq)
     a.q_off, a.k_off, a.v_off = _pair(C.c_int32, *L.q), _pair(C.c_int32, *L.k), _pair(C.c_int32, *L.v)
-    a.eg = _pair(C.c_void_p, p, p)
-    a.ld_eg = _pair(C.c_int64, L.width, L.width)
-    a.e_off, a.g_off = _pair(C.c_int32, *L.e), _pair(C.c_int32, *L.g)
+    pe = eg.data_ptr() if split else p
+    a.eg = _pair(C.c_void_p, pe, pe)
+    a.ld_eg = _pair(C.c_int64, we, we)
+    a.e_off, a.g_off = _pair(C.c_int32, L.e[0] - eo, L.e[1] - eo), _pair(C.c_int32, L.g[0] - eo, L.g[1] - eo)
     a.mask = mask3.data_ptr()
     a.out, a.ld_out = out.data_ptr(), 2 * L.C
     a.o_off = _pair(C.c_int32, 0, L.C)
@@ -109,13 +115,17 @@ def _tri_args(fused, mask3, out, L, d_out=None, d_fused=None, colsum=None, dropo
     if d_out is not None:
         a.d_out = d_out.data_ptr()
         dp = d_fused.data_ptr()
+        esz = d_fused.element_size()
         a.d_qkv = _pair(C.c_void_p, dp, dp)
-        a.d_eg = _pair(C.c_void_p, dp, dp)
+        a.d_eg = _pair(C.c_void_p, dp + eo * esz, dp + eo * esz)
+        if split:
+            a.ld_dqkv = _pair(C.c_int64, L.width, L.width)
+            a.ld_deg = _pair(C.c_int64, L.width, L.width)
         if colsum is not None:            # (B, width) fp32: per-graph column sums of d_fused
             cp = colsum.data_ptr()
             a.d_qkv_colsum = _pair(C.c_void_p, cp, cp)
             if L.biased:
-                a.d_eg_colsum = _pair(C.c_void_p, cp, cp)
+                a.d_eg_colsum = _pair(C.c_void_p, cp + eo * 4, cp + eo * 4)
     return a
 
 
@@ -240,6 +250,17 @@ def _unfuse_grads(table, params, dW, db):
     return grads
 
 
+_SPLIT_MIN_ROWS = 65536          # below this the single GEMM is as good (tests lower it)
+
+
+def _split_projection_ok(x, L):
+    """Q/K/V and E/G projected by two GEMMs into two tensors (big inputs, biased layouts whose E/G row
+    is 16-byte aligned and unpadded); TGT_TRI_SPLIT=0: one fused GEMM (A/B knob)"""
+    nb = L.used - 6 * L.C
+    return (os.environ.get('TGT_TRI_SPLIT', '1') != '0' and L.biased and L.width == L.used and nb > 0 and nb % 8 == 0 and
+            x.numel() // L.C >= _SPLIT_MIN_ROWS)
+
+
 def _proj_fused_ok(x, N, L, cd):
     """the projection-fused forward kernel (tgt_triplet_attention_proj_fwd): opt-in with
     TGT_TRI_PROJ=1 -- correct, but in round 1 still slower than the library GEMM + attention
@@ -276,6 +297,7 @@ class _ProjectedTripletAttention(torch.autograd.Function):
         B, N = x.shape[0], x.shape[1]
         weight, bias = wb if table is None else _fuse_params(table, wb, cd)
         out = torch.empty(B, N, N, 2 * L.C, dtype=cd, device=x.device)
+        eg = None
         if dropout[0] == 0 and _proj_fused_ok(x, N, L, cd):
             # Q/K/V projected inside the attention kernel (it still writes them once, for the
             # backward); only the narrow E/G third-arm projection stays a library GEMM, written
@@ -291,27 +313,40 @@ class _ProjectedTripletAttention(torch.autograd.Function):
             _lib.check(_lib.lib().tgt_triplet_attention_proj_fwd(C.byref(a), _ptr(x2), L.C, _ptr(w), _ptr(b), _stream()),
                        'tgt_triplet_attention_proj_fwd')
             _prof_end('tgt_triplet_attention_fwd', s0, s1)
+        elif _split_projection_ok(x, L):
+            # two GEMMs: Q/K/V (6C = 1536 channels: six full 256-wide tile columns, 294 us) and the
+            # narrow E/G (39 us) instead of one ragged 1600-wide GEMM (376 us; tools/gemm_probe.py);
+            # the backward still writes ONE fused gradient row (ld_dqkv / ld_deg)
+            x2 = x.reshape(-1, L.C)
+            x2 = x2 if x2.dtype == cd else x2.to(cd)
+            w, b = _as_dtype(weight, cd), _as_dtype(bias, cd)
+            fused = torch.addmm(b[:6 * L.C], x2, w[:6 * L.C].t()).view(B, N, N, 6 * L.C)
+            eg = torch.addmm(b[6 * L.C:L.used], x2, w[6 * L.C:L.used].t()).view(B, N, N, L.used - 6 * L.C)
+            a = _tri_args(fused, mask3, out, L, dropout=dropout, eg=eg)
+            _call('tgt_triplet_attention_fwd', _lib.lib().tgt_triplet_attention_fwd, a)
         else:
             x2, w, fused = _linear_forward(x, weight, bias, cd)
             a = _tri_args(fused, mask3, out, L, dropout=dropout)
             _call('tgt_triplet_attention_fwd', _lib.lib().tgt_triplet_attention_fwd, a)
-        ctx.save_for_backward(x2, w, fused, mask3, out, *(wb if table is not None else ()))
+        ctx.save_for_backward(x2, w, fused, mask3, out, eg if eg is not None else fused.new_empty(0),
+                              *(wb if table is not None else ()))
         ctx.L, ctx.table, ctx.dropout = L, table, dropout
         ctx.meta = (x.shape, x.dtype, weight.dtype, bias.dtype)
         return out
 
     @staticmethod
     def backward(ctx, d_out):
-        x2, w, fused, mask3, out = ctx.saved_tensors[:5]
-        params = ctx.saved_tensors[5:]
+        x2, w, fused, mask3, out, eg = ctx.saved_tensors[:6]
+        params = ctx.saved_tensors[6:]
+        eg = eg if eg.numel() else None
         L, table = ctx.L, ctx.table
         xs, xdt, wdt, bdt = ctx.meta
         d_out = d_out.contiguous()
-        d_fused = torch.empty_like(fused)          # every used column is written by the kernel
+        d_fused = torch.empty(*fused.shape[:3], L.width, dtype=fused.dtype, device=fused.device)   # every used column is written
         if L.width > L.used:
             d_fused[..., L.used:] = 0
         colsum = _colsum_workspace(fused.shape[0], L.width, fused.device)
-        a = _tri_args(fused, mask3, out, L, d_out, d_fused, colsum, dropout=ctx.dropout)
+        a = _tri_args(fused, mask3, out, L, d_out, d_fused, colsum, dropout=ctx.dropout, eg=eg)
         _call('tgt_triplet_attention_bwd', _lib.lib().tgt_triplet_attention_bwd, a)
         need_p = any(ctx.needs_input_grad[6:])
         db = sum_rows(colsum) if need_p else None
