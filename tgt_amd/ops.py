@@ -350,8 +350,18 @@ class _ProjectedTripletAttention(torch.autograd.Function):
         _call('tgt_triplet_attention_bwd', _lib.lib().tgt_triplet_attention_bwd, a)
         need_p = any(ctx.needs_input_grad[6:])
         db = sum_rows(colsum) if need_p else None
-        dx, dw, _ = _linear_backward(x2, w, d_fused.view(-1, L.width), xs, xdt, torch.float32, None,
-                                     ctx.needs_input_grad[0], need_p, False)
+        d2 = d_fused.view(-1, L.width)
+        if eg is not None and need_p:
+            # weight gradient as two batched GEMMs as well: the 1536-row block has no ragged tile row
+            # (213 us with 32 chunks) and the 64-row E/G block is cheap (35 us), against 303 us for the
+            # 1600-row product (tools/wgrad_chunk_probe.py); dx stays one GEMM over the fused row
+            dx, _, _ = _linear_backward(x2, w, d2, xs, xdt, torch.float32, None, ctx.needs_input_grad[0], False, False)
+            dw = torch.empty(L.width, L.C, dtype=torch.float32, device=d2.device)
+            _wgrad_into(dw[:6 * L.C], d2[:, :6 * L.C], x2, 32)
+            _wgrad_into(dw[6 * L.C:], d2[:, 6 * L.C:], x2, 128)
+        else:
+            dx, dw, _ = _linear_backward(x2, w, d2, xs, xdt, torch.float32, None,
+                                         ctx.needs_input_grad[0], need_p, False)
         if not need_p:
             return (dx, None, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 6)
         if table is None:
@@ -869,6 +879,22 @@ def _wgrad_chunks(M, out_in=0):
         if M % P == 0 and M // P >= 1024:
             return P
     return 1
+
+
+def _wgrad_into(out, dy2, x2, chunks):
+    """out (rows(dy2^T), in) fp32 <- dy2^T x2 as `chunks` batched partial products + their sum; dy2 may
+    be a column slice of a wider row-major matrix"""
+    M = x2.shape[0]
+    P = chunks
+    while P > 1 and (M % P or M // P < 1024):
+        P //= 2
+    if P > 1:
+        a = dy2.unflatten(0, (P, M // P)).transpose(1, 2)
+        part = torch.bmm(a, x2.view(P, M // P, -1), out_dtype=torch.float32) if dy2.dtype != torch.float32 else \
+            torch.bmm(a, x2.view(P, M // P, -1))
+        torch.sum(part, 0, out=out)
+    else:
+        out.copy_(dy2.t() @ x2)
 
 
 def _as_dtype(p, cd):
