@@ -59,9 +59,15 @@ __global__ void __launch_bounds__(HG * 64, (NT == 1 && sizeof(T) == 2) ? 4 : 1) 
     const TriDrop drop = tri_drop(a.dropout_p, a.dropout_seed);
     const uint32_t drop_unit0 = (uint32_t)(((c.b * 2 + c.dir) * a.H + c.h) * N);
 
-    const int64_t sz = sizeof(T);
-    char* obase = reinterpret_cast<char*>(a.out) + ((int64_t)c.b * N * N * a.ld_out + a.o_off[c.dir] + c.g * HG * D) * sz;
-    const int64_t o_row = (int64_t)N * a.ld_out * sz, o_j = a.ld_out * sz;
+    // buffer-addressed slabs (triplet_common.hpp): scalar offsets along j, no vector address arithmetic
+    const int64_t sz = sizeof(T), Nl = N;
+    const uint32_t hch = (uint32_t)(c.g * HG * D * sz), lds_ = (uint32_t)(a.ld_qkv[c.dir] * sz), ldo_ = (uint32_t)(a.ld_out * sz);
+    const __amdgpu_buffer_rsrc_t r_src = graph_rsrc(a.qkv[c.dir], Nl * Nl * a.ld_qkv[c.dir] * sz, c.b);
+    const SlabBuf bQ = {r_src, (uint32_t)(a.q_off[c.dir] * sz) + hch, (uint32_t)N * lds_, lds_};
+    const SlabBuf bK = {r_src, (uint32_t)(a.k_off[c.dir] * sz) + hch, c.dir == 0 ? lds_ : (uint32_t)N * lds_,
+                        c.dir == 0 ? (uint32_t)N * lds_ : lds_};
+    const SlabBuf bV = {r_src, (uint32_t)(a.v_off[c.dir] * sz) + hch, bK.row_stride, bK.j_stride};
+    const SlabBuf bO = {graph_rsrc(a.out, Nl * Nl * a.ld_out * sz, c.b), (uint32_t)(a.o_off[c.dir] * sz) + hch, (uint32_t)N * ldo_, ldo_};
 
     for (int it = 0; it < NT; ++it) {
         const int i0 = 32 * it;
@@ -78,22 +84,22 @@ __global__ void __launch_bounds__(HG * 64, (NT == 1 && sizeof(T) == 2) ? 4 : 1) 
         uint4 pqA[SlabIO<G, 32>::kIters], pkA[SlabIO<G, KR>::kIters], pvA[SlabIO<G, KR>::kIters];
         uint4 pqB[PF > 1 ? SlabIO<G, 32>::kIters : 1], pkB[PF > 1 ? SlabIO<G, KR>::kIters : 1],
             pvB[PF > 1 ? SlabIO<G, KR>::kIters : 1];
-        slab_issue<G, 32>(pqA, c.q, 0, i0, N, tid);
-        slab_issue<G, KR>(pkA, c.k, 0, 0, N, tid);
-        slab_issue<G, KR>(pvA, c.v, 0, 0, N, tid);
+        slab_issue<G, 32>(pqA, bQ, 0, i0, N, tid);
+        slab_issue<G, KR>(pkA, bK, 0, 0, N, tid);
+        slab_issue<G, KR>(pvA, bV, 0, 0, N, tid);
         slab_commit<G, 32>(pqA, smem, tid);
         slab_commit<G, KR>(pkA, smem + G::kSlabBytes, tid);
         slab_commit<G, KR>(pvA, smem + (1 + NT) * G::kSlabBytes, tid);
         if (N > 1) {
-            slab_issue<G, 32>(pqA, c.q, 1, i0, N, tid);
-            slab_issue<G, KR>(pkA, c.k, 1, 0, N, tid);
-            slab_issue<G, KR>(pvA, c.v, 1, 0, N, tid);
+            slab_issue<G, 32>(pqA, bQ, 1, i0, N, tid);
+            slab_issue<G, KR>(pkA, bK, 1, 0, N, tid);
+            slab_issue<G, KR>(pvA, bV, 1, 0, N, tid);
         }
         if constexpr (PF > 1) {
             if (N > 2) {
-                slab_issue<G, 32>(pqB, c.q, 2, i0, N, tid);
-                slab_issue<G, KR>(pkB, c.k, 2, 0, N, tid);
-                slab_issue<G, KR>(pvB, c.v, 2, 0, N, tid);
+                slab_issue<G, 32>(pqB, bQ, 2, i0, N, tid);
+                slab_issue<G, KR>(pkB, bK, 2, 0, N, tid);
+                slab_issue<G, KR>(pvB, bV, 2, 0, N, tid);
             }
         }
         __syncthreads();
@@ -115,9 +121,9 @@ __global__ void __launch_bounds__(HG * 64, (NT == 1 && sizeof(T) == 2) ? 4 : 1) 
                 slab_commit<G, KR>(pv, nQ + (1 + NT) * G::kSlabBytes, tid);
             }
             if (j + 1 + PF < N) {
-                slab_issue<G, 32>(pq, c.q, j + 1 + PF, i0, N, tid);
-                slab_issue<G, KR>(pk, c.k, j + 1 + PF, 0, N, tid);
-                slab_issue<G, KR>(pv, c.v, j + 1 + PF, 0, N, tid);
+                slab_issue<G, 32>(pq, bQ, j + 1 + PF, i0, N, tid);
+                slab_issue<G, KR>(pk, bK, j + 1 + PF, 0, N, tid);
+                slab_issue<G, KR>(pv, bV, j + 1 + PF, 0, N, tid);
             }
             F fq[G::kDC];
             read_frags<T, D, HG>(fq, sQ, wave, r, hi);
@@ -169,7 +175,7 @@ __global__ void __launch_bounds__(HG * 64, (NT == 1 && sizeof(T) == 2) ? 4 : 1) 
             }
             write_rows<T, D, HG>(sQ, o, wave, r, hi);     // in place of this head's Q columns
             __syncthreads();
-            slab_store<G, 32>(sQ, obase, o_row, o_j, j, i0, N, tid);
+            slab_store<G, 32>(sQ, bO, j, i0, N, tid);
         };
         for (int j = 0; j < N; j += PF) {
             step(j, pqA, pkA, pvA);
@@ -217,19 +223,26 @@ __global__ void __launch_bounds__(HG * 64, OCC) tri_att_bwd_kernel(const tgt_tri
     make_ident_k<T>(ident_k, r, hi);
 
     const int64_t sz = sizeof(T), Nl = N;
-    const SlabSrc dO = {reinterpret_cast<const char*>(a.d_out) +
-                            ((int64_t)c.b * Nl * Nl * a.ld_out + a.o_off[c.dir] + c.g * HG * D) * sz,
-                        Nl * a.ld_out * sz, a.ld_out * sz};
     // gradient slabs mirror the source slabs (same channel offsets) inside d_qkv, whose rows may be
     // longer than the sources' (ld_dqkv: one fused gradient row for the projection's GEMMs)
     const int64_t ldq = a.ld_dqkv[c.dir] ? a.ld_dqkv[c.dir] : a.ld_qkv[c.dir];
     const int64_t lde = a.ld_deg[c.dir] ? a.ld_deg[c.dir] : a.ld_eg[c.dir];
-    char* dbase = reinterpret_cast<char*>(a.d_qkv[c.dir]) + ((int64_t)c.b * Nl * Nl * ldq + c.g * HG * D) * sz;
-    char* dq_base = dbase + (int64_t)a.q_off[c.dir] * sz;
-    const int64_t dq_row = Nl * ldq * sz, dq_j = ldq * sz;
-    const SlabSrc dK = {dbase + (int64_t)a.k_off[c.dir] * sz, c.dir == 0 ? ldq * sz : Nl * ldq * sz,
-                        c.dir == 0 ? Nl * ldq * sz : ldq * sz};
-    const SlabSrc dV = {dbase + (int64_t)a.v_off[c.dir] * sz, dK.row_stride, dK.j_stride};
+    // buffer-addressed slabs (see triplet_common.hpp): one resource per tensor and graph
+    const uint32_t hch = (uint32_t)(c.g * HG * D * sz);
+    const uint32_t lds_ = (uint32_t)(a.ld_qkv[c.dir] * sz), ldg_ = (uint32_t)(ldq * sz), ldo_ = (uint32_t)(a.ld_out * sz);
+    const __amdgpu_buffer_rsrc_t r_src = graph_rsrc(a.qkv[c.dir], Nl * Nl * a.ld_qkv[c.dir] * sz, c.b);
+    const __amdgpu_buffer_rsrc_t r_grd = graph_rsrc(a.d_qkv[c.dir], Nl * Nl * ldq * sz, c.b);
+    const __amdgpu_buffer_rsrc_t r_do = graph_rsrc(a.d_out, Nl * Nl * a.ld_out * sz, c.b);
+    const uint32_t qo = (uint32_t)(a.q_off[c.dir] * sz) + hch, ko = (uint32_t)(a.k_off[c.dir] * sz) + hch,
+                   vo = (uint32_t)(a.v_off[c.dir] * sz) + hch;
+    // Q-type rows (i, j): row stride N*ld, j stride ld;  partner rows (j,k) inward / (k,j) outward
+    const SlabBuf bQ = {r_src, qo, (uint32_t)N * lds_, lds_};
+    const SlabBuf bK = {r_src, ko, c.dir == 0 ? lds_ : (uint32_t)N * lds_, c.dir == 0 ? (uint32_t)N * lds_ : lds_};
+    const SlabBuf bV = {r_src, vo, bK.row_stride, bK.j_stride};
+    const SlabBuf dO = {r_do, (uint32_t)(a.o_off[c.dir] * sz) + hch, (uint32_t)N * ldo_, ldo_};
+    const SlabBuf gQ = {r_grd, qo, (uint32_t)N * ldg_, ldg_};
+    const SlabBuf dK = {r_grd, ko, c.dir == 0 ? ldg_ : (uint32_t)N * ldg_, c.dir == 0 ? (uint32_t)N * ldg_ : ldg_};
+    const SlabBuf dV = {r_grd, vo, dK.row_stride, dK.j_stride};
     ThirdArm dta = ta;                      // third-arm gradient rows
     dta.ld = lde;
 
@@ -264,19 +277,19 @@ __global__ void __launch_bounds__(HG * 64, OCC) tri_att_bwd_kernel(const tgt_tri
 
         uint4 pq[SlabIO<G, 32>::kIters], po[SlabIO<G, 32>::kIters];
         uint4 pk[SlabIO<G, KR>::kIters], pv[SlabIO<G, KR>::kIters];
-        slab_issue<G, 32>(pq, c.q, 0, i0, N, tid);
+        slab_issue<G, 32>(pq, bQ, 0, i0, N, tid);
         slab_issue<G, 32>(po, dO, 0, i0, N, tid);
-        slab_issue<G, KR>(pk, c.k, 0, 0, N, tid);
-        slab_issue<G, KR>(pv, c.v, 0, 0, N, tid);
+        slab_issue<G, KR>(pk, bK, 0, 0, N, tid);
+        slab_issue<G, KR>(pv, bV, 0, 0, N, tid);
         slab_commit<G, 32>(pq, smem, tid);
         slab_commit<G, 32>(po, smem + G::kSlabBytes, tid);
         slab_commit<G, KR>(pk, smem + 2 * G::kSlabBytes, tid);
         slab_commit<G, KR>(pv, smem + (2 + NT) * G::kSlabBytes, tid);
         if (N > 1) {
-            slab_issue<G, 32>(pq, c.q, 1, i0, N, tid);
+            slab_issue<G, 32>(pq, bQ, 1, i0, N, tid);
             slab_issue<G, 32>(po, dO, 1, i0, N, tid);
-            slab_issue<G, KR>(pk, c.k, 1, 0, N, tid);
-            slab_issue<G, KR>(pv, c.v, 1, 0, N, tid);
+            slab_issue<G, KR>(pk, bK, 1, 0, N, tid);
+            slab_issue<G, KR>(pv, bV, 1, 0, N, tid);
         }
         __syncthreads();
 
@@ -293,10 +306,10 @@ __global__ void __launch_bounds__(HG * 64, OCC) tri_att_bwd_kernel(const tgt_tri
                 slab_commit<G, KR>(pv, nQ + (2 + NT) * G::kSlabBytes, tid);
             }
             if (j + 2 < N) {
-                slab_issue<G, 32>(pq, c.q, j + 2, i0, N, tid);
+                slab_issue<G, 32>(pq, bQ, j + 2, i0, N, tid);
                 slab_issue<G, 32>(po, dO, j + 2, i0, N, tid);
-                slab_issue<G, KR>(pk, c.k, j + 2, 0, N, tid);
-                slab_issue<G, KR>(pv, c.v, j + 2, 0, N, tid);
+                slab_issue<G, KR>(pk, bK, j + 2, 0, N, tid);
+                slab_issue<G, KR>(pv, bV, j + 2, 0, N, tid);
             }
             // partial dK/dV the previous query-tile pass stored for THIS j (added at the store below)
             uint4 curk[NT > 1 ? SlabIO<G, KR>::kIters : 1], curv[NT > 1 ? SlabIO<G, KR>::kIters : 1];
@@ -431,30 +444,30 @@ __global__ void __launch_bounds__(HG * 64, OCC) tri_att_bwd_kernel(const tgt_tri
             __syncthreads();
             bool plain = true;
             if constexpr (CS) {
-                slab_store_sum<G, 32, T, false>(sQ, pq, dq_base, dq_row, dq_j, j, i0, N, tid, cs);
+                slab_store_sum<G, 32, T, false>(sQ, pq, gQ, j, i0, N, tid, cs);
                 if constexpr (NT > 1) {
                     if (it > 0) {
                         plain = false;
-                        slab_store_sum<G, KR, T, true>(sK, curk, const_cast<char*>(dK.base), dK.row_stride, dK.j_stride, j, 0, N, tid, cs + kPlane);
-                        slab_store_sum<G, KR, T, true>(sV, curv, const_cast<char*>(dV.base), dV.row_stride, dV.j_stride, j, 0, N, tid, cs + 2 * kPlane);
+                        slab_store_sum<G, KR, T, true>(sK, curk, dK, j, 0, N, tid, cs + kPlane);
+                        slab_store_sum<G, KR, T, true>(sV, curv, dV, j, 0, N, tid, cs + 2 * kPlane);
                     }
                 }
                 if (plain) {
-                    slab_store_sum<G, KR, T, false>(sK, pk, const_cast<char*>(dK.base), dK.row_stride, dK.j_stride, j, 0, N, tid, cs + kPlane);
-                    slab_store_sum<G, KR, T, false>(sV, pv, const_cast<char*>(dV.base), dV.row_stride, dV.j_stride, j, 0, N, tid, cs + 2 * kPlane);
+                    slab_store_sum<G, KR, T, false>(sK, pk, dK, j, 0, N, tid, cs + kPlane);
+                    slab_store_sum<G, KR, T, false>(sV, pv, dV, j, 0, N, tid, cs + 2 * kPlane);
                 }
             } else {
-                slab_store<G, 32>(sQ, dq_base, dq_row, dq_j, j, i0, N, tid);
+                slab_store<G, 32>(sQ, gQ, j, i0, N, tid);
                 if constexpr (NT > 1) {
                     if (it > 0) {
                         plain = false;
-                        slab_store_add<G, KR, T>(sK, curk, const_cast<char*>(dK.base), dK.row_stride, dK.j_stride, j, 0, N, tid);
-                        slab_store_add<G, KR, T>(sV, curv, const_cast<char*>(dV.base), dV.row_stride, dV.j_stride, j, 0, N, tid);
+                        slab_store_add<G, KR, T>(sK, curk, dK, j, 0, N, tid);
+                        slab_store_add<G, KR, T>(sV, curv, dV, j, 0, N, tid);
                     }
                 }
                 if (plain) {
-                    slab_store<G, KR>(sK, const_cast<char*>(dK.base), dK.row_stride, dK.j_stride, j, 0, N, tid);
-                    slab_store<G, KR>(sV, const_cast<char*>(dV.base), dV.row_stride, dV.j_stride, j, 0, N, tid);
+                    slab_store<G, KR>(sK, dK, j, 0, N, tid);
+                    slab_store<G, KR>(sV, dV, j, 0, N, tid);
                 }
             }
         }

@@ -165,6 +165,114 @@ __device__ __forceinline__ void slab_colsum_finish(const float* cs, float* out, 
     }
 }
 
+// ---------------------------------------------------------------------------
+// Buffer-addressed slab IO (the backward kernel is VALU-bound: 64-bit vector address arithmetic
+// per slab and j is work it cannot afford).  A slab lives in ONE graph of a (B,N,N,ld) tensor:
+//   buffer resource = that graph (base, N*N*ld bytes; accesses past it read 0 / are dropped),
+//   soffset (scalar)  = channel offset + j*j_stride + row0*row_stride   -- changes with j
+//   voffset (vector)  = row*row_stride + slot*16                        -- fixed per thread
+// so the walk over j issues buffer_load/store ... s[rsrc], s_off offen with no vector address math.
+// ---------------------------------------------------------------------------
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+struct SlabBuf {
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t chan;         // byte offset of this group's first channel of the tensor in a row
+    uint32_t row_stride;   // bytes between consecutive slab rows
+    uint32_t j_stride;     // bytes between consecutive j
+};
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t graph_rsrc(const void* tensor, int64_t graph_bytes, int b) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(tensor)) + (int64_t)b * graph_bytes, 0,
+                                             (int)graph_bytes, 0x00020000);
+}
+template <typename G, int ROWS, int IT = SlabIO<G, ROWS>::kIters>
+__device__ __forceinline__ void slab_issue(uint4 (&pre)[IT], const SlabBuf& s, int j, int row0, int N, int tid) {
+    const uint32_t so = s.chan + (uint32_t)j * s.j_stride + (uint32_t)row0 * s.row_stride;
+#pragma unroll
+    for (int it = 0; it < SlabIO<G, ROWS>::kIters; ++it) {
+        const int c = it * G::kThreads + tid;
+        const int row = c / G::kSlots, slot = c % G::kSlots;
+        u32x4_t v = {0, 0, 0, 0};
+        if (c < SlabIO<G, ROWS>::kChunks && row0 + row < N)
+            v = __builtin_amdgcn_raw_buffer_load_b128(s.rsrc, (int)((uint32_t)row * s.row_stride + (uint32_t)slot * 16u), (int)so, 0);
+        pre[it] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+}
+__device__ __forceinline__ void buf_store16(const SlabBuf& s, uint4 v, uint32_t voff, uint32_t so) {
+    u32x4_t d = {v.x, v.y, v.z, v.w};
+    __builtin_amdgcn_raw_buffer_store_b128(d, s.rsrc, (int)voff, (int)so, 0);
+}
+template <typename G, int ROWS>
+__device__ __forceinline__ void slab_store(const char* slab, const SlabBuf& s, int j, int row0, int N, int tid) {
+    const uint32_t so = s.chan + (uint32_t)j * s.j_stride + (uint32_t)row0 * s.row_stride;
+#pragma unroll
+    for (int it = 0; it < SlabIO<G, ROWS>::kIters; ++it) {
+        const int c = it * G::kThreads + tid;
+        const int row = c / G::kSlots, slot = c % G::kSlots;
+        if (c < SlabIO<G, ROWS>::kChunks && row0 + row < N)
+            buf_store16(s, *reinterpret_cast<const uint4*>(slab + G::lds_off(row, slot)),
+                        (uint32_t)row * s.row_stride + (uint32_t)slot * 16u, so);
+    }
+}
+template <typename G, int ROWS, typename T, int IT = SlabIO<G, ROWS>::kIters>
+__device__ __forceinline__ void slab_store_add(const char* slab, const uint4 (&prior)[IT], const SlabBuf& s, int j,
+                                               int row0, int N, int tid) {
+    constexpr int E = 16 / (int)sizeof(T);
+    const uint32_t so = s.chan + (uint32_t)j * s.j_stride + (uint32_t)row0 * s.row_stride;
+#pragma unroll
+    for (int it = 0; it < SlabIO<G, ROWS>::kIters; ++it) {
+        const int c = it * G::kThreads + tid;
+        const int row = c / G::kSlots, slot = c % G::kSlots;
+        if (c < SlabIO<G, ROWS>::kChunks && row0 + row < N) {
+            uint4 a = *reinterpret_cast<const uint4*>(slab + G::lds_off(row, slot)), b = prior[it], o;
+            T xa[E], xb[E];
+            __builtin_memcpy(xa, &a, 16);
+            __builtin_memcpy(xb, &b, 16);
+#pragma unroll
+            for (int t = 0; t < E; ++t) xa[t] = from_f32<T>(to_f32(xa[t]) + to_f32(xb[t]));
+            __builtin_memcpy(&o, xa, 16);
+            buf_store16(s, o, (uint32_t)row * s.row_stride + (uint32_t)slot * 16u, so);
+        }
+    }
+}
+template <typename G, int ROWS, typename T, bool ADD, int IT = SlabIO<G, ROWS>::kIters>
+__device__ __forceinline__ void slab_store_sum(const char* slab, const uint4 (&prior)[IT], const SlabBuf& s, int j, int row0,
+                                               int N, int tid, float* cs) {
+    constexpr int E = 16 / (int)sizeof(T);
+    static_assert(G::kThreads % G::kSlots == 0, "a thread must own one column chunk");
+    float4* mine = reinterpret_cast<float4*>(cs + tid * E);
+    const uint32_t so = s.chan + (uint32_t)j * s.j_stride + (uint32_t)row0 * s.row_stride;
+    float acc[E];
+#pragma unroll
+    for (int t = 0; t < E / 4; ++t) *reinterpret_cast<float4*>(acc + 4 * t) = mine[t];
+#pragma unroll
+    for (int it = 0; it < SlabIO<G, ROWS>::kIters; ++it) {
+        const int c = it * G::kThreads + tid;
+        const int row = c / G::kSlots, slot = c % G::kSlots;
+        if (c < SlabIO<G, ROWS>::kChunks && row0 + row < N) {
+            uint4 a = *reinterpret_cast<const uint4*>(slab + G::lds_off(row, slot));
+            T xa[E];
+            __builtin_memcpy(xa, &a, 16);
+            if constexpr (ADD) {
+                T xb[E];
+                __builtin_memcpy(xb, &prior[it], 16);
+#pragma unroll
+                for (int t = 0; t < E; ++t) {
+                    const float old = to_f32(xb[t]);
+                    xa[t] = from_f32<T>(to_f32(xa[t]) + old);
+                    acc[t] += to_f32(xa[t]) - old;
+                }
+                __builtin_memcpy(&a, xa, 16);
+            } else {
+#pragma unroll
+                for (int t = 0; t < E; ++t) acc[t] += to_f32(xa[t]);
+            }
+            buf_store16(s, a, (uint32_t)row * s.row_stride + (uint32_t)slot * 16u, so);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < E / 4; ++t) mine[t] = *reinterpret_cast<const float4*>(acc + 4 * t);
+}
+
 // operand fragments of head `wave` for slab row r: d in [16*dc + 8*hi, +8)
 template <typename T, int D, int HG>
 __device__ __forceinline__ void read_frags(frag_t<T> (&f)[(D + 15) / 16], const char* slab,
