@@ -201,7 +201,8 @@ __global__ void __launch_bounds__(HG * 64, (NT == 1 && sizeof(T) == 2) ? 4 : 1) 
 // FL >= 0: the BIASED/GATED flags are compile-time (the hot gated+biased instantiation: no
 // per-element selects); FL < 0: read from the arguments.
 template <typename T, int D, int HG, int NT, int OCC, bool CS, int FL, bool DROP>
-__global__ void __launch_bounds__(HG * 64, OCC) tri_att_bwd_kernel(const tgt_triplet_attention_args a) {
+// (waves_per_eu(1,1) for the one-wave variants: lets the allocator park values in the 256 AGPRs instead of scratch)
+__global__ void __launch_bounds__(HG * 64, OCC) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) tri_att_bwd_kernel(const tgt_triplet_attention_args a) {
     using G = TriGeo<T, D, HG>;
     using F = frag_t<T>;
     constexpr int KR = 32 * NT;
