@@ -169,7 +169,10 @@ int tgt_triangular_update_bwd(const void* e4, const void* v4, const float* mask,
  * ---------------------------------------------------------------------- */
 typedef struct tgt_node_attention_args {
     int32_t B, N, H, D;
-    int32_t dtype, scale_degree, logits_only, _pad0;
+    int32_t dtype, scale_degree, logits_only;
+    int32_t head_major;               /* 0: channel = d*H + h (the reference's order); 1: channel = h*D + d inside each of
+                                       * Q, K, V (and V_att): the caller permuted the projection's weight rows.  Same
+                                       * arithmetic; a lane's D values are then one contiguous block (16-byte fetches). */
     float   scale;                    /* D^-0.5 */
     int32_t _pad1;
     const void* qkv;   int64_t ld_qkv;  int32_t q_off, k_off, v_off, _pad2;

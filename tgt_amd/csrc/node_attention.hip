@@ -82,10 +82,72 @@ __device__ __forceinline__ void ldf(const float* p, int64_t i, float (&o)[HV]) {
     for (int k = 0; k < HV; ++k) o[k] = p[i + k];
 }
 
+// All D values of HV adjacent heads of one Q/K/V (or V_att) row, kept packed in T.
+//   HM = false: the reference's head-MINOR channel order c = d*H + h  -> D accesses of HV elements
+//   HM = true : head-MAJOR c = h*D + d (tgt_node_attention_args.head_major: the projection's weight
+//               rows are permuted instead) -> ONE contiguous block of HV*D elements, fetched with
+//               16-byte accesses.  These kernels are bound by the NUMBER of vector-memory
+//               instructions (2*D four-byte K/V fetches per key and lane otherwise).
+template <typename T, int D, int HV, bool HM>
+struct DH {
+    T v[D * HV];
+    __device__ __forceinline__ float at(int d, int k) const { return to_f32(HM ? v[k * D + d] : v[d * HV + k]); }
+    __device__ __forceinline__ void load(const T* p, int64_t base, int H, int h) {
+        if constexpr (HM) {
+            constexpr int NB = HV * D * (int)sizeof(T);
+            const char* src = reinterpret_cast<const char*>(p + base + (int64_t)h * D);
+            if constexpr (NB % 16 == 0) {
+#pragma unroll
+                for (int x = 0; x < NB / 16; ++x) { uint4 w = reinterpret_cast<const uint4*>(src)[x]; __builtin_memcpy(reinterpret_cast<char*>(v) + 16 * x, &w, 16); }
+            } else if constexpr (NB % 8 == 0) {
+#pragma unroll
+                for (int x = 0; x < NB / 8; ++x) { uint2 w = reinterpret_cast<const uint2*>(src)[x]; __builtin_memcpy(reinterpret_cast<char*>(v) + 8 * x, &w, 8); }
+            } else {
+#pragma unroll
+                for (int x = 0; x < HV * D; ++x) v[x] = p[base + (int64_t)h * D + x];
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                constexpr int NB = HV * (int)sizeof(T);
+                const T* src = p + base + (int64_t)d * H + h;
+                if constexpr (NB == 16) { uint4 w = *reinterpret_cast<const uint4*>(src); __builtin_memcpy(v + d * HV, &w, 16); }
+                else if constexpr (NB == 8) { uint2 w = *reinterpret_cast<const uint2*>(src); __builtin_memcpy(v + d * HV, &w, 8); }
+                else if constexpr (NB == 4) { uint32_t w = *reinterpret_cast<const uint32_t*>(src); __builtin_memcpy(v + d * HV, &w, 4); }
+                else { v[d * HV] = src[0]; }
+            }
+        }
+    }
+    __device__ static __forceinline__ void store(T* p, int64_t base, int H, int h, const float (&x)[D][HV]) {
+        if constexpr (HM) {
+            T t[D * HV];
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+#pragma unroll
+                for (int k = 0; k < HV; ++k) t[k * D + d] = from_f32<T>(x[d][k]);
+            constexpr int NB = HV * D * (int)sizeof(T);
+            char* dst = reinterpret_cast<char*>(p + base + (int64_t)h * D);
+            if constexpr (NB % 16 == 0) {
+#pragma unroll
+                for (int y = 0; y < NB / 16; ++y) { uint4 w; __builtin_memcpy(&w, reinterpret_cast<const char*>(t) + 16 * y, 16); reinterpret_cast<uint4*>(dst)[y] = w; }
+            } else if constexpr (NB % 8 == 0) {
+#pragma unroll
+                for (int y = 0; y < NB / 8; ++y) { uint2 w; __builtin_memcpy(&w, reinterpret_cast<const char*>(t) + 8 * y, 8); reinterpret_cast<uint2*>(dst)[y] = w; }
+            } else {
+#pragma unroll
+                for (int y = 0; y < HV * D; ++y) p[base + (int64_t)h * D + y] = t[y];
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < D; ++d) stv<T, HV>(p, base + (int64_t)d * H + h, x[d]);
+        }
+    }
+};
+
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
-template <typename T, int D, int HV>
+template <typename T, int D, int HV, bool HM>
 __global__ void __launch_bounds__(256) node_att_fwd_kernel(const tgt_node_attention_args a) {
     const NodeLane n = node_lane<HV>(a);
     if (!n.active) return;
@@ -96,14 +158,16 @@ __global__ void __launch_bounds__(256) node_att_fwd_kernel(const tgt_node_attent
     const int64_t row0 = (int64_t)n.b * N, row_l = row0 + n.x;
 
     float q[D][HV], acc[D][HV], mx[HV], sum[HV], gsum[HV];
+    {
+        DH<T, D, HV, HM> qb;
+        qb.load(qkv, row_l * a.ld_qkv + a.q_off, H, h);
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        ldv<T, HV>(qkv, row_l * a.ld_qkv + a.q_off + d * H + h, q[d]);
+        for (int d = 0; d < D; ++d)
 #pragma unroll
-        for (int k = 0; k < HV; ++k) {
-            q[d][k] *= a.scale;
-            acc[d][k] = 0.f;
-        }
+            for (int k = 0; k < HV; ++k) {
+                q[d][k] = qb.at(d, k) * a.scale;
+                acc[d][k] = 0.f;
+            }
     }
 #pragma unroll
     for (int k = 0; k < HV; ++k) {
@@ -117,12 +181,13 @@ __global__ void __launch_bounds__(256) node_att_fwd_kernel(const tgt_node_attent
         if (!a.logits_only) ldv<T, HV>(eg, lm * a.ld_eg + a.g_off + h, g);
 #pragma unroll
         for (int k = 0; k < HV; ++k) s[k] = e[k];
+        {
+            DH<T, D, HV, HM> kb;
+            kb.load(qkv, row_m * a.ld_qkv + a.k_off, H, h);
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            float kk[HV];
-            ldv<T, HV>(qkv, row_m * a.ld_qkv + a.k_off + d * H + h, kk);
+            for (int d = 0; d < D; ++d)
 #pragma unroll
-            for (int k = 0; k < HV; ++k) s[k] += q[d][k] * kk[k];
+                for (int k = 0; k < HV; ++k) s[k] += q[d][k] * kb.at(d, k);
         }
         if (hhat) stv<T, HV>(hhat, lm * H + h, s);
         if (a.logits_only) continue;
@@ -142,12 +207,13 @@ __global__ void __launch_bounds__(256) node_att_fwd_kernel(const tgt_node_attent
             gsum[k] += gt;
             mx[k] = mnew;
         }
+        {
+            DH<T, D, HV, HM> vb;
+            vb.load(qkv, row_m * a.ld_qkv + a.v_off, H, h);
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            float vv[HV];
-            ldv<T, HV>(qkv, row_m * a.ld_qkv + a.v_off + d * H + h, vv);
+            for (int d = 0; d < D; ++d)
 #pragma unroll
-            for (int k = 0; k < HV; ++k) acc[d][k] = acc[d][k] * corr[k] + w[k] * vv[k];
+                for (int k = 0; k < HV; ++k) acc[d][k] = acc[d][k] * corr[k] + w[k] * vb.at(d, k);
         }
     }
     if (a.logits_only) return;
@@ -159,12 +225,10 @@ __global__ void __launch_bounds__(256) node_att_fwd_kernel(const tgt_node_attent
         lse[k] = mx[k] + __logf(sum[k]);
     }
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        float o[HV];
+    for (int d = 0; d < D; ++d)
 #pragma unroll
-        for (int k = 0; k < HV; ++k) o[k] = acc[d][k] * f[k];
-        stv<T, HV>(vatt, row_l * (int64_t)(D * H) + d * H + h, o);
-    }
+        for (int k = 0; k < HV; ++k) acc[d][k] *= f[k];
+    DH<T, D, HV, HM>::store(vatt, row_l * (int64_t)(D * H), H, h, acc);
 #pragma unroll
     for (int k = 0; k < HV; ++k) {
         a.lse[row_l * H + h + k] = lse[k];
@@ -179,7 +243,7 @@ __global__ void __launch_bounds__(256) node_att_fwd_kernel(const tgt_node_attent
 // (written), 8 bytes per lane -- and those run PD keys ahead in a register ring.
 //   lane = (query l, HV heads), lanes of the same wave that share heads read the same LDS words.
 // ---------------------------------------------------------------------------
-template <typename T, int D, int HV, int MT>
+template <typename T, int D, int HV, int MT, bool HM>
 __global__ void __launch_bounds__(512) node_att_fwd_lds_kernel(const tgt_node_attention_args a, int lpr, int qb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int N = a.N, H = a.H, W = D * H;
@@ -195,14 +259,16 @@ __global__ void __launch_bounds__(512) node_att_fwd_lds_kernel(const tgt_node_at
     const int64_t row0 = (int64_t)b * N, row_l = row0 + (active ? l : 0);
 
     float q[D][HV], acc[D][HV], mx[HV], sum[HV], gsum[HV];
+    {
+        DH<T, D, HV, HM> qb;
+        if (active) qb.load(qkv, row_l * a.ld_qkv + a.q_off, H, h);
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        if (active) ldv<T, HV>(qkv, row_l * a.ld_qkv + a.q_off + d * H + h, q[d]);
+        for (int d = 0; d < D; ++d)
 #pragma unroll
-        for (int k = 0; k < HV; ++k) {
-            q[d][k] = active ? q[d][k] * a.scale : 0.f;
-            acc[d][k] = 0.f;
-        }
+            for (int k = 0; k < HV; ++k) {
+                q[d][k] = active ? qb.at(d, k) * a.scale : 0.f;
+                acc[d][k] = 0.f;
+            }
     }
 #pragma unroll
     for (int k = 0; k < HV; ++k) {
@@ -246,12 +312,13 @@ __global__ void __launch_bounds__(512) node_att_fwd_lds_kernel(const tgt_node_at
                     float s[HV];
 #pragma unroll
                     for (int k = 0; k < HV; ++k) s[k] = er[kk][k];
+                    {
+                        DH<T, D, HV, HM> kb;
+                        kb.load(sK, (int64_t)m * W, H, h);
 #pragma unroll
-                    for (int d = 0; d < D; ++d) {
-                        float kv[HV];
-                        ldv<T, HV>(sK, (int64_t)m * W + d * H + h, kv);
+                        for (int d = 0; d < D; ++d)
 #pragma unroll
-                        for (int k = 0; k < HV; ++k) s[k] += q[d][k] * kv[k];
+                            for (int k = 0; k < HV; ++k) s[k] += q[d][k] * kb.at(d, k);
                     }
                     if (hhat) stv<T, HV>(hhat, lm * H + h, s);
                     if (!a.logits_only) {
@@ -270,12 +337,13 @@ __global__ void __launch_bounds__(512) node_att_fwd_lds_kernel(const tgt_node_at
                             gsum[k] += gt;
                             mx[k] = mnew;
                         }
+                        {
+                            DH<T, D, HV, HM> vb;
+                            vb.load(sV, (int64_t)m * W, H, h);
 #pragma unroll
-                        for (int d = 0; d < D; ++d) {
-                            float vv[HV];
-                            ldv<T, HV>(sV, (int64_t)m * W + d * H + h, vv);
+                            for (int d = 0; d < D; ++d)
 #pragma unroll
-                            for (int k = 0; k < HV; ++k) acc[d][k] = acc[d][k] * corr[k] + w[k] * vv[k];
+                                for (int k = 0; k < HV; ++k) acc[d][k] = acc[d][k] * corr[k] + w[k] * vb.at(d, k);
                         }
                     }
                     if (m + PD < mt) fetch(kk, m + PD);
@@ -293,18 +361,16 @@ __global__ void __launch_bounds__(512) node_att_fwd_lds_kernel(const tgt_node_at
         a.gsum[row_l * H + h + k] = gsum[k];
     }
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        float o[HV];
+    for (int d = 0; d < D; ++d)
 #pragma unroll
-        for (int k = 0; k < HV; ++k) o[k] = acc[d][k] * f[k];
-        stv<T, HV>(vatt, row_l * (int64_t)(D * H) + d * H + h, o);
-    }
+        for (int k = 0; k < HV; ++k) acc[d][k] *= f[k];
+    DH<T, D, HV, HM>::store(vatt, row_l * (int64_t)(D * H), H, h, acc);
 }
 
 // ---------------------------------------------------------------------------
 // backward, row pass: lane = (query l, HV heads).  Writes dE, dG and dQ.
 // ---------------------------------------------------------------------------
-template <typename T, int D, int HV>
+template <typename T, int D, int HV, bool HM>
 __global__ void __launch_bounds__(256) node_att_bwd_row_kernel(const tgt_node_attention_args a) {
     const NodeLane n = node_lane<HV>(a);
     if (!n.active) return;
@@ -317,14 +383,16 @@ __global__ void __launch_bounds__(256) node_att_bwd_row_kernel(const tgt_node_at
     const int64_t row0 = (int64_t)n.b * N, row_l = row0 + n.x;
 
     float q[D][HV], dq[D][HV];
+    {
+        DH<T, D, HV, HM> qb;
+        qb.load(qkv, row_l * a.ld_qkv + a.q_off, H, h);
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        ldv<T, HV>(qkv, row_l * a.ld_qkv + a.q_off + d * H + h, q[d]);
+        for (int d = 0; d < D; ++d)
 #pragma unroll
-        for (int k = 0; k < HV; ++k) {
-            q[d][k] *= a.scale;
-            dq[d][k] = 0.f;
-        }
+            for (int k = 0; k < HV; ++k) {
+                q[d][k] = qb.at(d, k) * a.scale;
+                dq[d][k] = 0.f;
+            }
     }
 
     if (a.logits_only) {
@@ -335,13 +403,12 @@ __global__ void __launch_bounds__(256) node_att_bwd_row_kernel(const tgt_node_at
             for (int k = 0; k < HV; ++k) dH[k] = 0.f;
             if (dhh) ldv<T, HV>(dhh, lm * H + h, dH);
             stv<T, HV>(deg, lm * a.ld_eg + a.e_off + h, dH);
+            DH<T, D, HV, HM> kb;
+            kb.load(qkv, (row0 + m) * a.ld_qkv + a.k_off, H, h);
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
-                float kk[HV];
-                ldv<T, HV>(qkv, (row0 + m) * a.ld_qkv + a.k_off + d * H + h, kk);
+            for (int d = 0; d < D; ++d)
 #pragma unroll
-                for (int k = 0; k < HV; ++k) dq[d][k] += dH[k] * kk[k];
-            }
+                for (int k = 0; k < HV; ++k) dq[d][k] += dH[k] * kb.at(d, k);
         }
     } else {
         const T* dva = reinterpret_cast<const T*>(a.d_vatt);
@@ -356,18 +423,20 @@ __global__ void __launch_bounds__(256) node_att_bwd_row_kernel(const tgt_node_at
             d_dsc[k] = delta[k] = 0.f;
         }
         // unscaled V_att from the saved forward output: V_att = vu * log(1+gsum)
+        {
+            DH<T, D, HV, HM> db, ob;
+            db.load(dva, row_l * (int64_t)(D * H), H, h);
+            ob.load(va, row_l * (int64_t)(D * H), H, h);
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            float vu[HV];
-            ldv<T, HV>(dva, row_l * (int64_t)(D * H) + d * H + h, dvu[d]);
-            ldv<T, HV>(va, row_l * (int64_t)(D * H) + d * H + h, vu);
+            for (int d = 0; d < D; ++d)
 #pragma unroll
-            for (int k = 0; k < HV; ++k) {
-                vu[k] *= inv[k];
-                d_dsc[k] += dvu[d][k] * vu[k];
-                dvu[d][k] *= dsc[k];                       // gradient wrt the unscaled V_att
-                delta[k] += dvu[d][k] * vu[k];
-            }
+                for (int k = 0; k < HV; ++k) {
+                    const float vu = ob.at(d, k) * inv[k];
+                    dvu[d][k] = db.at(d, k);
+                    d_dsc[k] += dvu[d][k] * vu;
+                    dvu[d][k] *= dsc[k];                       // gradient wrt the unscaled V_att
+                    delta[k] += dvu[d][k] * vu;
+                }
         }
 #pragma unroll
         for (int k = 0; k < HV; ++k) dgsum[k] = a.scale_degree ? d_dsc[k] * fast_rcp(1.f + gsum[k]) : 0.f;
@@ -381,18 +450,16 @@ __global__ void __launch_bounds__(256) node_att_bwd_row_kernel(const tgt_node_at
             if (dhh) ldv<T, HV>(dhh, lm * H + h, dH);
 #pragma unroll
             for (int k = 0; k < HV; ++k) dot[k] = dA[k] = 0.f;
-            float kk[D][HV];
+            DH<T, D, HV, HM> kb, vb;
+            kb.load(qkv, row_m * a.ld_qkv + a.k_off, H, h);
+            vb.load(qkv, row_m * a.ld_qkv + a.v_off, H, h);
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
-                float vv[HV];
-                ldv<T, HV>(qkv, row_m * a.ld_qkv + a.k_off + d * H + h, kk[d]);
-                ldv<T, HV>(qkv, row_m * a.ld_qkv + a.v_off + d * H + h, vv);
+            for (int d = 0; d < D; ++d)
 #pragma unroll
                 for (int k = 0; k < HV; ++k) {
-                    dot[k] += q[d][k] * kk[d][k];
-                    dA[k] += dvu[d][k] * vv[k];
+                    dot[k] += q[d][k] * kb.at(d, k);
+                    dA[k] += dvu[d][k] * vb.at(d, k);
                 }
-            }
             const float mk = a.mask[lm];
 #pragma unroll
             for (int k = 0; k < HV; ++k) {
@@ -407,22 +474,21 @@ __global__ void __launch_bounds__(256) node_att_bwd_row_kernel(const tgt_node_at
 #pragma unroll
             for (int d = 0; d < D; ++d)
 #pragma unroll
-                for (int k = 0; k < HV; ++k) dq[d][k] += dH[k] * kk[d][k];
+                for (int k = 0; k < HV; ++k) dq[d][k] += dH[k] * kb.at(d, k);
         }
     }
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
+    for (int d = 0; d < D; ++d)
 #pragma unroll
         for (int k = 0; k < HV; ++k) dq[d][k] *= a.scale;
-        stv<T, HV>(dqkv, row_l * a.ld_qkv + a.q_off + d * H + h, dq[d]);
-    }
+    DH<T, D, HV, HM>::store(dqkv, row_l * a.ld_qkv + a.q_off, H, h, dq);
 }
 
 // ---------------------------------------------------------------------------
 // backward, column pass: lane = (key m, HV heads).  dK and dV, reading the
 // dH = dE the row pass stored (same stream, so ordered).
 // ---------------------------------------------------------------------------
-template <typename T, int D, int HV>
+template <typename T, int D, int HV, bool HM>
 __global__ void __launch_bounds__(256) node_att_bwd_col_kernel(const tgt_node_attention_args a) {
     const NodeLane n = node_lane<HV>(a);
     if (!n.active) return;
@@ -435,11 +501,16 @@ __global__ void __launch_bounds__(256) node_att_bwd_col_kernel(const tgt_node_at
     const int64_t row0 = (int64_t)n.b * N, row_m = row0 + m;
 
     float kv[D][HV], dk[D][HV], dv[D][HV];
+    {
+        DH<T, D, HV, HM> kb;
+        kb.load(qkv, row_m * a.ld_qkv + a.k_off, H, h);
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        ldv<T, HV>(qkv, row_m * a.ld_qkv + a.k_off + d * H + h, kv[d]);
+        for (int d = 0; d < D; ++d)
 #pragma unroll
-        for (int k = 0; k < HV; ++k) dk[d][k] = dv[d][k] = 0.f;
+            for (int k = 0; k < HV; ++k) {
+                kv[d][k] = kb.at(d, k);
+                dk[d][k] = dv[d][k] = 0.f;
+            }
     }
     for (int l = 0; l < N; ++l) {
         const int64_t row_l = row0 + l, lm = row_l * N + m;
@@ -447,15 +518,17 @@ __global__ void __launch_bounds__(256) node_att_bwd_col_kernel(const tgt_node_at
         ldv<T, HV>(deg, lm * a.ld_eg + a.e_off + h, dH);
 #pragma unroll
         for (int k = 0; k < HV; ++k) dot[k] = 0.f;
+        {
+            DH<T, D, HV, HM> qb;
+            qb.load(qkv, row_l * a.ld_qkv + a.q_off, H, h);
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            float ql[HV];
-            ldv<T, HV>(qkv, row_l * a.ld_qkv + a.q_off + d * H + h, ql);
+            for (int d = 0; d < D; ++d)
 #pragma unroll
-            for (int k = 0; k < HV; ++k) {
-                dot[k] += ql[k] * kv[d][k];
-                dk[d][k] += dH[k] * ql[k];
-            }
+                for (int k = 0; k < HV; ++k) {
+                    const float ql = qb.at(d, k);
+                    dot[k] += ql * kv[d][k];
+                    dk[d][k] += dH[k] * ql;
+                }
         }
         if (a.logits_only) continue;
         float e[HV], g[HV], lse[HV], gsum[HV], w[HV];
@@ -470,21 +543,21 @@ __global__ void __launch_bounds__(256) node_att_bwd_col_kernel(const tgt_node_at
             const float gt = fast_sigmoid(g[k] + mk);
             w[k] = p * gt * (a.scale_degree ? __logf(1.f + gsum[k]) : 1.f);
         }
+        {
+            DH<T, D, HV, HM> db;
+            db.load(dva, row_l * (int64_t)(D * H), H, h);
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            float dvl[HV];
-            ldv<T, HV>(dva, row_l * (int64_t)(D * H) + d * H + h, dvl);
+            for (int d = 0; d < D; ++d)
 #pragma unroll
-            for (int k = 0; k < HV; ++k) dv[d][k] += w[k] * dvl[k];
+                for (int k = 0; k < HV; ++k) dv[d][k] += w[k] * db.at(d, k);
         }
     }
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
+    for (int d = 0; d < D; ++d)
 #pragma unroll
         for (int k = 0; k < HV; ++k) dk[d][k] *= a.scale;
-        stv<T, HV>(dqkv, row_m * a.ld_qkv + a.k_off + d * H + h, dk[d]);
-        if (!a.logits_only) stv<T, HV>(dqkv, row_m * a.ld_qkv + a.v_off + d * H + h, dv[d]);
-    }
+    DH<T, D, HV, HM>::store(dqkv, row_m * a.ld_qkv + a.k_off, H, h, dk);
+    if (!a.logits_only) DH<T, D, HV, HM>::store(dqkv, row_m * a.ld_qkv + a.v_off, H, h, dv);
 }
 
 // ---------------------------------------------------------------------------
@@ -510,13 +583,18 @@ static int node_vec(const tgt_node_attention_args& a, int esz, int want) {
 
 static int env_int(const char* name, int dflt) { return getenv(name) ? atoi(getenv(name)) : dflt; }
 
-#define TGT_NODE_LAUNCH(KERNEL, NAME, WANT)                                                                       \
+#define TGT_NODE_LAUNCH_HM(KERNEL, NAME, WANT, HM)                                                                 \
     do {                                                                                                          \
         const int hv = node_vec(a, (int)sizeof(T), (D <= 16) ? (WANT) : ((WANT) > 2 ? 2 : (WANT)));               \
-        if (hv == 4) { if constexpr (D <= 16) hipLaunchKernelGGL((KERNEL<T, D, 4>), dim3(node_grid(a, 4)), dim3(256), 0, st, a); } \
-        else if (hv == 2) hipLaunchKernelGGL((KERNEL<T, D, 2>), dim3(node_grid(a, 2)), dim3(256), 0, st, a);       \
-        else hipLaunchKernelGGL((KERNEL<T, D, 1>), dim3(node_grid(a, 1)), dim3(256), 0, st, a);                    \
+        if (hv == 4) { if constexpr (D <= 16) hipLaunchKernelGGL((KERNEL<T, D, 4, HM>), dim3(node_grid(a, 4)), dim3(256), 0, st, a); } \
+        else if (hv == 2) hipLaunchKernelGGL((KERNEL<T, D, 2, HM>), dim3(node_grid(a, 2)), dim3(256), 0, st, a);   \
+        else hipLaunchKernelGGL((KERNEL<T, D, 1, HM>), dim3(node_grid(a, 1)), dim3(256), 0, st, a);                \
         if (int e = check_launch(NAME)) return e;                                                                 \
+    } while (0)
+#define TGT_NODE_LAUNCH(KERNEL, NAME, WANT)                                    \
+    do {                                                                       \
+        if (a.head_major) TGT_NODE_LAUNCH_HM(KERNEL, NAME, WANT, true);        \
+        else TGT_NODE_LAUNCH_HM(KERNEL, NAME, WANT, false);                    \
     } while (0)
 
 template <typename T, int D>
@@ -540,7 +618,10 @@ static int launch_node(const tgt_node_attention_args& a, bool bwd, hipStream_t s
                 if (qb > 32) qb = 32;
                 const int threads = ((qb * lpr + 63) / 64) * 64;
                 const int grid = a.B * ((a.N + qb - 1) / qb);
-                hipLaunchKernelGGL((node_att_fwd_lds_kernel<T, D, 4, MT>), dim3(grid), dim3(threads), lds, st, a, lpr, qb);
+                if (a.head_major)
+                    hipLaunchKernelGGL((node_att_fwd_lds_kernel<T, D, 4, MT, true>), dim3(grid), dim3(threads), lds, st, a, lpr, qb);
+                else
+                    hipLaunchKernelGGL((node_att_fwd_lds_kernel<T, D, 4, MT, false>), dim3(grid), dim3(threads), lds, st, a, lpr, qb);
                 return check_launch("node_att_fwd_lds_kernel");
             }
         }
@@ -574,6 +655,13 @@ int node_attention_run(const tgt_node_attention_args* a, bool bwd, hipStream_t s
         if (!bwd && !a->hhat) return set_error(TGT_ERR_INVALID, "node attention: logits_only needs hhat");
     } else if (!a->mask || !a->lse || !a->gsum || !a->vatt) {
         return set_error(TGT_ERR_INVALID, "node attention: null mask/vatt/lse/gsum");
+    }
+    if (a->head_major) {       // Q/K/V and V_att rows as [h][d]: blocks are fetched with 16-byte accesses
+        const int64_t esz = a->dtype == TGT_F32 ? 4 : 2;
+        if ((a->ld_qkv * esz) % 16 || (a->q_off * esz) % 16 || (a->k_off * esz) % 16 || (a->v_off * esz) % 16 ||
+            ((int64_t)a->D * esz * 2) % 16 || a->H % 2 || (uintptr_t)a->qkv % 16 || (uintptr_t)a->vatt % 16 ||
+            (uintptr_t)a->d_qkv % 16 || (uintptr_t)a->d_vatt % 16)
+            return set_error(TGT_ERR_INVALID, "node attention: head_major needs 16-byte aligned rows/offsets/tensors, an even H and 2*D*sizeof(T) %% 16 == 0");
     }
     if (bwd) {
         if (!a->d_qkv || !a->d_eg) return set_error(TGT_ERR_INVALID, "node attention bwd: null d_qkv/d_eg");

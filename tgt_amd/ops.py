@@ -517,13 +517,14 @@ def _node_args(qkv, eg, mask3, H, scale_degree, logits_only):
 
 class _NodeAttention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, eg, mask3, H, scale_degree, want_edges):
+    def forward(ctx, qkv, eg, mask3, H, scale_degree, want_edges, head_major=False):
         _dev(qkv, eg, mask3)
         qkv, eg = qkv.contiguous(), eg.contiguous()
         if eg.dtype != qkv.dtype:
             eg = eg.to(qkv.dtype)
         B, N = qkv.shape[0], qkv.shape[1]
         a, W = _node_args(qkv, eg, mask3, H, scale_degree, False)
+        a.head_major = int(bool(head_major))
         vatt = torch.empty(B, N, W, dtype=qkv.dtype, device=qkv.device)
         hhat = torch.empty(B, N, N, H, dtype=qkv.dtype, device=qkv.device) if want_edges else None
         lse = torch.empty(B, N, H, dtype=torch.float32, device=qkv.device)
@@ -531,7 +532,7 @@ class _NodeAttention(torch.autograd.Function):
         a.vatt, a.hhat, a.lse, a.gsum = vatt.data_ptr(), _ptr(hhat), lse.data_ptr(), gsum.data_ptr()
         _call('tgt_node_attention_fwd', _lib.lib().tgt_node_attention_fwd, a)
         ctx.save_for_backward(qkv, eg, mask3, lse, gsum, vatt)
-        ctx.cfg = (H, scale_degree, want_edges)
+        ctx.cfg = (H, scale_degree, want_edges, bool(head_major))
         if want_edges:
             return vatt, hhat
         return vatt, None
@@ -539,8 +540,9 @@ class _NodeAttention(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_vatt, d_hhat):
         qkv, eg, mask3, lse, gsum, vatt = ctx.saved_tensors
-        H, scale_degree, want_edges = ctx.cfg
+        H, scale_degree, want_edges, head_major = ctx.cfg
         a, W = _node_args(qkv, eg, mask3, H, scale_degree, False)
+        a.head_major = int(head_major)
         d_vatt = torch.zeros_like(qkv[..., :W]).contiguous() if d_vatt is None else d_vatt.contiguous()
         if d_hhat is not None:
             d_hhat = d_hhat.contiguous()
@@ -548,14 +550,18 @@ class _NodeAttention(torch.autograd.Function):
         a.lse, a.gsum, a.vatt = lse.data_ptr(), gsum.data_ptr(), vatt.data_ptr()
         a.d_vatt, a.d_hhat, a.d_qkv, a.d_eg = d_vatt.data_ptr(), _ptr(d_hhat), d_qkv.data_ptr(), d_eg.data_ptr()
         _call('tgt_node_attention_bwd', _lib.lib().tgt_node_attention_bwd, a)
-        return d_qkv, d_eg, None, None, None, None
+        return d_qkv, d_eg, None, None, None, None, None
 
 
-def node_attention(qkv, eg, mask3, num_heads, scale_degree=True, want_edges=True):
-    """qkv (B,N,3W) and eg (B,N,N,2H) in the reference's head-minor layout;
+def node_attention(qkv, eg, mask3, num_heads, scale_degree=True, want_edges=True, head_major=False):
+    """qkv (B,N,3W) and eg (B,N,N,2H) in the reference's head-minor layout (channel = d*H + h);
     returns V_att (B,N,W) and H_hat (B,N,N,H) (or None).
+    head_major: Q, K, V and V_att use channel = h*D + d instead (a caller would permute the rows
+    of lin_QKV and the columns of lin_O_h) -- same arithmetic, a lane's D values in one block.
+    Measured SLOWER at the BASELINE shape (0.112 / 0.210 ms against 0.074 / 0.179 ms forward /
+    backward), so the modules do not use it.
     Reference arithmetic: lib/tgt/layers/layers.py:62-77."""
-    return _NodeAttention.apply(qkv, eg, mask3, num_heads, scale_degree, want_edges)
+    return _NodeAttention.apply(qkv, eg, mask3, num_heads, scale_degree, want_edges, head_major)
 
 
 class _EdgeLogits(torch.autograd.Function):
@@ -749,6 +755,13 @@ class _DropMaskPool:
         out = st[0][st[1]]
         st[1] += 1
         return out
+
+
+def reset_random_pools():
+    """forget the pre-drawn DropPath / source-dropout vectors: call after torch.manual_seed() when a
+    run has to be reproducible from that seed (the pools otherwise carry draws over)"""
+    _ScalePool._pools.clear()
+    _DropMaskPool._pools.clear()
 
 
 def source_drop_mask(B, N, p, fill, device):

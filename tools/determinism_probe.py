@@ -19,6 +19,8 @@ mk = dict(mk, model_height=layers)
 
 def run():
     torch.manual_seed(0)
+    from tgt_amd import ops
+    ops.reset_random_pools()
     model = TGT_Multi(**mk).cuda()
     tr = Trainer(model, cfg)
     model.train()
