@@ -1,0 +1,62 @@
+"""Host-side logic that needs no GPU: the row tables that assemble the kernel-order projections from
+the reference's separate nn.Linear parameters, and the numpy restatement of the kernels'
+attention-dropout generator."""
+import numpy as np
+import torch
+
+import golden_util as gu
+
+
+def test_triplet_attention_param_table_matches_reference_channel_order():
+    from tgt_amd import layout
+    from tgt_amd.tgt.layers.triplet import TripletAttention, TripletAttentionUngated, AxialAttention
+    C, H = 64, 8
+    D = C // H
+    for cls, nb in ((TripletAttention, 2 * H), (TripletAttentionUngated, H), (AxialAttention, 0)):
+        mod = cls(C, H)
+        t, L = mod._table, mod._layout
+        src, idx = t.row_src.tolist(), t.row_idx.tolist()
+        assert len(src) == L.width and t.n_cols == C
+        for dir_ in (0, 1):
+            for part, off in enumerate((L.q[dir_], L.k[dir_], L.v[dir_])):
+                for h in range(H):
+                    for d in range(D):
+                        r = off + h * D + d                       # kernel row: head-major
+                        assert src[r] == dir_                      # lin_QKV_in / lin_QKV_out
+                        assert idx[r] == part * C + d * H + h      # reference channel: head-minor (triplet.py:213-215)
+        if nb:
+            for dir_ in (0, 1):
+                for j in range(nb):
+                    r = 6 * C + dir_ * nb + j
+                    assert src[r] == 2 + dir_ and idx[r] == j
+        assert all(s == -1 for s in src[L.used:])
+        # the permutation really is one: every reference row of the QKV weights is used exactly once
+        assert sorted(i for s_, i in zip(src, idx) if s_ == 0) == list(range(3 * C))
+        assert torch.equal(torch.tensor(idx[:3 * C]), layout.qkv_rows_head_major(C, H).to(torch.int64))
+
+
+def test_triplet_aggregate_param_table():
+    from tgt_amd.tgt.layers.triplet import TripletAggregate, TripletAggregateUngated
+    C, H = 32, 4
+    D = C // H
+    for cls, nb in ((TripletAggregate, 4 * H), (TripletAggregateUngated, 2 * H)):
+        mod = cls(C, H)
+        src, idx = mod._table.row_src.tolist(), mod._table.row_idx.tolist()
+        for dir_ in (0, 1):
+            for h in range(H):
+                for d in range(D):
+                    r = dir_ * C + h * D + d
+                    assert src[r] == 0 and idx[r] == dir_ * C + d * H + h
+        assert src[2 * C:2 * C + nb] == [1] * nb and idx[2 * C:2 * C + nb] == list(range(nb))
+
+
+def test_dropout_generator_restatement_is_deterministic_and_calibrated():
+    units = np.arange(40)
+    keep, scale = gu.triplet_dropout_keep(0xDEADBEEF12345678, 0.2, units, 32)
+    keep2, _ = gu.triplet_dropout_keep(0xDEADBEEF12345678, 0.2, units, 32)
+    other, _ = gu.triplet_dropout_keep(0xDEADBEEF12345679, 0.2, units, 32)
+    assert keep.shape == (40, 32, 32) and keep.dtype == bool
+    assert (keep == keep2).all() and (keep != other).any()
+    assert abs(keep.mean() - 0.8) < 0.01 and abs(scale - 1.25) < 1e-6
+    # neighbouring keys share one hash word but not their decision
+    assert (keep[:, :, 0::2] != keep[:, :, 1::2]).mean() > 0.2
