@@ -93,7 +93,13 @@ __device__ __forceinline__ uint32_t mix32(uint32_t h) {      // "lowbias32" inte
     return h;
 }
 // exchange with the lane holding the other half of the same column (l ^ 32)
-__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
+// v_permlane32_swap (gfx950): a VALU exchange of the two 32-lane halves -- __shfl_xor(v, 32) goes through
+// the LDS crossbar (ds_bpermute), whose latency sits on the softmax dependency chain three times per j
+__device__ __forceinline__ float xhalf(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);     // r[0] = [lo, lo], r[1] = [hi, hi]
+    return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
+}
 
 template <typename T> struct DType;
 template <> struct DType<float>  { static constexpr int id = TGT_F32; };
