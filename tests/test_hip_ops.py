@@ -138,13 +138,14 @@ def test_projected_triplet_attention_bias_gradient(case, dtype, variant, proj_ke
     assert torch.isfinite(new_in[2].grad).all()
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('case', [CASES[0], CASES[2], CASES[4], CASES[5]])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('case', [CASES[0], CASES[2], CASES[4], CASES[5], (2, 40, [40, 33], 48, 3)])
 @pytest.mark.parametrize('variant', ['gated', 'axial'])
 def test_triplet_attention_dropout(case, dtype, variant):
     """attention dropout inside the kernels (reference triplet.py:223-225): forward and backward
     against the oracle given the SAME keep pattern (numpy restatement of the counter-based
-    generator), plus the keep rate."""
+    generator), plus the keep rate.  (Two node tiles + dropout in 16-bit -- CASES[5] and the
+    H = 3 case -- are the instantiations hipcc once miscompiled: tools/isa_defuse_lint.py.)"""
     from tgt_amd import ops, layout
     B, N, nn_, C, H = case
     gated, biased = variant == 'gated', variant != 'axial'

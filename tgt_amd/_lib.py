@@ -5,7 +5,9 @@ RuntimeError is raised.  The library is built in-tree by `build_library()`
 (`__graft_entry__.build()` calls it) with hipcc for gfx950.
 """
 import ctypes as C
+import importlib.util
 import os
+import shutil
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -101,6 +103,18 @@ SYMBOLS = {
 }
 
 _lib = None
+_isa_lint = None
+
+
+def isa_lint():
+    """tools/isa_defuse_lint.py as a module (build-time only)."""
+    global _isa_lint
+    if _isa_lint is None:
+        spec = importlib.util.spec_from_file_location(
+            'isa_defuse_lint', os.path.join(os.path.dirname(_HERE), 'tools', 'isa_defuse_lint.py'))
+        _isa_lint = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(_isa_lint)
+    return _isa_lint
 
 
 def build_library(force=False, verbose=False):
@@ -115,18 +129,37 @@ def build_library(force=False, verbose=False):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     objs = []
     procs = []
-    os.makedirs(os.path.join(_HERE, 'build'), exist_ok=True)
+    build = os.path.join(_HERE, 'build')
     for s, (_, flags, suffix) in zip(srcs, units):
-        o = os.path.join(_HERE, 'build', os.path.basename(s) + suffix + '.o')
+        # one directory per unit: -save-temps=obj drops the device assembly next to the object, and the
+        # three triplet_attention units share a source name
+        d = os.path.join(build, os.path.basename(s) + suffix)
+        shutil.rmtree(d, ignore_errors=True)
+        os.makedirs(d)
+        o = os.path.join(d, 'unit.o')
         objs.append(o)
-        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', *flags, '-c', s, '-o', o]
-        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    for cmd, p in procs:
+        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-save-temps=obj', *flags, '-c', s, '-o', o]
+        procs.append((cmd, d, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    undefined = {}
+    for cmd, d, p in procs:
         out, _ = p.communicate()
         if p.returncode:
             raise RuntimeError('hipcc failed: ' + ' '.join(cmd) + '\n' + out.decode(errors='replace'))
         if verbose and out:
             print(out.decode(errors='replace'))
+        # the shipped ISA is linted for registers read but never written (a hipcc spill miscompile this
+        # library has hit: tools/isa_defuse_lint.py); then the temporaries go, they are large
+        for f in os.listdir(d):
+            path = os.path.join(d, f)
+            if f.endswith('-gfx950.s'):
+                with open(path) as fh:
+                    for k, regs in isa_lint().lint_text(fh.read()).items():
+                        undefined[f'{os.path.basename(d)}:{k}'] = regs
+            if f != 'unit.o' and not (f.endswith('-gfx950.s') and os.environ.get('TGT_KEEP_ISA')):
+                os.remove(path)
+    if undefined:
+        raise RuntimeError('hipcc produced kernels that read vector registers no instruction writes (miscompiled spill?):\n' +
+                           '\n'.join(f'  {k}: {v}' for k, v in undefined.items()))
     cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode:

@@ -295,6 +295,16 @@ __global__ void __launch_bounds__(HG * 64, OCC) __attribute__((amdgpu_waves_per_
         __syncthreads();
 
         for (int j = 0; j < N; ++j) {
+            if constexpr (DROP && NT > 1) {
+                // The two-tile dropout variants are the most register-starved instantiations, and hipcc
+                // (ROCm 7.2) miscompiled the spill of these loop-invariant fragments there (3 dwords to
+                // scratch, the 4th parked in an AGPR and never restored: tools/isa_defuse_lint.py).
+                // Rebuilding them per j from an opaque copy of r keeps them out of the spill set.
+                int rr = r;
+                asm volatile("" : "+v"(rr));
+                make_ident_d<T, G::kDC>(ident_d, rr, hi);
+                make_ident_k<T>(ident_k, rr, hi);
+            }
             char* sQ = smem + (j & 1) * kSet;
             char* sO = sQ + G::kSlabBytes;
             char* sK = sQ + 2 * G::kSlabBytes;
@@ -618,10 +628,6 @@ int triplet_attention_run(const tgt_triplet_attention_args* a, bool bwd, hipStre
     if (a->B == 0 || a->N == 0) return TGT_OK;                 // empty batch: nothing to do
     if (a->N > 64) return set_error(TGT_ERR_UNSUPPORTED, "triplet attention: N=%d > 64 not supported", a->N);
     if (!(a->dropout_p >= 0.f && a->dropout_p < 1.f)) return set_error(TGT_ERR_INVALID, "triplet attention: dropout_p=%f outside [0,1)", a->dropout_p);
-    // KNOWN ISSUE (round 1): the bf16 two-node-tile backward with dropout is not reproducible run to run
-    // (fp16 / fp32 and every other combination are, and match the oracle); refuse it rather than be wrong
-    if (a->dropout_p > 0.f && a->N > 32 && a->dtype == TGT_BF16)
-        return set_error(TGT_ERR_UNSUPPORTED, "triplet attention: dropout with N > 32 is not available in bf16 (use fp32/fp16 rows)");
     const int64_t esz = a->dtype == TGT_F32 ? 4 : 2;
     for (int dir = 0; dir < 2; ++dir) {
         if (!a->qkv[dir] || !a->out || !a->mask) return set_error(TGT_ERR_INVALID, "triplet attention: null tensor");

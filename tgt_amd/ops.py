@@ -167,9 +167,6 @@ def triplet_attention(fused, mask3, layout, dropout=(0.0, 0)):
     (B,N,N) float32.  Returns Va (B,N,N,2C) with channel = dir*C + h*D + d.
     dropout: (p, seed) of the attention dropout on the gated weights (draw_dropout).
     Reference arithmetic: lib/tgt/layers/triplet.py:213-246."""
-    if dropout[0] > 0 and fused.shape[1] > 32 and fused.dtype == torch.bfloat16:
-        # the one combination the bf16 kernels refuse (two node tiles + dropout): fp32 rows for this call
-        return _TripletAttention.apply(fused.float(), mask3, layout, dropout).to(fused.dtype)
     return _TripletAttention.apply(fused, mask3, layout, dropout)
 
 
@@ -377,10 +374,6 @@ def projected_triplet_attention(x, weight, bias, mask3, layout, table=None, drop
     if os.environ.get('TGT_TRI_COLSUM', '1') == '0' and table is None:      # A/B knob: separate bias-gradient pass
         return triplet_attention(linear(x, weight, bias), mask3, layout, dropout)
     cd = torch.get_autocast_dtype('cuda') if (x.is_cuda and torch.is_autocast_enabled('cuda')) else x.dtype
-    if dropout[0] > 0 and x.shape[1] > 32 and cd == torch.bfloat16:          # see triplet_attention()
-        if table is not None:
-            weight, bias = _FuseRowsOnly.apply(table, cd, *weight)
-        return triplet_attention(linear(x, weight, bias), mask3, layout, dropout)
     wb = (weight, bias) if table is None else tuple(weight)
     return _ProjectedTripletAttention.apply(x, mask3, layout, cd, table, dropout, *wb)
 
