@@ -40,7 +40,7 @@ namespace tgt {
 // per query tile `it`; inside a pass the key axis spans all NT tiles.
 // ---------------------------------------------------------------------------
 template <typename T, int D, int HG, int NT, int PF, bool DROP>
-__global__ void __launch_bounds__(HG * 64, (NT == 1 && sizeof(T) == 2) ? 4 : 1) tri_att_fwd_kernel(const tgt_triplet_attention_args a) {
+__global__ void __launch_bounds__(HG * 64, (NT == 1 && sizeof(T) == 2) ? 4 : (sizeof(T) == 2 ? 2 : 1)) tri_att_fwd_kernel(const tgt_triplet_attention_args a) {
     using G = TriGeo<T, D, HG>;
     using F = frag_t<T>;
     constexpr int KR = 32 * NT;

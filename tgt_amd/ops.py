@@ -266,21 +266,6 @@ def _proj_fused_ok(x, N, L, cd):
             cd in (torch.bfloat16, torch.float16) and L.C in (64, 128, 256))
 
 
-class _FuseRowsOnly(torch.autograd.Function):
-    """(weight, bias) of a fused projection as differentiable tensors (the rare paths that cannot
-    use the one-node projection + kernel functions)"""
-
-    @staticmethod
-    def forward(ctx, table, cd, *params):
-        ctx.save_for_backward(*params)
-        ctx.table = table
-        return _fuse_params(table, params, cd)
-
-    @staticmethod
-    def backward(ctx, dw, db):
-        return (None, None, *_unfuse_grads(ctx.table, ctx.saved_tensors, dw.float(), db.float()))
-
-
 class _ProjectedTripletAttention(torch.autograd.Function):
     """fused projection GEMM + triplet attention core as ONE autograd node, so that the backward
     kernel can hand the projection its bias gradient (column sums of d_fused, accumulated while
