@@ -706,3 +706,109 @@ def test_empty_batch_is_a_no_op():
     v, hh = ops.node_attention(torch.zeros(0, 5, 144, device='cuda'), torch.zeros(0, 5, 5, 8, device='cuda'),
                                torch.zeros(0, 5, 5, device='cuda'), 4)
     assert v.shape == (0, 5, 48) and hh.shape == (0, 5, 5, 4)
+
+
+def _ragged_mask3(B, N, rng):
+    nn_ = rng.integers(N // 2, N + 1, B).tolist()
+    nn_[0] = N
+    return gu.additive_mask(nn_, N, torch.float32).reshape(B, N, N).cuda(), nn_
+
+
+@pytest.mark.parametrize('op', ['triplet_attention', 'triplet_aggregate', 'node_attention'])
+def test_baseline_size_properties(op):
+    """BASELINE.json size (B=256 graphs, N=32, C=256/Ht=16, W=768/Hn=64, bf16), where the oracle would
+    take minutes: properties that hold EXACTLY whatever the size --
+      * graphs are independent: graphs [s:e] of the full launch == a launch on that slice alone, bit for
+        bit, forward and backward (a wrong batch stride, a workgroup reading its neighbour's slab, or a
+        grid that drops / repeats work at 4096 workgroups breaks this);
+      * the values enter linearly: doubling V (a power of two, exact in bf16) doubles the output bits,
+        doubling d_out doubles every gradient;
+      * rows/columns of padded nodes: the slice anchors them (same bits as the small launch, which the
+        oracle tests pin), and everything stays finite."""
+    from tgt_amd import ops
+    B, N, C, Ht, W, Hn = 256, 32, 256, 16, 768, 64
+    dt = torch.bfloat16
+    rng = np.random.default_rng(2024)
+    m3, _ = _ragged_mask3(B, N, rng)
+    g = torch.Generator(device='cuda').manual_seed(7)
+    randn = lambda *s: torch.randn(*s, device='cuda', generator=g).to(dt)
+    if op == 'node_attention':
+        qkv, eg = randn(B, N, 3 * W), randn(B, N, N, 2 * Hn)
+        gv, gh = randn(B, N, W), randn(B, N, N, Hn)
+
+        def run(sl, vmul=1.0, gmul=1.0):
+            q = qkv[sl].clone()
+            q[..., 2 * W:] *= vmul
+            q.requires_grad_(True)
+            e = eg[sl].clone().requires_grad_(True)
+            v, hh = ops.node_attention(q, e, m3[sl], Hn)
+            dq, de = torch.autograd.grad([v, hh], [q, e], [gv[sl] * gmul, gh[sl] * gmul])
+            return v, hh, dq, de
+        full = run(slice(None))
+        for s, e_ in ((0, 3), (101, 104), (253, 256)):
+            part = run(slice(s, e_))
+            for a, b in zip(full, part):
+                assert torch.equal(a[s:e_], b)
+        v2 = run(slice(0, 8), vmul=2.0)[0]
+        assert torch.equal(v2, full[0][:8] * 2)
+        g2 = run(slice(0, 8), gmul=2.0)
+        assert torch.equal(g2[2], full[2][:8] * 2) and torch.equal(g2[3], full[3][:8] * 2)
+        assert all(torch.isfinite(t).all() for t in full)
+        return
+    att = op == 'triplet_attention'
+    L = ops.TripletLayout(C, Ht) if att else ops.AggregateLayout(C, Ht)
+    fn = ops.triplet_attention if att else ops.triplet_aggregate
+    fused, d_out = randn(B, N, N, L.width), randn(B, N, N, 2 * C)
+
+    def run(sl, vmul=1.0, gmul=1.0):
+        f = fused[sl].clone()
+        if vmul != 1.0:
+            for d in (0, 1):
+                lo = L.v[d]
+                f[..., lo:lo + C] *= vmul
+        f.requires_grad_(True)
+        y = fn(f, m3[sl], L)
+        df, = torch.autograd.grad(y, f, d_out[sl] * gmul)
+        return y, df
+    full = run(slice(None))
+    for s, e_ in ((0, 3), (101, 104), (253, 256)):
+        part = run(slice(s, e_))
+        assert torch.equal(full[0][s:e_], part[0]) and torch.equal(full[1][s:e_], part[1])
+    assert torch.equal(run(slice(0, 8), vmul=2.0)[0], full[0][:8] * 2)
+    assert torch.equal(run(slice(0, 8), gmul=2.0)[1], full[1][:8] * 2)
+    assert torch.isfinite(full[0]).all() and torch.isfinite(full[1][..., :L.used]).all()
+
+
+def test_baseline_size_projection_bias_gradient():
+    """the training path at BASELINE size: projection (1536- + 64-wide GEMMs) + attention as one node,
+    bias gradient summed inside the backward kernel over 256 graphs x 1024 rows -- against the plain
+    composition (separate linear, torch reductions) of the same kernels, and batch-slice exactness of
+    the activations' gradient."""
+    from tgt_amd import ops
+    B, N, C, Ht = 256, 32, 256, 16
+    dt = torch.bfloat16
+    L = ops.TripletLayout(C, Ht)
+    rng = np.random.default_rng(5)
+    m3, _ = _ragged_mask3(B, N, rng)
+    g = torch.Generator(device='cuda').manual_seed(11)
+    randn = lambda *s: torch.randn(*s, device='cuda', generator=g)
+    x = randn(B, N, N, C).to(dt).requires_grad_(True)
+    w = (randn(L.width, C) * C ** -0.5).to(dt).requires_grad_(True)
+    b = (randn(L.width) * 0.1).to(dt).requires_grad_(True)
+    d_out = randn(B, N, N, 2 * C).to(dt)
+    y1 = ops.projected_triplet_attention(x, w, b, m3, L)
+    dx1, dw1, db1 = torch.autograd.grad(y1, (x, w, b), d_out)
+    fused = ops.linear(x, w, b)
+    y0 = ops.triplet_attention(fused, m3, L)
+    dfused, = torch.autograd.grad(y0, fused, d_out, retain_graph=True)
+    dx0, dw0, _ = torch.autograd.grad(y0, (x, w, b), d_out)
+    assert rel(y1, y0) < 1e-3 and rel(dx1, dx0) < 1e-3 and rel(dw1, dw0) < 5e-3
+    want = dfused.double().sum((0, 1, 2))[:L.used]
+    scale = float(dfused.double().abs().sum((0, 1, 2)).max())
+    assert float((db1.double()[:L.used] - want).abs().max()) / scale < 2e-3
+    xs = x[100:102].detach().clone().requires_grad_(True)
+    ys = ops.projected_triplet_attention(xs, w, b, m3[100:102], L)
+    dxs, = torch.autograd.grad(ys, xs, d_out[100:102])
+    # (2 graphs take the one-GEMM projection, 256 the split one: same products, so only the GEMM kernels'
+    # summation order differs)
+    assert rel(ys, y1[100:102]) < 1e-3 and rel(dxs, dx1[100:102]) < 1e-3
