@@ -302,6 +302,12 @@ int tgt_permute_cols(const void* src, int32_t src_dtype, const int32_t* idx, voi
  * stage of the two-stage reductions; finishes tgt_triplet_attention_args.d_*_colsum). */
 int tgt_sum_rows(const float* x, int32_t rows, int32_t C, float* out, void* stream);
 
+/* out[i] = sum_p x[p*n + i] over `planes` contiguous float32 planes of n elements, fixed summation
+ * order: the closing sum of a weight gradient computed as per-row-chunk partial products
+ * (dW = sum_c dY_c^T X_c -- what `grad_weight` of nn.Linear is in lib/tgt/layers/*.py, contracted
+ * over B*N*N = 262144 rows). */
+int tgt_sum_planes(const float* x, int32_t planes, int64_t n, float* out, void* stream);
+
 int tgt_layer_norm_bwd(const void* dy, int32_t dy_dtype, const void* x, int32_t x_dtype,
                        const float* gamma, const float* mean, const float* rstd,
                        void* dx, int32_t dx_dtype, float* dgamma, float* dbeta, float* partial,

@@ -812,3 +812,19 @@ def test_baseline_size_projection_bias_gradient():
     # (2 graphs take the one-GEMM projection, 256 the split one: same products, so only the GEMM kernels'
     # summation order differs)
     assert rel(ys, y1[100:102]) < 1e-3 and rel(dxs, dx1[100:102]) < 1e-3
+
+
+@pytest.mark.parametrize('shape', [(8, 768, 768), (128, 256, 256), (32, 1536, 256), (128, 64, 256), (3, 5, 7), (1, 16), (33, 1030)])
+def test_sum_planes(shape):
+    """closing sum of the chunked weight gradients (tgt_sum_planes): fixed order, so two launches agree
+    bit for bit; value against an fp64 sum; odd sizes take the scalar path."""
+    from tgt_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(3)
+    part = torch.randn(*shape, device='cuda', generator=g)
+    out = ops.sum_planes(part, torch.empty(shape[1:], device='cuda'))
+    again = ops.sum_planes(part, torch.full(shape[1:], float('nan'), device='cuda'))
+    assert torch.equal(out, again)
+    want = part.double().sum(0)
+    assert float((out.double() - want).abs().max()) <= 4e-6 * float(part.abs().sum(0).max())
+    with pytest.raises(RuntimeError):
+        ops.sum_planes(part, torch.empty(shape[1:], device='cuda', dtype=torch.bfloat16))

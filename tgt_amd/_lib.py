@@ -17,7 +17,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 SOURCES = ['capi.hip', 'params.hip', 'triplet_attention_proj.hip',
            ('triplet_attention.hip', ['-DTGT_TRI_INST=9'], '.f32'), ('triplet_attention.hip', ['-DTGT_TRI_INST=2'], '.bf16'),
            ('triplet_attention.hip', ['-DTGT_TRI_INST=4'], '.f16'), 'triplet_aggregate.hip', 'node_attention.hip', 'layernorm.hip', 'triangular_update.hip', 'elementwise.hip']
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 TGT_F32, TGT_BF16, TGT_F16 = 0, 1, 2
 TRI_BIASED, TRI_GATED, TRI_MASK_OUT = 1, 2, 4
@@ -94,6 +94,7 @@ SYMBOLS = {
     'tgt_layer_norm_parts': (C.c_int, []),
     'tgt_colsum': (C.c_int, [_vp, _i32, _i64, _i32, _vp, _vp, _vp]),
     'tgt_sum_rows': (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
+    'tgt_sum_planes': (C.c_int, [_vp, _i32, _i64, _vp, _vp]),
     'tgt_fuse_rows': (C.c_int, [C.POINTER(FuseRowsArgs), _vp]),
     'tgt_unfuse_rows': (C.c_int, [C.POINTER(FuseRowsArgs), _vp]),
     'tgt_permute_cols': (C.c_int, [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),

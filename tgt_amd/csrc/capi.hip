@@ -44,6 +44,7 @@ int triplet_attention_proj_run(const tgt_triplet_attention_args* a, const void* 
                                hipStream_t st);
 int fuse_rows_run(const tgt_fuse_rows_args* a, bool scatter, hipStream_t st);
 int permute_cols_run(const void* src, int sd, const int32_t* idx, void* dst, int dd, int rows, int cols, hipStream_t st);
+int sum_planes_run(const float* x, int planes, int64_t n, float* out, hipStream_t st);
 int layer_norm_fwd_run(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
                        float* mean, float* rstd, int64_t rows, int C, float eps, hipStream_t st);
 int layer_norm_bwd_run(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, const float* mean,
@@ -112,7 +113,7 @@ using namespace tgt;
 extern "C" {
 
 const char* tgt_last_error(void) { return g_err; }
-int tgt_abi_version(void) { return 14; }
+int tgt_abi_version(void) { return 15; }
 
 int tgt_triplet_attention_fwd(const tgt_triplet_attention_args* a, void* stream) {
     return triplet_attention_run(a, false, reinterpret_cast<hipStream_t>(stream));
@@ -175,6 +176,9 @@ int tgt_unfuse_rows(const tgt_fuse_rows_args* a, void* stream) { return fuse_row
 int tgt_permute_cols(const void* src, int32_t src_dtype, const int32_t* idx, void* dst, int32_t dst_dtype, int32_t rows,
                      int32_t cols, void* stream) {
     return permute_cols_run(src, src_dtype, idx, dst, dst_dtype, rows, cols, reinterpret_cast<hipStream_t>(stream));
+}
+int tgt_sum_planes(const float* x, int32_t planes, int64_t n, float* out, void* stream) {
+    return sum_planes_run(x, planes, n, out, reinterpret_cast<hipStream_t>(stream));
 }
 int tgt_sum_rows(const float* x, int32_t rows, int32_t C, float* out, void* stream) {
     return sum_rows_run(x, rows, C, out, reinterpret_cast<hipStream_t>(stream));

@@ -99,4 +99,59 @@ int permute_cols_run(const void* src, int sd, const int32_t* idx, void* dst, int
     }
 }
 
+// ---------------------------------------------------------------------------
+// out[i] = sum_p x[p*n + i]: the last stage of the weight gradients (dW = sum over row chunks of
+// dY_c^T X_c, ops._wgrad_into).  Block = 32 float4 columns x 8 plane slices; a thread sums its slice's
+// planes (4 loads in flight), the 8 slices meet in LDS -- fixed order, so bit-reproducible.  ATen's
+// generic reduction takes 10-40 us on these (8..128 planes of 16K..590K elements); this is HBM/L2-bound.
+// ---------------------------------------------------------------------------
+template <int V>
+struct PlaneVec;
+template <>
+struct PlaneVec<4> { using type = float4; };
+template <>
+struct PlaneVec<1> { using type = float; };
+__device__ __forceinline__ void vadd(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+__device__ __forceinline__ void vadd(float& a, const float& b) { a += b; }
+
+template <int V>
+__global__ void __launch_bounds__(256) sum_planes_kernel(const float* x, int planes, int64_t nv, float* out) {
+    using VT = typename PlaneVec<V>::type;
+    __shared__ VT red[8][32];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int64_t col = (int64_t)blockIdx.x * 32 + cl;
+    const VT* xv = reinterpret_cast<const VT*>(x);
+    VT s0 = {}, s1 = {}, s2 = {}, s3 = {};
+    if (col < nv) {
+        int p = sl;
+        for (; p + 24 < planes; p += 32) {
+            const VT a = xv[(int64_t)p * nv + col], b = xv[(int64_t)(p + 8) * nv + col];
+            const VT c = xv[(int64_t)(p + 16) * nv + col], d = xv[(int64_t)(p + 24) * nv + col];
+            vadd(s0, a); vadd(s1, b); vadd(s2, c); vadd(s3, d);
+        }
+        for (; p < planes; p += 8) vadd(s0, xv[(int64_t)p * nv + col]);
+        vadd(s0, s1); vadd(s2, s3); vadd(s0, s2);
+    }
+    red[sl][cl] = s0;
+    __syncthreads();
+    if (sl == 0 && col < nv) {
+        VT t = red[0][cl];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) vadd(t, red[k][cl]);
+        reinterpret_cast<VT*>(out)[col] = t;
+    }
+}
+
+int sum_planes_run(const float* x, int planes, int64_t n, float* out, hipStream_t st) {
+    if (!x || !out || planes <= 0 || n < 0) return set_error(TGT_ERR_INVALID, "sum_planes: bad arguments");
+    if (n == 0) return TGT_OK;
+    if (n % 4 == 0 && ((uintptr_t)x | (uintptr_t)out) % 16 == 0) {
+        const int64_t nv = n / 4;
+        hipLaunchKernelGGL((sum_planes_kernel<4>), dim3((unsigned)((nv + 31) / 32)), dim3(256), 0, st, x, planes, nv, out);
+    } else {
+        hipLaunchKernelGGL((sum_planes_kernel<1>), dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, x, planes, n, out);
+    }
+    return check_launch("sum_planes_kernel");
+}
+
 }  // namespace tgt

@@ -61,12 +61,21 @@ def _pair(cls, a, b):
     return (cls * 2)(a, b)
 
 
+_mask3_memo = [None, -1, None]        # (source tensor, its version, float32 image)
+
+
 def as_mask3(mask, B, N):
-    """(B,N,N,1) additive mask of any float dtype -> contiguous float32 (B,N,N)."""
+    """(B,N,N,1) additive mask of any float dtype -> contiguous float32 (B,N,N).  The 48 calls of a
+    24-layer step pass the same tensor: its conversion is kept while that object is unmodified."""
+    if _mask3_memo[0] is mask and _mask3_memo[1] == mask._version and _mask3_memo[2].shape == (B, N, N):
+        return _mask3_memo[2]
     m = mask.reshape(B, N, N)
     if m.dtype != torch.float32:
         m = m.float()
-    return m.contiguous()
+    m = m.contiguous()
+    if m.data_ptr() != mask.data_ptr():           # a real conversion / copy: worth remembering
+        _mask3_memo[:] = [mask, mask._version, m]
+    return m
 
 
 # ---------------------------------------------------------------------------
@@ -182,6 +191,22 @@ def _colsum_workspace(B, width, device):
     if ws is None:
         ws = _colsum_ws[key] = torch.zeros(B, width, dtype=torch.float32, device=device)
     return ws
+
+
+_ATEN_PLANE_SUM = os.environ.get('TGT_PLANE_SUM', '1') == '0'       # A/B knob: ATen's reduction instead of tgt_sum_planes
+
+
+def sum_planes(part, out):
+    """out <- part.sum(0) for contiguous fp32 part (P, ...) and out (...), fixed order (tgt_sum_planes)."""
+    _dev(part, out)
+    if _ATEN_PLANE_SUM:
+        return torch.sum(part, 0, out=out)
+    if part.dtype != torch.float32 or out.dtype != torch.float32 or not part.is_contiguous() or not out.is_contiguous() or \
+            part.shape[1:] != out.shape:
+        raise RuntimeError(f'sum_planes: contiguous float32 (P, ...) -> (...) expected, got {tuple(part.shape)} {part.dtype} -> '
+                           f'{tuple(out.shape)} {out.dtype}')
+    _lib.check(_lib.lib().tgt_sum_planes(_ptr(part), part.shape[0], out.numel(), _ptr(out), _stream()), 'tgt_sum_planes')
+    return out
 
 
 def sum_rows(x):
@@ -883,7 +908,7 @@ def _wgrad_into(out, dy2, x2, chunks):
         a = dy2.unflatten(0, (P, M // P)).transpose(1, 2)
         part = torch.bmm(a, x2.view(P, M // P, -1), out_dtype=torch.float32) if dy2.dtype != torch.float32 else \
             torch.bmm(a, x2.view(P, M // P, -1))
-        torch.sum(part, 0, out=out)
+        sum_planes(part, out)
     else:
         out.copy_(dy2.t() @ x2)
 
@@ -941,7 +966,7 @@ def _linear_backward(x2, w, dy2, xs, xdt, wdt, bdt, need_dx, need_dw, need_db):
             part = torch.bmm(dy2.view(P, M // P, -1).transpose(1, 2), x2.view(P, M // P, -1),
                              out_dtype=torch.float32) if dy2.dtype != torch.float32 else \
                 torch.bmm(dy2.view(P, M // P, -1).transpose(1, 2), x2.view(P, M // P, -1))
-            dw = part.sum(0).to(wdt)
+            dw = sum_planes(part, torch.empty(part.shape[1:], dtype=torch.float32, device=part.device)).to(wdt)
         else:
             dw = (dy2.t() @ x2).to(wdt)
     if need_db:
