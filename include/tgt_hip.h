@@ -308,6 +308,20 @@ int tgt_sum_rows(const float* x, int32_t rows, int32_t C, float* out, void* stre
  * over B*N*N = 262144 rows). */
 int tgt_sum_planes(const float* x, int32_t planes, int64_t n, float* out, void* stream);
 
+/* Row-wise cross entropy of the binned-distance head: replaces
+ * `F.cross_entropy(dist_logits.view(-1, num_bins), dist_targ.view(-1), reduction='none')`
+ * (reference lib/training_schemes/pcqm/commons.py:36-38) and its autograd chain, on the logits in
+ * their storage dtype (fp32 math on the stored values, which is what autocast's fp32 cast computes).
+ *   fwd: lse[r] = log sum_c exp(logits[r][c]);  xent[r] = lse[r] - logits[r][target[r]]
+ *   bwd: d_logits[r][c] = row_weight[r] * (exp(logits[r][c] - lse[r]) - [c == target[r]])
+ * row_weight is the upstream gradient of xent (the reference's mask / (mask.sum() + 1e-9), :44-46,
+ * times whatever scales the loss); rows with weight 0 are written as zeros without being read.
+ * logits / d_logits: (rows, C) contiguous, 16-byte aligned, C a multiple of 8, <= 2048; target int64. */
+int tgt_cross_entropy_fwd(const void* logits, int32_t dtype, const int64_t* target, int64_t rows, int32_t C,
+                          float* lse, float* xent, void* stream);
+int tgt_cross_entropy_bwd(const void* logits, int32_t dtype, const int64_t* target, const float* lse,
+                          const float* row_weight, int64_t rows, int32_t C, void* d_logits, void* stream);
+
 int tgt_layer_norm_bwd(const void* dy, int32_t dy_dtype, const void* x, int32_t x_dtype,
                        const float* gamma, const float* mean, const float* rstd,
                        void* dx, int32_t dx_dtype, float* dgamma, float* dbeta, float* partial,

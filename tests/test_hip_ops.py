@@ -828,3 +828,32 @@ def test_sum_planes(shape):
     assert float((out.double() - want).abs().max()) <= 4e-6 * float(part.abs().sum(0).max())
     with pytest.raises(RuntimeError):
         ops.sum_planes(part, torch.empty(shape[1:], device='cuda', dtype=torch.bfloat16))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape', [(2 * 20 * 20, 512), (1000, 256), (37, 1024), (513, 40), (64, 2048)])
+def test_cross_entropy_rows(shape, dtype):
+    """binned-distance cross entropy (reference commons.py:36-46) on the stored logits: values and the
+    gradient of the masked mean against fp64 F.cross_entropy of the SAME (rounded) logits."""
+    from tgt_amd import ops
+    import torch.nn.functional as F
+    rows, C = shape
+    rng = np.random.default_rng(rows + C)
+    logits = (rnd(rng, rows, C) * 3).to(dtype)
+    target = torch.from_numpy(rng.integers(0, C, rows))
+    target[0], target[-1] = 0, C - 1
+    mask = torch.from_numpy((rng.random(rows) < 0.7).astype(np.float32))
+    ref_in = logits.double().requires_grad_(True)
+    xent_ref = F.cross_entropy(ref_in, target, reduction='none')
+    loss_ref = (xent_ref * mask.double()).sum() / (mask.double().sum() + 1e-9)
+    loss_ref.backward()
+    x = logits.cuda().requires_grad_(True)
+    xent = ops.cross_entropy_rows(x, target.cuda())
+    assert xent.dtype == torch.float32
+    m = mask.cuda()
+    loss = (xent * m).sum() / (m.sum() + 1e-9)
+    loss.backward()
+    assert rel(xent, xent_ref) < 2e-6
+    assert abs(float(loss) - float(loss_ref)) < 2e-6 * abs(float(loss_ref))
+    assert x.grad.dtype == dtype and rel(x.grad, ref_in.grad) < TOL[dtype] / 4
+    assert (x.grad[m == 0] == 0).all()            # masked pairs: exact zeros

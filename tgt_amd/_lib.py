@@ -14,10 +14,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtgt_hip.so')
 CSRC = os.path.join(_HERE, 'csrc')
 # (source, extra flags, object suffix): the triplet attention kernels compile one dtype per translation unit
-SOURCES = ['capi.hip', 'params.hip', 'triplet_attention_proj.hip',
+SOURCES = ['capi.hip', 'params.hip', 'loss.hip', 'triplet_attention_proj.hip',
            ('triplet_attention.hip', ['-DTGT_TRI_INST=9'], '.f32'), ('triplet_attention.hip', ['-DTGT_TRI_INST=2'], '.bf16'),
            ('triplet_attention.hip', ['-DTGT_TRI_INST=4'], '.f16'), 'triplet_aggregate.hip', 'node_attention.hip', 'layernorm.hip', 'triangular_update.hip', 'elementwise.hip']
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 TGT_F32, TGT_BF16, TGT_F16 = 0, 1, 2
 TRI_BIASED, TRI_GATED, TRI_MASK_OUT = 1, 2, 4
@@ -95,6 +95,8 @@ SYMBOLS = {
     'tgt_colsum': (C.c_int, [_vp, _i32, _i64, _i32, _vp, _vp, _vp]),
     'tgt_sum_rows': (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     'tgt_sum_planes': (C.c_int, [_vp, _i32, _i64, _vp, _vp]),
+    'tgt_cross_entropy_fwd': (C.c_int, [_vp, _i32, _vp, _i64, _i32, _vp, _vp, _vp]),
+    'tgt_cross_entropy_bwd': (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     'tgt_fuse_rows': (C.c_int, [C.POINTER(FuseRowsArgs), _vp]),
     'tgt_unfuse_rows': (C.c_int, [C.POINTER(FuseRowsArgs), _vp]),
     'tgt_permute_cols': (C.c_int, [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),

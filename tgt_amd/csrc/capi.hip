@@ -45,6 +45,8 @@ int triplet_attention_proj_run(const tgt_triplet_attention_args* a, const void* 
 int fuse_rows_run(const tgt_fuse_rows_args* a, bool scatter, hipStream_t st);
 int permute_cols_run(const void* src, int sd, const int32_t* idx, void* dst, int dd, int rows, int cols, hipStream_t st);
 int sum_planes_run(const float* x, int planes, int64_t n, float* out, hipStream_t st);
+int xent_run(const void* x, int dtype, const int64_t* target, const float* lse_in, const float* w, int64_t rows, int C,
+             float* lse, float* xent, void* dx, hipStream_t st);
 int layer_norm_fwd_run(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
                        float* mean, float* rstd, int64_t rows, int C, float eps, hipStream_t st);
 int layer_norm_bwd_run(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, const float* mean,
@@ -113,7 +115,7 @@ using namespace tgt;
 extern "C" {
 
 const char* tgt_last_error(void) { return g_err; }
-int tgt_abi_version(void) { return 15; }
+int tgt_abi_version(void) { return 16; }
 
 int tgt_triplet_attention_fwd(const tgt_triplet_attention_args* a, void* stream) {
     return triplet_attention_run(a, false, reinterpret_cast<hipStream_t>(stream));
@@ -176,6 +178,15 @@ int tgt_unfuse_rows(const tgt_fuse_rows_args* a, void* stream) { return fuse_row
 int tgt_permute_cols(const void* src, int32_t src_dtype, const int32_t* idx, void* dst, int32_t dst_dtype, int32_t rows,
                      int32_t cols, void* stream) {
     return permute_cols_run(src, src_dtype, idx, dst, dst_dtype, rows, cols, reinterpret_cast<hipStream_t>(stream));
+}
+int tgt_cross_entropy_fwd(const void* logits, int32_t dtype, const int64_t* target, int64_t rows, int32_t C, float* lse,
+                          float* xent, void* stream) {
+    return xent_run(logits, dtype, target, nullptr, nullptr, rows, C, lse, xent, nullptr, reinterpret_cast<hipStream_t>(stream));
+}
+int tgt_cross_entropy_bwd(const void* logits, int32_t dtype, const int64_t* target, const float* lse, const float* row_weight,
+                          int64_t rows, int32_t C, void* d_logits, void* stream) {
+    if (!d_logits) return set_error(TGT_ERR_INVALID, "cross entropy bwd: null d_logits");
+    return xent_run(logits, dtype, target, lse, row_weight, rows, C, nullptr, nullptr, d_logits, reinterpret_cast<hipStream_t>(stream));
 }
 int tgt_sum_planes(const float* x, int32_t planes, int64_t n, float* out, void* stream) {
     return sum_planes_run(x, planes, n, out, reinterpret_cast<hipStream_t>(stream));

@@ -1211,3 +1211,37 @@ def add_layer_norm(x, res, scale, weight, bias, eps=1e-5, out_dtype=None):
     if out_dtype is None:
         out_dtype = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled('cuda') else x.dtype
     return _AddLayerNorm.apply(x, res, scale, weight, bias, eps, out_dtype)
+
+
+# ---------------------------------------------------------------------------
+# loss head
+# ---------------------------------------------------------------------------
+class _CrossEntropyRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        _dev(logits, target)
+        if logits.dim() != 2 or not logits.is_contiguous() or target.shape != logits.shape[:1] or target.dtype != torch.int64:
+            raise RuntimeError('cross_entropy_rows: contiguous (rows, C) logits and int64 (rows,) targets expected')
+        target = target.contiguous()
+        rows, C_ = logits.shape
+        lse = torch.empty(rows, dtype=torch.float32, device=logits.device)
+        xent = torch.empty(rows, dtype=torch.float32, device=logits.device)
+        _lib.check(_lib.lib().tgt_cross_entropy_fwd(_ptr(logits), _DT[logits.dtype], _ptr(target), rows, C_, _ptr(lse), _ptr(xent),
+                                                    _stream()), 'tgt_cross_entropy_fwd')
+        ctx.save_for_backward(logits, target, lse)
+        return xent
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, lse = ctx.saved_tensors
+        g = g.contiguous().float()
+        d = torch.empty_like(logits)
+        _lib.check(_lib.lib().tgt_cross_entropy_bwd(_ptr(logits), _DT[logits.dtype], _ptr(target), _ptr(lse), _ptr(g), logits.shape[0],
+                                                    logits.shape[1], _ptr(d), _stream()), 'tgt_cross_entropy_bwd')
+        return d, None
+
+
+def cross_entropy_rows(logits, target):
+    """F.cross_entropy(logits, target, reduction='none') for (rows, C) logits in their storage dtype ->
+    float32 (rows,), without an fp32 image of the logits (reference commons.py:36-38)."""
+    return _CrossEntropyRows.apply(logits, target)

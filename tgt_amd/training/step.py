@@ -15,6 +15,7 @@ training.py:152 DDP gradient averaging), re-designed for one process per GPU:
    the caller logs.
 """
 import math
+import os
 from dataclasses import dataclass, field
 
 import torch
@@ -78,11 +79,17 @@ def preprocess_batch(batch, device, cfg, training=True, generator=None):
     return b
 
 
+_HIP_XENT = os.environ.get('TGT_HIP_XENT', '1') != '0'       # A/B knob: ATen's cross entropy on an fp32 image of the logits
+
+
 def binned_distance_loss(logits, dist_target, edge_mask, num_bins, range_bins):
     """reference lib/training_schemes/pcqm/commons.py:19-48"""
     bsz = logits.size(0)
     bins = (dist_target * ((num_bins - 1) / range_bins)).long().clamp(0, num_bins - 1)
-    xent = F.cross_entropy(logits.reshape(-1, num_bins), bins.reshape(-1), reduction='none').view(bsz, -1)
+    if logits.is_cuda and _HIP_XENT:          # (268 MB of bf16 logits at the BASELINE batch: no fp32 image, no separate softmax passes)
+        xent = ops.cross_entropy_rows(logits.reshape(-1, num_bins), bins.reshape(-1)).view(bsz, -1)
+    else:
+        xent = F.cross_entropy(logits.reshape(-1, num_bins), bins.reshape(-1), reduction='none').view(bsz, -1)
     m = edge_mask.to(xent.dtype).view(bsz, -1)
     return (xent * m).sum() / (m.sum() + 1e-9)
 
