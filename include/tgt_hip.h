@@ -304,7 +304,7 @@ int tgt_sum_rows(const float* x, int32_t rows, int32_t C, float* out, void* stre
 
 /* out[i] = sum_p x[p*n + i] over `planes` contiguous float32 planes of n elements, fixed summation
  * order: the closing sum of a weight gradient computed as per-row-chunk partial products
- * (dW = sum_c dY_c^T X_c -- what `grad_weight` of nn.Linear is in lib/tgt/layers/*.py, contracted
+ * (dW = sum_c dY_c^T X_c -- what `grad_weight` of nn.Linear is in the lib/tgt/layers modules, contracted
  * over B*N*N = 262144 rows). */
 int tgt_sum_planes(const float* x, int32_t planes, int64_t n, float* out, void* stream);
 
