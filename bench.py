@@ -110,6 +110,50 @@ def cpu_baseline(timeout_s=240):
                     sample=f'cpu baseline exceeded its {timeout_s}s bound (one 8-graph oracle step did not finish)')
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start one process per GPU of this node (the
+    reference's execute.py:91-107 spawns its ranks the same way), each re-running this file with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would; returns the first
+    non-zero exit code.  Only rank 0 prints, and the children share this process's stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env))
+    rc = 0
+    try:
+        for p in procs:
+            p.wait()
+            rc = rc or p.returncode
+            if p.returncode:                    # a rank died: do not leave the others blocked in a collective
+                for q in procs:
+                    if q.poll() is None:
+                        q.terminate()
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    return rc
+
+
+def launcher_selftest(rank, world):
+    """the launcher path without a GPU: rendezvous over gloo, one all-reduce, rank 0 prints one line"""
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps(dict(launcher_selftest=world, ranks_sum=float(t.item()))), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -119,6 +163,7 @@ def main():
     ap.add_argument('--nodes', type=int, default=32)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-worker', type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument('--launcher-selftest', action='store_true', help=argparse.SUPPRESS)   # tests/test_bench_launcher.py
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp16', 'fp32'])
     ap.add_argument('--no-gemm-tuning', action='store_true', help='library default GEMM heuristics')
     ap.add_argument('--write-gemm-tuning', default='', help='tune online and write the TunableOp file here')
@@ -127,9 +172,18 @@ def main():
         cpu_baseline_worker(args.cpu_baseline_worker)
         return
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` by itself: one process per GPU, as the reference's launcher does
+        # (execute.py:91-107); rank 0 prints the JSON line
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}; start it as '
+                         f'`python bench.py --gpus N` (self-launching) or with torch.distributed.run --nproc-per-node N')
+    if args.launcher_selftest:
+        return launcher_selftest(rank, world)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the TGT kernels have no CPU path')
     torch.cuda.set_device(local_rank)
@@ -137,7 +191,6 @@ def main():
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=dev)
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     from tgt_amd import ops
     from tgt_amd.pcqm import TGT_Multi
