@@ -198,14 +198,56 @@ int tgt_node_attention_bwd(const tgt_node_attention_args* a, void* stream);
  * torch.optim.Adam).  All buffers float32 of length n.
  *   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g
  *   p -= lr * (m/(1-b1^t)) / (sqrt(v/(1-b2^t)) + eps)   [+ lr*wd*p decoupled]
- * grad_scale multiplies g first (1/world_size or AMP unscale).
+ * grad_scale multiplies g first (1/world_size or AMP unscale); clip_value > 0
+ * clamps the scaled gradient to [-clip_value, clip_value] (nn.utils.clip_grad_value_,
+ * reference training.py:455-460).
  * shadow (may be NULL): n-element bf16/f16 buffer that receives the updated
  * parameters in the same pass (the GEMM-dtype copy the next step reads).
+ * ctl (may be NULL): device control block written by tgt_grad_scaler_step; when given,
+ * `step` / `grad_scale` are ignored: the update is skipped if ctl[TGT_CTL_FOUND_INF] != 0,
+ * g is multiplied by ctl[TGT_CTL_MULT] (clamped) then by ctl[TGT_CTL_COEF], and the bias
+ * corrections use t = ctl[TGT_CTL_STEPS] (optimizer steps actually applied).
  * ---------------------------------------------------------------------- */
 int tgt_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                   int64_t n, float lr, float beta1, float beta2, float eps,
-                  float weight_decay, int32_t step, float grad_scale,
-                  void* shadow, int32_t shadow_dtype, void* stream);
+                  float weight_decay, int32_t step, float grad_scale, float clip_value,
+                  const float* ctl, void* shadow, int32_t shadow_dtype, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Device-side GradScaler + gradient clipping decisions (no host sync).  Replaces the
+ * host logic of reference lib/training/training.py:451-469: GradScaler.unscale_ /
+ * found_inf (a `.item()` per step in torch), nn.utils.clip_grad_value_, clip_grad_norm_,
+ * GradScaler.step's skip and GradScaler.update's backoff / growth.
+ * ctl: 16 float32 on the device:
+ *   [0] loss scale S (in/out; the loss is multiplied by it before backward)
+ *   [1] growth tracker (in/out)        [2] found_inf of this step (out)
+ *   [3] optimizer steps applied (in/out: +1 unless skipped)
+ *   [4] gradient multiplier 1/(S*world) of THIS step (out)   [5] clip_grad_norm coefficient (out)
+ *   [6] gradient norm after unscale + value clip (out)        [7] skipped steps (in/out)
+ *   [8] total loss*samples  [9] total samples  [10] consecutive NaN losses (tgt_loss_accumulate)
+ *   [12],[13] scratch pair (loss*samples, samples) between the two halves of tgt_loss_accumulate
+ * grad: the (all-reduced, still scaled) flat gradient; partial: tgt_grad_stats_parts() floats.
+ * dynamic != 0: GradScaler semantics (skip + S *= backoff_factor on a non-finite gradient,
+ * S *= growth_factor after growth_interval consecutive clean steps); dynamic == 0: S is left alone
+ * and nothing is skipped (bf16 / fp32 with clip_grad_norm).  clip_norm <= 0: coefficient 1.
+ * ---------------------------------------------------------------------- */
+enum { TGT_CTL_SCALE = 0, TGT_CTL_TRACKER = 1, TGT_CTL_FOUND_INF = 2, TGT_CTL_STEPS = 3, TGT_CTL_MULT = 4,
+       TGT_CTL_COEF = 5, TGT_CTL_NORM = 6, TGT_CTL_SKIPPED = 7, TGT_CTL_LOSS = 8, TGT_CTL_SAMPLES = 9,
+       TGT_CTL_NAN = 10, TGT_CTL_PAIR = 12, TGT_CTL_SIZE = 16 };
+int tgt_grad_stats_parts(void);
+int tgt_grad_scaler_step(const float* grad, int64_t n, float* ctl, float* partial, int32_t world,
+                         float clip_value, float clip_norm, int32_t dynamic, float growth_factor,
+                         float backoff_factor, int32_t growth_interval, void* stream);
+
+/* ------------------------------------------------------------------------
+ * update_losses without `.item()` (reference lib/training_schemes/pcqm/tgt_training.py:141-171):
+ * mode 1: ctl[12..13] <- (loss*samples, samples)   (then the caller all-reduces those two floats)
+ * mode 2: accumulate ctl[12..13] into ctl[8..9]; with mixed != 0 a NaN step loss is skipped unless
+ *         it is the 11th in a row (the reference's _nan_loss_count rule)
+ * mode 3: both (single rank).  loss: one device scalar, float32 or (loss_is_f64) float64.
+ * ---------------------------------------------------------------------- */
+int tgt_loss_accumulate(const void* loss, int32_t loss_is_f64, float samples, float* ctl, int32_t mixed,
+                        int32_t mode, void* stream);
 
 /* ------------------------------------------------------------------------
  * LayerNorm over the last axis (the five per-layer norms of the TGT layer:

@@ -66,7 +66,9 @@ def test_invalid_arguments_return_error_codes():
     a = _lib.TripletAttentionArgs()
     a.B, a.N, a.H, a.D = 1, 100, 4, 16
     assert L.tgt_triplet_attention_fwd(C.byref(a), None) != 0
-    assert L.tgt_adam_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 1.0, None, 0, None) != 0
+    assert L.tgt_adam_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 1.0, 0.0, None, None, 0, None) != 0
+    assert L.tgt_grad_scaler_step(None, 10, None, None, 1, 0.0, 0.0, 1, 2.0, 0.5, 2000, None) != 0
+    assert L.tgt_loss_accumulate(None, 0, 1.0, None, 1, 3, None) != 0
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU behaviour')

@@ -165,7 +165,7 @@ def test_trainer_step_runs_and_matches_torch_adam():
     opt = torch.optim.Adam(m2.parameters(), lr=1.0)
     from tgt_amd.training.step import pretrain_loss, lr_at
     for step in range(1, 4):
-        batch = preprocess_batch(make_batch(3, 7, seed=40 + step, ragged=True), 'cuda', cfg, training=False)
+        batch = preprocess_batch(make_batch(3, 7, seed=40 + step, ragged=True), 'cuda', cfg, add_noise=False)
         _, loss1 = tr.training_step(batch)
         for g in opt.param_groups:
             g['lr'] = lr_at(step, cfg)
@@ -202,7 +202,7 @@ def test_node_side_stream_gives_identical_gradients():
             tr = Trainer(model, cfg, force_distributed=True)
             outs = []
             for step in range(3):
-                batch = preprocess_batch(make_batch(16, 24, seed=70 + step, ragged=True), 'cuda', cfg, training=False)
+                batch = preprocess_batch(make_batch(16, 24, seed=70 + step, ragged=True), 'cuda', cfg, add_noise=False)
                 model.eval()                               # dropouts off: runs are comparable bit for bit
                 loss = tr.compute_gradients(batch)[1]
                 outs.append((float(loss), tr.flat.grad.clone()))
@@ -312,7 +312,7 @@ def test_trainer_rccl_bucket_path_single_rank():
         t2 = Trainer(m2, cfg)
         assert t1.distributed and t1.buckets is not None and len(t1.buckets) > 10 and not t2.distributed
         for step in range(3):
-            batch = preprocess_batch(make_batch(3, 7, seed=50 + step, ragged=True), 'cuda', cfg, training=False)
+            batch = preprocess_batch(make_batch(3, 7, seed=50 + step, ragged=True), 'cuda', cfg, add_noise=False)
             _, l1 = t1.training_step(batch)
             _, l2 = t2.training_step(batch)
             assert abs(float(l1) - float(l2)) < 1e-6 * abs(float(l2))

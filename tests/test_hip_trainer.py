@@ -1,0 +1,163 @@
+"""The optimizer side of the step on the GPU (csrc/optimizer.hip through the C ABI) against what the reference
+runs on the host: torch.amp.GradScaler + nn.utils.clip_grad_* + Adam (lib/training/training.py:439-470) and
+update_losses (lib/training_schemes/pcqm/tgt_training.py:141-171)."""
+import math
+
+import pytest
+import torch
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _pair(precision, **cfg_kw):
+    from tgt_amd.pcqm import TGT_Multi
+    from tgt_amd.training.step import Trainer, StepConfig
+    kwargs = gu.MODEL_CASES['multi_at_tiny'][1]
+    cfg = StepConfig(num_dist_bins=24, mixed_precision=precision, coords_noise=0.0, lr_warmup_steps=10, lr_total_steps=100,
+                     **cfg_kw)
+    m1 = gu.fill_params(TGT_Multi(**kwargs), seed=3).cuda().eval()       # dropouts off: both sides see the same function
+    m2 = gu.fill_params(TGT_Multi(**kwargs), seed=3).cuda().eval()
+    return m1, m2, Trainer(m1, cfg), cfg
+
+
+def _batch(cfg, step):
+    from tgt_amd.training.step import preprocess_batch
+    from tgt_amd.training.synthetic import make_batch
+    return preprocess_batch(make_batch(3, 7, seed=40 + step, ragged=True), 'cuda', cfg, add_noise=False)
+
+
+def _params(m):
+    return torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+
+
+def test_fp16_trainer_follows_grad_scaler_semantics_with_forced_overflow():
+    """init_scale 2^40 overflows the fp16 backward: both sides must skip the same steps, halve the scale in
+    step, never advance Adam's step count on a skip, and (growth_interval=2) grow again afterwards"""
+    from tgt_amd.training.step import pretrain_loss, lr_at
+    kw = dict(init_scale=2.0 ** 40, growth_interval=2)
+    m1, m2, tr, cfg = _pair('fp16', **kw)
+    opt = torch.optim.Adam(m2.parameters(), lr=1.0)
+    scaler = torch.amp.GradScaler('cuda', init_scale=kw['init_scale'], growth_interval=2)
+    skipped_ref = 0
+    scales = []
+    for step in range(1, 41):
+        batch = _batch(cfg, step % 4)
+        tr.training_step(batch)
+        for g in opt.param_groups:
+            g['lr'] = lr_at(step, cfg)
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast('cuda', dtype=torch.float16):
+            loss2 = pretrain_loss(m2(batch), batch, cfg)
+        scaler.scale(loss2).backward()
+        before = scaler.get_scale()
+        scaler.step(opt)
+        scaler.update()
+        skipped_ref += scaler.get_scale() < before
+        st = tr.step_stats()
+        scales.append(st['loss_scale'])
+        assert st['loss_scale'] == scaler.get_scale(), (step, st, scaler.get_scale())
+        assert st['skipped_steps'] == skipped_ref and st['applied_steps'] == step - skipped_ref
+    assert skipped_ref >= 5, 'the forced overflow did not happen'           # 2^40 must back off many times
+    assert max(scales[-10:]) > min(scales), 'the scale never grew back'
+    some = next(iter(opt.state.values()))
+    assert float(some['step']) == tr.step_stats()['applied_steps']
+    assert rel(_params(m1), _params(m2)) < 2e-3
+    assert torch.equal(tr.flat.shadow.float(), tr.flat.param.to(torch.float16).float())       # shadow followed every applied step
+
+
+@pytest.mark.parametrize('clip', [dict(clip_grad_value=1e-3), dict(clip_grad_norm=0.05),
+                                  dict(clip_grad_value=2e-3, clip_grad_norm=0.02)])
+def test_gradient_clipping_matches_torch(clip):
+    from tgt_amd.training.step import pretrain_loss, lr_at
+    m1, m2, tr, cfg = _pair(None, **clip)
+    opt = torch.optim.Adam(m2.parameters(), lr=1.0)
+    for step in range(1, 4):
+        batch = _batch(cfg, step)
+        tr.training_step(batch)
+        for g in opt.param_groups:
+            g['lr'] = lr_at(step, cfg)
+        opt.zero_grad(set_to_none=True)
+        pretrain_loss(m2(batch), batch, cfg).backward()
+        if cfg.clip_grad_value is not None:
+            torch.nn.utils.clip_grad_value_(m2.parameters(), cfg.clip_grad_value)
+        if cfg.clip_grad_norm is not None:
+            norm = torch.nn.utils.clip_grad_norm_(m2.parameters(), cfg.clip_grad_norm)
+            st = tr.step_stats()
+            assert abs(st['grad_norm'] - float(norm)) < 1e-4 * float(norm)
+            assert st['clip_coef'] < 1.0, 'pick a max_norm that actually clips'
+        opt.step()
+    assert rel(_params(m1), _params(m2)) < 1e-4
+    # and clipping is not a no-op: an unclipped run ends somewhere else
+    m3, _, tr3, cfg3 = _pair(None)
+    for step in range(1, 4):
+        tr3.training_step(_batch(cfg3, step))
+    assert rel(_params(m3), _params(m2)) > 1e-3
+
+
+def test_update_losses_accumulates_like_the_reference():
+    m1, _, tr, cfg = _pair('bf16')
+    tr.initialize_losses()
+    total, samples = 0.0, 0.0
+    for step in range(1, 4):
+        batch = _batch(cfg, step)
+        _, loss = tr.training_step(batch)
+        tr.update_losses(loss, batch)
+        n = float(batch['num_nodes'].shape[0])
+        total, samples = total + float(loss) * n, samples + n
+    assert abs(tr.mean_loss() - total / samples) < 1e-5 * abs(total / samples)
+    # NaN rule under mixed precision: skipped ... unless more than 10 arrive in a row
+    nan = torch.full((), float('nan'), device='cuda', dtype=torch.float64)
+    batch = _batch(cfg, 1)
+    for _ in range(10):
+        tr.update_losses(nan, batch)
+    assert abs(tr.mean_loss() - total / samples) < 1e-5 * abs(total / samples)
+    tr.update_losses(nan, batch)
+    assert math.isnan(tr.mean_loss())
+    tr.initialize_losses()
+    assert tr.mean_loss() == 0.0
+
+
+def test_resume_from_state_dict_continues_bit_identically():
+    """state_dict -> new Trainer on a new model copy -> same next step, and torch.optim.Adam resumes from it too"""
+    from tgt_amd.pcqm import TGT_Multi
+    from tgt_amd.training.step import Trainer, pretrain_loss, lr_at
+    m1, m2, tr, cfg = _pair(None)
+    for step in range(1, 4):
+        tr.training_step(_batch(cfg, step))
+    sd, msd = tr.state_dict(), {k: v.clone() for k, v in m1.state_dict().items()}
+    m3 = TGT_Multi(**gu.MODEL_CASES['multi_at_tiny'][1]).cuda().eval()
+    tr3 = Trainer(m3, cfg)
+    m3.load_state_dict(msd)
+    tr3.load_state_dict(sd)
+    m2.load_state_dict(msd)
+    opt = torch.optim.Adam(m2.parameters(), lr=1.0)
+    opt.load_state_dict(sd['optimizer'])
+    batch = _batch(cfg, 9)
+    tr.training_step(batch)
+    tr3.training_step(batch)
+    assert tr3.global_step == tr.global_step == 4
+    assert torch.equal(_params(m1), _params(m3))
+    for g in opt.param_groups:
+        g['lr'] = lr_at(4, cfg)
+    opt.zero_grad(set_to_none=True)
+    pretrain_loss(m2(batch), batch, cfg).backward()
+    opt.step()
+    assert rel(_params(m1), _params(m2)) < 1e-5
+
+
+def test_shadow_follows_load_state_dict():
+    """the reference loads pretrained weights AFTER the trainer exists (tgt_training.py:174-189): the 16-bit
+    parameter shadows the kernels read must follow without a manual refresh"""
+    m1, m2, tr, cfg = _pair('bf16')
+    sd = {k: v + 0.25 for k, v in m2.state_dict().items()}
+    m1.load_state_dict(sd)
+    assert torch.equal(tr.flat.shadow, tr.flat.param.to(torch.bfloat16))
+    for p in tr.flat.params:
+        assert torch.equal(p._lp, p.detach().to(torch.bfloat16))

@@ -14,10 +14,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtgt_hip.so')
 CSRC = os.path.join(_HERE, 'csrc')
 # (source, extra flags, object suffix): the triplet attention kernels compile one dtype per translation unit
-SOURCES = ['capi.hip', 'params.hip', 'loss.hip', 'triplet_attention_proj.hip',
+SOURCES = ['capi.hip', 'optimizer.hip', 'params.hip', 'loss.hip', 'triplet_attention_proj.hip',
            ('triplet_attention.hip', ['-DTGT_TRI_INST=9'], '.f32'), ('triplet_attention.hip', ['-DTGT_TRI_INST=2'], '.bf16'),
            ('triplet_attention.hip', ['-DTGT_TRI_INST=4'], '.f16'), 'triplet_aggregate.hip', 'node_attention.hip', 'layernorm.hip', 'triangular_update.hip', 'elementwise.hip']
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 TGT_F32, TGT_BF16, TGT_F16 = 0, 1, 2
 TRI_BIASED, TRI_GATED, TRI_MASK_OUT = 1, 2, 4
@@ -102,7 +102,10 @@ SYMBOLS = {
     'tgt_permute_cols': (C.c_int, [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
     'tgt_layer_norm_fwd': (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _f32, _vp]),
     'tgt_layer_norm_bwd': (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp]),
-    'tgt_adam_step': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp, _i32, _vp]),
+    'tgt_adam_step': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _f32, _vp, _vp, _i32, _vp]),
+    'tgt_grad_stats_parts': (C.c_int, []),
+    'tgt_grad_scaler_step': (C.c_int, [_vp, _i64, _vp, _vp, _i32, _f32, _f32, _i32, _f32, _f32, _i32, _vp]),
+    'tgt_loss_accumulate': (C.c_int, [_vp, _i32, _f32, _vp, _i32, _i32, _vp]),
 }
 
 _lib = None
@@ -133,14 +136,17 @@ def build_library(force=False, verbose=False):
     objs = []
     procs = []
     build = os.path.join(_HERE, 'build')
+    shared = max(os.path.getmtime(d) for d in deps[len(srcs):])        # headers: every unit depends on them
     for s, (_, flags, suffix) in zip(srcs, units):
         # one directory per unit: -save-temps=obj drops the device assembly next to the object, and the
         # three triplet_attention units share a source name
         d = os.path.join(build, os.path.basename(s) + suffix)
-        shutil.rmtree(d, ignore_errors=True)
-        os.makedirs(d)
         o = os.path.join(d, 'unit.o')
         objs.append(o)
+        if not force and os.path.exists(o) and os.path.getmtime(o) >= max(shared, os.path.getmtime(s)):
+            continue                                                    # this unit's object is current
+        shutil.rmtree(d, ignore_errors=True)
+        os.makedirs(d)
         cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-save-temps=obj', *flags, '-c', s, '-o', o]
         procs.append((cmd, d, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     undefined = {}

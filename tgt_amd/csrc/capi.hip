@@ -1,5 +1,5 @@
 // extern "C" entry points of libtgt_hip.so (include/tgt_hip.h) + error plumbing
-// + the flat-buffer Adam kernel.
+// (the optimizer kernels live in optimizer.hip).
 #include <cstdarg>
 #include <cstdio>
 #include "common.hpp"
@@ -53,61 +53,6 @@ int layer_norm_bwd_run(const void* dy, int dy_dtype, const void* x, int x_dtype,
                        const float* rstd, void* dx, int dx_dtype, float* dgamma, float* dbeta, float* partial,
                        int64_t rows, int C, hipStream_t st);
 
-// Adam over flat float32 buffers: 4 reads + 3 writes per element, HBM-bound.
-template <typename S>
-__device__ __forceinline__ void shadow_store4(void* shadow, int64_t i, const float* P) {
-    S t[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) t[k] = from_f32<S>(P[k]);
-    uint2 raw;
-    __builtin_memcpy(&raw, t, 8);
-    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(shadow) + i) = raw;
-}
-
-// shadow (optional): 16-bit copy of the updated parameters for the next step's GEMMs,
-// written in the same pass (saves one cast kernel per weight tensor per step).
-__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                   float* __restrict__ m, float* __restrict__ v, int64_t n,
-                                                   float lr, float b1, float b2, float eps, float wd,
-                                                   float bc1, float bc2_rsqrt, float gscale, void* shadow,
-                                                   int shadow_dtype) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
-    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
-        if (i + 4 <= n) {
-            float4 pp = *reinterpret_cast<float4*>(p + i), gg = *reinterpret_cast<const float4*>(g + i);
-            float4 mm = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
-            float* P = &pp.x; float* Gp = &gg.x; float* M = &mm.x; float* V = &vv.x;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float gr = Gp[t] * gscale;
-                M[t] = b1 * M[t] + (1.f - b1) * gr;
-                V[t] = b2 * V[t] + (1.f - b2) * gr * gr;
-                const float denom = sqrtf(V[t]) * bc2_rsqrt + eps;
-                P[t] = P[t] * (1.f - lr * wd) - (lr / bc1) * (M[t] / denom);
-            }
-            *reinterpret_cast<float4*>(p + i) = pp;
-            *reinterpret_cast<float4*>(m + i) = mm;
-            *reinterpret_cast<float4*>(v + i) = vv;
-            if (shadow) {
-                if (shadow_dtype == TGT_BF16) shadow_store4<bf16_t>(shadow, i, P);
-                else shadow_store4<f16_t>(shadow, i, P);
-            }
-        } else {
-            for (int64_t k = i; k < n; ++k) {
-                const float gr = g[k] * gscale;
-                m[k] = b1 * m[k] + (1.f - b1) * gr;
-                v[k] = b2 * v[k] + (1.f - b2) * gr * gr;
-                const float denom = sqrtf(v[k]) * bc2_rsqrt + eps;
-                p[k] = p[k] * (1.f - lr * wd) - (lr / bc1) * (m[k] / denom);
-                if (shadow) {
-                    if (shadow_dtype == TGT_BF16) reinterpret_cast<bf16_t*>(shadow)[k] = from_f32<bf16_t>(p[k]);
-                    else reinterpret_cast<f16_t*>(shadow)[k] = from_f32<f16_t>(p[k]);
-                }
-            }
-        }
-    }
-}
-
 }  // namespace tgt
 
 using namespace tgt;
@@ -115,7 +60,7 @@ using namespace tgt;
 extern "C" {
 
 const char* tgt_last_error(void) { return g_err; }
-int tgt_abi_version(void) { return 16; }
+int tgt_abi_version(void) { return 17; }
 
 int tgt_triplet_attention_fwd(const tgt_triplet_attention_args* a, void* stream) {
     return triplet_attention_run(a, false, reinterpret_cast<hipStream_t>(stream));
@@ -207,27 +152,6 @@ int tgt_layer_norm_bwd(const void* dy, int32_t dy_dtype, const void* x, int32_t 
                        float* partial, int64_t rows, int32_t C, void* stream) {
     return layer_norm_bwd_run(dy, dy_dtype, x, x_dtype, gamma, mean, rstd, dx, dx_dtype, dgamma, dbeta, partial, rows, C,
                               reinterpret_cast<hipStream_t>(stream));
-}
-
-int tgt_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
-                  float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_scale,
-                  void* shadow, int32_t shadow_dtype, void* stream) {
-    if (!param || !grad || !exp_avg || !exp_avg_sq || n < 0 || step < 1)
-        return set_error(TGT_ERR_INVALID, "adam: null buffer or bad n/step");
-    if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16)
-        return set_error(TGT_ERR_INVALID, "adam: buffers must be 16-byte aligned");
-    if (shadow && shadow_dtype != TGT_BF16 && shadow_dtype != TGT_F16)
-        return set_error(TGT_ERR_INVALID, "adam: shadow dtype must be bf16 or f16");
-    if (shadow && ((uintptr_t)shadow % 8)) return set_error(TGT_ERR_INVALID, "adam: shadow must be 8-byte aligned");
-    if (n == 0) return TGT_OK;
-    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    int64_t blocks = (n / 4 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), param,
-                       grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (float)bc1,
-                       (float)(1.0 / sqrt(bc2)), grad_scale, shadow, shadow_dtype);
-    return check_launch("adam_kernel");
 }
 
 }  // extern "C"

@@ -603,18 +603,52 @@ def edge_logits(qk, e_bias, num_heads):
 # flat Adam
 # ---------------------------------------------------------------------------
 def adam_step_(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8,
-               weight_decay=0.0, grad_scale=1.0, shadow=None):
+               weight_decay=0.0, grad_scale=1.0, shadow=None, clip_value=0.0, ctl=None):
     """In-place Adam on flat float32 buffers (replaces apex FusedAdam,
-    reference lib/training/training.py:159-171)."""
-    _dev(param, grad, exp_avg, exp_avg_sq)
+    reference lib/training/training.py:159-171).  clip_value > 0: clip_grad_value_ folded in
+    (training.py:455-460).  ctl: the device control block of grad_scaler_step_ (skip flag, gradient
+    multiplier, applied-step count); `step` / `grad_scale` are then ignored."""
+    _dev(param, grad, exp_avg, exp_avg_sq, ctl)
     for t in (param, grad, exp_avg, exp_avg_sq):
         assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == param.numel()
     if shadow is not None:
         assert shadow.is_cuda and shadow.numel() == param.numel() and shadow.dtype in (torch.bfloat16, torch.float16)
+    if ctl is not None:
+        assert ctl.dtype == torch.float32 and ctl.is_contiguous() and ctl.numel() >= CTL_SIZE
     _lib.check(_lib.lib().tgt_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq),
                                         param.numel(), lr, betas[0], betas[1], eps, weight_decay,
-                                        int(step), grad_scale, _ptr(shadow),
+                                        int(step), grad_scale, float(clip_value or 0.0), _ptr(ctl), _ptr(shadow),
                                         0 if shadow is None else _DT[shadow.dtype], _stream()), 'tgt_adam_step')
+
+
+# layout of the optimizer control block (include/tgt_hip.h TGT_CTL_*)
+CTL_SCALE, CTL_TRACKER, CTL_FOUND_INF, CTL_STEPS, CTL_MULT, CTL_COEF, CTL_NORM, CTL_SKIPPED = range(8)
+CTL_LOSS, CTL_SAMPLES, CTL_NAN, CTL_PAIR, CTL_SIZE = 8, 9, 10, 12, 16
+
+
+def grad_scaler_step_(grad, ctl, world=1, clip_value=0.0, clip_norm=0.0, dynamic=False, growth_factor=2.0,
+                      backoff_factor=0.5, growth_interval=2000):
+    """One pass over the flat (all-reduced, still loss-scaled) gradient + a one-thread decision kernel:
+    GradScaler's found_inf / skip / scale update and clip_grad_norm_'s coefficient, all left on the
+    device in `ctl` for adam_step_ (reference training.py:451-469 does this with a host sync)."""
+    _dev(grad, ctl)
+    assert grad.dtype == torch.float32 and grad.is_contiguous() and ctl.dtype == torch.float32 and ctl.numel() >= CTL_SIZE
+    L = _lib.lib()
+    partial = torch.empty(L.tgt_grad_stats_parts(), dtype=torch.float32, device=grad.device)
+    _lib.check(L.tgt_grad_scaler_step(_ptr(grad), grad.numel(), _ptr(ctl), _ptr(partial), int(world), float(clip_value or 0.0),
+                                      float(clip_norm or 0.0), int(bool(dynamic)), float(growth_factor), float(backoff_factor),
+                                      int(growth_interval), _stream()), 'tgt_grad_scaler_step')
+
+
+def loss_accumulate_(loss, samples, ctl, mixed, mode=3):
+    """update_losses on the device (reference tgt_training.py:141-171): mode 1 writes
+    (loss*samples, samples) to ctl[12:14] (all-reduce those between the halves), mode 2 accumulates
+    them into ctl[8:10] with the reference's NaN-skipping rule, mode 3 does both."""
+    _dev(ctl, loss)
+    if loss is not None:
+        assert loss.numel() == 1 and loss.dtype in (torch.float32, torch.float64)
+    _lib.check(_lib.lib().tgt_loss_accumulate(_ptr(loss), int(loss is not None and loss.dtype == torch.float64), float(samples),
+                                              _ptr(ctl), int(bool(mixed)), int(mode), _stream()), 'tgt_loss_accumulate')
 
 
 # ---------------------------------------------------------------------------
@@ -820,7 +854,9 @@ class _MultiHotEmbed(torch.autograd.Function):
     """sum_f W[idx[..., f]]  as  counts(idx) @ W: both directions are small GEMMs
     instead of a gather and a sort-based scatter (the ATen embedding backward spends
     ~5 ms per call on these few-hundred-row tables).  Row `padding_idx` gets no
-    gradient, like nn.Embedding(padding_idx=...)."""
+    gradient, like nn.Embedding(padding_idx=...).  Sums and weight gradients are float32 whatever
+    autocast says: nn.Embedding is not an autocast op, the reference's embeddings stay fp32
+    (lib/models/pcqm/layers.py:62-76)."""
 
     @staticmethod
     def forward(ctx, idx, weight, padding_idx, out_dtype):
@@ -842,10 +878,12 @@ class _MultiHotEmbed(torch.autograd.Function):
 
 
 def multi_hot_embed(idx, weight, padding_idx=None, out_dtype=None):
-    """idx: (..., F) long with values < weight.shape[0]; returns (..., C) = sum over F of rows."""
+    """idx: (..., F) long with values < weight.shape[0]; returns (..., C) = sum over F of rows,
+    in weight.dtype unless out_dtype says otherwise."""
     if out_dtype is None:
-        out_dtype = torch.get_autocast_dtype('cuda') if (weight.is_cuda and torch.is_autocast_enabled('cuda')) else weight.dtype
-    return _MultiHotEmbed.apply(idx, weight, padding_idx, out_dtype)
+        out_dtype = weight.dtype
+    with torch.autocast('cuda', enabled=False):
+        return _MultiHotEmbed.apply(idx, weight, padding_idx, out_dtype)
 
 
 # ---------------------------------------------------------------------------
@@ -1146,11 +1184,23 @@ class side_stream:
     block.  Used to run the small node-channel kernels (8192 rows: latency-bound, a few
     workgroups) under the edge-channel kernels of the same layer.  Autograd replays the block's
     backward on the same side stream and inserts the cross-stream waits itself.
-    TGT_NODE_STREAM=0 disables it (everything stays on the current stream)."""
+    TGT_NODE_STREAM=0 disables it (everything stays on the current stream).
+
+    It is only used while a tgt_amd Trainer owns the step (`owner_present`): the Trainer's gradient
+    collection waits for both streams (wait_side_streams) before it reads or all-reduces gradients.
+    Anything else that consumes parameter gradients from hooks -- torch DistributedDataParallel's
+    reducer when these modules are aliased into the reference's run_training.py -- only orders its
+    collectives after the stream of the hook that closed a bucket, and would race with gradients still
+    being produced on the side stream; without an owner the block therefore runs on the current stream."""
     enabled = os.environ.get('TGT_NODE_STREAM', '1') != '0'
+    _owners = 0
+
+    @classmethod
+    def owner_present(cls, present):
+        cls._owners = max(0, cls._owners + (1 if present else -1))
 
     def __init__(self, *inputs):
-        self.active = self.enabled and len(inputs) > 0 and all(t.is_cuda for t in inputs)
+        self.active = self.enabled and self._owners > 0 and len(inputs) > 0 and all(t.is_cuda for t in inputs)
         if self.active:
             dev = inputs[0].device
             self.main = torch.cuda.current_stream(dev)

@@ -45,6 +45,14 @@ class StepConfig:
     # precision: None (fp32) | 'bf16' | 'fp16'
     mixed_precision: str = 'bf16'
     bucket_mbytes: int = 64
+    # gradient clipping (reference training.py:446-462; None = off, as in the shipped YAMLs)
+    clip_grad_value: float = None
+    clip_grad_norm: float = None
+    # fp16 loss scaling: torch.cuda.amp.GradScaler() defaults (reference training.py:427-431)
+    init_scale: float = 65536.0
+    growth_factor: float = 2.0
+    backoff_factor: float = 0.5
+    growth_interval: int = 2000
 
 
 def lr_at(step, cfg):
@@ -61,15 +69,17 @@ def coords2dist(coords):
     return torch.norm(coords.unsqueeze(-2) - coords.unsqueeze(-3), dim=-1)
 
 
-def preprocess_batch(batch, device, cfg, training=True, generator=None):
+def preprocess_batch(batch, device, cfg, training=True, generator=None, add_noise=True):
     """host batch -> device, + edge_mask, + noised distance input
-    (reference training.py:410-418, pretrain/scheme.py:60-76, commons.py:10-16)."""
+    (reference training.py:410-418, pretrain/scheme.py:60-76, commons.py:10-16).  The coordinate
+    noise is added in training AND validation, as the reference's scheme does; add_noise=False is for
+    tests that need the un-noised distances."""
     b = {k: v.to(device, non_blocking=True) for k, v in batch.items()}
     nm = b['node_mask']
     em = nm.unsqueeze(-1) * nm.unsqueeze(-2)
     b['edge_mask'] = em
     coords = b['dft_coords']
-    if training and cfg.coords_noise > 0:
+    if add_noise and cfg.coords_noise > 0:
         noise = torch.randn(coords.shape, dtype=coords.dtype, device=coords.device, generator=generator)
         noise = noise * cfg.coords_noise
         dm = coords2dist(coords) + (1 - em.float()) * 1e9
@@ -115,6 +125,9 @@ class FlatState:
                 seen.add(id(p))
                 uniq.append(p)
         self.params = uniq
+        for p in self.params:              # shadows of an earlier Trainer on this model would go stale silently
+            if hasattr(p, '_lp'):
+                del p._lp
         dev = self.params[0].device
         self.offsets, off = [], 0
         for p in self.params:
@@ -133,6 +146,10 @@ class FlatState:
             self.grad_views.append(self.grad[o:o + p.numel()].view_as(p))
             p.grad = None
         self.shadow = None
+
+    def views(self, flat):
+        """per-parameter views of a flat buffer laid out like self.param"""
+        return [flat[o:o + p.numel()].view_as(p) for p, o in zip(self.params, self.offsets)]
 
     def make_shadow(self, dtype):
         """16-bit copy of all parameters (views hung on each parameter as `_lp`); the Adam
@@ -170,25 +187,47 @@ class FlatState:
 
 
 class Trainer:
+    """The reference's per-step sequence (lib/training/training.py:439-470 + the loop body of
+    :520-532) on flat buffers.  Everything the reference decides on the host per step -- GradScaler's
+    found_inf / skip / scale update, the clipping coefficient, the running loss -- is decided on the
+    device in a 16-float control block (`self.ctl`, ops.CTL_*), so the step never synchronises."""
+
     def __init__(self, model, cfg=None, loss_fn=pretrain_loss, process_group=None, force_distributed=False):
         self.model, self.cfg, self.loss_fn = model, (cfg or StepConfig()), loss_fn
         self.flat = FlatState(model)
         self.global_step = 0
+        self._applied_steps = 0            # optimizer steps applied (host count; the fp16 path counts on the device)
         # force_distributed: run the bucketed all-reduce path even with one rank (tests)
         self.distributed = dist.is_available() and dist.is_initialized() and \
             (dist.get_world_size(process_group) > 1 or force_distributed)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if self.distributed else 1
-        self.loss_scale = 65536.0 if self.cfg.mixed_precision == 'fp16' else 1.0
-        self._good_steps = 0
         self._handles = []
         self._armed = False
+        dev = self.flat.param.device
+        self.dynamic_scale = self.cfg.mixed_precision == 'fp16'
+        # the device control block drives the step whenever a per-step decision exists
+        self.use_ctl = dev.type == 'cuda' and (self.dynamic_scale or bool(self.cfg.clip_grad_norm))
+        self.ctl = torch.zeros(ops.CTL_SIZE, dtype=torch.float32, device=dev)
+        self.ctl[ops.CTL_SCALE] = self.cfg.init_scale if self.dynamic_scale else 1.0
+        self.ctl[ops.CTL_COEF] = 1.0
         if self.distributed:
             # replicas start from rank 0's parameters (DDP's broadcast at wrap, training.py:152)
             dist.broadcast(self.flat.param, src=0, group=self.pg)
             self._setup_buckets()
         if self.cfg.mixed_precision in ('bf16', 'fp16') and self.flat.param.is_cuda:
             self.flat.make_shadow(torch.bfloat16 if self.cfg.mixed_precision == 'bf16' else torch.float16)
+        # parameters changed behind the trainer's back (the reference loads pretrained weights AFTER the
+        # trainer exists, tgt_training.py:174-189): the 16-bit shadows must follow
+        self._hooks = [model.register_load_state_dict_post_hook(lambda m, keys: self.refresh_shadow())]
+        # this trainer orders its own gradient collection after both streams; the node side stream is
+        # only safe under it (torch DDP's reducer does not know about it): see ops.side_stream
+        ops.side_stream.owner_present(True)
+
+    @property
+    def loss_scale(self):
+        """current loss scale (a host read of the device value: a sync; for logging / checkpoints)"""
+        return float(self.ctl[ops.CTL_SCALE])
 
     # ---- data-parallel gradient exchange ---------------------------------
     def _setup_buckets(self):
@@ -243,7 +282,8 @@ class Trainer:
         self._pending = [b[2] for b in self.buckets]
 
     def refresh_shadow(self):
-        """call after changing parameters outside the trainer (e.g. load_state_dict)"""
+        """the 16-bit parameter shadows <- the float32 parameters.  Runs by itself after
+        model.load_state_dict (hook); call it after any other out-of-band parameter change."""
         if self.flat.shadow is not None:
             self.flat.shadow.copy_(self.flat.param)
 
@@ -256,35 +296,36 @@ class Trainer:
 
     def compute_gradients(self, batch):
         """zero grads -> autocast forward + loss -> backward (+ overlapped RCCL
-        all-reduce of gradient buckets).  Leaves SUMMED gradients in flat.grad."""
+        all-reduce of gradient buckets).  Leaves SUMMED (and, in fp16, still loss-scaled) gradients
+        in flat.grad."""
         cfg, f = self.cfg, self.flat
         f.clear_grads()
         self._armed = True
         with self.autocast():
             outputs = self.model(batch)
             loss = self.loss_fn(outputs, batch, cfg)
-        (loss * self.loss_scale if self.loss_scale != 1.0 else loss).backward()
+        # GradScaler.scale(loss): the scale is a device scalar, so a changed scale costs no sync
+        (loss * self.ctl[ops.CTL_SCALE].to(loss.dtype) if self.dynamic_scale else loss).backward()
         self._armed = False
         self._finish_reduce()
         return outputs, loss
 
     def apply_gradients(self):
-        """Adam on the flat buffers (one HIP kernel); averages over ranks and
-        undoes the fp16 loss scale via grad_scale."""
+        """[GradScaler.unscale_ + found_inf] -> clip_grad_value_ -> clip_grad_norm_ -> Adam ->
+        [GradScaler.update], the order of training.py:451-469, as (at most) two passes over the flat
+        gradient and one over the optimizer state; averages over ranks via the gradient multiplier."""
         cfg, f = self.cfg, self.flat
         lr = lr_at(self.global_step, cfg)
-        grad_scale = 1.0 / (self.world * self.loss_scale)
-        if cfg.mixed_precision == 'fp16':                    # GradScaler semantics (training.py:467-469)
-            if not bool(torch.isfinite(f.grad.sum())):
-                self.loss_scale, self._good_steps = self.loss_scale / 2, 0
-                return False
-            self._good_steps += 1
-            if self._good_steps >= 2000:
-                self.loss_scale, self._good_steps = self.loss_scale * 2, 0
-        ops.adam_step_(f.param, f.grad, f.exp_avg, f.exp_avg_sq, self.global_step, lr,
-                       betas=cfg.betas, eps=cfg.eps, weight_decay=cfg.weight_decay, grad_scale=grad_scale,
-                       shadow=f.shadow)
-        return True
+        if self.use_ctl:
+            ops.grad_scaler_step_(f.grad, self.ctl, self.world, cfg.clip_grad_value, cfg.clip_grad_norm, self.dynamic_scale,
+                                  cfg.growth_factor, cfg.backoff_factor, cfg.growth_interval)
+            ops.adam_step_(f.param, f.grad, f.exp_avg, f.exp_avg_sq, 0, lr, betas=cfg.betas, eps=cfg.eps,
+                           weight_decay=cfg.weight_decay, shadow=f.shadow, clip_value=cfg.clip_grad_value, ctl=self.ctl)
+        else:
+            self._applied_steps += 1
+            ops.adam_step_(f.param, f.grad, f.exp_avg, f.exp_avg_sq, self._applied_steps, lr,
+                           betas=cfg.betas, eps=cfg.eps, weight_decay=cfg.weight_decay, grad_scale=1.0 / self.world,
+                           shadow=f.shadow, clip_value=cfg.clip_grad_value)
 
     def training_step(self, batch):
         """batch: device tensors incl. edge_mask / dist_input (see preprocess_batch).
@@ -293,3 +334,100 @@ class Trainer:
         outputs, loss = self.compute_gradients(batch)
         self.apply_gradients()
         return outputs, loss
+
+    # ---- running loss (reference tgt_training.py:137-171), sync-free -------
+    def initialize_losses(self):
+        self.ctl[ops.CTL_LOSS:ops.CTL_NAN + 1] = 0
+
+    def update_losses(self, loss, batch):
+        """total_loss += loss * samples, total_samples += samples (summed over ranks; a NaN step loss is
+        skipped under mixed precision unless 10 came in a row).  The reference pays two scalar
+        all-reduces and two `.item()` per step for this; here it is one 8-byte all-reduce between two
+        one-thread kernels, and the host reads the mean only when it logs (mean_loss)."""
+        samples = float(batch['num_nodes'].shape[0])
+        mixed = self.cfg.mixed_precision is not None
+        loss = loss.detach()
+        if loss.dtype not in (torch.float32, torch.float64):
+            loss = loss.float()
+        if not self.distributed:
+            ops.loss_accumulate_(loss, samples, self.ctl, mixed, 3)
+            return
+        ops.loss_accumulate_(loss, samples, self.ctl, mixed, 1)
+        dist.all_reduce(self.ctl[ops.CTL_PAIR:ops.CTL_PAIR + 2], group=self.pg)
+        ops.loss_accumulate_(None, samples, self.ctl, mixed, 2)
+
+    def mean_loss(self):
+        """running mean loss per sample since initialize_losses (host read: synchronises)"""
+        c = self.ctl.tolist()
+        return c[ops.CTL_LOSS] / (c[ops.CTL_SAMPLES] + 1e-12)
+
+    def step_stats(self):
+        """host copy of the control block's counters (synchronises; for logging / tests)"""
+        c = self.ctl.tolist()
+        applied = int(c[ops.CTL_STEPS]) if self.use_ctl else self._applied_steps
+        return dict(loss_scale=c[ops.CTL_SCALE], growth_tracker=int(c[ops.CTL_TRACKER]), found_inf=bool(c[ops.CTL_FOUND_INF]),
+                    applied_steps=applied, skipped_steps=int(c[ops.CTL_SKIPPED]), grad_norm=c[ops.CTL_NORM],
+                    clip_coef=c[ops.CTL_COEF])
+
+    # ---- checkpoint / resume (reference training.py:290-360: training_state.pt, optimizer_state.pt,
+    #      grad_scaler_state.pt; model_state.pt is model.state_dict()) ---------
+    def optimizer_state_dict(self):
+        """torch.optim.Adam-format state ({'state': {i: {step, exp_avg, exp_avg_sq}}, 'param_groups': [...]}),
+        parameter order = model.parameters(): loads into torch.optim.Adam(model.parameters())"""
+        f = self.flat
+        steps = self.step_stats()['applied_steps']
+        state = {i: dict(step=torch.tensor(float(steps)), exp_avg=m.detach().clone().cpu(), exp_avg_sq=v.detach().clone().cpu())
+                 for i, (m, v) in enumerate(zip(f.views(f.exp_avg), f.views(f.exp_avg_sq)))} if steps > 0 else {}
+        group = dict(lr=lr_at(self.global_step, self.cfg), betas=tuple(self.cfg.betas), eps=self.cfg.eps,
+                     weight_decay=self.cfg.weight_decay, amsgrad=False, maximize=False, foreach=None, capturable=False,
+                     differentiable=False, fused=None, params=list(range(len(f.params))))
+        return dict(state=state, param_groups=[group])
+
+    def load_optimizer_state_dict(self, sd):
+        """accepts torch.optim.Adam's layout (per-parameter 'step') and apex FusedAdam's (the step lives in
+        param_groups[0]['step'], reference training.py:339)"""
+        f = self.flat
+        st = sd.get('state', {})
+        steps = 0
+        if st:
+            if len(st) != len(f.params):
+                raise ValueError(f'optimizer state has {len(st)} entries, the model {len(f.params)} parameters')
+            for i, (m, v) in enumerate(zip(f.views(f.exp_avg), f.views(f.exp_avg_sq))):
+                e = st[i] if i in st else st[str(i)]
+                m.copy_(e['exp_avg'])
+                v.copy_(e['exp_avg_sq'])
+                if 'step' in e:
+                    steps = int(float(e['step']))
+        else:
+            f.exp_avg.zero_()
+            f.exp_avg_sq.zero_()
+        if steps == 0 and sd.get('param_groups') and 'step' in sd['param_groups'][0]:
+            steps = int(sd['param_groups'][0]['step'])
+        self._applied_steps = steps
+        self.ctl[ops.CTL_STEPS] = float(steps)
+
+    def grad_scaler_state_dict(self):
+        """torch.cuda.amp.GradScaler.state_dict() layout"""
+        s = self.step_stats()
+        return dict(scale=s['loss_scale'], growth_factor=self.cfg.growth_factor, backoff_factor=self.cfg.backoff_factor,
+                    growth_interval=self.cfg.growth_interval, _growth_tracker=s['growth_tracker'])
+
+    def load_grad_scaler_state_dict(self, sd):
+        if not sd:
+            return
+        self.ctl[ops.CTL_SCALE] = float(sd['scale'])
+        self.ctl[ops.CTL_TRACKER] = float(sd.get('_growth_tracker', 0))
+        for k in ('growth_factor', 'backoff_factor', 'growth_interval'):
+            if k in sd:
+                setattr(self.cfg, k, type(getattr(self.cfg, k))(sd[k]))
+
+    def state_dict(self):
+        """everything a run needs to resume besides model.state_dict()"""
+        return dict(training_state=dict(global_step=self.global_step), optimizer=self.optimizer_state_dict(),
+                    grad_scaler=self.grad_scaler_state_dict() if self.dynamic_scale else {})
+
+    def load_state_dict(self, sd):
+        self.global_step = int(sd.get('training_state', {}).get('global_step', 0))
+        self.load_optimizer_state_dict(sd.get('optimizer', {}))
+        self.load_grad_scaler_state_dict(sd.get('grad_scaler', {}))
+        self.refresh_shadow()
