@@ -250,6 +250,52 @@ int tgt_loss_accumulate(const void* loss, int32_t loss_is_f64, float samples, fl
                         int32_t mode, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Edge-channel Linear with the neighbouring passes fused in (csrc/edge_gemm.hip):
+ *     out[M, N] = epilogue( prologue(a[M, K]) . w[N, K]^T + bias )
+ * Replaces, on the (B*N*N, C) edge rows, the nn.LayerNorm -> nn.Linear -> GELU/Dropout -> nn.Linear ->
+ * residual add_ chains of reference lib/tgt/layers/layers.py:37-38,:62-80 (mha_ln_e, lin_EG, lin_O_e),
+ * :155-160 (FFN), :270-290 (residual wiring) and lib/tgt/layers/triplet.py:207-211,:248-249
+ * (tri_ln_e, lin_QKV/lin_EG projections, lin_O), forward and data-gradient.
+ *   prologue (gamma != NULL and epilogue != LN_BWD): x = LayerNorm(a) over K (K <= 256), gamma/beta float32;
+ *       mean / rstd (M) float32 written when given; y (M, K) = the normalised rows when given.
+ *   TGT_EPI_BIAS     out = z * out_scale[row / rows_per_sample]        (out_scale may be NULL)
+ *   TGT_EPI_GELU     out2 = z (pre-activation);  out = dropout(gelu(z), dropout_p, dropout_seed)
+ *                    (generator of tgt_gelu_dropout_fwd on the (M, N) index space)
+ *   TGT_EPI_RESID    out = res + row_scale[row / rows_per_sample] * z   (row_scale may be NULL)
+ *   TGT_EPI_GELU_BWD out = z' * gelu'(res) * keep / (1-p), z' = z * out_scale[..]; res = the forward's pre-activation
+ *   TGT_EPI_LN_BWD   z = dy, the gradient at the output of LayerNorm(res; gamma) with saved mean / rstd (N <= 256):
+ *                    out  = ds_in + rstd * (dy*gamma - mean_n(dy*gamma) - xhat * mean_n(dy*gamma*xhat))   (ds_in may be NULL)
+ *                    out2 = out * row_scale[..]  (when given: the gradient of the branch DropPath scaled)
+ *                    colsum_partial (tgt_edge_linear_parts(M, epilogue), 3N) float32, when given: per row tile
+ *                    [sum dy*xhat | sum dy | sum out2-or-out]: dgamma, dbeta and the bias gradient of the Linear
+ *                    that produced the branch, to be summed over the tiles (tgt_sum_planes)
+ * Element type 16-bit (TGT_BF16 / TGT_F16; bias in the same type); N % 8 == 0; K in {16,32,64,128} or a multiple
+ * of 16 >= 256; not both K > 256 and N > 256.  tgt_edge_linear_supported() tells; anything else is the
+ * caller's library GEMM + tgt_layer_norm_* path.
+ * ---------------------------------------------------------------------- */
+enum { TGT_EPI_BIAS = 0, TGT_EPI_GELU = 1, TGT_EPI_RESID = 2, TGT_EPI_GELU_BWD = 3, TGT_EPI_LN_BWD = 4 };
+typedef struct tgt_edge_linear_args {
+    int64_t M;
+    int32_t K, N, dtype, epilogue;
+    const void* a;      int64_t lda;
+    const void* w;      int64_t ldw;
+    const void* bias;
+    const float* gamma; const float* beta; float eps; int32_t _pad0;
+    float* mean;        float* rstd;
+    void* y;            int64_t ldy;
+    void* out;          int64_t ldo;
+    void* out2;         int64_t ldo2;
+    const void* res;    int64_t ldr;
+    const void* ds_in;  int64_t ld_ds;
+    const float* row_scale; const float* out_scale; int64_t rows_per_sample;
+    float dropout_p;    uint32_t _pad1;  uint64_t dropout_seed;
+    float* colsum_partial;
+} tgt_edge_linear_args;
+int tgt_edge_linear_supported(const tgt_edge_linear_args* a);
+int tgt_edge_linear_parts(int64_t M, int32_t epilogue);
+int tgt_edge_linear(const tgt_edge_linear_args* a, void* stream);
+
+/* ------------------------------------------------------------------------
  * LayerNorm over the last axis (the five per-layer norms of the TGT layer:
  * reference lib/tgt/layers/layers.py:37-38,:150, lib/tgt/layers/triplet.py:195,
  * i.e. the ATen layer_norm forward/backward behind nn.LayerNorm).

@@ -1,0 +1,182 @@
+"""tgt_edge_linear (csrc/edge_gemm.hip) through the C ABI against float64 restatements of the chains it replaces:
+nn.LayerNorm -> nn.Linear -> GELU/Dropout -> nn.Linear -> residual add_ on the edge rows
+(reference lib/tgt/layers/layers.py:37-38,:62-80,:155-160,:270-290; triplet.py:207-211,:248-249) and their
+autograd backward.  Tolerances: the kernel rounds its result once to the 16-bit storage type, so against a float64
+evaluation of the same rounded operands the error is one rounding of the output (bf16: 2^-8 relative per element;
+rel-L2 <= 4e-3; fp16 <= 5e-4), plus fp32 accumulation noise."""
+import math
+
+import pytest
+import torch
+
+from tgt_amd import _lib, ops
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.bfloat16: 4e-3, torch.float16: 5e-4}
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _mk(M, K, N, dtype, seed, bias=True):
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    a = torch.randn(M, K, device='cuda', generator=g).to(dtype)
+    w = (torch.randn(N, K, device='cuda', generator=g) / math.sqrt(K)).to(dtype)
+    b = (torch.randn(N, device='cuda', generator=g) * 0.5).to(dtype) if bias else None
+    return a, w, b, g
+
+
+def _ln64(x, gamma, beta, eps):
+    x = x.double()
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    rstd = 1 / torch.sqrt(var + eps)
+    return (x - mu) * rstd * gamma.double() + beta.double(), mu.squeeze(-1), rstd.squeeze(-1)
+
+
+SHAPES = [(300, 16, 8), (300, 32, 24), (257, 64, 256), (1000, 128, 128), (1024, 256, 128), (513, 256, 256),
+          (640, 256, 1600), (384, 512, 256), (200, 1600, 256), (130, 272, 64), (128, 256, 64)]
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('M,K,N', SHAPES)
+def test_plain_linear_matches_float64(M, K, N, dtype):
+    a, w, b, g = _mk(M, K, N, dtype, 1)
+    out = ops.edge_linear_raw(a, w, b)
+    ref = a.double() @ w.double().t() + b.double()
+    assert rel(out, ref) < TOL[dtype]
+    # no bias, per-graph output scale, strided operand views
+    big = torch.randn(M, K + 8, device='cuda', generator=g).to(dtype)
+    av = big[:, 8:]
+    sc = torch.rand(math.ceil(M / 100), device='cuda', generator=g) + 0.5
+    dst = torch.full((M, N + 8), 7.0, dtype=dtype, device='cuda')
+    ops.edge_linear_raw(av, w, None, out=dst[:, :N], out_scale=sc, rows_per_sample=100)
+    ref = (av.double() @ w.double().t()) * sc.double().repeat_interleave(100)[:M, None]
+    assert rel(dst[:, :N], ref) < TOL[dtype]
+    assert torch.all(dst[:, N:] == 7.0)                 # nothing written past the N columns
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('M,K,N', [s for s in SHAPES if s[1] <= 256 and s[1] in (16, 32, 64, 128, 256)])
+def test_layernorm_prologue(M, K, N, dtype):
+    a, w, b, g = _mk(M, K, N, dtype, 2)
+    a = (a.float() * 1.7 + 0.3).to(dtype)
+    gamma = torch.rand(K, device='cuda', generator=g) + 0.5
+    beta = torch.randn(K, device='cuda', generator=g) * 0.2
+    mean = torch.empty(M, device='cuda')
+    rstd = torch.empty(M, device='cuda')
+    y = torch.empty(M, K, dtype=dtype, device='cuda')
+    out = ops.edge_linear_raw(a, w, b, ln=(gamma, beta, 1e-5), stats=(mean, rstd), y=y)
+    y64, mu64, rs64 = _ln64(a, gamma, beta, 1e-5)
+    assert rel(mean, mu64) < 1e-5 and rel(rstd, rs64) < 1e-5
+    assert rel(y, y64) < TOL[dtype]
+    # the GEMM consumes the normalised rows as stored (rounded): compare against exactly that
+    ref = y.double() @ w.double().t() + b.double()
+    assert rel(out, ref) < TOL[dtype]
+    # bit-identical to the standalone LayerNorm kernel's output and statistics
+    y2 = ops.layer_norm(a, gamma, beta, 1e-5, out_dtype=dtype)
+    assert rel(y, y2) < 2e-3 if dtype == torch.bfloat16 else 3e-4
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('p', [0.0, 0.1])
+@pytest.mark.parametrize('M,K,N', [(300, 64, 64), (513, 256, 256), (1024, 256, 512), (260, 128, 128)])
+def test_gelu_dropout_epilogue_equals_standalone_kernel(M, K, N, dtype, p):
+    a, w, b, g = _mk(M, K, N, dtype, 3)
+    seed = 0x1234567 if p else 0
+    pre = torch.empty(M, N, dtype=dtype, device='cuda')
+    out = ops.edge_linear_raw(a, w, b, _lib.EPI_GELU, out2=pre, dropout=(p, seed))
+    ref = a.double() @ w.double().t() + b.double()
+    assert rel(pre, ref) < TOL[dtype]
+    # the activation is the standalone kernel's function of the STORED pre-activation, same keep pattern
+    y = torch.empty_like(pre)
+    _lib.check(_lib.lib().tgt_gelu_dropout_fwd(pre.data_ptr(), y.data_ptr(), pre.numel(), ops._DT[dtype], p, seed, None), 'gd')
+    torch.cuda.synchronize()
+    assert torch.equal(out, y)
+    if p:
+        kept = float((out != 0).float().mean())
+        assert abs(kept - (1 - p)) < 0.02
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('M,K,N', [(300, 16, 64), (700, 64, 256), (513, 256, 256), (384, 512, 256)])
+def test_residual_epilogue(M, K, N, dtype):
+    a, w, b, g = _mk(M, K, N, dtype, 4)
+    res = torch.randn(M, N, device='cuda', generator=g).to(dtype)
+    sc = (torch.rand(math.ceil(M / 64), device='cuda', generator=g) > 0.3).float() / 0.7       # DropPath factors
+    out = ops.edge_linear_raw(a, w, b, _lib.EPI_RESID, res=res, row_scale=sc, rows_per_sample=64)
+    ref = res.double() + (a.double() @ w.double().t() + b.double()) * sc.double().repeat_interleave(64)[:M, None]
+    assert rel(out, ref) < TOL[dtype]
+    out = ops.edge_linear_raw(a, w, b, _lib.EPI_RESID, res=res)
+    assert rel(out, res.double() + a.double() @ w.double().t() + b.double()) < TOL[dtype]
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('p', [0.0, 0.1])
+def test_gelu_backward_epilogue_equals_standalone_kernel(dtype, p):
+    M, K, N = 520, 256, 256            # dz (M,K) @ W2 (K_out=256 rows of W2^T) -> d_a, then through the activation
+    a, w, _, g = _mk(M, K, N, dtype, 5, bias=False)
+    pre = torch.randn(M, N, device='cuda', generator=g).to(dtype)
+    sc = torch.rand(math.ceil(M / 40), device='cuda', generator=g) + 0.5
+    seed = 0xabcdef if p else 0
+    out = ops.edge_linear_raw(a, w, None, _lib.EPI_GELU_BWD, res=pre, out_scale=sc, rows_per_sample=40, dropout=(p, seed))
+    dy = ((a.double() @ w.double().t()) * sc.double().repeat_interleave(40)[:M, None]).to(dtype)
+    dx = torch.empty_like(pre)
+    _lib.check(_lib.lib().tgt_gelu_dropout_bwd(pre.data_ptr(), dy.data_ptr(), dx.data_ptr(), pre.numel(), ops._DT[dtype], p, seed,
+                                               None), 'gd')
+    torch.cuda.synchronize()
+    # dy is rounded once in both paths, but from fp32 (kernel) vs float64 (here): allow the last-bit flips that causes
+    assert rel(out, dx) < TOL[dtype]
+    assert float(((out == 0) != (dx == 0)).float().mean()) < 1e-3
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('M,K,N,with_ds,with_scale', [(300, 128, 256, True, True), (513, 1600, 256, True, False),
+                                                      (260, 256, 128, False, True), (200, 64, 64, False, False),
+                                                      (1024, 256, 256, True, True)])
+def test_layernorm_backward_epilogue(M, K, N, with_ds, with_scale, dtype):
+    """dz (M,K) @ Wt (N,K)^T = dy (M,N), LayerNorm backward over N with the stream gradient added"""
+    a, w, _, g = _mk(M, K, N, dtype, 6, bias=False)
+    s = (torch.randn(M, N, device='cuda', generator=g) * 1.3 + 0.2).to(dtype)
+    gamma = torch.rand(N, device='cuda', generator=g) + 0.5
+    _, mu, rs = _ln64(s, gamma, torch.zeros_like(gamma), 1e-5)
+    mean, rstd = mu.float().contiguous(), rs.float().contiguous()
+    ds = torch.randn(M, N, device='cuda', generator=g).to(dtype) if with_ds else None
+    rps = 50
+    sc = (torch.rand(math.ceil(M / rps), device='cuda', generator=g) + 0.5) if with_scale else None
+    parts = _lib.lib().tgt_edge_linear_parts(M, _lib.EPI_LN_BWD)
+    partial = torch.full((parts, 3 * N), float('nan'), device='cuda')
+    dres = torch.empty(M, N, dtype=dtype, device='cuda')
+    dx = torch.empty(M, N, dtype=dtype, device='cuda') if with_scale else None
+    ops.edge_linear_raw(a, w, None, _lib.EPI_LN_BWD, ln=(gamma, None, 1e-5), stats=(mean, rstd), res=s, ds_in=ds, out=dres,
+                        out2=dx, row_scale=sc, rows_per_sample=rps if with_scale else 0, colsum_partial=partial)
+    dy = (a.double() @ w.double().t()).to(dtype).double()               # the unfused chain stores dy in the 16-bit type
+    xh = (s.double() - mu[:, None]) * rs[:, None]
+    gg = dy * gamma.double()
+    ref = rs[:, None] * (gg - gg.mean(-1, keepdim=True) - xh * (gg * xh).mean(-1, keepdim=True))
+    if with_ds:
+        ref = ref + ds.double()
+    assert rel(dres, ref) < TOL[dtype]
+    tot = partial.double().sum(0)
+    assert rel(tot[:N], (dy * xh).sum(0)) < 1e-4
+    assert rel(tot[N:2 * N], dy.sum(0)) < 1e-4
+    if with_scale:
+        refx = dres.double() * sc.double().repeat_interleave(rps)[:M, None]
+        assert rel(dx, refx) < TOL[dtype]
+        assert rel(tot[2 * N:], dx.double().sum(0)) < 1e-4            # column sums of the gradient AS STORED
+    else:
+        assert rel(tot[2 * N:], dres.double().sum(0)) < 1e-4
+
+
+def test_unsupported_shapes_raise_instead_of_falling_back():
+    a, w, b, _ = _mk(64, 48, 64, torch.bfloat16, 7)
+    with pytest.raises(RuntimeError, match='unsupported'):
+        ops.edge_linear_raw(a, w, b)
+    a, w, b, _ = _mk(64, 512, 512, torch.bfloat16, 7)
+    with pytest.raises(RuntimeError, match='unsupported'):
+        ops.edge_linear_raw(a, w, b)
+    with pytest.raises(RuntimeError):
+        ops.edge_linear_raw(a.float(), w.float(), b.float())

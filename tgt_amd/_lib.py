@@ -14,10 +14,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtgt_hip.so')
 CSRC = os.path.join(_HERE, 'csrc')
 # (source, extra flags, object suffix): the triplet attention kernels compile one dtype per translation unit
-SOURCES = ['capi.hip', 'optimizer.hip', 'params.hip', 'loss.hip', 'triplet_attention_proj.hip',
+SOURCES = ['capi.hip', 'optimizer.hip', 'edge_gemm.hip', 'params.hip', 'loss.hip', 'triplet_attention_proj.hip',
            ('triplet_attention.hip', ['-DTGT_TRI_INST=9'], '.f32'), ('triplet_attention.hip', ['-DTGT_TRI_INST=2'], '.bf16'),
            ('triplet_attention.hip', ['-DTGT_TRI_INST=4'], '.f16'), 'triplet_aggregate.hip', 'node_attention.hip', 'layernorm.hip', 'triangular_update.hip', 'elementwise.hip']
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 TGT_F32, TGT_BF16, TGT_F16 = 0, 1, 2
 TRI_BIASED, TRI_GATED, TRI_MASK_OUT = 1, 2, 4
@@ -73,6 +73,23 @@ class FuseRowsArgs(C.Structure):
     ]
 
 
+class EdgeLinearArgs(C.Structure):
+    _fields_ = [
+        ('M', _i64), ('K', _i32), ('N', _i32), ('dtype', _i32), ('epilogue', _i32),
+        ('a', _vp), ('lda', _i64), ('w', _vp), ('ldw', _i64), ('bias', _vp),
+        ('gamma', _vp), ('beta', _vp), ('eps', _f32), ('_pad0', _i32),
+        ('mean', _vp), ('rstd', _vp), ('y', _vp), ('ldy', _i64),
+        ('out', _vp), ('ldo', _i64), ('out2', _vp), ('ldo2', _i64),
+        ('res', _vp), ('ldr', _i64), ('ds_in', _vp), ('ld_ds', _i64),
+        ('row_scale', _vp), ('out_scale', _vp), ('rows_per_sample', _i64),
+        ('dropout_p', _f32), ('_pad1', C.c_uint32), ('dropout_seed', C.c_uint64),
+        ('colsum_partial', _vp),
+    ]
+
+
+EPI_BIAS, EPI_GELU, EPI_RESID, EPI_GELU_BWD, EPI_LN_BWD = range(5)
+
+
 # symbol -> (restype, argtypes); every symbol include/tgt_hip.h declares
 SYMBOLS = {
     'tgt_last_error': (C.c_char_p, []),
@@ -102,6 +119,9 @@ SYMBOLS = {
     'tgt_permute_cols': (C.c_int, [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
     'tgt_layer_norm_fwd': (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _f32, _vp]),
     'tgt_layer_norm_bwd': (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp]),
+    'tgt_edge_linear_supported': (C.c_int, [C.POINTER(EdgeLinearArgs)]),
+    'tgt_edge_linear_parts': (C.c_int, [_i64, _i32]),
+    'tgt_edge_linear': (C.c_int, [C.POINTER(EdgeLinearArgs), _vp]),
     'tgt_adam_step': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _f32, _vp, _vp, _i32, _vp]),
     'tgt_grad_stats_parts': (C.c_int, []),
     'tgt_grad_scaler_step': (C.c_int, [_vp, _i64, _vp, _vp, _i32, _f32, _f32, _i32, _f32, _f32, _i32, _vp]),

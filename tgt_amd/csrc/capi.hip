@@ -47,6 +47,9 @@ int permute_cols_run(const void* src, int sd, const int32_t* idx, void* dst, int
 int sum_planes_run(const float* x, int planes, int64_t n, float* out, hipStream_t st);
 int xent_run(const void* x, int dtype, const int64_t* target, const float* lse_in, const float* w, int64_t rows, int C,
              float* lse, float* xent, void* dx, hipStream_t st);
+int edge_linear_supported(const tgt_edge_linear_args* a);
+int edge_linear_parts(int64_t M, int epilogue);
+int edge_linear_run(const tgt_edge_linear_args* a, hipStream_t st);
 int layer_norm_fwd_run(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
                        float* mean, float* rstd, int64_t rows, int C, float eps, hipStream_t st);
 int layer_norm_bwd_run(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, const float* mean,
@@ -60,7 +63,7 @@ using namespace tgt;
 extern "C" {
 
 const char* tgt_last_error(void) { return g_err; }
-int tgt_abi_version(void) { return 17; }
+int tgt_abi_version(void) { return 18; }
 
 int tgt_triplet_attention_fwd(const tgt_triplet_attention_args* a, void* stream) {
     return triplet_attention_run(a, false, reinterpret_cast<hipStream_t>(stream));
@@ -153,5 +156,9 @@ int tgt_layer_norm_bwd(const void* dy, int32_t dy_dtype, const void* x, int32_t 
     return layer_norm_bwd_run(dy, dy_dtype, x, x_dtype, gamma, mean, rstd, dx, dx_dtype, dgamma, dbeta, partial, rows, C,
                               reinterpret_cast<hipStream_t>(stream));
 }
+
+int tgt_edge_linear_supported(const tgt_edge_linear_args* a) { return edge_linear_supported(a); }
+int tgt_edge_linear_parts(int64_t M, int32_t epilogue) { return edge_linear_parts(M, epilogue); }
+int tgt_edge_linear(const tgt_edge_linear_args* a, void* stream) { return edge_linear_run(a, reinterpret_cast<hipStream_t>(stream)); }
 
 }  // extern "C"

@@ -101,6 +101,30 @@ __device__ __forceinline__ float xhalf(float v) {
     return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
 }
 
+// keep/drop of the V consecutive elements of vector `vec` (= first element index / V): one hash
+// of (seed, vec), then one 32-bit word per TWO elements, 16 bits each;
+// P(keep) = 1 - thresh16 / 65536.
+template <int V>
+__device__ __forceinline__ void keep_vector(uint64_t seed, int64_t vec, uint32_t thresh16, bool (&keep)[V]) {
+    const uint32_t lo = (uint32_t)vec, hi = (uint32_t)((uint64_t)vec >> 32);
+    const uint32_t base = mix32(lo ^ (uint32_t)seed) ^ mix32(hi + (uint32_t)(seed >> 32) + 0x9e3779b9u);
+#pragma unroll
+    for (int w = 0; w < V / 2; ++w) {
+        const uint32_t r = mix32(base + (uint32_t)(w + 1) * 0x9e3779b9u);
+        keep[2 * w] = (r & 0xffffu) >= thresh16;
+        keep[2 * w + 1] = (r >> 16) >= thresh16;
+    }
+}
+// Phi(v) = 0.5 (1 + erf(v / sqrt2)) and exp(-v^2/2): erf by Abramowitz & Stegun 7.1.26
+// (|error| <= 1.5e-7, below fp32 parity tolerance); the kernel is otherwise ALU-bound on erff.
+__device__ __forceinline__ float gelu_cdf(float v, float& e) {
+    const float ax = fabsf(v) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * ax);
+    e = __expf(-ax * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    return 0.5f + copysignf(0.5f - 0.5f * poly * e, v);
+}
+
 template <typename T> struct DType;
 template <> struct DType<float>  { static constexpr int id = TGT_F32; };
 template <> struct DType<bf16_t> { static constexpr int id = TGT_BF16; };

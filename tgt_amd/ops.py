@@ -1116,6 +1116,76 @@ def linear(x, weight, bias=None):
 
 
 # ---------------------------------------------------------------------------
+# edge-channel Linear with fused LayerNorm prologue / GELU / residual / backward epilogues
+# ---------------------------------------------------------------------------
+def edge_linear_raw(a, w, bias=None, epilogue=_lib.EPI_BIAS, *, ln=None, y=None, out=None, out2=None, res=None, ds_in=None,
+                    row_scale=None, out_scale=None, rows_per_sample=0, dropout=(0.0, 0), stats=None, colsum_partial=None):
+    """One launch of tgt_edge_linear on 2-D operands (rows may be strided views with a contiguous last axis).
+    a (M,K), w (N,K), bias (N) in one 16-bit dtype; ln = (gamma, beta, eps) float32 for the LayerNorm prologue /
+    the LN_BWD epilogue; stats = (mean, rstd) float32 (M) (written by the prologue, read by LN_BWD).
+    Returns out (allocated when not given).  No fallback: an unsupported shape raises."""
+    _dev(a, w, bias, out, out2, res, ds_in, y)
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=a.dtype, device=a.device)
+    g = _lib.EdgeLinearArgs()
+    g.M, g.K, g.N, g.dtype, g.epilogue = M, K, N, _DT[a.dtype], epilogue
+
+    def mat(t, name):
+        if t is None:
+            return None, 0
+        if t.dtype != a.dtype or t.stride(-1) != 1 or t.shape[0] != M:
+            raise RuntimeError(f'edge_linear: operand {name} must be ({M}, ..) {a.dtype} with a contiguous last axis, got '
+                               f'{tuple(t.shape)} {t.dtype} stride {t.stride()}')
+        return t.data_ptr(), t.stride(0)
+
+    g.a, g.lda = mat(a, 'a')
+    if w.dtype != a.dtype or w.stride(-1) != 1 or w.shape[1] != K:
+        raise RuntimeError(f'edge_linear: weight must be (N, {K}) {a.dtype}, got {tuple(w.shape)} {w.dtype}')
+    g.w, g.ldw = w.data_ptr(), w.stride(0)
+    if bias is not None:
+        if bias.dtype != a.dtype or not bias.is_contiguous() or bias.numel() != N:
+            raise RuntimeError('edge_linear: bias must be a contiguous (N,) tensor of the operand dtype')
+        g.bias = bias.data_ptr()
+    if ln is not None:
+        gamma, beta, eps = ln
+        assert gamma.dtype == torch.float32 and gamma.is_contiguous()
+        g.gamma, g.eps = gamma.data_ptr(), float(eps)
+        if beta is not None:
+            assert beta.dtype == torch.float32 and beta.is_contiguous()
+            g.beta = beta.data_ptr()
+    if stats is not None:
+        g.mean, g.rstd = stats[0].data_ptr(), stats[1].data_ptr()
+    g.y, g.ldy = mat(y, 'y')
+    g.out, g.ldo = mat(out, 'out')
+    g.out2, g.ldo2 = mat(out2, 'out2')
+    g.res, g.ldr = mat(res, 'res')
+    g.ds_in, g.ld_ds = mat(ds_in, 'ds_in')
+    if row_scale is not None:
+        g.row_scale = row_scale.data_ptr()
+    if out_scale is not None:
+        g.out_scale = out_scale.data_ptr()
+    g.rows_per_sample = int(rows_per_sample)
+    g.dropout_p, g.dropout_seed = float(dropout[0]), int(dropout[1]) & 0xFFFFFFFFFFFFFFFF
+    if colsum_partial is not None:
+        g.colsum_partial = colsum_partial.data_ptr()
+    _call('tgt_edge_linear', _lib.lib().tgt_edge_linear, g)
+    return out
+
+
+def edge_linear_supported(K, N, dtype, epilogue=_lib.EPI_BIAS, ln=False):
+    if dtype not in (torch.bfloat16, torch.float16):
+        return False
+    g = _lib.EdgeLinearArgs()
+    g.M, g.K, g.N, g.dtype, g.epilogue = 128, K, N, _DT[dtype], epilogue
+    one = C.c_void_p(16)
+    if ln or epilogue == _lib.EPI_LN_BWD:
+        g.gamma = g.beta = g.mean = g.rstd = g.res = one
+    return bool(_lib.lib().tgt_edge_linear_supported(C.byref(g)))
+
+
+# ---------------------------------------------------------------------------
 # residual entry of a pre-norm block: s = res + x*scale ; y = LN(s)   (one pass each way)
 # ---------------------------------------------------------------------------
 class _AddLayerNorm(torch.autograd.Function):

@@ -1,0 +1,67 @@
+"""Micro-benchmark of tgt_edge_linear against the library GEMM (+ the passes it absorbs) at the BASELINE shapes
+(M = 256*32*32 edge rows, bf16).  python tools/edge_gemm_bench.py"""
+import os
+import sys
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tgt_amd import _lib, ops
+
+
+def timeit(fn, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+
+
+def main():
+    M = 256 * 32 * 32
+    dt = torch.bfloat16
+    dev = 'cuda'
+    g = torch.Generator(device=dev).manual_seed(0)
+    rows = []
+    for name, K, N, epi, ln in [('lin_EG (LN)', 256, 128, _lib.EPI_BIAS, True), ('tri proj (LN)', 256, 1600, _lib.EPI_BIAS, True),
+                                ('W1 (LN+GELU)', 256, 256, _lib.EPI_GELU, True), ('W2 (+res)', 256, 256, _lib.EPI_RESID, False),
+                                ('lin_O (+res)', 512, 256, _lib.EPI_RESID, False), ('lin_O_e (+res)', 64, 256, _lib.EPI_RESID, False),
+                                ('plain 256x256', 256, 256, _lib.EPI_BIAS, False), ('dgrad tri (K=1600)', 1600, 256, _lib.EPI_BIAS, False),
+                                ('dgrad tri + LN_BWD', 1600, 256, _lib.EPI_LN_BWD, False), ('dgrad W1 + LN_BWD', 256, 256, _lib.EPI_LN_BWD, False),
+                                ('dgrad W2 + GELU_BWD', 256, 256, _lib.EPI_GELU_BWD, False)]:
+        a = torch.randn(M, K, device=dev, generator=g).to(dt)
+        w = (torch.randn(N, K, device=dev, generator=g) / K ** 0.5).to(dt)
+        b = torch.randn(N, device=dev, generator=g).to(dt)
+        gamma, beta = torch.rand(K if ln else N, device=dev) + 0.5, torch.randn(K if ln else N, device=dev)
+        mean, rstd = torch.zeros(M, device=dev), torch.ones(M, device=dev)
+        res = torch.randn(M, N, device=dev, generator=g).to(dt)
+        out, out2, y = torch.empty(M, N, dtype=dt, device=dev), torch.empty(M, N, dtype=dt, device=dev), torch.empty(M, K, dtype=dt, device=dev)
+        sc = torch.ones(256, device=dev)
+        kw = {}
+        if ln:
+            kw.update(ln=(gamma, beta, 1e-5), stats=(mean, rstd), y=y)
+        if epi == _lib.EPI_GELU:
+            kw.update(out2=out2, dropout=(0.1, 1234))
+        if epi == _lib.EPI_RESID:
+            kw.update(res=res, row_scale=sc, rows_per_sample=1024)
+        if epi == _lib.EPI_GELU_BWD:
+            kw.update(res=res, dropout=(0.1, 1234))
+        if epi == _lib.EPI_LN_BWD:
+            parts = _lib.lib().tgt_edge_linear_parts(M, epi)
+            kw.update(ln=(gamma, None, 1e-5), stats=(mean, rstd), res=res, ds_in=out2.clone(), out2=out2, row_scale=sc, rows_per_sample=1024,
+                      colsum_partial=torch.empty(parts, 3 * N, device=dev))
+        t_mine = timeit(lambda: ops.edge_linear_raw(a, w, None if epi in (_lib.EPI_LN_BWD, _lib.EPI_GELU_BWD) else b, epi, out=out, **kw))
+        t_lib = timeit(lambda: torch.addmm(b, a, w.t(), out=out))
+        flops = 2.0 * M * K * N
+        rows.append((name, K, N, t_mine, t_lib, flops / t_mine / 1e9, flops / t_lib / 1e9))
+    print(f'{"op":24s} {"K":>5s} {"N":>5s} {"edge_linear ms":>15s} {"addmm ms":>10s} {"TF/s":>7s} {"lib TF/s":>9s}')
+    for r in rows:
+        print(f'{r[0]:24s} {r[1]:5d} {r[2]:5d} {r[3]:15.4f} {r[4]:10.4f} {r[5]:7.0f} {r[6]:9.0f}')
+
+
+if __name__ == '__main__':
+    main()
