@@ -266,7 +266,7 @@ int tgt_loss_accumulate(const void* loss, int32_t loss_is_f64, float samples, fl
  *   TGT_EPI_LN_BWD   z = dy, the gradient at the output of LayerNorm(res; gamma) with saved mean / rstd (N <= 256):
  *                    out  = ds_in + rstd * (dy*gamma - mean_n(dy*gamma) - xhat * mean_n(dy*gamma*xhat))   (ds_in may be NULL)
  *                    out2 = out * row_scale[..]  (when given: the gradient of the branch DropPath scaled)
- *                    colsum_partial (tgt_edge_linear_parts(M, epilogue), 3N) float32, when given: per row tile
+ *                    colsum_partial (tgt_edge_linear_parts(M, N), 3N) float32, ZERO-FILLED by the caller, when given: per row tile
  *                    [sum dy*xhat | sum dy | sum out2-or-out]: dgamma, dbeta and the bias gradient of the Linear
  *                    that produced the branch, to be summed over the tiles (tgt_sum_planes)
  * Element type 16-bit (TGT_BF16 / TGT_F16; bias in the same type); N % 8 == 0; K in {16,32,64,128} or a multiple
@@ -292,7 +292,7 @@ typedef struct tgt_edge_linear_args {
     float* colsum_partial;
 } tgt_edge_linear_args;
 int tgt_edge_linear_supported(const tgt_edge_linear_args* a);
-int tgt_edge_linear_parts(int64_t M, int32_t epilogue);
+int tgt_edge_linear_parts(int64_t M, int32_t N);
 int tgt_edge_linear(const tgt_edge_linear_args* a, void* stream);
 
 /* ------------------------------------------------------------------------

@@ -115,6 +115,29 @@ def test_residual_epilogue(M, K, N, dtype):
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('M,K,N', [(300, 64, 256), (1000, 256, 256), (257, 128, 128), (640, 256, 64), (129, 64, 200)])
+def test_residual_epilogue_with_layernorm_of_the_new_row(M, K, N, dtype):
+    """out = res + scale*(a W^T + b) and y = LayerNorm(out as stored): the fused `residual add + LayerNorm` entry of
+    the next sub-block (reference layers.py:270-290 followed by the next block's nn.LayerNorm)"""
+    a, w, b, g = _mk(M, K, N, dtype, 8)
+    res = (torch.randn(M, N, device='cuda', generator=g) * 1.5).to(dtype)
+    sc = (torch.rand(math.ceil(M / 64), device='cuda', generator=g) > 0.3).float() / 0.7
+    gamma = torch.rand(N, device='cuda', generator=g) + 0.5
+    beta = torch.randn(N, device='cuda', generator=g) * 0.2
+    mean, rstd = torch.empty(M, device='cuda'), torch.empty(M, device='cuda')
+    y = torch.empty(M, N, dtype=dtype, device='cuda')
+    out = ops.edge_linear_raw(a, w, b, _lib.EPI_RESID, res=res, row_scale=sc, rows_per_sample=64, ln=(gamma, beta, 1e-5),
+                              stats=(mean, rstd), y=y)
+    ref = res.double() + (a.double() @ w.double().t() + b.double()) * sc.double().repeat_interleave(64)[:M, None]
+    assert rel(out, ref) < TOL[dtype]
+    y64, mu64, rs64 = _ln64(out, gamma, beta, 1e-5)                 # of the row AS STORED
+    assert rel(mean, mu64) < 1e-5 and rel(rstd, rs64) < 1e-5
+    assert rel(y, y64) < TOL[dtype]
+    y2 = ops.layer_norm(out, gamma, beta, 1e-5, out_dtype=dtype)    # the standalone kernel on the same stored row
+    assert rel(y, y2) < (2e-3 if dtype == torch.bfloat16 else 3e-4)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('p', [0.0, 0.1])
 def test_gelu_backward_epilogue_equals_standalone_kernel(dtype, p):
     M, K, N = 520, 256, 256            # dz (M,K) @ W2 (K_out=256 rows of W2^T) -> d_a, then through the activation
@@ -147,8 +170,8 @@ def test_layernorm_backward_epilogue(M, K, N, with_ds, with_scale, dtype):
     ds = torch.randn(M, N, device='cuda', generator=g).to(dtype) if with_ds else None
     rps = 50
     sc = (torch.rand(math.ceil(M / rps), device='cuda', generator=g) + 0.5) if with_scale else None
-    parts = _lib.lib().tgt_edge_linear_parts(M, _lib.EPI_LN_BWD)
-    partial = torch.full((parts, 3 * N), float('nan'), device='cuda')
+    parts = _lib.lib().tgt_edge_linear_parts(M, N)
+    partial = torch.zeros(parts, 3 * N, device='cuda')
     dres = torch.empty(M, N, dtype=dtype, device='cuda')
     dx = torch.empty(M, N, dtype=dtype, device='cuda') if with_scale else None
     ops.edge_linear_raw(a, w, None, _lib.EPI_LN_BWD, ln=(gamma, None, 1e-5), stats=(mean, rstd), res=s, ds_in=ds, out=dres,
@@ -180,3 +203,35 @@ def test_unsupported_shapes_raise_instead_of_falling_back():
         ops.edge_linear_raw(a, w, b)
     with pytest.raises(RuntimeError):
         ops.edge_linear_raw(a.float(), w.float(), b.float())
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('B,N,K,C,with_scale', [(3, 10, 64, 256, True), (2, 16, 256, 256, False), (4, 9, 128, 64, True)])
+def test_linear_residual_layer_norm_op_matches_the_two_launch_composition(B, N, K, C, with_scale, dtype, monkeypatch):
+    """autograd op used by TGT_Layer (lin_O_e / lin_W2 + residual + next LayerNorm): fused launch vs
+    ops.linear -> ops.add_layer_norm, outputs and every gradient"""
+    monkeypatch.setattr(ops, '_EDGE_MIN_ROWS', 1)
+    g = torch.Generator(device='cuda').manual_seed(11)
+
+    def mk(*shape, scale=1.0):
+        return (torch.randn(*shape, device='cuda', generator=g) * scale)
+
+    x0, res0 = mk(B, N, N, K).to(dtype), mk(B, N, N, C).to(dtype)
+    w0, b0 = mk(C, K, scale=K ** -0.5), mk(C, scale=0.3)
+    lw0, lb0 = torch.rand(C, device='cuda', generator=g) + 0.5, mk(C, scale=0.2)
+    sc = ((torch.rand(B, device='cuda', generator=g) > 0.3).float() / 0.7) if with_scale else None
+    gs, gy = mk(B, N, N, C).to(dtype), mk(B, N, N, C).to(dtype)
+    outs = []
+    for fused in (True, False):
+        monkeypatch.setattr(ops, '_EDGE_GEMM', fused)
+        leaves = [t.clone().requires_grad_(True) for t in (x0, res0, w0, b0, lw0, lb0)]
+        x, res, w, b, lw, lb = leaves
+        with torch.autocast('cuda', dtype=dtype):
+            s, y = ops.linear_residual_layer_norm(x, w, b, res, sc, lw, lb, 1e-5)
+        assert (type(s.grad_fn).__name__ == '_LinearResidualLNBackward') == fused
+        ((s.float() * gs.float()).sum() + (y.float() * gy.float()).sum()).backward()
+        outs.append([s, y] + [t.grad for t in leaves])
+    names = ['s', 'y', 'dx', 'dres', 'dW', 'db', 'dln_w', 'dln_b']
+    for name, a, b_ in zip(names, *outs):
+        tol = 3 * TOL[dtype] if name.startswith('d') else TOL[dtype]
+        assert rel(a, b_) < tol, (name, rel(a, b_))

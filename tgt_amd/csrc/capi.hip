@@ -48,7 +48,7 @@ int sum_planes_run(const float* x, int planes, int64_t n, float* out, hipStream_
 int xent_run(const void* x, int dtype, const int64_t* target, const float* lse_in, const float* w, int64_t rows, int C,
              float* lse, float* xent, void* dx, hipStream_t st);
 int edge_linear_supported(const tgt_edge_linear_args* a);
-int edge_linear_parts(int64_t M, int epilogue);
+int edge_linear_parts(int64_t M, int N);
 int edge_linear_run(const tgt_edge_linear_args* a, hipStream_t st);
 int layer_norm_fwd_run(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
                        float* mean, float* rstd, int64_t rows, int C, float eps, hipStream_t st);
@@ -158,7 +158,7 @@ int tgt_layer_norm_bwd(const void* dy, int32_t dy_dtype, const void* x, int32_t 
 }
 
 int tgt_edge_linear_supported(const tgt_edge_linear_args* a) { return edge_linear_supported(a); }
-int tgt_edge_linear_parts(int64_t M, int32_t epilogue) { return edge_linear_parts(M, epilogue); }
+int tgt_edge_linear_parts(int64_t M, int32_t N) { return edge_linear_parts(M, N); }
 int tgt_edge_linear(const tgt_edge_linear_args* a, void* stream) { return edge_linear_run(a, reinterpret_cast<hipStream_t>(stream)); }
 
 }  // extern "C"

@@ -28,6 +28,8 @@
 // activation rows as the B operand: the result is transposed (lane = row, registers = columns), which makes
 // row reductions (LayerNorm backward) in-lane, and leaves 4 consecutive columns per register quad: a
 // v_permlane32_swap pairs two quads into one 16-byte store / load per lane.
+#include <cstdlib>
+#include <type_traits>
 #include "common.hpp"
 
 namespace tgt {
@@ -115,220 +117,822 @@ __device__ __forceinline__ void keep4(uint64_t seed, int64_t m, int N, int n, ui
     }
 }
 
-// MB = 32-row blocks per wave (rows per workgroup kBM = 32*MB): 4, or 2 for the register-hungry LN_BWD epilogue
-template <typename T, int MB, int NB, int EPI, bool LN>
-__global__ void __launch_bounds__(256, 2) edge_linear_kernel(const tgt_edge_linear_args a) {
+// raw 16-byte pieces of one 32x32 block in the store_block / load_block addressing (issued early, decoded late)
+__device__ __forceinline__ void load_raw(const void* base, int esz_ld_bytes_unused, int64_t off_elems, bool ok, uint4& L) {
+    L = make_uint4(0, 0, 0, 0);
+    if (ok) L = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(base) + off_elems);
+}
+template <typename T>
+__device__ __forceinline__ void load_block_raw(const T* base, int64_t ld, int64_t m, int64_t M, int nbase, int N, int hi, uint4 (&L)[2]) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int col = nbase + 16 * p + 8 * hi;
+        load_raw(base, 0, m * ld + col, m < M && col < N, L[p]);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void decode_block(const uint4 (&L)[2], float* v) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        uint2 a = make_uint2(L[p].x, L[p].y), b = make_uint2(L[p].z, L[p].w);
+        swap_halves(a, b);
+        unpack4<T>(a, v + 8 * p);
+        unpack4<T>(b, v + 8 * p + 4);
+    }
+}
+
+// One workgroup per CU (4 waves, one per SIMD, the whole 512-register file each), persistent over row tiles of
+// 128 rows.  Work is a sequence of PHASES = (row tile, k-chunk, column tile); a phase multiplies the A block in LDS
+// by a weight panel (<= 256 k x 64*NB/2.. columns per wave) held in REGISTERS.  While phase p runs on the matrix
+// cores, the weight panel of phase p+1 streams from L2 into the other register set and the next A block streams
+// from HBM into the other LDS buffer (LDS-DMA): the k-loop itself issues no vector-memory instruction, so nothing
+// in it waits.  One `s_waitcnt vmcnt(0)` per phase sits AFTER the k-loop (everything prefetched has had the whole
+// loop to land) and BEFORE the epilogue's stores, which therefore stay in flight under the next phase.
+// MULTI = false: one phase per row tile (K <= 256, one column tile): the weight panel is loaded once.
+template <typename T, int NB, int EPI, bool LN, bool MULTI>
+__global__ void __launch_bounds__(256, 1) edge_linear_kernel(const tgt_edge_linear_args a) {
     using F = frag_t<T>;
-    constexpr int kBM = 32 * MB;
+    constexpr int MB = 4, kBM = 128, kBufBytes = kBM * kKC * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hi = lane >> 5;
-    const int64_t m0 = (int64_t)blockIdx.x * kBM;
     const int K = a.K, N = a.N;
-    const int kc_max = K < kKC ? K : kKC;
-    const EgGeo geo(kc_max);
-    char* xs = smem;
-    float* st_mean = reinterpret_cast<float*>(smem + kBM * geo.rowbytes);
+    float* st_mean = reinterpret_cast<float*>(smem + 2 * kBufBytes);
     float* st_rstd = st_mean + kBM;
     float* red = st_rstd + kBM;                         // EPI_LN_BWD: [4 waves][128 rows][2]
     const T* A = reinterpret_cast<const T*>(a.a);
     const T* W = reinterpret_cast<const T*>(a.w);
     constexpr int NT = 4 * NB * 32;
     const int n_tiles = (N + NT - 1) / NT, chunks = (K + kKC - 1) / kKC;
+    constexpr int KP = MULTI ? 8 : 16;                  // k-steps per weight panel (MULTI: two register sets of 8)
+    constexpr int PAN = 16 / KP;                        // panels per 256-wide chunk
+    const int PPT = MULTI ? n_tiles * chunks * PAN : 1; // phases per row tile (n_tiles or chunks is 1)
+    const int64_t row_tiles = (a.M + kBM - 1) / kBM;
+    const int ntl = (int)((row_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
+    const int nph = ntl * PPT;
+    const int ablate = a._pad0;
 
-    auto stage = [&](int kc0, int kcl) {
-        const int spr = kcl >> 3, total = kBM * spr;       // 16-byte pieces: a multiple of 64 (kBM >= 64, spr >= 2 ... 256-thread strides)
-        for (int p0 = tid; p0 < total; p0 += 256 * 4) {
-            uint4 v[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int p = p0 + 256 * i;
-                const int row = p / spr, slot = p - row * spr;
-                v[i] = make_uint4(0, 0, 0, 0);
-                if (p < total && m0 + row < a.M) v[i] = *reinterpret_cast<const uint4*>(A + (m0 + row) * a.lda + kc0 + slot * 8);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int p = p0 + 256 * i;
-                const int row = p / spr, slot = p - row * spr;
-                if (p < total) *reinterpret_cast<uint4*>(xs + geo.off(row, slot)) = v[i];
-            }
+    // a phase = one weight panel (KP k-steps of one column tile) against the A block (row tile, 256-wide k-chunk)
+    struct Ph { int64_t m0; int kc0, kcl, ks0, nks, nt, ab; bool newblock, first, last, endblock; };
+    auto decode = [&](int q) {
+        Ph p;
+        const int tl = q / PPT, w = q - tl * PPT;
+        p.m0 = (blockIdx.x + (int64_t)tl * gridDim.x) * kBM;
+        const int u = w / PAN, h = w - u * PAN;          // u: (chunk | column tile), h: panel inside the chunk
+        int c = 0;
+        if (chunks > 1) { c = u; p.nt = 0; p.ab = tl * chunks + c; p.newblock = h == 0; p.endblock = h == PAN - 1; }
+        else { p.nt = u; p.ab = tl; p.newblock = w == 0; p.endblock = w == PPT - 1; }
+        p.kc0 = c * kKC;
+        p.kcl = (K - p.kc0) < kKC ? (K - p.kc0) : kKC;
+        p.ks0 = h * KP;
+        const int left = (p.kcl >> 4) - p.ks0;
+        p.nks = left < 0 ? 0 : (left < KP ? left : KP);
+        p.first = c == 0 && h == 0;
+        p.last = c == chunks - 1 && h == PAN - 1;
+        return p;
+    };
+    // A block -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, asynchronous).  A wave instruction
+    // fills 1 KB of LDS linearly (lane l at +16 l), so the image is plain [row][physical slot] and the XOR swizzle is
+    // applied to the SOURCE column: physical slot ps of a row holds logical slot ps ^ key(row) (same cache lines).
+    // Rows past M re-read row M-1 (never stored; statistics of those rows are masked where they matter).
+    auto stage = [&](const Ph& p) {
+        const EgGeo g(p.kcl);
+        char* xs = smem + (p.ab & 1) * kBufBytes;
+        const int spr = p.kcl >> 3, total = kBM * spr;
+        for (int p0 = wave * 64; p0 < total; p0 += 256) {
+            const int pc = p0 + lane;
+            const int row = pc / spr, ps = pc - row * spr;
+            int64_t m = p.m0 + row;
+            m = m < a.M ? m : a.M - 1;
+            const T* src = A + m * a.lda + p.kc0 + ((ps ^ ((row / g.rpw) & g.mask)) << 3);
+            if (!(ablate & 4))
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(xs + p0 * 16), 16, 0, 0);
         }
     };
-
-    f32x16 acc[MB][NB];
-    auto init_acc = [&](int n0) {
+    auto load_w = [&](F (&wp)[KP][NB], const Ph& p) {
+        const int n0 = p.nt * NT + wave * NB * 32;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            float bv[16];
+        for (int ks = 0; ks < KP; ++ks)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int n = n0 + nb * 32 + acc_row(q, hi);
-                bv[q] = (a.bias && n < N) ? to_f32(reinterpret_cast<const T*>(a.bias)[n]) : 0.f;
+            for (int nb = 0; nb < NB; ++nb) {
+                const int n = n0 + nb * 32 + r;
+                if (ks < p.nks && !(ablate & 1))
+                    wp[ks][nb] = n < N ? load_frag<T>(W + (int64_t)n * a.ldw + p.kc0 + (p.ks0 + ks) * 16 + 8 * hi) : zero_frag<T>();
             }
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) acc[mb][nb][q] = bv[q];
-        }
-    };
-    auto wfrag = [&](int n, int k) -> F {
-        return n < N ? load_frag<T>(W + (int64_t)n * a.ldw + k) : zero_frag<T>();
-    };
-    auto kloop = [&](int n0, int kc0, int kcl) {
-        if (n0 >= N) return;                             // whole slice past the last column (wave-uniform)
-        const int nks = kcl >> 4;
-        F wc[NB], wn[NB];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) wc[nb] = wfrag(n0 + nb * 32 + r, kc0 + 8 * hi);
-        for (int ks = 0; ks < nks; ++ks) {
-            if (ks + 1 < nks) {
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) wn[nb] = wfrag(n0 + nb * 32 + r, kc0 + (ks + 1) * 16 + 8 * hi);
-            }
-            F xf[MB];
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) xf[mb] = load_frag<T>(reinterpret_cast<const T*>(xs + geo.off(mb * 32 + r, 2 * ks + hi)));
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = mma32(wc[nb], xf[mb], acc[mb][nb]);
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) wc[nb] = wn[nb];
-        }
     };
 
     const uint32_t thresh = a.dropout_p <= 0.f ? 0u : (uint32_t)fminf(65535.f, fmaxf(1.f, rintf(a.dropout_p * 65536.f)));
     const float inv_keep = a.dropout_p <= 0.f ? 1.f : 1.f / (1.f - a.dropout_p);
+    constexpr bool kOperand = EPI == EPI_RESID || EPI == EPI_GELU_BWD || EPI == EPI_LN_BWD;   // epilogue reads an (M, N) tensor
+    constexpr bool kEarly = kOperand && !(EPI == EPI_LN_BWD && MULTI);     // ... issued before the k-loop (registers permitting)
 
-    auto epilogue = [&](int n0) {
-        if (n0 >= N && EPI != EPI_LN_BWD) return;
+    f32x16 acc[MB][NB];
+    F wp[MULTI ? 2 : 1][KP][NB];
+
+    auto phase = [&](auto S_, int q) {
+        constexpr int S = decltype(S_)::value;
+        const Ph p = decode(q);
+        const EgGeo g(p.kcl);
+        char* xs = smem + (p.ab & 1) * kBufBytes;
+        const int n0 = p.nt * NT + wave * NB * 32;
+        const bool active = n0 < N;                       // the wave's column slice exists (wave-uniform)
+
+        // ---- 1. everything this phase and the next will need from memory, oldest-needed first
+        uint2 braw[NB][4];
+        uint4 op1[MB][NB][2], op2[MB][NB][2];
+        float mu[MB], rs[MB];
+        if (p.last) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int n = n0 + nb * 32 + 8 * gq + 4 * hi;
+                    braw[nb][gq] = make_uint2(0, 0);
+                    if (a.bias && n < N) braw[nb][gq] = *reinterpret_cast<const uint2*>(reinterpret_cast<const T*>(a.bias) + n);
+                }
+            if constexpr (kEarly) {
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const int64_t m = p.m0 + mb * 32 + r;
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        load_block_raw<T>(reinterpret_cast<const T*>(a.res), a.ldr, m, a.M, n0 + nb * 32, N, hi, op1[mb][nb]);
+                        if constexpr (EPI == EPI_LN_BWD) {
+                            if (a.ds_in) load_block_raw<T>(reinterpret_cast<const T*>(a.ds_in), a.ld_ds, m, a.M, n0 + nb * 32, N, hi, op2[mb][nb]);
+                        }
+                    }
+                    if constexpr (EPI == EPI_LN_BWD) {
+                        mu[mb] = m < a.M ? a.mean[m] : 0.f;
+                        rs[mb] = m < a.M ? a.rstd[m] : 0.f;
+                    }
+                }
+            }
+        }
+        if constexpr (MULTI) {
+            if (q + 1 < nph) load_w(wp[S ^ 1], decode(q + 1));
+        }
+        if (p.newblock) {                                 // the next A block goes to the other buffer (last read one block ago)
+            const int qn = chunks > 1 ? q + PAN : q + PPT;
+            if (qn < nph) stage(decode(qn));
+        }
+
+        // ---- 2. LayerNorm prologue, in place in LDS (first phase of a row tile)
+        if constexpr (LN) {
+            if (p.newblock) {
+                // statistics: 2 threads per row; thread `half` walks its 16-byte slots starting 8 later (other bank groups)
+                const int row = tid >> 1, half = tid & 1;
+                const int spr = K >> 3, per = spr >> 1;
+                float s = 0.f;
+                for (int j = 0; j < per; ++j) {
+                    const int slot = half * per + ((j + 8 * half) % per);
+                    F f = load_frag<T>(reinterpret_cast<const T*>(xs + g.off(row, slot)));
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) s += to_f32(f[t]);
+                }
+                s += __shfl_xor(s, 1, 64);
+                const float mean = s / (float)K;
+                float qv = 0.f;
+                for (int j = 0; j < per; ++j) {
+                    const int slot = half * per + ((j + 8 * half) % per);
+                    F f = load_frag<T>(reinterpret_cast<const T*>(xs + g.off(row, slot)));
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const float d = to_f32(f[t]) - mean;
+                        qv += d * d;
+                    }
+                }
+                qv += __shfl_xor(qv, 1, 64);
+                const float rstd = rsqrtf(qv / (float)K + a.eps);
+                if (half == 0) {
+                    st_mean[row] = mean;
+                    st_rstd[row] = rstd;
+                    if (p.m0 + row < a.M) {
+                        if (a.mean) a.mean[p.m0 + row] = mean;
+                        if (a.rstd) a.rstd[p.m0 + row] = rstd;
+                    }
+                }
+                __syncthreads();
+                // normalise in place: thread -> fixed 16-byte column slot, rows tid/spr + (256/spr)*i
+                const int slot = tid % spr, rstep = 256 / spr;
+                float gam[8], bet[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    gam[t] = a.gamma[slot * 8 + t];
+                    bet[t] = a.beta[slot * 8 + t];
+                }
+                T* Y = reinterpret_cast<T*>(a.y);
+                for (int row2 = tid / spr; row2 < kBM; row2 += rstep) {
+                    T* px = reinterpret_cast<T*>(xs + g.off(row2, slot));
+                    F f = load_frag<T>(px);
+                    const float m_ = st_mean[row2], r_ = st_rstd[row2];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) f[t] = from_f32<T>((to_f32(f[t]) - m_) * r_ * gam[t] + bet[t]);
+                    uint4 raw;
+                    __builtin_memcpy(&raw, &f, 16);
+                    *reinterpret_cast<uint4*>(px) = raw;
+                    if (Y && p.m0 + row2 < a.M) *reinterpret_cast<uint4*>(Y + (p.m0 + row2) * a.ldy + slot * 8) = raw;
+                }
+                __syncthreads();
+            }
+        }
+
+        // ---- 3. the k-loop: LDS reads + MFMA only
+        if (p.first) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int q_ = 0; q_ < 16; ++q_) acc[mb][nb][q_] = 0.f;
+        }
+        if (active && !(ablate & 8)) {
+#pragma unroll
+            for (int ks = 0; ks < KP; ++ks) {
+                if (ks < p.nks) {
+                    F xf[MB];
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+                        xf[mb] = load_frag<T>(reinterpret_cast<const T*>(xs + g.off(mb * 32 + r, 2 * (p.ks0 + ks) + hi)));
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = mma32(wp[MULTI ? S : 0][ks][nb], xf[mb], acc[mb][nb]);
+                }
+            }
+        }
+        // everything prefetched during the loop has landed; nothing younger is outstanding (the previous phase's
+        // stores are older): a full drain costs no more than the newest prefetch
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+        // ---- 4. epilogue
+        if (p.last && (active || EPI == EPI_LN_BWD)) {
+            if (ablate & 2) {                             // (ablation) keep the accumulators live, store nothing
+                float t = 0.f;
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) t += acc[mb][nb][0] + acc[mb][nb][15];
+                if (t == 123.456f) reinterpret_cast<float*>(a.out)[tid] = t;
+            } else {
+                float bv[NB][16];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) unpack4<T>(braw[nb][gq], bv[nb] + 4 * gq);
+                T* out = reinterpret_cast<T*>(a.out);
+                if constexpr (EPI == EPI_BIAS) {
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) {
+                        const int64_t m = p.m0 + mb * 32 + r;
+                        const float al = a.out_scale ? a.out_scale[(m < a.M ? m : a.M - 1) / a.rows_per_sample] : 1.f;
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            float v[16];
+#pragma unroll
+                            for (int q_ = 0; q_ < 16; ++q_) v[q_] = (acc[mb][nb][q_] + bv[nb][q_]) * al;
+                            store_block<T>(out, a.ldo, m, a.M, n0 + nb * 32, N, hi, v);
+                        }
+                    }
+                } else if constexpr (EPI == EPI_GELU) {
+                    T* pre = reinterpret_cast<T*>(a.out2);
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) {
+                        const int64_t m = p.m0 + mb * 32 + r;
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            float v[16], gl[16];
+#pragma unroll
+                            for (int q_ = 0; q_ < 16; ++q_) v[q_] = acc[mb][nb][q_] + bv[nb][q_];
+                            store_block<T>(pre, a.ldo2, m, a.M, n0 + nb * 32, N, hi, v);
+#pragma unroll
+                            for (int gq = 0; gq < 4; ++gq) {
+                                bool keep[4] = {true, true, true, true};
+                                if (thresh) keep4(a.dropout_seed, m, N, n0 + nb * 32 + 8 * gq + 4 * hi, thresh, keep);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    const float x = to_f32(from_f32<T>(v[4 * gq + j]));      // gelu of the value as stored
+                                    float e;
+                                    const float cdf = gelu_cdf(x, e);
+                                    gl[4 * gq + j] = keep[j] ? x * cdf * inv_keep : 0.f;
+                                }
+                            }
+                            store_block<T>(out, a.ldo, m, a.M, n0 + nb * 32, N, hi, gl);
+                        }
+                    }
+                } else if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) {
+                        const int64_t m = p.m0 + mb * 32 + r;
+                        const float sc = a.row_scale ? a.row_scale[(m < a.M ? m : a.M - 1) / a.rows_per_sample] : 1.f;
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            float rv[16], v[16];
+                            decode_block<T>(op1[mb][nb], rv);
+#pragma unroll
+                            for (int q_ = 0; q_ < 16; ++q_) v[q_] = rv[q_] + (acc[mb][nb][q_] + bv[nb][q_]) * sc;
+                            store_block<T>(out, a.ldo, m, a.M, n0 + nb * 32, N, hi, v);
+                        }
+                    }
+                } else if constexpr (EPI == EPI_GELU_BWD) {
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) {
+                        const int64_t m = p.m0 + mb * 32 + r;
+                        const float al = a.out_scale ? a.out_scale[(m < a.M ? m : a.M - 1) / a.rows_per_sample] : 1.f;
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            float pv[16], v[16];
+                            decode_block<T>(op1[mb][nb], pv);             // the forward's pre-activation
+#pragma unroll
+                            for (int gq = 0; gq < 4; ++gq) {
+                                bool keep[4] = {true, true, true, true};
+                                if (thresh) keep4(a.dropout_seed, m, N, n0 + nb * 32 + 8 * gq + 4 * hi, thresh, keep);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    const float x = pv[4 * gq + j];
+                                    float e;
+                                    const float cdf = gelu_cdf(x, e);
+                                    // the incoming gradient is rounded to the storage type first, as the unfused chain stores it
+                                    const float dy = to_f32(from_f32<T>(acc[mb][nb][4 * gq + j] * al));
+                                    v[4 * gq + j] = keep[j] ? dy * (cdf + x * 0.3989422804014327f * e) * inv_keep : 0.f;
+                                }
+                            }
+                            store_block<T>(out, a.ldo, m, a.M, n0 + nb * 32, N, hi, v);
+                        }
+                    }
+                } else {     // EPI_LN_BWD: acc = dy (gradient at the LayerNorm output); N = the normalised width, one column tile
+                    const T* Sg = reinterpret_cast<const T*>(a.res);          // the LayerNorm input (residual stream)
+                    const T* dsin = reinterpret_cast<const T*>(a.ds_in);      // gradient arriving on the residual stream (may be NULL)
+                    auto gamma4 = [&](int nb, int gq, float* g4) {            // gamma of the quad's 4 consecutive columns (L1-resident)
+                        const int n = n0 + nb * 32 + 8 * gq + 4 * hi;
+                        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (n < N) t = *reinterpret_cast<const float4*>(a.gamma + n);
+                        g4[0] = t.x; g4[1] = t.y; g4[2] = t.z; g4[3] = t.w;
+                    };
+                    if constexpr (!kEarly) {
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb) {
+                            const int64_t m = p.m0 + mb * 32 + r;
+                            mu[mb] = m < a.M ? a.mean[m] : 0.f;
+                            rs[mb] = m < a.M ? a.rstd[m] : 0.f;
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb) load_block_raw<T>(Sg, a.ldr, m, a.M, n0 + nb * 32, N, hi, op1[mb][nb]);
+                        }
+                    }
+                    float cs_a[NB][16], cs_b[NB][16];                         // per-lane column partials over the row blocks
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                        for (int q_ = 0; q_ < 16; ++q_) cs_a[nb][q_] = cs_b[nb][q_] = 0.f;
+                    float s1[MB], s2[MB];
+                    // pass 1: row sums of g = dy*gamma and g*xhat; column sums of dy*xhat (dgamma) and dy (dbeta);
+                    // acc <- dy as stored, op1 keeps the raw stream rows for pass 2
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) {
+                        const int64_t m = p.m0 + mb * 32 + r;
+                        const bool ok = m < a.M;
+                        float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            float sv[16];
+                            decode_block<T>(op1[mb][nb], sv);
+#pragma unroll
+                            for (int gq = 0; gq < 4; ++gq) {
+                                float g4[4];
+                                gamma4(nb, gq, g4);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    const int q_ = 4 * gq + j;
+                                    const bool cok = ok && (n0 + nb * 32 + acc_row(q_, hi) < N);
+                                    const float dy = cok ? to_f32(from_f32<T>(acc[mb][nb][q_])) : 0.f;     // dy as the unfused chain stores it
+                                    acc[mb][nb][q_] = dy;
+                                    const float x = cok ? (sv[q_] - mu[mb]) * rs[mb] : 0.f;
+                                    const float gg = dy * g4[j];
+                                    p1 += gg;
+                                    p2 += gg * x;
+                                    cs_a[nb][q_] += dy * x;
+                                    cs_b[nb][q_] += dy;
+                                }
+                            }
+                        }
+                        s1[mb] = p1 + xhalf(p1);
+                        s2[mb] = p2 + xhalf(p2);
+                    }
+                    if (hi == 0) {
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb) {
+                            red[(wave * kBM + mb * 32 + r) * 2] = s1[mb];
+                            red[(wave * kBM + mb * 32 + r) * 2 + 1] = s2[mb];
+                        }
+                    }
+                    // fold a per-lane 16-column partial over the 32 lanes of each half-wave: 16 + 8+4+2+1 exchanges;
+                    // lanes r < 16 end up with the total of register index q = r (column nbase + (q&3) + 8(q>>2) + 4hi)
+                    auto fold_store = [&](float (&v)[16], int nb, float* dst) {
+#pragma unroll
+                        for (int q_ = 0; q_ < 16; ++q_) v[q_] += __shfl_xor(v[q_], 16, 64);
+#pragma unroll
+                        for (int s_ = 0; s_ < 4; ++s_) {
+                            const int width = 8 >> s_;
+                            const bool upper = (r & width) != 0;
+#pragma unroll
+                            for (int c = 0; c < width; ++c) {
+                                const float mine = upper ? v[c + width] : v[c];
+                                const float send = upper ? v[c] : v[c + width];
+                                v[c] = mine + __shfl_xor(send, width, 64);
+                            }
+                        }
+                        const int q_ = r & 15;
+                        const int n = n0 + nb * 32 + (q_ & 3) + 8 * (q_ >> 2) + 4 * hi;
+                        if (r < 16 && n < N) dst[n] = v[0];
+                    };
+                    float* part = a.colsum_partial ? a.colsum_partial + (p.m0 / kBM) * 3 * N : nullptr;
+                    if (part) {
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            fold_store(cs_a[nb], nb, part);
+                            fold_store(cs_b[nb], nb, part + N);
+                        }
+                    }
+                    __syncthreads();
+                    const float invC = 1.f / (float)N;
+                    T* dres = reinterpret_cast<T*>(a.out);
+                    T* dx = reinterpret_cast<T*>(a.out2);                     // d_res * row_scale (may be NULL)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                        for (int q_ = 0; q_ < 16; ++q_) cs_a[nb][q_] = 0.f;   // now: column sums of the x-branch gradient
+                    // pass 2: dx = rstd * (g - mean(g) - xhat * mean(g*xhat)) + ds_in
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) {
+                        const int row = mb * 32 + r;
+                        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+                        for (int w_ = 0; w_ < 4; ++w_) {
+                            c1 += red[(w_ * kBM + row) * 2];
+                            c2 += red[(w_ * kBM + row) * 2 + 1];
+                        }
+                        c1 *= invC;
+                        c2 *= invC;
+                        const int64_t m = p.m0 + row;
+                        const float sc = a.row_scale ? a.row_scale[(m < a.M ? m : a.M - 1) / a.rows_per_sample] : 1.f;
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            float sv[16], dv[16], ds[16];
+                            decode_block<T>(op1[mb][nb], sv);
+                            if (dsin) {
+                                if constexpr (!kEarly) load_block_raw<T>(dsin, a.ld_ds, m, a.M, n0 + nb * 32, N, hi, op2[mb][nb]);
+                                decode_block<T>(op2[mb][nb], ds);
+                            }
+#pragma unroll
+                            for (int gq = 0; gq < 4; ++gq) {
+                                float g4[4];
+                                gamma4(nb, gq, g4);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    const int q_ = 4 * gq + j;
+                                    const float x = (sv[q_] - mu[mb]) * rs[mb];
+                                    float d = rs[mb] * (acc[mb][nb][q_] * g4[j] - c1 - x * c2);
+                                    if (dsin) d += ds[q_];
+                                    dv[q_] = d;
+                                }
+                            }
+                            store_block<T>(dres, a.ldo, m, a.M, n0 + nb * 32, N, hi, dv);
+                            if (dx || part) {
+#pragma unroll
+                                for (int q_ = 0; q_ < 16; ++q_) {
+                                    // the x-branch gradient as it is stored (rounded), so that its column sums equal a separate pass's
+                                    const float t = to_f32(from_f32<T>(to_f32(from_f32<T>(dv[q_])) * sc));
+                                    dv[q_] = t;
+                                    cs_a[nb][q_] += (m < a.M && n0 + nb * 32 + acc_row(q_, hi) < N) ? t : 0.f;
+                                }
+                                if (dx) store_block<T>(dx, a.ldo2, m, a.M, n0 + nb * 32, N, hi, dv);
+                            }
+                        }
+                    }
+                    if (part) {
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) fold_store(cs_a[nb], nb, part + 2 * N);
+                    }
+                }
+            }
+        }
+        // ---- 5. leaving an A block: every wave is done reading it (the first phase of the NEXT block issues the DMA that
+        //         overwrites it) and has waited for its own pieces of the next block, so after the barrier that block is
+        //         complete for everyone.  Raw barrier: __syncthreads() would also drain the stores just issued.
+        if (p.endblock) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    };
+
+    if (nph <= 0) return;
+    {   // pipeline fill: first A block and first weight panel
+        const Ph p0 = decode(0);
+        stage(p0);
+        load_w(wp[0], p0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    for (int q = 0; q < nph; q += 2) {
+        phase(std::integral_constant<int, 0>{}, q);
+        if constexpr (MULTI) {
+            if (q + 1 < nph) phase(std::integral_constant<int, 1>{}, q + 1);
+        } else {
+            if (q + 1 < nph) phase(std::integral_constant<int, 0>{}, q + 1);
+        }
+    }
+}
+
+static int eg_num_cus();
+// ---------------------------------------------------------------------------------------------------------------
+// Weight-resident slice kernel: the fast path for K <= 256.
+//
+// A workgroup (8 waves, one per CU) owns ONE column slice of the output (32*WN columns) for its whole life and
+// keeps that slice of the weight in registers (K/16 operand fragments = 32 columns per wave, <= 64 VGPRs): after
+// the first microsecond it never fetches a weight again.  It walks 128-row tiles of A; tile i+1 streams HBM -> LDS by
+// LDS-DMA into the other buffer while the matrix cores work on tile i, and the k-loop is straight-line LDS reads +
+// MFMAs (no vector-memory instruction, so nothing in it can wait on the DMA: vmcnt is an in-order counter).  The
+// epilogue's stores stay in flight under the next tile.  WN = waves along the columns (8: 256 columns x 4 row blocks
+// per wave; 4: 128 columns x 2 row blocks; 2: 64 columns x 1 row block).  Wide outputs (the 1536-channel Q/K/V
+// projection) are cut into 256-column slices; the workgroups of one row group sit on one XCD (block b runs on XCD
+// b % 8), so an A tile comes from HBM once and from that XCD's L2 for the other slices.
+// Epilogues as above, plus EPI_RESID with gamma != NULL: LayerNorm of the NEW stream row as a second output
+// (y = LN(out), mean, rstd) -- the fused `residual add + LayerNorm` entry of the next sub-block, so the consumer
+// needs no LayerNorm prologue.
+// ---------------------------------------------------------------------------------------------------------------
+// RB = 32-row blocks per tile (rows per tile kBM = 32*RB): 4, or 2 for the register-hungry epilogues
+template <typename T, int KS, int WN, int EPI, int RB>
+__global__ void __launch_bounds__(512, 2) edge_slice_kernel(const tgt_edge_linear_args a, int groups) {
+    using F = frag_t<T>;
+    constexpr int WM = 8 / WN, MB = RB / WM, kBM = 32 * RB, K = KS * 16, kRowBytes = K * 2, kBufBytes = kBM * kRowBytes, NT = WN * 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hi = lane >> 5;
+    const int wn = wave % WN, wm = wave / WN;             // column block / row group of this wave
+    const int N = a.N;
+    float* red = reinterpret_cast<float*>(smem + 2 * kBufBytes);      // [WN][128 rows][2]
+    const T* A = reinterpret_cast<const T*>(a.a);
+    const T* W = reinterpret_cast<const T*>(a.w);
+    const EgGeo g(K);
+    // block -> (row group, column slice): slices of one row group are consecutive blocks of ONE XCD
+    const int n_slices = (N + NT - 1) / NT;
+    const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+    const int grp = (j / n_slices) * 8 + xcd, slice = j % n_slices;
+    if (grp >= groups) return;
+    const int n0 = slice * NT + wn * 32;
+    const bool active = n0 < N;
+    const int64_t row_tiles = (a.M + kBM - 1) / kBM;
+    const int ablate = a._pad0;
+    const int rbase = wm * MB * 32;                        // first row (inside the tile) of this wave
+
+    auto stage = [&](int64_t tile, int buf) {
+        char* xs = smem + buf * kBufBytes;
+        constexpr int spr = K >> 3, total = kBM * spr;     // a multiple of 64 (whole wave instructions)
+#pragma unroll
+        for (int p0 = 0; p0 < total; p0 += 512) {
+            const int pc = p0 + tid;
+            const int row = pc / spr, ps = pc % spr;
+            int64_t m = tile * kBM + row;
+            m = m < a.M ? m : a.M - 1;
+            const T* src = A + m * a.lda + ((ps ^ ((row / g.rpw) & g.mask)) << 3);
+            if ((total % 512 == 0 || p0 + wave * 64 < total) && !(ablate & 4))
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(xs + (p0 + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+
+    // the weight slice of this wave (32 columns x K), resident
+    F wr[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int n = n0 + r;
+        wr[ks] = n < N ? load_frag<T>(W + (int64_t)n * a.ldw + ks * 16 + 8 * hi) : zero_frag<T>();
+    }
+    uint2 braw[4];
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        const int n = n0 + 8 * gq + 4 * hi;
+        braw[gq] = make_uint2(0, 0);
+        if (a.bias && n < N) braw[gq] = *reinterpret_cast<const uint2*>(reinterpret_cast<const T*>(a.bias) + n);
+    }
+    const uint32_t thresh = a.dropout_p <= 0.f ? 0u : (uint32_t)fminf(65535.f, fmaxf(1.f, rintf(a.dropout_p * 65536.f)));
+    const float inv_keep = a.dropout_p <= 0.f ? 1.f : 1.f / (1.f - a.dropout_p);
+
+    int64_t tile = grp;
+    if (tile >= row_tiles) return;
+    stage(tile, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    for (int it = 0; tile < row_tiles; ++it, tile += groups) {
+        const char* xs = smem + (it & 1) * kBufBytes;
+        const int64_t m0 = tile * kBM + rbase;
+        if (tile + groups < row_tiles) stage(tile + groups, (it + 1) & 1);
+
+        // the epilogue's (M, N) operand (residual / pre-activation / LayerNorm input) comes from HBM: issue it now, use it
+        // after the k-loop (issued BEFORE nothing it must wait for: the DMA above is older, but has the same k-loop to land)
+        uint4 opr[MB][2];
+        if constexpr (EPI == EPI_RESID || EPI == EPI_GELU_BWD || EPI == EPI_LN_BWD) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+                load_block_raw<T>(reinterpret_cast<const T*>(a.res), a.ldr, m0 + mb * 32 + r, a.M, n0, N, hi, opr[mb]);
+        }
+
+        f32x16 acc[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[mb][q] = 0.f;
+        if (active && !(ablate & 8)) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                F xf[MB];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) xf[mb] = load_frag<T>(reinterpret_cast<const T*>(xs + g.off(rbase + mb * 32 + r, 2 * ks + hi)));
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) acc[mb] = mma32(wr[ks], xf[mb], acc[mb]);
+            }
+        }
+
+        // the next tile's DMA has had the whole k-loop to land and nothing younger is outstanding (the previous tile's
+        // stores are older): draining here costs nothing, and this tile's stores stay in flight under the next k-loop
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+        float bv[16];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) unpack4<T>(braw[gq], bv + 4 * gq);
         T* out = reinterpret_cast<T*>(a.out);
-        if constexpr (EPI == EPI_BIAS) {
+        if (ablate & 2) {
+            float t = 0.f;
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                const int64_t m = m0 + mb * 32 + r;
-                const float al = a.out_scale ? a.out_scale[(m < a.M ? m : a.M - 1) / a.rows_per_sample] : 1.f;
+            for (int mb = 0; mb < MB; ++mb) t += acc[mb][0] + acc[mb][15];
+            if (t == 123.456f) reinterpret_cast<float*>(a.out)[tid] = t;
+        } else if constexpr (EPI == EPI_BIAS) {
+            if (active) {
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
+                for (int mb = 0; mb < MB; ++mb) {
+                    const int64_t m = m0 + mb * 32 + r;
+                    const float al = a.out_scale ? a.out_scale[(m < a.M ? m : a.M - 1) / a.rows_per_sample] : 1.f;
                     float v[16];
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) v[q] = acc[mb][nb][q] * al;
-                    store_block<T>(out, a.ldo, m, a.M, n0 + nb * 32, N, hi, v);
+                    for (int q = 0; q < 16; ++q) v[q] = (acc[mb][q] + bv[q]) * al;
+                    store_block<T>(out, a.ldo, m, a.M, n0, N, hi, v);
                 }
             }
         } else if constexpr (EPI == EPI_GELU) {
             T* pre = reinterpret_cast<T*>(a.out2);
+            if (active) {
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                const int64_t m = m0 + mb * 32 + r;
+                for (int mb = 0; mb < MB; ++mb) {
+                    const int64_t m = m0 + mb * 32 + r;
+                    float v[16], gl[16];
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    float v[16], g[16];
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) v[q] = acc[mb][nb][q];
-                    store_block<T>(pre, a.ldo2, m, a.M, n0 + nb * 32, N, hi, v);
+                    for (int q = 0; q < 16; ++q) v[q] = acc[mb][q] + bv[q];
+                    store_block<T>(pre, a.ldo2, m, a.M, n0, N, hi, v);
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
                         bool keep[4] = {true, true, true, true};
-                        if (thresh) keep4(a.dropout_seed, m, N, n0 + nb * 32 + 8 * gq + 4 * hi, thresh, keep);
+                        if (thresh) keep4(a.dropout_seed, m, N, n0 + 8 * gq + 4 * hi, thresh, keep);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float x = to_f32(from_f32<T>(v[4 * gq + j]));      // gelu of the value as stored
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const float x = to_f32(from_f32<T>(v[4 * gq + jj]));      // gelu of the value as stored
                             float e;
                             const float cdf = gelu_cdf(x, e);
-                            g[4 * gq + j] = keep[j] ? x * cdf * inv_keep : 0.f;
+                            gl[4 * gq + jj] = keep[jj] ? x * cdf * inv_keep : 0.f;
                         }
                     }
-                    store_block<T>(out, a.ldo, m, a.M, n0 + nb * 32, N, hi, g);
+                    store_block<T>(out, a.ldo, m, a.M, n0, N, hi, gl);
                 }
             }
         } else if constexpr (EPI == EPI_RESID) {
-            const T* res = reinterpret_cast<const T*>(a.res);
+            const bool ln = a.gamma != nullptr;               // LayerNorm of the new stream row as a second output
+            float v[MB][16];
+            float s1[MB];
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
                 const int64_t m = m0 + mb * 32 + r;
                 const float sc = a.row_scale ? a.row_scale[(m < a.M ? m : a.M - 1) / a.rows_per_sample] : 1.f;
+                float rv[16], p1 = 0.f;
+                decode_block<T>(opr[mb], rv);
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    float rv[16], v[16];
-                    load_block<T>(res, a.ldr, m, a.M, n0 + nb * 32, N, hi, rv);
+                for (int q = 0; q < 16; ++q) {
+                    // LayerNorm sees the stream value as stored (rounded to its storage type)
+                    const float t = to_f32(from_f32<T>(rv[q] + (acc[mb][q] + bv[q]) * sc));
+                    v[mb][q] = t;
+                    p1 += (n0 + acc_row(q, hi) < N) ? t : 0.f;
+                }
+                if (active) store_block<T>(out, a.ldo, m, a.M, n0, N, hi, v[mb]);
+                s1[mb] = p1 + xhalf(p1);
+            }
+            if (ln) {                                           // uniform over the grid
+                const float invC = 1.f / (float)N;
+                if (hi == 0) {
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) v[q] = rv[q] + acc[mb][nb][q] * sc;
-                    store_block<T>(out, a.ldo, m, a.M, n0 + nb * 32, N, hi, v);
+                    for (int mb = 0; mb < MB; ++mb) red[(wn * kBM + rbase + mb * 32 + r) * 2] = s1[mb];
+                }
+                { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+                float mean[MB], rstd[MB];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const int row = rbase + mb * 32 + r;
+                    float t = 0.f;
+#pragma unroll
+                    for (int w_ = 0; w_ < WN; ++w_) t += red[(w_ * kBM + row) * 2];
+                    mean[mb] = t * invC;
+                    float p2 = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const float d = (n0 + acc_row(q, hi) < N) ? v[mb][q] - mean[mb] : 0.f;
+                        p2 += d * d;
+                    }
+                    p2 += xhalf(p2);
+                    if (hi == 0) red[(wn * kBM + row) * 2 + 1] = p2;
+                }
+                { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+                T* Y = reinterpret_cast<T*>(a.y);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const int row = rbase + mb * 32 + r;
+                    const int64_t m = m0 + mb * 32 + r;
+                    float t = 0.f;
+#pragma unroll
+                    for (int w_ = 0; w_ < WN; ++w_) t += red[(w_ * kBM + row) * 2 + 1];
+                    rstd[mb] = rsqrtf(t * invC + a.eps);
+                    if (wn == 0 && hi == 0 && m < a.M) {
+                        if (a.mean) a.mean[m] = mean[mb];
+                        if (a.rstd) a.rstd[m] = rstd[mb];
+                    }
+                    float yv[16];
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int n = n0 + 8 * gq + 4 * hi;
+                        float4 gm = make_float4(0.f, 0.f, 0.f, 0.f), bt = gm;
+                        if (n < N) {
+                            gm = *reinterpret_cast<const float4*>(a.gamma + n);
+                            bt = *reinterpret_cast<const float4*>(a.beta + n);
+                        }
+                        yv[4 * gq + 0] = (v[mb][4 * gq + 0] - mean[mb]) * rstd[mb] * gm.x + bt.x;
+                        yv[4 * gq + 1] = (v[mb][4 * gq + 1] - mean[mb]) * rstd[mb] * gm.y + bt.y;
+                        yv[4 * gq + 2] = (v[mb][4 * gq + 2] - mean[mb]) * rstd[mb] * gm.z + bt.z;
+                        yv[4 * gq + 3] = (v[mb][4 * gq + 3] - mean[mb]) * rstd[mb] * gm.w + bt.w;
+                    }
+                    if (active) store_block<T>(Y, a.ldy, m, a.M, n0, N, hi, yv);
                 }
             }
         } else if constexpr (EPI == EPI_GELU_BWD) {
-            const T* pre = reinterpret_cast<const T*>(a.res);         // the forward's pre-activation
+            if (active) {
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                const int64_t m = m0 + mb * 32 + r;
-                const float al = a.out_scale ? a.out_scale[(m < a.M ? m : a.M - 1) / a.rows_per_sample] : 1.f;
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
+                for (int mb = 0; mb < MB; ++mb) {
+                    const int64_t m = m0 + mb * 32 + r;
+                    const float al = a.out_scale ? a.out_scale[(m < a.M ? m : a.M - 1) / a.rows_per_sample] : 1.f;
                     float pv[16], v[16];
-                    load_block<T>(pre, a.ldr, m, a.M, n0 + nb * 32, N, hi, pv);
+                    decode_block<T>(opr[mb], pv);
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
                         bool keep[4] = {true, true, true, true};
-                        if (thresh) keep4(a.dropout_seed, m, N, n0 + nb * 32 + 8 * gq + 4 * hi, thresh, keep);
+                        if (thresh) keep4(a.dropout_seed, m, N, n0 + 8 * gq + 4 * hi, thresh, keep);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float x = pv[4 * gq + j];
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const float x = pv[4 * gq + jj];
                             float e;
                             const float cdf = gelu_cdf(x, e);
-                            // the incoming gradient is rounded to the storage type first, as the unfused chain stores it
-                            const float dy = to_f32(from_f32<T>(acc[mb][nb][4 * gq + j] * al));
-                            v[4 * gq + j] = keep[j] ? dy * (cdf + x * 0.3989422804014327f * e) * inv_keep : 0.f;
+                            const float dy = to_f32(from_f32<T>(acc[mb][4 * gq + jj] * al));
+                            v[4 * gq + jj] = keep[jj] ? dy * (cdf + x * 0.3989422804014327f * e) * inv_keep : 0.f;
                         }
                     }
-                    store_block<T>(out, a.ldo, m, a.M, n0 + nb * 32, N, hi, v);
+                    store_block<T>(out, a.ldo, m, a.M, n0, N, hi, v);
                 }
             }
-        } else {     // EPI_LN_BWD: acc = dy (gradient at the LayerNorm output); N = the normalised width, one column tile
-            const T* S = reinterpret_cast<const T*>(a.res);           // the LayerNorm input (residual stream)
-            const T* dsin = reinterpret_cast<const T*>(a.ds_in);      // gradient arriving on the residual stream (may be NULL)
-            auto gamma4 = [&](int nb, int gq, float* g4) {             // gamma of the quad's 4 consecutive columns (L1-resident)
-                const int n = n0 + nb * 32 + 8 * gq + 4 * hi;
+        } else {       // EPI_LN_BWD: acc = dy at the output of LayerNorm(res; gamma), whole rows in this workgroup (one slice)
+            const T* dsin = reinterpret_cast<const T*>(a.ds_in);
+            float g16[16];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int n = n0 + 8 * gq + 4 * hi;
                 float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (n < N) t = *reinterpret_cast<const float4*>(a.gamma + n);
-                g4[0] = t.x; g4[1] = t.y; g4[2] = t.z; g4[3] = t.w;
-            };
-            float cs_a[NB][16], cs_b[NB][16];                         // per-lane column partials over the row blocks
+                g16[4 * gq] = t.x; g16[4 * gq + 1] = t.y; g16[4 * gq + 2] = t.z; g16[4 * gq + 3] = t.w;
+            }
+            float cs_a[16], cs_b[16], mu[MB], rs[MB], s1[MB], s2[MB];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) cs_a[nb][q] = cs_b[nb][q] = 0.f;
-            float rs[MB], mu[MB], s1[MB], s2[MB];
-            // pass 1: row sums of g = dy*gamma and g*xhat; column sums of dy*xhat (dgamma) and dy (dbeta)
+            for (int q = 0; q < 16; ++q) cs_a[q] = cs_b[q] = 0.f;
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
                 const int64_t m = m0 + mb * 32 + r;
                 const bool ok = m < a.M;
                 mu[mb] = ok ? a.mean[m] : 0.f;
                 rs[mb] = ok ? a.rstd[m] : 0.f;
-                float p1 = 0.f, p2 = 0.f;
+                float sv[16], p1 = 0.f, p2 = 0.f;
+                decode_block<T>(opr[mb], sv);
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    float sv[16];
-                    load_block<T>(S, a.ldr, m, a.M, n0 + nb * 32, N, hi, sv);
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        float g4[4];
-                        gamma4(nb, gq, g4);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int q = 4 * gq + j;
-                            const bool cok = ok && (n0 + nb * 32 + acc_row(q, hi) < N);
-                            const float dy = cok ? to_f32(from_f32<T>(acc[mb][nb][q])) : 0.f;     // dy as the unfused chain stores it
-                            acc[mb][nb][q] = dy;
-                            const float x = cok ? (sv[q] - mu[mb]) * rs[mb] : 0.f;
-                            const float g = dy * g4[j];
-                            p1 += g;
-                            p2 += g * x;
-                            cs_a[nb][q] += dy * x;
-                            cs_b[nb][q] += dy;
-                        }
-                    }
+                for (int q = 0; q < 16; ++q) {
+                    const bool cok = ok && (n0 + acc_row(q, hi) < N);
+                    const float dy = cok ? to_f32(from_f32<T>(acc[mb][q])) : 0.f;      // dy as the unfused chain stores it
+                    const float x = cok ? (sv[q] - mu[mb]) * rs[mb] : 0.f;
+                    const float gg = dy * g16[q];
+                    acc[mb][q] = gg;
+                    p1 += gg;
+                    p2 += gg * x;
+                    cs_a[q] += dy * x;
+                    cs_b[q] += dy;
                 }
                 s1[mb] = p1 + xhalf(p1);
                 s2[mb] = p2 + xhalf(p2);
@@ -336,13 +940,13 @@ __global__ void __launch_bounds__(256, 2) edge_linear_kernel(const tgt_edge_line
             if (hi == 0) {
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {
-                    red[(wave * kBM + mb * 32 + r) * 2] = s1[mb];
-                    red[(wave * kBM + mb * 32 + r) * 2 + 1] = s2[mb];
+                    red[(wn * kBM + rbase + mb * 32 + r) * 2] = s1[mb];
+                    red[(wn * kBM + rbase + mb * 32 + r) * 2 + 1] = s2[mb];
                 }
             }
-            // fold a per-lane 16-column partial over the 32 lanes of each half-wave: 16 + 8+4+2+1 exchanges; lanes
-            // r < 16 end up with the total of register index q = r (column nbase + (q&3) + 8(q>>2) + 4hi)
-            auto fold_store = [&](float (&v)[16], int nb, float* dst) {
+            // fold a per-lane 16-column partial over the 32 lanes of each half-wave (16 + 8+4+2+1 exchanges): lanes
+            // r < 16 end with the total of register index q = r; the WM row groups of the workgroup write separate rows
+            auto fold_store = [&](float (&v)[16], float* dst) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) v[q] += __shfl_xor(v[q], 16, 64);
 #pragma unroll
@@ -357,189 +961,164 @@ __global__ void __launch_bounds__(256, 2) edge_linear_kernel(const tgt_edge_line
                     }
                 }
                 const int q = r & 15;
-                const int n = n0 + nb * 32 + (q & 3) + 8 * (q >> 2) + 4 * hi;
+                const int n = n0 + (q & 3) + 8 * (q >> 2) + 4 * hi;
                 if (r < 16 && n < N) dst[n] = v[0];
             };
-            float* part = a.colsum_partial ? a.colsum_partial + (int64_t)blockIdx.x * 3 * N : nullptr;
+            float* part = a.colsum_partial ? a.colsum_partial + (tile * WM + wm) * 3 * N : nullptr;
             if (part) {
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    fold_store(cs_a[nb], nb, part);
-                    fold_store(cs_b[nb], nb, part + N);
-                }
+                fold_store(cs_a, part);
+                fold_store(cs_b, part + N);
             }
-            __syncthreads();
+            { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
             const float invC = 1.f / (float)N;
             T* dres = reinterpret_cast<T*>(a.out);
-            T* dx = reinterpret_cast<T*>(a.out2);                     // d_res * row_scale (may be NULL)
+            T* dx = reinterpret_cast<T*>(a.out2);
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) cs_a[nb][q] = 0.f;       // now: column sums of the x-branch gradient
-            // pass 2: dx = rstd * (g - mean(g) - xhat * mean(g*xhat)) + ds_in
+            for (int q = 0; q < 16; ++q) cs_a[q] = 0.f;
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
-                const int row = mb * 32 + r;
+                const int row = rbase + mb * 32 + r;
                 float c1 = 0.f, c2 = 0.f;
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    c1 += red[(w * kBM + row) * 2];
-                    c2 += red[(w * kBM + row) * 2 + 1];
+                for (int w_ = 0; w_ < WN; ++w_) {
+                    c1 += red[(w_ * kBM + row) * 2];
+                    c2 += red[(w_ * kBM + row) * 2 + 1];
                 }
                 c1 *= invC;
                 c2 *= invC;
-                const int64_t m = m0 + row;
+                const int64_t m = m0 + mb * 32 + r;
                 const float sc = a.row_scale ? a.row_scale[(m < a.M ? m : a.M - 1) / a.rows_per_sample] : 1.f;
+                float dv[16], ds[16], sv[16];
+                if (dsin) load_block<T>(dsin, a.ld_ds, m, a.M, n0, N, hi, ds);
+                decode_block<T>(opr[mb], sv);                  // the raw stream rows are still in registers
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    float sv[16], dv[16], ds[16];
-                    load_block<T>(S, a.ldr, m, a.M, n0 + nb * 32, N, hi, sv);          // second touch: L2
-                    if (dsin) load_block<T>(dsin, a.ld_ds, m, a.M, n0 + nb * 32, N, hi, ds);
+                for (int q = 0; q < 16; ++q) {
+                    const float x = (m < a.M && n0 + acc_row(q, hi) < N) ? (sv[q] - mu[mb]) * rs[mb] : 0.f;
+                    float d = rs[mb] * (acc[mb][q] - c1 - x * c2);
+                    if (dsin) d += ds[q];
+                    dv[q] = d;
+                }
+                if (active) store_block<T>(dres, a.ldo, m, a.M, n0, N, hi, dv);
+                if (dx || part) {
 #pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        float g4[4];
-                        gamma4(nb, gq, g4);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int q = 4 * gq + j;
-                            const float x = (sv[q] - mu[mb]) * rs[mb];
-                            float d = rs[mb] * (acc[mb][nb][q] * g4[j] - c1 - x * c2);
-                            if (dsin) d += ds[q];
-                            dv[q] = d;
-                        }
+                    for (int q = 0; q < 16; ++q) {
+                        const float t = to_f32(from_f32<T>(to_f32(from_f32<T>(dv[q])) * sc));
+                        dv[q] = t;
+                        cs_a[q] += (m < a.M && n0 + acc_row(q, hi) < N) ? t : 0.f;
                     }
-                    store_block<T>(dres, a.ldo, m, a.M, n0 + nb * 32, N, hi, dv);
-                    if (dx || part) {
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) {
-                            // the x-branch gradient as it is stored (rounded), so that its column sums equal a separate pass's
-                            const float t = to_f32(from_f32<T>(to_f32(from_f32<T>(dv[q])) * sc));
-                            dv[q] = t;
-                            cs_a[nb][q] += (m < a.M && n0 + nb * 32 + acc_row(q, hi) < N) ? t : 0.f;
-                        }
-                        if (dx) store_block<T>(dx, a.ldo2, m, a.M, n0 + nb * 32, N, hi, dv);
-                    }
+                    if (dx && active) store_block<T>(dx, a.ldo2, m, a.M, n0, N, hi, dv);
                 }
             }
-            if (part) {
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) fold_store(cs_a[nb], nb, part + 2 * N);
-            }
+            if (part) fold_store(cs_a, part + 2 * N);
         }
-    };
-
-    // ------------------------------------------------------------------ body
-    if (chunks == 1) {
-        stage(0, K);
-        __syncthreads();
-        if constexpr (LN) {
-            // statistics: 2 threads per row, 16-byte slots; thread `half` starts 8 slots later (other bank groups)
-            static_assert(kBM == 128, "the LayerNorm prologue maps 2 threads to each of 128 rows");
-            const int row = tid >> 1, half = tid & 1;
-            const int spr = K >> 3, per = spr >> 1;
-            float s = 0.f;
-            for (int j = 0; j < per; ++j) {
-                const int slot = half * per + ((j + 8 * half) % per);
-                F f = load_frag<T>(reinterpret_cast<const T*>(xs + geo.off(row, slot)));
-#pragma unroll
-                for (int t = 0; t < 8; ++t) s += to_f32(f[t]);
-            }
-            s += __shfl_xor(s, 1, 64);
-            const float mean = s / (float)K;
-            float qv = 0.f;
-            for (int j = 0; j < per; ++j) {
-                const int slot = half * per + ((j + 8 * half) % per);
-                F f = load_frag<T>(reinterpret_cast<const T*>(xs + geo.off(row, slot)));
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const float d = to_f32(f[t]) - mean;
-                    qv += d * d;
-                }
-            }
-            qv += __shfl_xor(qv, 1, 64);
-            const float rstd = rsqrtf(qv / (float)K + a.eps);
-            if (half == 0) {
-                st_mean[row] = mean;
-                st_rstd[row] = rstd;
-                if (m0 + row < a.M) {
-                    if (a.mean) a.mean[m0 + row] = mean;
-                    if (a.rstd) a.rstd[m0 + row] = rstd;
-                }
-            }
-            __syncthreads();
-            // normalise in place: thread -> fixed 16-byte column slot, rows tid/spr + (256/spr)*i
-            const int spr2 = K >> 3;
-            const int slot = tid % spr2, rstep = 256 / spr2;
-            float gam[8], bet[8];
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                gam[t] = a.gamma[slot * 8 + t];
-                bet[t] = a.beta[slot * 8 + t];
-            }
-            T* Y = reinterpret_cast<T*>(a.y);
-            for (int row2 = tid / spr2; row2 < kBM; row2 += rstep) {
-                T* p = reinterpret_cast<T*>(xs + geo.off(row2, slot));
-                F f = load_frag<T>(p);
-                const float mu = st_mean[row2], rsd = st_rstd[row2];
-#pragma unroll
-                for (int t = 0; t < 8; ++t) f[t] = from_f32<T>((to_f32(f[t]) - mu) * rsd * gam[t] + bet[t]);
-                uint4 raw;
-                __builtin_memcpy(&raw, &f, 16);
-                *reinterpret_cast<uint4*>(p) = raw;
-                if (Y && m0 + row2 < a.M) *reinterpret_cast<uint4*>(Y + (m0 + row2) * a.ldy + slot * 8) = raw;
-            }
-            __syncthreads();
-        }
-        for (int nt = 0; nt < n_tiles; ++nt) {
-            const int n0 = nt * NT + wave * NB * 32;
-            init_acc(n0);
-            kloop(n0, 0, K);
-            epilogue(n0);
-        }
-    } else {
-        const int n0 = wave * NB * 32;
-        init_acc(n0);
-        for (int c = 0; c < chunks; ++c) {
-            const int kc0 = c * kKC, kcl = (K - kc0) < kKC ? (K - kc0) : kKC;
-            if (c) __syncthreads();                     // every wave is done reading the previous chunk
-            stage(kc0, kcl);
-            __syncthreads();
-            kloop(n0, kc0, kcl);
-        }
-        epilogue(n0);
+        // my pieces of the next tile have landed; after the barrier they have for every wave, and every wave is done
+        // reading this tile's buffer (the DMA issued at the top of the next iteration but one overwrites it).
+        // Raw barrier: __syncthreads() would also drain the stores just issued.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
 }
 
-template <typename T, int MB, int NB, int EPI, bool LN>
-static int eg_launch(const tgt_edge_linear_args& a, hipStream_t st) {
-    constexpr int kBM = 32 * MB;
-    const int kc = a.K < kKC ? a.K : kKC;
-    const int lds = kBM * kc * 2 + 2 * kBM * 4 + (EPI == EPI_LN_BWD ? 4 * kBM * 2 * 4 : 0);
+template <typename T, int KS, int WN, int EPI, int RB>
+static int es_launch(const tgt_edge_linear_args& a, hipStream_t st) {
+    constexpr int kBM = 32 * RB;
+    constexpr int lds = 2 * kBM * KS * 32 + WN * kBM * 2 * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_linear_kernel<T, MB, NB, EPI, LN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, kBM * kKC * 2 + 2 * kBM * 4 + 4 * kBM * 2 * 4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_slice_kernel<T, KS, WN, EPI, RB>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    const int64_t grid = (a.M + kBM - 1) / kBM;
-    hipLaunchKernelGGL((edge_linear_kernel<T, MB, NB, EPI, LN>), dim3((unsigned)grid), dim3(256), lds, st, a);
+    const int n_slices = (a.N + 32 * WN - 1) / (32 * WN);
+    const int64_t row_tiles = (a.M + kBM - 1) / kBM;
+    // one workgroup per CU; per XCD (blocks b % 8) a whole number of row groups x all their slices
+    int per_xcd = (eg_num_cus() / 8) / n_slices;
+    if (per_xcd < 1) per_xcd = 1;
+    int64_t groups = (int64_t)per_xcd * 8;
+    if (groups > row_tiles) groups = row_tiles;
+    const int64_t blocks = ((groups + 7) / 8) * n_slices * 8;
+    hipLaunchKernelGGL((edge_slice_kernel<T, KS, WN, EPI, RB>), dim3((unsigned)blocks), dim3(512), lds, st, a, (int)groups);
+    return check_launch("edge_slice_kernel");
+}
+
+template <typename T, int KS, int WN>
+static int es_dispatch(const tgt_edge_linear_args& a, hipStream_t st) {
+    switch (a.epilogue) {
+        case EPI_BIAS: return es_launch<T, KS, WN, EPI_BIAS, 4>(a, st);
+        case EPI_GELU: return es_launch<T, KS, WN, EPI_GELU, WN == 8 ? 2 : 4>(a, st);
+        case EPI_RESID: return es_launch<T, KS, WN, EPI_RESID, WN == 8 ? 2 : 4>(a, st);
+        case EPI_GELU_BWD: return es_launch<T, KS, WN, EPI_GELU_BWD, WN == 8 ? 2 : 4>(a, st);
+        case EPI_LN_BWD: return es_launch<T, KS, WN, EPI_LN_BWD, WN == 8 ? 2 : 4>(a, st);
+        default: return set_error(TGT_ERR_INVALID, "edge linear (slice kernel): bad epilogue %d", a.epilogue);
+    }
+}
+
+// the slice kernel takes K in {64, 128, 256} without a LayerNorm prologue; the row-wise epilogues (LayerNorm of
+// the new stream row, LN_BWD) need the whole row in one slice (N <= 256)
+static bool es_eligible(const tgt_edge_linear_args& a) {
+    if (a.K != 64 && a.K != 128 && a.K != 256) return false;
+    if (a.epilogue == EPI_LN_BWD) return a.N <= 256;
+    if (a.gamma && a.epilogue != EPI_RESID) return false;
+    if (a.gamma && a.epilogue == EPI_RESID && (a.N > 256 || !a.beta || !a.y)) return false;
+    static const bool off = getenv("TGT_EG_SLICE") && atoi(getenv("TGT_EG_SLICE")) == 0;
+    return !off;
+}
+
+template <typename T>
+static int es_run(const tgt_edge_linear_args& a, hipStream_t st) {
+    const int wn = a.N <= 64 ? 2 : (a.N <= 128 ? 4 : 8);
+    switch (a.K) {
+        case 64: return wn == 2 ? es_dispatch<T, 4, 2>(a, st) : (wn == 4 ? es_dispatch<T, 4, 4>(a, st) : es_dispatch<T, 4, 8>(a, st));
+        case 128: return wn == 2 ? es_dispatch<T, 8, 2>(a, st) : (wn == 4 ? es_dispatch<T, 8, 4>(a, st) : es_dispatch<T, 8, 8>(a, st));
+        default: return wn == 2 ? es_dispatch<T, 16, 2>(a, st) : (wn == 4 ? es_dispatch<T, 16, 4>(a, st) : es_dispatch<T, 16, 8>(a, st));
+    }
+}
+
+static int eg_num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+template <typename T, int NB, int EPI, bool LN, bool MULTI>
+static int eg_launch(const tgt_edge_linear_args& a, hipStream_t st) {
+    constexpr int lds = 2 * 128 * kKC * 2 + 2 * 128 * 4 + 4 * 128 * 2 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_linear_kernel<T, NB, EPI, LN, MULTI>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    const int64_t tiles = (a.M + 127) / 128;
+    const int64_t grid = tiles < eg_num_cus() ? tiles : eg_num_cus();
+    hipLaunchKernelGGL((edge_linear_kernel<T, NB, EPI, LN, MULTI>), dim3((unsigned)grid), dim3(256), lds, st, a);
     return check_launch("edge_linear_kernel");
 }
 
-template <typename T, int NB>
+template <typename T, int NB, bool MULTI>
 static int eg_dispatch(const tgt_edge_linear_args& a, hipStream_t st) {
     const bool ln = a.gamma != nullptr && a.epilogue != EPI_LN_BWD;
     switch (a.epilogue) {
-        case EPI_BIAS: return ln ? eg_launch<T, 4, NB, EPI_BIAS, true>(a, st) : eg_launch<T, 4, NB, EPI_BIAS, false>(a, st);
-        case EPI_GELU: return ln ? eg_launch<T, 4, NB, EPI_GELU, true>(a, st) : eg_launch<T, 4, NB, EPI_GELU, false>(a, st);
-        case EPI_RESID: return eg_launch<T, 4, NB, EPI_RESID, false>(a, st);
-        case EPI_GELU_BWD: return eg_launch<T, 4, NB, EPI_GELU_BWD, false>(a, st);
-        case EPI_LN_BWD: return eg_launch<T, 2, NB, EPI_LN_BWD, false>(a, st);
+        case EPI_BIAS: return ln ? eg_launch<T, NB, EPI_BIAS, true, MULTI>(a, st) : eg_launch<T, NB, EPI_BIAS, false, MULTI>(a, st);
+        case EPI_GELU: return ln ? eg_launch<T, NB, EPI_GELU, true, MULTI>(a, st) : eg_launch<T, NB, EPI_GELU, false, MULTI>(a, st);
+        case EPI_RESID: if (a.gamma) return set_error(TGT_ERR_UNSUPPORTED, "edge linear: the LayerNorm epilogue needs K in {64,128,256}");
+            return eg_launch<T, NB, EPI_RESID, false, MULTI>(a, st);
+        case EPI_GELU_BWD: return eg_launch<T, NB, EPI_GELU_BWD, false, MULTI>(a, st);
+        case EPI_LN_BWD: return eg_launch<T, NB, EPI_LN_BWD, false, MULTI>(a, st);
         default: return set_error(TGT_ERR_INVALID, "edge linear: bad epilogue %d", a.epilogue);
     }
 }
 
-int edge_linear_parts(int64_t M, int epilogue) { return (int)((M + (epilogue == EPI_LN_BWD ? 64 : 128) - 1) / (epilogue == EPI_LN_BWD ? 64 : 128)); }
+// rows of colsum_partial: one per (128-row tile, row group of waves WM = 8 / WN of the slice kernel)
+int edge_linear_parts(int64_t M, int N) {
+    const int wn = N <= 64 ? 2 : (N <= 128 ? 4 : 8);
+    return wn == 8 ? (int)((M + 63) / 64) : (int)((M + 127) / 128) * (8 / wn);
+}
 
 int edge_linear_supported(const tgt_edge_linear_args* a) {
     if (!a) return 0;
@@ -549,6 +1128,7 @@ int edge_linear_supported(const tgt_edge_linear_args* a) {
     if (K >= kKC ? (K % 16 != 0) : (K != 16 && K != 32 && K != 64 && K != 128)) return 0;
     const int nt = (N + 255) / 256, chunks = (K + kKC - 1) / kKC;
     if (nt > 1 && chunks > 1) return 0;
+    if (a->gamma && a->epilogue == EPI_RESID && (N > 256 || (K != 64 && K != 128 && K != 256))) return 0;
     if (a->gamma && a->epilogue != EPI_LN_BWD && chunks > 1) return 0;
     if (a->epilogue == EPI_LN_BWD && (N > 256 || !a->gamma || !a->mean || !a->rstd || !a->res)) return 0;
     return 1;
@@ -562,6 +1142,10 @@ int edge_linear_run(const tgt_edge_linear_args* a, hipStream_t st) {
                          "dtype, N %% 8 == 0, K in {16,32,64,128} or a multiple of 16 >= 256, and not both K > 256 and N > 256",
                          a->K, a->N, a->dtype, a->epilogue);
     if (a->M == 0) return TGT_OK;
+    static const int ablate = getenv("TGT_EG_ABLATE") ? atoi(getenv("TGT_EG_ABLATE")) : 0;   // kernel_bench probes: 1 no W stream, 2 no stores, 4 no A loads, 8 no MFMA
+    tgt_edge_linear_args aa = *a;
+    aa._pad0 = ablate;
+    a = &aa;
     const uintptr_t al = (uintptr_t)a->a | (uintptr_t)a->w | (uintptr_t)a->out | (uintptr_t)a->out2 | (uintptr_t)a->res |
                          (uintptr_t)a->y | (uintptr_t)a->ds_in;
     if (al % 16 || (a->lda * 2) % 16 || (a->ldw * 2) % 16 || (a->ldo * 2) % 16 || (a->ldo2 * 2) % 16 || (a->ldr * 2) % 16 ||
@@ -573,10 +1157,16 @@ int edge_linear_run(const tgt_edge_linear_args* a, hipStream_t st) {
         return set_error(TGT_ERR_INVALID, "edge linear: rows_per_sample missing");
     if (a->gamma && a->epilogue != EPI_LN_BWD && !a->beta) return set_error(TGT_ERR_INVALID, "edge linear: beta missing");
     if (a->dropout_p < 0.f || a->dropout_p >= 1.f) return set_error(TGT_ERR_INVALID, "edge linear: dropout_p outside [0,1)");
+    if (es_eligible(*a)) return a->dtype == TGT_BF16 ? es_run<bf16_t>(*a, st) : es_run<f16_t>(*a, st);
     // narrow outputs: one 32-column block per wave keeps all four waves busy
     const bool narrow = a->N <= 128;
-    if (a->dtype == TGT_BF16) return narrow ? eg_dispatch<bf16_t, 1>(*a, st) : eg_dispatch<bf16_t, 2>(*a, st);
-    return narrow ? eg_dispatch<f16_t, 1>(*a, st) : eg_dispatch<f16_t, 2>(*a, st);
+    const bool multi = a->K > kKC || a->N > (narrow ? 128 : 256);
+    if (a->dtype == TGT_BF16) {
+        if (narrow) return multi ? eg_dispatch<bf16_t, 1, true>(*a, st) : eg_dispatch<bf16_t, 1, false>(*a, st);
+        return multi ? eg_dispatch<bf16_t, 2, true>(*a, st) : eg_dispatch<bf16_t, 2, false>(*a, st);
+    }
+    if (narrow) return multi ? eg_dispatch<f16_t, 1, true>(*a, st) : eg_dispatch<f16_t, 1, false>(*a, st);
+    return multi ? eg_dispatch<f16_t, 2, true>(*a, st) : eg_dispatch<f16_t, 2, false>(*a, st);
 }
 
 }  // namespace tgt

@@ -969,6 +969,16 @@ def _as_dtype_view(p, cd):
     return lp if (lp is not None and lp.dtype == cd and p.dtype != cd) else p.detach()
 
 
+_EDGE_GEMM = os.environ.get('TGT_EDGE_GEMM', '1') != '0'          # A/B knob: the weight-resident slice kernel where it wins
+_EDGE_MIN_ROWS = 65536                                            # (tests lower it)
+
+
+def _edge_kernel_ok(x2, N, cd):
+    """edge-row GEMMs the slice kernel of csrc/edge_gemm.hip takes: device, 16-bit, K in {64,128,256}, many rows"""
+    return (_EDGE_GEMM and x2.is_cuda and cd in (torch.bfloat16, torch.float16) and x2.shape[1] in (64, 128, 256) and
+            N % 8 == 0 and x2.shape[0] >= _EDGE_MIN_ROWS and x2.stride(-1) == 1 and (x2.stride(0) * 2) % 16 == 0)
+
+
 def _linear_forward(x, weight, bias, cd):
     """(x2, w, y): the operands saved for the backward and y = x W^T + b in dtype cd"""
     xs = x.shape
@@ -980,6 +990,10 @@ def _linear_forward(x, weight, bias, cd):
     # the result must own its storage (not be a view): the layer adds the residual in place
     y = torch.empty(*xs[:-1], weight.shape[0], dtype=cd, device=x.device)
     y2 = y.view(-1, weight.shape[0])
+    if weight.shape[0] <= 128 and w.is_contiguous() and _edge_kernel_ok(x2, weight.shape[0], cd):
+        # narrow outputs (lin_EG: 128, third-arm E/G: 64): 41 vs 47 us and 29 vs 37 us against the tuned library GEMM
+        edge_linear_raw(x2, w, b, out=y2)
+        return x2, w, y
     if b is None:
         torch.mm(x2, w.t(), out=y2)
     else:
@@ -1242,6 +1256,89 @@ class _AddLayerNorm(torch.autograd.Function):
             d_x = d_res
         _hand_colsum(d_x, db_cs[C_:])
         return d_x, (d_res if rdt == d_res.dtype else d_res.to(rdt)), None, dg.to(wdt), db_cs[:C_].to(wdt), None, None
+
+
+class _LinearResidualLN(torch.autograd.Function):
+    """s = res + scale * (x W^T + b);  y = LayerNorm(s): the Linear that closes a sub-block (lin_O_e, lin_W2), the
+    residual add (+ DropPath) and the LayerNorm that opens the next sub-block (reference layers.py:270-290) in ONE
+    launch (tgt_edge_linear, TGT_EPI_RESID with the LayerNorm epilogue) instead of GEMM -> x -> add+LN pass.
+    Backward: the add+LN backward kernel (it also yields the bias gradient), then the Linear's gradients."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, res, scale, ln_w, ln_b, eps, cd, out_dtype):
+        _dev(x, weight, res, ln_w, ln_b)
+        xs = x.shape
+        x2 = x.reshape(-1, xs[-1])
+        if x2.dtype != cd:
+            x2 = x2.to(cd)
+        w = _as_dtype(weight, cd).contiguous()
+        b = None if bias is None else _as_dtype(bias, cd).contiguous()
+        N, rows = weight.shape[0], x2.shape[0]
+        res2 = res.reshape(rows, N)
+        if res2.dtype != cd:
+            res2 = res2.to(cd)
+        g, be = ln_w.detach().float().contiguous(), ln_b.detach().float().contiguous()
+        s = torch.empty(*xs[:-1], N, dtype=cd, device=x.device)
+        y = torch.empty(*xs[:-1], N, dtype=out_dtype, device=x.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rps = rows // xs[0]
+        edge_linear_raw(x2, w, b, _lib.EPI_RESID, out=s.view(rows, N), res=res2, row_scale=scale, rows_per_sample=rps,
+                        ln=(g, be, eps), stats=(mean, rstd), y=y.view(rows, N))
+        ctx.save_for_backward(x2, w, s, g, mean, rstd, scale)
+        ctx.meta = (xs, x.dtype, weight.dtype, None if bias is None else bias.dtype, ln_w.dtype, res.dtype, rps)
+        return s, y
+
+    @staticmethod
+    def backward(ctx, ds, dy):
+        x2, w, s, g, mean, rstd, scale = ctx.saved_tensors
+        xs, xdt, wdt, bdt, lndt, rdt, rps = ctx.meta
+        N = s.shape[-1]
+        rows = s.numel() // N
+        L = _lib.lib()
+        if dy is None:                                  # the LayerNorm branch was not used
+            d_res = ds
+            d_z = ds if scale is None else ds * scale.view(-1, *([1] * (ds.ndim - 1))).to(ds.dtype)
+            dg = dbeta = None
+            cs = None
+        else:
+            dy = dy.contiguous()
+            ds = None if ds is None else ds.contiguous()
+            d_res = torch.empty_like(s)
+            d_z = torch.empty_like(s) if scale is not None else None
+            dg = torch.empty(N, dtype=torch.float32, device=s.device)
+            db_cs = torch.empty(2 * N, dtype=torch.float32, device=s.device)
+            partial = torch.empty(L.tgt_layer_norm_parts() * 3 * N, dtype=torch.float32, device=s.device)
+            p0, p1 = _prof_begin()
+            _lib.check(L.tgt_add_layer_norm_bwd(_ptr(dy), _DT[dy.dtype], _ptr(s), _DT[s.dtype], _ptr(ds),
+                                                0 if ds is None else _DT[ds.dtype], _ptr(scale), rps, _ptr(g), _ptr(mean),
+                                                _ptr(rstd), _ptr(d_res), _ptr(d_z), _DT[s.dtype], _ptr(dg), _ptr(db_cs),
+                                                db_cs.data_ptr() + 4 * N, _ptr(partial), rows, N, _stream()),
+                       'tgt_add_layer_norm_bwd')
+            _prof_end('tgt_add_layer_norm_bwd', p0, p1)
+            if d_z is None:
+                d_z = d_res
+            dbeta, cs = db_cs[:N], db_cs[N:]
+        need_db = bdt is not None and ctx.needs_input_grad[2]
+        dx, dw, db = _linear_backward(x2, w, d_z.reshape(rows, N), xs, xdt, wdt, bdt, ctx.needs_input_grad[0],
+                                      ctx.needs_input_grad[1], need_db and cs is None)
+        if need_db and cs is not None:
+            db = cs.to(bdt)
+        return (dx, dw, db, d_res if rdt == d_res.dtype else d_res.to(rdt), None,
+                None if dg is None else dg.to(lndt), None if dbeta is None else dbeta.to(lndt), None, None, None)
+
+
+def linear_residual_layer_norm(x, weight, bias, res, scale, ln_weight, ln_bias, eps=1e-5):
+    """(s, y): s = res + scale[graph] * linear(x, weight, bias) (scale: per-sample DropPath factors or None),
+    y = LayerNorm(s).  One fused launch on the MI355X slice kernel when the shape qualifies (16-bit compute dtype,
+    in_features in {64,128,256}, out_features <= 256 and a multiple of 8, >= 65536 rows); otherwise the composition of
+    ops.linear and ops.add_layer_norm (same arithmetic, two launches + one more pass over the rows)."""
+    cd = torch.get_autocast_dtype('cuda') if (x.is_cuda and torch.is_autocast_enabled('cuda')) else x.dtype
+    N = weight.shape[0]
+    x2 = x.reshape(-1, x.shape[-1])
+    if N <= 256 and res.is_cuda and _edge_kernel_ok(x2, N, cd) and res.dtype in (cd,) and res.is_contiguous():
+        return _LinearResidualLN.apply(x, weight, bias, res, scale, ln_weight, ln_bias, eps, cd, cd)
+    return add_layer_norm(linear(x, weight, bias), res, scale, ln_weight, ln_bias, eps)
 
 
 _side_streams = {}

@@ -37,20 +37,21 @@ class Linear(nn.Linear):
 
 
 class PendingResidual:
-    """`res + DropPath(x)` not yet added: the edge residual that closes a layer is handed to the
-    next layer un-added, so that the add happens inside the LayerNorm pass that opens that layer
-    (one read/write of the edge tensor instead of two, and one fused pass in the backward).
+    """`res + DropPath(lin(x))` not yet computed: the edge residual that closes a layer is handed to the
+    next layer un-added, together with the Linear (lin_W2 of the edge FFN) that feeds it, so that Linear,
+    residual add and the LayerNorm that opens the next layer are ONE launch (ops.linear_residual_layer_norm).
     Only TGT_Encoder asks layers for this (defer_edge=True) and resolves the last one."""
 
-    def __init__(self, x, res, scale):
-        self.x, self.res, self.scale = x, res, scale
+    def __init__(self, x, lin, res, scale):
+        self.x, self.lin, self.res, self.scale = x, lin, res, scale
 
     def materialize(self):
-        return ops.scaled_add_(self.x, self.res, self.scale)
+        return ops.scaled_add_(self.lin(self.x), self.res, self.scale)
 
     def enter(self, ln):
-        """(res + x*scale, LayerNorm of it)"""
-        return ops.add_layer_norm(self.x, self.res, self.scale, ln.weight, ln.bias, ln.eps)
+        """(res + lin(x)*scale, LayerNorm of it)"""
+        return ops.linear_residual_layer_norm(self.x, self.lin.weight, self.lin.bias, self.res, self.scale,
+                                              ln.weight, ln.bias, ln.eps)
 
 
 class EGT_Attention(nn.Module):
@@ -89,9 +90,10 @@ class EGT_Attention(nn.Module):
         v_att, e = self.attend(h, e_hat, mask, e, qkv)
         return self.lin_O_h(v_att), e
 
-    def attend(self, h, e_hat, mask, e=None, qkv=None):
+    def attend(self, h, e_hat, mask, e=None, qkv=None, project_edges=True):
         """(V_att before lin_O_h, updated edge channels): forward_normed without the node output
-        projection, which TGT_Layer runs on the node stream together with the node FFN"""
+        projection, which TGT_Layer runs on the node stream together with the node FFN.
+        project_edges=False: return H_hat itself; the caller fuses lin_O_e with what follows it"""
         B, N = h.shape[0], h.shape[1]
         if qkv is None:
             qkv = self.project_nodes(h)
@@ -104,7 +106,7 @@ class EGT_Attention(nn.Module):
         v_att, h_hat = ops.node_attention(qkv, eg, mask3, self.num_heads,
                                           self.scale_degree, self.edge_update)
         if self.edge_update:
-            e = self.lin_O_e(h_hat)
+            e = self.lin_O_e(h_hat) if project_edges else h_hat
         return v_att, e
 
 
@@ -175,12 +177,15 @@ class FFN(nn.Module):
 
     def forward_normed(self, x):
         """the block after ffn_ln (TGT_Layer fuses that LayerNorm with the residual add before it)"""
+        return self.lin_W2(self.hidden(x))
+
+    def hidden(self, x):
+        """activation(lin_W1(x)) with dropout: the input of lin_W2 (TGT_Layer fuses lin_W2 with the residual add and
+        the next LayerNorm)"""
         x = self.lin_W1(x)
         if self.activation == 'gelu' and x.dtype in (torch.float32, torch.bfloat16, torch.float16):
-            x = ops.gelu_dropout(x, self.act_dropout, self.training)      # one pass each way, no mask tensor
-        else:
-            x = self.dropout(self.ffn_fn(x))
-        return self.lin_W2(x)
+            return ops.gelu_dropout(x, self.act_dropout, self.training)      # one pass each way, no mask tensor
+        return self.dropout(self.ffn_fn(x))
 
 
 class DropPath(nn.Module):
@@ -256,15 +261,20 @@ class TGT_Layer(nn.Module):
         if side is not None:
             side.join(h, qkv)
         h_in, e_in = h, e
+        fuse_oe = self.node_update and self.edge_update          # lin_O_e joins the entry of the next edge sub-block
         if self.node_update:
-            v_att, e = self.update.attend(h, e_hat, mask, e, qkv)      # lin_O_h follows on the node stream
+            v_att, e = self.update.attend(h, e_hat, mask, e, qkv, project_edges=not fuse_oe)   # lin_O_h follows on the node stream
         else:
             h, e = self.update.forward_normed(h, e_hat, mask, e, qkv)
         # Each residual add is fused with the LayerNorm that opens the next sub-block
         # (s = res + DropPath(x); y = LN(s) in one pass, and one pass in the backward).
         dp, tr = self.drop_path.drop_path, self.training
 
-        def enter(x, res, ln):
+        def enter(x, res, ln, lin=None):
+            """(s, LayerNorm(s)) with s = res + DropPath(x), or res + DropPath(lin(x)) in one launch"""
+            if lin is not None:
+                return ops.linear_residual_layer_norm(x, lin.weight, lin.bias, res, ops.drop_path_scale(x, dp, tr),
+                                                      ln.weight, ln.bias, ln.eps)
             return ops.add_layer_norm(x, res, ops.drop_path_scale(x, dp, tr), ln.weight, ln.bias, ln.eps)
 
         node_side = None
@@ -277,12 +287,13 @@ class TGT_Layer(nn.Module):
                 h, x = enter(h, h_in, self.node_ffn.ffn_ln)
                 h = ops.drop_path_add_(self.node_ffn.forward_normed(x), h, dp, tr)
         if self.edge_update:
+            lin_oe = self.update.lin_O_e if fuse_oe else None        # then `e` is still H_hat
             if self._triplet_update:
-                e, x = enter(e, e_in, self.tria.tri_ln_e)
+                e, x = enter(e, e_in, self.tria.tri_ln_e, lin_oe)
                 e, x = enter(self.tria.forward_normed(x, mask), e, self.edge_ffn.ffn_ln)
             else:
-                e, x = enter(e, e_in, self.edge_ffn.ffn_ln)
-            closing = PendingResidual(self.edge_ffn.forward_normed(x), e, ops.drop_path_scale(x, dp, tr))
+                e, x = enter(e, e_in, self.edge_ffn.ffn_ln, lin_oe)
+            closing = PendingResidual(self.edge_ffn.hidden(x), self.edge_ffn.lin_W2, e, ops.drop_path_scale(x, dp, tr))
             e = closing if defer_edge else closing.materialize()
         g = g.copy()
         g.pop('node_side', None)

@@ -27,7 +27,12 @@ def main():
     dev = 'cuda'
     g = torch.Generator(device=dev).manual_seed(0)
     rows = []
-    for name, K, N, epi, ln in [('lin_EG (LN)', 256, 128, _lib.EPI_BIAS, True), ('tri proj (LN)', 256, 1600, _lib.EPI_BIAS, True),
+    for name, K, N, epi, ln in [('lin_EG', 256, 128, _lib.EPI_BIAS, False), ('tri QKV', 256, 1536, _lib.EPI_BIAS, False),
+                                ('tri QKV+EG', 256, 1600, _lib.EPI_BIAS, False), ('tri EG', 256, 64, _lib.EPI_BIAS, False),
+                                ('W1 (GELU)', 256, 256, _lib.EPI_GELU, False), ('W2 (+res+LN)', 256, 256, 'resid_ln', False),
+                                ('lin_O_e (+res+LN)', 64, 256, 'resid_ln', False),
+                                ('dgrad lin_EG + LN_BWD', 128, 256, _lib.EPI_LN_BWD, False),
+                                ('lin_EG (LN)', 256, 128, _lib.EPI_BIAS, True), ('tri proj (LN)', 256, 1600, _lib.EPI_BIAS, True),
                                 ('W1 (LN+GELU)', 256, 256, _lib.EPI_GELU, True), ('W2 (+res)', 256, 256, _lib.EPI_RESID, False),
                                 ('lin_O (+res)', 512, 256, _lib.EPI_RESID, False), ('lin_O_e (+res)', 64, 256, _lib.EPI_RESID, False),
                                 ('plain 256x256', 256, 256, _lib.EPI_BIAS, False), ('dgrad tri (K=1600)', 1600, 256, _lib.EPI_BIAS, False),
@@ -42,16 +47,19 @@ def main():
         out, out2, y = torch.empty(M, N, dtype=dt, device=dev), torch.empty(M, N, dtype=dt, device=dev), torch.empty(M, K, dtype=dt, device=dev)
         sc = torch.ones(256, device=dev)
         kw = {}
-        if ln:
+        if epi == 'resid_ln':
+            epi = _lib.EPI_RESID
+            kw.update(res=res, row_scale=sc, rows_per_sample=1024, ln=(gamma, beta, 1e-5), stats=(mean, rstd), y=out2)
+        elif ln:
             kw.update(ln=(gamma, beta, 1e-5), stats=(mean, rstd), y=y)
         if epi == _lib.EPI_GELU:
             kw.update(out2=out2, dropout=(0.1, 1234))
-        if epi == _lib.EPI_RESID:
+        if epi == _lib.EPI_RESID and 'res' not in kw:
             kw.update(res=res, row_scale=sc, rows_per_sample=1024)
         if epi == _lib.EPI_GELU_BWD:
             kw.update(res=res, dropout=(0.1, 1234))
         if epi == _lib.EPI_LN_BWD:
-            parts = _lib.lib().tgt_edge_linear_parts(M, epi)
+            parts = _lib.lib().tgt_edge_linear_parts(M, N)
             kw.update(ln=(gamma, None, 1e-5), stats=(mean, rstd), res=res, ds_in=out2.clone(), out2=out2, row_scale=sc, rows_per_sample=1024,
                       colsum_partial=torch.empty(parts, 3 * N, device=dev))
         t_mine = timeit(lambda: ops.edge_linear_raw(a, w, None if epi in (_lib.EPI_LN_BWD, _lib.EPI_GELU_BWD) else b, epi, out=out, **kw))
