@@ -203,6 +203,21 @@ GRAD_PROBE_KEYS = [
     'input_embed.nodef_embed.weight',
 ]
 
+# parameters whose gradients test_full_width_24L_training_gradients_vs_oracle compares (TGT-At 24L)
+FULL_GRAD_KEYS = [
+    'encoder.TGT_layers.0.update.lin_QKV.weight', 'encoder.TGT_layers.0.tria.lin_QKV_in.weight',
+    'encoder.TGT_layers.5.tria.lin_EG_out.weight', 'encoder.TGT_layers.11.tria.tri_ln_e.weight',
+    'encoder.TGT_layers.17.edge_ffn.lin_W1.weight', 'encoder.TGT_layers.23.tria.lin_O.weight',
+    'encoder.TGT_layers.23.update.lin_O_e.bias', 'input_embed.dist_embed.weight', 'dist_pred.weight',
+]
+
+
+def bf16_drift(case):
+    """{tensor name: rel-L2 drift of the REFERENCE under bf16 autocast vs itself without} for a golden case
+    (tests/golden/bf16_drift.npz, written by tools/make_golden.py drift)"""
+    z = np.load(os.path.join(GOLDEN_DIR, 'bf16_drift.npz'))
+    return {k.split('::', 1)[1]: float(z[k]) for k in z.files if k.startswith(case + '::')}
+
 
 # ---------------------------------------------------------------------------
 # numpy restatement of the kernels' attention-dropout generator

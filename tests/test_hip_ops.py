@@ -138,6 +138,56 @@ def test_projected_triplet_attention_bias_gradient(case, dtype, variant, proj_ke
     assert torch.isfinite(new_in[2].grad).all()
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('case', [(2, 20, [20, 13], 256, 16), (3, 32, [32, 17, 32], 256, 16), (2, 17, [17, 9], 128, 8),
+                                  (2, 32, [32, 30], 128, 8)])
+@pytest.mark.parametrize('variant', ['gated', 'ungated', 'axial'])
+def test_projection_fused_triplet_attention_vs_oracle(case, dtype, variant, monkeypatch):
+    """tgt_triplet_attention_proj_fwd (the Q/K/V projection computed INSIDE the attention kernel) and its backward,
+    directly against the float64 oracle: lin(x) -> oracle.core.triplet_attention_core in the reference's channel
+    layout (reference triplet.py:205-250), outputs and the gradients of x, W and b."""
+    from tgt_amd import ops, layout
+    B, N, nn_, C, H = case
+    gated, biased = variant == 'gated', variant != 'axial'
+    L = ops.TripletLayout(C, H, gated=gated, biased=biased)
+    monkeypatch.setenv('TGT_TRI_PROJ', '1')
+    assert ops._proj_fused_ok(torch.empty(0), N, L, dtype), 'shape must be one the projection-fused kernel takes'
+    rng = np.random.default_rng(11 + hash((B, N, C, H)) % 1000)
+    x = rnd(rng, B, N, N, C).to(dtype)
+    w = (rnd(rng, L.width, C) * C ** -0.5).to(dtype)
+    b = (rnd(rng, L.width) * 0.1).to(dtype)
+    if L.width > L.used:
+        w[L.used:] = 0
+        b[L.used:] = 0
+    d_out = rnd(rng, B, N, N, 2 * C).to(dtype)
+    mask = gu.additive_mask(nn_, N, torch.float32)
+
+    # ---- oracle (float64, reference layout) on the values as the kernel sees them ----
+    x64, w64, b64 = (t.double().requires_grad_(True) for t in (x, w, b))
+    f64 = torch.nn.functional.linear(x64, w64, b64)
+    idx, oidx = layout.head_major_index(C, H), layout.va_cols_head_major(C, H)
+
+    def blk(lo):
+        return torch.cat([to_ref(f64[..., lo + p * C: lo + (p + 1) * C], idx) for p in range(3)], -1)
+    nb = (2 if gated else 1) * H
+    eg_in = f64[..., 6 * C: 6 * C + nb] if biased else None
+    eg_out = f64[..., 6 * C + nb: 6 * C + 2 * nb] if biased else None
+    va_ref = from_ref(core.triplet_attention_core(blk(0), eg_in, blk(3 * C), eg_out, mask.double(), H, gated, biased), oidx)
+    (va_ref * d_out.double()).sum().backward()
+
+    # ---- HIP: projection inside the attention kernel ----
+    xin, win, bin_ = (t.cuda().requires_grad_(True) for t in (x, w, b))
+    va = ops.projected_triplet_attention(xin, win, bin_, mask.reshape(B, N, N).cuda(), L)
+    va.backward(d_out.cuda())
+    torch.cuda.synchronize()
+    tol = TOL[dtype]
+    assert torch.isfinite(va).all()
+    assert rel(va, va_ref) < tol, ('fwd', rel(va, va_ref))
+    assert rel(xin.grad, x64.grad) < 2 * tol, ('dx', rel(xin.grad, x64.grad))
+    assert rel(win.grad[:L.used], w64.grad[:L.used]) < 2 * tol, ('dw', rel(win.grad[:L.used], w64.grad[:L.used]))
+    assert rel(bin_.grad[:L.used], b64.grad[:L.used]) < 2 * tol, ('db', rel(bin_.grad[:L.used], b64.grad[:L.used]))
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('case', [CASES[0], CASES[2], CASES[4], CASES[5], (2, 40, [40, 33], 48, 3)])
 @pytest.mark.parametrize('variant', ['gated', 'axial'])

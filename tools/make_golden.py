@@ -151,8 +151,67 @@ def misc_cases():
     save('misc', out)
 
 
+def _rel(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
+def bf16_drift_cases():
+    """The reference's OWN bf16-autocast drift, the anchor of the bf16 tolerances of tests/test_hip_model.py
+    ('grads <= 2x ...'): the reference model in fp32 under torch.autocast(bfloat16) against the same
+    model in fp64 / fp32 without autocast, same parameters and batch as the golden cases; stored: rel-L2 of the
+    outputs, the loss and every probed parameter gradient.  (CPU autocast: the container has no GPU; Linear / matmul /
+    bmm run in bf16 exactly as under CUDA autocast, softmax / layer_norm / losses stay fp32.)"""
+    out = {}
+
+    def run(model, batch, cls_name, num_bins, autocast):
+        model.zero_grad(set_to_none=True)
+        with torch.autocast('cpu', dtype=torch.bfloat16, enabled=autocast):
+            o = model(batch)
+            if cls_name == 'TGT_Multi':
+                loss = pretrain_loss(o, batch, num_bins)
+                res = dict(gap=o[0], logits=o[1])
+            elif cls_name == 'TGT_Distance':
+                loss = ref_commons.DiscreteDistLoss(num_bins, 8)(o, ref_commons.coords2dist(batch['dft_coords']),
+                                                                 batch['edge_mask'])
+                res = dict(logits=o)
+            else:
+                loss = torch.nn.functional.l1_loss(o, batch['target'])
+                res = dict(gap=o)
+        res['loss'] = loss
+        loss.backward()
+        for k, p in model.named_parameters():
+            if p.grad is not None:
+                res['pgrad.' + k] = p.grad.clone()
+        return {k: v.detach().clone() for k, v in res.items()}
+
+    for i, (name, (cls_name, kwargs, geom)) in enumerate(gu.MODEL_CASES.items()):
+        model = gu.fill_params(REF_CLASSES[cls_name](**kwargs), seed=500 + i).train()
+        batch = gu.model_batch(geom, seed=600 + i)
+        exact = run(model, batch, cls_name, kwargs.get('num_dist_bins', 0), False)
+        low = run(model, batch, cls_name, kwargs.get('num_dist_bins', 0), True)
+        for k in exact:
+            if k.startswith('pgrad.') and k[6:] not in gu.GRAD_PROBE_KEYS:
+                continue
+            out[f'{name}::{k}'] = np.array(_rel(low[k], exact[k]))
+        print(name, {k.split('::')[1][-28:]: float(v) for k, v in out.items() if k.startswith(name)})
+    # TGT-At 24L at BASELINE widths, the case of test_full_width_24L_training_gradients_vs_oracle
+    geom = dict(B=2, N=12, num_nodes=[12, 9])
+    model = gu.fill_params(TGT_Multi(**gu.FULL_AT_CFG), seed=910).train()
+    batch = gu.model_batch(geom, seed=911)
+    t0 = time.time()
+    exact = run(model, batch, 'TGT_Multi', 512, False)
+    low = run(model, batch, 'TGT_Multi', 512, True)
+    for k in exact:
+        if k.startswith('pgrad.') and k[6:] not in gu.FULL_GRAD_KEYS:
+            continue
+        out[f'full_at_24L::{k}'] = np.array(_rel(low[k], exact[k]))
+    print(f'full_at_24L {time.time()-t0:.0f}s', {k[-40:]: float(v) for k, v in out.items() if k.startswith('full_at_24L')})
+    save('bf16_drift', out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[2:] or ['op', 'model', 'misc', 'full']
+    which = sys.argv[2:] or ['op', 'model', 'misc', 'full', 'drift']
     if 'op' in which:
         op_cases()
     if 'model' in which:
@@ -161,3 +220,5 @@ if __name__ == '__main__':
         misc_cases()
     if 'full' in which:
         full_width_case()
+    if 'drift' in which:
+        bf16_drift_cases()
