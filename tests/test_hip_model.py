@@ -110,12 +110,20 @@ def test_task_model_matches_reference_golden(name, mode):
         if k in named and named[k].grad is not None:
             res['pgrad.' + k] = named[k].grad
     assert set(res) == set(gold)
-    # fp32 HIP path vs fp64 reference; bf16: ~2x the reference's own bf16 drift
-    tol_out, tol_grad = (3e-4, 2e-3) if mode == 'fp32' else (3e-2, 1.5e-1)
+    # fp32 HIP path vs the fp64 reference: 3e-4 outputs, 2e-3 gradients.
+    # bf16: 2x the REFERENCE's own bf16-autocast drift on this very case, tensor by tensor (tests/golden/bf16_drift.npz,
+    # written by tools/make_golden.py from the reference; SURVEY 8c "grads <= 2x"): 1.2e-2 .. 2.9e-2 for the probed
+    # gradients and the logits.  `gap` (B numbers) and `loss` (one number) are too few values for a relative L2 to be
+    # stable at that level: they keep absolute floors of 3e-2 / 1e-3.
+    drift = gu.bf16_drift(name)
+    floors = dict(gap=3e-2, loss=1e-3)
     for k, t in res.items():
         g = torch.from_numpy(gold[k])
-        tol = tol_grad if k.startswith('pgrad.') else tol_out
-        assert rel(t, g) < tol, (k, rel(t, g))
+        if mode == 'fp32':
+            tol = 2e-3 if k.startswith('pgrad.') else 3e-4
+        else:
+            tol = max(2.0 * drift[k], floors.get(k, 0.0))
+        assert rel(t, g) < tol, (k, rel(t, g), tol)
 
 
 def test_full_width_24L_forward_vs_reference_golden():
@@ -336,13 +344,11 @@ def test_full_width_24L_training_gradients_vs_oracle():
         l_ref, core.pairwise_dist(cpu['dft_coords']), cpu['edge_mask'], 512, 8)
     loss_ref.backward()
     pr = dict(ref.named_parameters())
-    keys = ['encoder.TGT_layers.0.update.lin_QKV.weight', 'encoder.TGT_layers.0.tria.lin_QKV_in.weight',
-            'encoder.TGT_layers.5.tria.lin_EG_out.weight', 'encoder.TGT_layers.11.tria.tri_ln_e.weight',
-            'encoder.TGT_layers.17.edge_ffn.lin_W1.weight', 'encoder.TGT_layers.23.tria.lin_O.weight',
-            'encoder.TGT_layers.23.update.lin_O_e.bias', 'input_embed.dist_embed.weight', 'dist_pred.weight']
+    keys = gu.FULL_GRAD_KEYS
+    drift = gu.bf16_drift('full_at_24L')       # the reference's own bf16-autocast drift on this case (0.3 .. 1.3e-2)
     batch = {k: v.cuda() for k, v in cpu.items()}
     cfg = StepConfig(num_dist_bins=512, mixed_precision=None)
-    for mode, tol_loss, tol_grad in (('fp32', 2e-5, 5e-3), ('bf16', 5e-3, 1.5e-1)):
+    for mode, tol_loss, tol_grad in (('fp32', 2e-5, 5e-3), ('bf16', 1e-3, None)):
         model = gu.fill_params(TGT_Multi(**gu.FULL_AT_CFG), seed=910).cuda().train()
         ctx = torch.autocast('cuda', dtype=torch.bfloat16) if mode == 'bf16' else torch.autocast('cuda', enabled=False)
         with ctx:
@@ -351,5 +357,6 @@ def test_full_width_24L_training_gradients_vs_oracle():
         assert abs(float(loss.detach()) - float(loss_ref.detach())) < tol_loss * abs(float(loss_ref.detach())), mode
         pm = dict(model.named_parameters())
         for k in keys:
-            assert rel(pm[k].grad, pr[k].grad) < tol_grad, (mode, k, rel(pm[k].grad, pr[k].grad))
+            tol = tol_grad if tol_grad is not None else 2.0 * drift['pgrad.' + k]      # bf16: 2x the reference's drift
+            assert rel(pm[k].grad, pr[k].grad) < tol, (mode, k, rel(pm[k].grad, pr[k].grad), tol)
         del model

@@ -764,10 +764,18 @@ def _ragged_mask3(B, N, rng):
     return gu.additive_mask(nn_, N, torch.float32).reshape(B, N, N).cuda(), nn_
 
 
-@pytest.mark.parametrize('op', ['triplet_attention', 'triplet_aggregate', 'node_attention'])
-def test_baseline_size_properties(op):
-    """BASELINE.json size (B=256 graphs, N=32, C=256/Ht=16, W=768/Hn=64, bf16), where the oracle would
-    take minutes: properties that hold EXACTLY whatever the size --
+# BASELINE.json configs at their full size: (graphs per GPU, padded nodes, storage dtype, kernels the model uses)
+SIZE_CONFIGS = {
+    'cfg2_at_b256_n32_bf16': (256, 32, torch.bfloat16, ['triplet_attention', 'triplet_aggregate', 'node_attention']),
+    'cfg4_at_b128_n48_bf16': (128, 48, torch.bfloat16, ['triplet_attention', 'node_attention']),       # two node tiles
+    'cfg5_agx2_b512_n32_fp16': (512, 32, torch.float16, ['triplet_aggregate', 'node_attention']),      # inference batch
+}
+
+
+@pytest.mark.parametrize('cfg,op', [(c, o) for c, v in SIZE_CONFIGS.items() for o in v[3]])
+def test_baseline_size_properties(cfg, op):
+    """BASELINE.json sizes (cfg 2: B=256 graphs, N=32, bf16; cfg 4: B=128, N up to 48, bf16; cfg 5: B=512, fp16,
+    aggregate; C=256/Ht=16, W=768/Hn=64), where the oracle would take minutes: properties that hold EXACTLY whatever the size --
       * graphs are independent: graphs [s:e] of the full launch == a launch on that slice alone, bit for
         bit, forward and backward (a wrong batch stride, a workgroup reading its neighbour's slab, or a
         grid that drops / repeats work at 4096 workgroups breaks this);
@@ -776,10 +784,11 @@ def test_baseline_size_properties(op):
       * rows/columns of padded nodes: the slice anchors them (same bits as the small launch, which the
         oracle tests pin), and everything stays finite."""
     from tgt_amd import ops
-    B, N, C, Ht, W, Hn = 256, 32, 256, 16, 768, 64
-    dt = torch.bfloat16
+    B, N, dt, _ = SIZE_CONFIGS[cfg]
+    C, Ht, W, Hn = 256, 16, 768, 64
     rng = np.random.default_rng(2024)
     m3, _ = _ragged_mask3(B, N, rng)
+    slices = ((0, 3), (B // 2 - 27, B // 2 - 24), (B - 3, B))
     g = torch.Generator(device='cuda').manual_seed(7)
     randn = lambda *s: torch.randn(*s, device='cuda', generator=g).to(dt)
     if op == 'node_attention':
@@ -795,7 +804,7 @@ def test_baseline_size_properties(op):
             dq, de = torch.autograd.grad([v, hh], [q, e], [gv[sl] * gmul, gh[sl] * gmul])
             return v, hh, dq, de
         full = run(slice(None))
-        for s, e_ in ((0, 3), (101, 104), (253, 256)):
+        for s, e_ in slices:
             part = run(slice(s, e_))
             for a, b in zip(full, part):
                 assert torch.equal(a[s:e_], b)
@@ -821,7 +830,7 @@ def test_baseline_size_properties(op):
         df, = torch.autograd.grad(y, f, d_out[sl] * gmul)
         return y, df
     full = run(slice(None))
-    for s, e_ in ((0, 3), (101, 104), (253, 256)):
+    for s, e_ in slices:
         part = run(slice(s, e_))
         assert torch.equal(full[0][s:e_], part[0]) and torch.equal(full[1][s:e_], part[1])
     assert torch.equal(run(slice(0, 8), vmul=2.0)[0], full[0][:8] * 2)

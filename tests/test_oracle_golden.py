@@ -166,3 +166,18 @@ def test_fully_padded_rows_stay_finite():
     va = core.triplet_attention_core(x['tq_in'], x['te_in'], x['tq_out'], x['te_out'], x['mask'], 2)
     assert torch.isfinite(v_att).all() and torch.isfinite(h_hat).all() and torch.isfinite(va).all()
     assert v_att[1, 3:].abs().max() == 0
+
+
+def test_bf16_drift_fixture_anchors_every_compared_tensor():
+    """tests/golden/bf16_drift.npz (the reference's own bf16-autocast drift, tools/make_golden.py drift) holds a
+    positive, small rel-L2 for every tensor the bf16 model tests compare"""
+    import golden_util as gu
+    for name, (cls_name, kwargs, geom) in gu.MODEL_CASES.items():
+        d = gu.bf16_drift(name)
+        gold = np.load(os.path.join(gu.GOLDEN_DIR, f'model_{name}.npz'))
+        for k in {f.rsplit('::', 1)[0] for f in gold.files}:
+            assert k in d and 0 < d[k] < 5e-2, (name, k, d.get(k))
+    d = gu.bf16_drift('full_at_24L')
+    for k in gu.FULL_GRAD_KEYS:
+        assert 0 < d['pgrad.' + k] < 5e-2
+    assert 0 < d['logits'] < 3e-2
