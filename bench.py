@@ -55,59 +55,94 @@ def algorithmic_bytes(kind, B, N, C, Ht, esz=2):
     return B * per_graph
 
 
-def cpu_baseline_worker(threads, batch_graphs=8, nodes=32, budget_s=10.0, max_steps=3):
-    """(runs in a subprocess) the oracle's TGT-At 24L training step on the host CPU (fp32),
-    micro-batch of `batch_graphs` graphs of the same synthetic workload."""
+def cpu_baseline_worker(threads, micro=8, nodes=32, budget_s=40.0, full=False):
+    """(runs in a subprocess) the oracle's TGT-At 24L training step on the host CPU (fp32), SURVEY 8(d): all physical
+    cores (a quick calibration picks between them and 32 threads: oversubscribed hosts are slower with more), micro-batches
+    of `micro` graphs of the same synthetic workload with gradient accumulation (1.1 GB of activations per graph
+    forbid 256 at once), one Adam step at the end; fwd-only and fwd+loss+bwd graphs/s.  Bounded sample: as many
+    micro-batches as fit the budget (>= 5 fwd+bwd); --cpu-baseline-full accumulates all 256 graphs of one GPU step."""
     from oracle import modules as om, core
     from tgt_amd.training.configs import tgt_at_24l
     from tgt_amd.training.synthetic import make_batch, batch_seed
-    torch.set_num_threads(threads)
     torch.manual_seed(0)
     model = om.TGT_Multi(**tgt_at_24l()).train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
 
-    def one_step(step, graphs):
+    def batch_of(step, graphs):
         b = make_batch(graphs, nodes, batch_seed(step))
         nm = b['node_mask']
         b['edge_mask'] = nm.unsqueeze(-1) * nm.unsqueeze(-2)
         coords = core.smoothed_coord_noise(b['dft_coords'], b['edge_mask'], 0.2, 1.0)
         b['dist_input'] = core.pairwise_dist(coords)
-        opt.zero_grad(set_to_none=True)
+        return b
+
+    def loss_of(b):
         gap, logits = model(b)
-        loss = torch.nn.functional.l1_loss(gap, b['target']) + 0.1 * core.binned_distance_xent(
+        return torch.nn.functional.l1_loss(gap, b['target']) + 0.1 * core.binned_distance_xent(
             logits, core.pairwise_dist(b['dft_coords']), b['edge_mask'], 512, 8)
-        loss.backward()
-        opt.step()
 
-    one_step(0, 2)                                # untimed warm-up (allocator, thread pool)
-    t0, n = time.perf_counter(), 0
-    while n < max_steps and (n == 0 or time.perf_counter() - t0 < budget_s):
-        one_step(1 + n, batch_graphs)
-        n += 1
+    def forward_only(b):
+        with torch.no_grad():
+            loss_of(b)
+
+    cands = sorted({max(1, min(threads, 32)), threads})
+    rates = {}
+    probe = batch_of(0, 4)
+    for t in cands:                                   # calibration (also the allocator / thread-pool warm-up)
+        torch.set_num_threads(t)
+        forward_only(probe)
+        t0 = time.perf_counter()
+        forward_only(probe)
+        rates[t] = 4 / (time.perf_counter() - t0)
+    used = max(rates, key=rates.get)
+    torch.set_num_threads(used)
+
+    t0, nf = time.perf_counter(), 0
+    while nf < 2 or (nf < 4 and time.perf_counter() - t0 < 0.2 * budget_s):
+        forward_only(batch_of(100 + nf, micro))
+        nf += 1
+    fwd_rate = micro * nf / (time.perf_counter() - t0)
+
+    target = 256 // micro
+    opt.zero_grad(set_to_none=True)
+    t0, nb = time.perf_counter(), 0
+    while nb < target and (nb < 5 or full or time.perf_counter() - t0 < 0.7 * budget_s):
+        (loss_of(batch_of(200 + nb, micro)) * (micro / 256.0)).backward()          # accumulate towards the 256-graph batch
+        nb += 1
+    opt.step()
     dt = time.perf_counter() - t0
-    print(json.dumps(dict(value=round(batch_graphs * n / dt, 3), unit='graphs/s', cores=threads, kind='port',
-                          sample=f'oracle TGT-At 24L train step (fwd+loss+bwd+Adam), fp32, {n} step(s) of '
-                                 f'{batch_graphs} synthetic N={nodes} graphs, dropouts on, {threads} threads')),
-          flush=True)
+    print(json.dumps(dict(value=round(micro * nb / dt, 3), unit='graphs/s', cores=used, kind='port',
+                          fwd_only_graphs_per_s=round(fwd_rate, 3), micro_batch=micro, micro_batches_timed=nb,
+                          micro_batches_per_256_graph_step=target, thread_calibration={str(k): round(v, 2) for k, v in rates.items()},
+                          sample=f'oracle TGT-At 24L train step on the host CPU, fp32, dropouts on: {nb} of the {target} '
+                                 f'micro-batches ({micro} synthetic N={nodes} graphs each) of one 256-graph step, fwd+loss+bwd '
+                                 f'with gradient accumulation + one Adam step, {used} threads '
+                                 f'({threads} physical cores); fwd-only over {nf} micro-batches')), flush=True)
 
 
-def cpu_baseline(timeout_s=240):
-    """Bounded: a subprocess with a hard timeout, a capped thread count (256 oversubscribed
-    OpenMP threads on the GPU box's host make the eager CPU path ~100x slower)."""
+def cpu_baseline(timeout_s=280, full=False):
+    """Bounded: a subprocess (off the timed region, GPU hidden) with a hard timeout."""
     import subprocess
-    threads = max(1, min(32, os.cpu_count() or 1))
-    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', str(threads)]
-    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES='')
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or os.cpu_count() or 1
+    except Exception:
+        phys = os.cpu_count() or 1
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', str(phys)] + (['--cpu-baseline-full'] if full else [])
+    env = dict(os.environ, HIP_VISIBLE_DEVICES='')
+    env.pop('OMP_NUM_THREADS', None)
+    if full:
+        timeout_s = 1800
     try:
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
         line = [l for l in out.stdout.splitlines() if l.startswith('{')]
         if line:
             return json.loads(line[-1])
-        return dict(value=None, unit='graphs/s', cores=threads, kind='port',
+        return dict(value=None, unit='graphs/s', cores=phys, kind='port',
                     sample='cpu baseline worker failed: ' + out.stderr[-200:])
     except subprocess.TimeoutExpired:
-        return dict(value=None, unit='graphs/s', cores=threads, kind='port',
-                    sample=f'cpu baseline exceeded its {timeout_s}s bound (one 8-graph oracle step did not finish)')
+        return dict(value=None, unit='graphs/s', cores=phys, kind='port',
+                    sample=f'cpu baseline exceeded its {timeout_s}s bound')
 
 
 def launch_ranks(n, argv):
@@ -163,13 +198,15 @@ def main():
     ap.add_argument('--nodes', type=int, default=32)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-worker', type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument('--cpu-baseline-full', action='store_true',
+                    help='CPU baseline over all 256 graphs of one step (16 accumulated micro-batches; minutes)')
     ap.add_argument('--launcher-selftest', action='store_true', help=argparse.SUPPRESS)   # tests/test_bench_launcher.py
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp16', 'fp32'])
     ap.add_argument('--no-gemm-tuning', action='store_true', help='library default GEMM heuristics')
     ap.add_argument('--write-gemm-tuning', default='', help='tune online and write the TunableOp file here')
     args = ap.parse_args()
     if args.cpu_baseline_worker:
-        cpu_baseline_worker(args.cpu_baseline_worker)
+        cpu_baseline_worker(args.cpu_baseline_worker, full=args.cpu_baseline_full)
         return
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -295,7 +332,7 @@ def main():
             roofline=roofline,
         )
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline()
+            out['cpu_baseline'] = cpu_baseline(full=args.cpu_baseline_full)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -61,20 +61,20 @@ def _pair(cls, a, b):
     return (cls * 2)(a, b)
 
 
-_mask3_memo = [None, -1, None]        # (source tensor, its version, float32 image)
-
-
 def as_mask3(mask, B, N):
     """(B,N,N,1) additive mask of any float dtype -> contiguous float32 (B,N,N).  The 48 calls of a
-    24-layer step pass the same tensor: its conversion is kept while that object is unmodified."""
-    if _mask3_memo[0] is mask and _mask3_memo[1] == mask._version and _mask3_memo[2].shape == (B, N, N):
-        return _mask3_memo[2]
+    24-layer step pass the same tensor: a real conversion is remembered ON that tensor object (attribute
+    `_tgt_mask3`, keyed on its version counter) -- no process-global state, so two models or two threads
+    never see each other's masks, and the image dies with the mask."""
+    memo = getattr(mask, '_tgt_mask3', None)
+    if memo is not None and memo[0] == mask._version and memo[1].shape == (B, N, N):
+        return memo[1]
     m = mask.reshape(B, N, N)
     if m.dtype != torch.float32:
         m = m.float()
     m = m.contiguous()
     if m.data_ptr() != mask.data_ptr():           # a real conversion / copy: worth remembering
-        _mask3_memo[:] = [mask, mask._version, m]
+        mask._tgt_mask3 = (mask._version, m)
     return m
 
 
@@ -179,18 +179,14 @@ def triplet_attention(fused, mask3, layout, dropout=(0.0, 0)):
     return _TripletAttention.apply(fused, mask3, layout, dropout)
 
 
-_colsum_ws = {}
-
-
-def _colsum_workspace(B, width, device):
-    """(B, width) fp32 scratch for the kernels' per-graph column sums; zero-filled once (columns a
-    kernel never writes -- row padding -- stay zero), reused by every layer: stream order makes
-    the consumer (sum_rows) finish before the next producer starts."""
-    key = (device, B, width)
-    ws = _colsum_ws.get(key)
-    if ws is None:
-        ws = _colsum_ws[key] = torch.zeros(B, width, dtype=torch.float32, device=device)
-    return ws
+def _colsum_workspace(B, width, used, device):
+    """(B, width) fp32 per-graph column sums written by the backward kernels: a fresh block from the caching
+    allocator per call (owned by that call's autograd node -- no shared scratch whose reuse would rest on stream
+    order).  The kernels write every used column of every graph; only layouts with row padding (width > used) need
+    the zero fill."""
+    if width > used:
+        return torch.zeros(B, width, dtype=torch.float32, device=device)
+    return torch.empty(B, width, dtype=torch.float32, device=device)
 
 
 _ATEN_PLANE_SUM = os.environ.get('TGT_PLANE_SUM', '1') == '0'       # A/B knob: ATen's reduction instead of tgt_sum_planes
@@ -352,7 +348,7 @@ class _ProjectedTripletAttention(torch.autograd.Function):
         d_fused = torch.empty(*fused.shape[:3], L.width, dtype=fused.dtype, device=fused.device)   # every used column is written
         if L.width > L.used:
             d_fused[..., L.used:] = 0
-        colsum = _colsum_workspace(fused.shape[0], L.width, fused.device)
+        colsum = _colsum_workspace(fused.shape[0], L.width, L.used, fused.device)
         a = _tri_args(fused, mask3, out, L, d_out, d_fused, colsum, dropout=ctx.dropout, eg=eg)
         _call('tgt_triplet_attention_bwd', _lib.lib().tgt_triplet_attention_bwd, a)
         need_p = any(ctx.needs_input_grad[6:])
