@@ -212,6 +212,41 @@ FULL_GRAD_KEYS = [
 ]
 
 
+# ---- MC-sampled prediction cases ------------------------------------------------------------
+PREDICT_CASE = dict(B=3, N=7, num_nodes=[7, 5, 3], num_bins=24, range_bins=8, nb_samples=3, nan_at=(1,), seed=4711)
+
+
+def predict_logit_sequence(case=None, dtype=torch.float32):
+    """the stochastic forwards of a stand-in distance predictor: 2*S logit tensors (B, N, N, bins) from a seed; the ones
+    listed in `nan_at` carry a NaN (sample skipped by the prediction loops).  Sharp enough that argmax ties are absent."""
+    c = case or PREDICT_CASE
+    rng = np.random.default_rng(c['seed'])
+    seq = []
+    for t in range(2 * c['nb_samples']):
+        x = rng.standard_normal((c['B'], c['N'], c['N'], c['num_bins'])) * 3.0
+        if t in c['nan_at']:
+            x[c['B'] - 1, 0, 1, 2] = np.nan
+        seq.append(torch.from_numpy(x).to(dtype))
+    return seq
+
+
+def predict_gap_sequence(case=None):
+    """stand-in gap predictor: value depends on the dist_input it is given (so that the sample -> bins-sample cycling of
+    the gap prediction loop is observable); call 2 returns an Inf"""
+    c = case or PREDICT_CASE
+    calls = []
+
+    def model(batch):
+        t = len(calls)
+        calls.append(t)
+        g = batch['dist_input'].double().sum((-1, -2)) * 1e-2 + t
+        if t == 2:
+            g = g.clone()
+            g[0] = float('inf')
+        return g
+    return model
+
+
 def bf16_drift(case):
     """{tensor name: rel-L2 drift of the REFERENCE under bf16 autocast vs itself without} for a golden case
     (tests/golden/bf16_drift.npz, written by tools/make_golden.py drift)"""

@@ -181,3 +181,57 @@ def test_bf16_drift_fixture_anchors_every_compared_tensor():
     for k in gu.FULL_GRAD_KEYS:
         assert 0 < d['pgrad.' + k] < 5e-2
     assert 0 < d['logits'] < 3e-2
+
+
+# ---- MC-sampled prediction steps and the bin formats between the two inference stages ----
+def _predict_setup():
+    from oracle import predict as op
+    c = gu.PREDICT_CASE
+    z = np.load(os.path.join(gu.GOLDEN_DIR, 'predict.npz'))
+    batch = gu.model_batch(dict(B=c['B'], N=c['N'], num_nodes=c['num_nodes']), seed=c['seed'] + 1)
+
+    def replay():
+        it = iter(gu.predict_logit_sequence())
+        return lambda b: next(it)
+    return op, c, z, batch, replay
+
+
+def test_prediction_bins_and_probs_match_the_reference_scheme():
+    op, c, z, batch, replay = _predict_setup()
+    bins = op.predict_bins(replay(), batch, c['nb_samples'])
+    assert np.array_equal(bins.numpy(), z['bins::full'])                       # integer work: exact
+    probs, valid = op.predict_probs(replay(), batch, c['nb_samples'])
+    assert valid == c['nb_samples']
+    assert np.abs(probs.numpy() - z['probs::full']).max() < 1e-14
+    xent = op.eval_xent_from_probs(probs, core.pairwise_dist(batch['dft_coords']), batch['edge_mask'],
+                                   c['num_bins'], c['range_bins'])
+    assert np.abs(xent.numpy() - z['eval_xent::full']).max() < 1e-12
+    with pytest.raises(ValueError):                                             # every sample NaN
+        nan = torch.full((1, 2, 2, 4), float('nan'))
+        op.predict_bins(lambda b: nan, {}, 2)
+
+
+def test_prediction_bin_packing_and_distances_match_the_reference():
+    op, c, z, batch, replay = _predict_setup()
+    bins = torch.from_numpy(z['bins::full'])
+    saved = op.save_bins_step(bins, c['num_nodes'], c['num_bins'])
+    assert all(s.dtype == np.uint8 for s in saved)
+    assert np.array_equal(np.concatenate(saved), z['saved_bins_flat::full'])
+    assert [len(s) for s in saved] == z['saved_bins_lengths::full'].tolist()
+    N = c['N']
+    dist_bins = np.zeros((c['B'], c['nb_samples'], N, N), dtype=np.float32)
+    for i, n in enumerate(c['num_nodes']):
+        dist_bins[i, :, :n, :n] = op.unpack_bins_multi(saved[i].reshape(c['nb_samples'], -1), n).astype(np.float32)
+    assert np.array_equal(dist_bins, z['dist_bins::full'])
+    d = core.bins_to_dist(torch.from_numpy(dist_bins), c['range_bins'] / (c['num_bins'] - 1))
+    assert np.array_equal(d.numpy(), z['dist_input::full'])                    # same float32 operations: exact
+    assert op.bins_storage_dtype(256) == np.uint8 and op.bins_storage_dtype(512) == np.uint16
+
+
+def test_gap_prediction_step_matches_the_reference_scheme():
+    op, c, z, batch, replay = _predict_setup()
+    b = dict(batch)
+    b['dist_input'] = torch.from_numpy(z['dist_input::full'])
+    pred = op.gap_prediction_step(gu.predict_gap_sequence(), b, 4)
+    assert np.array_equal(pred.numpy(), z['gap_pred::full'])
+    assert abs(op.evaluate_gap(pred.numpy(), batch['target'].numpy()) - float(z['gap_mae::full'])) < 1e-12

@@ -151,6 +151,74 @@ def misc_cases():
     save('misc', out)
 
 
+def predict_cases():
+    """The reference's own prediction-scheme methods (dist_pred/scheme.py:139-229, gap_pred/scheme.py:78-135,
+    bin_ops.py, commons.BinsProcessor) run on stand-in models that replay seeded outputs: the methods are called
+    unbound on a small namespace carrying exactly the attributes they read.  numba is absent here: `njit` is
+    stubbed to the identity (the functions are plain numpy loops)."""
+    import types
+    from types import SimpleNamespace
+    nb = types.ModuleType('numba')
+    nb.njit = lambda *a, **k: (lambda f: f)
+    typed = types.ModuleType('numba.typed')
+    typed.List = list
+    nb.typed = typed
+    sys.modules.setdefault('numba', nb)
+    sys.modules.setdefault('numba.typed', typed)
+    from lib.training_schemes.pcqm.dist_pred.scheme import SCHEME as DistScheme
+    from lib.training_schemes.pcqm.gap_pred.scheme import SCHEME as GapScheme
+    from lib.data.pcqm import bin_ops
+
+    c = gu.PREDICT_CASE
+    out = {}
+
+    def replay():
+        it = iter(gu.predict_logit_sequence())
+        return lambda batch: next(it)
+
+    batch = gu.model_batch(dict(B=c['B'], N=c['N'], num_nodes=c['num_nodes']), seed=c['seed'] + 1)
+    batch['num_nodes'] = torch.tensor(c['num_nodes'])
+    batch['idx'] = torch.arange(100, 100 + c['B'])
+    lossfn = ref_commons.DiscreteDistLoss(c['num_bins'], c['range_bins'])
+    fake = SimpleNamespace(nb_draw_samples=c['nb_samples'], model=replay(),
+                           config=SimpleNamespace(num_dist_bins=c['num_bins']), xent_loss_fn=lossfn,
+                           get_dist_target=lambda b: ref_commons.coords2dist(b['dft_coords']))
+    fake.predict_bins = lambda b: DistScheme.predict_bins(fake, b)
+    fake.predict_probs = lambda b: DistScheme.predict_probs(fake, b)
+    bins = DistScheme.predict_bins(fake, batch)
+    out['bins::full'] = bins.numpy()
+    fake.model = replay()
+    out['probs::full'] = DistScheme.predict_probs(fake, batch).numpy()
+    fake.model = replay()
+    out['eval_xent::full'] = DistScheme.prediction_step4eval(fake, batch)['loss'].numpy()
+    fake.model = replay()
+    saved = DistScheme.prediction_step4savebins(fake, batch)
+    assert saved['bins'][0].dtype == np.uint8
+    out['saved_idx::full'] = saved['idx']
+    out['saved_bins_flat::full'] = np.concatenate(saved['bins'])
+    out['saved_bins_lengths::full'] = np.array([len(b) for b in saved['bins']])
+    # the gap stage's side: unpack (data.py:232-238) -> float32 -> BinsProcessor.bins2dist
+    bp = ref_commons.BinsProcessor.__new__(ref_commons.BinsProcessor)
+    bp.shift_half, bp.zero_diag, bp.bin_size = True, True, c['range_bins'] / (c['num_bins'] - 1)
+    N = c['N']
+    dist_bins = np.zeros((c['B'], c['nb_samples'], N, N), dtype=np.float32)      # padded_collate: zero padding
+    for i, n in enumerate(c['num_nodes']):
+        packed = saved['bins'][i].reshape(c['nb_samples'], -1)
+        dist_bins[i, :, :n, :n] = bin_ops.unpack_bins_multi(packed, n).astype(np.float32)
+    out['dist_bins::full'] = dist_bins
+    dist_input = bp.bins2dist(torch.from_numpy(dist_bins))
+    out['dist_input::full'] = dist_input.numpy()
+    gbatch = dict(batch)
+    gbatch['dist_input'] = dist_input
+    gfake = SimpleNamespace(nb_draw_samples=4, model=gu.predict_gap_sequence())
+    res = GapScheme.prediction_step(gfake, gbatch)
+    out['gap_pred::full'] = res['gap_pred'].numpy()
+    gp = dict(gap_pred=res['gap_pred'].numpy(), gap_target=res['gap_target'].numpy())
+    out['gap_mae::full'] = np.array(GapScheme.evaluate_predictions(gfake, gp)['loss'])
+    print('predict:', {k: v.shape for k, v in out.items()})
+    save('predict', out)
+
+
 def _rel(a, b):
     a, b = a.detach().double(), b.detach().double()
     return float((a - b).norm() / (b.norm() + 1e-300))
@@ -211,7 +279,7 @@ def bf16_drift_cases():
 
 
 if __name__ == '__main__':
-    which = sys.argv[2:] or ['op', 'model', 'misc', 'full', 'drift']
+    which = sys.argv[2:] or ['op', 'model', 'misc', 'full', 'drift', 'predict']
     if 'op' in which:
         op_cases()
     if 'model' in which:
@@ -222,3 +290,5 @@ if __name__ == '__main__':
         full_width_case()
     if 'drift' in which:
         bf16_drift_cases()
+    if 'predict' in which:
+        predict_cases()
