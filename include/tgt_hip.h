@@ -414,6 +414,48 @@ int tgt_layer_norm_bwd(const void* dy, int32_t dy_dtype, const void* x, int32_t 
                        const float* gamma, const float* mean, const float* rstd,
                        void* dx, int32_t dx_dtype, float* dgamma, float* dbeta, float* partial,
                        int64_t rows, int32_t C, void* stream);
+/* ---- MC-sampled prediction steps and the bin format between the two inference stages ----------
+ *
+ * The reference decides on the HOST, after every stochastic forward, whether the sample had a NaN/Inf
+ * (lib/training_schemes/pcqm/dist_pred/scheme.py:186-188, gap_pred/scheme.py:88-89: one device sync per sample).  Here
+ * the accept/skip decision is device state: `state` = 4 int32 {valid samples so far, non-finite seen in the sample in
+ * flight, tries, reserved}, zeroed by the caller before the loop; S = the number of samples wanted
+ * (`nb_draw_samples`).  Same sequence of accepted samples as the reference's loop, no sync until results are read. */
+
+/* One sample of `predict_bins` (dist_pred/scheme.py:186-196): softmax over the bins, p[i,j] + p[j,i], argmax (first
+ * maximum).  logits (B,N,N,NB) contiguous, NB % 8 == 0, <= 2048.  Written into slot state[0] of bins (B,S,N,N)
+ * (elements of bins_elem_size 1 / 2 / 4 bytes: uint8 / uint16 / int32; ld_b = elements between graphs = S*N*N);
+ * nothing is written once state[0] >= S.  Sets state[1] when a logit is NaN/Inf; follow with tgt_sample_commit. */
+int tgt_dist_bins_argmax(const void* logits, int32_t dtype, int64_t B, int32_t N, int32_t NB, void* bins,
+                         int32_t bins_elem_size, int64_t ld_b, int32_t S, int32_t* state, void* stream);
+/* if (!state[1] && state[0] < S) state[0]++;  state[1] = 0;  state[2]++ */
+int tgt_sample_commit(int32_t* state, int32_t S, void* stream);
+/* One sample of `predict_probs` (dist_pred/scheme.py:143-155): checks the logits (state[1]) and, when they are finite
+ * and the loop is not complete, acc[row][:] += softmax(logits[row][:]) (float32 acc, same shape); follow with
+ * tgt_sample_commit. */
+int tgt_softmax_accumulate(const void* logits, int32_t dtype, int64_t rows, int32_t NB, float* acc, int32_t* state,
+                           int32_t S, void* stream);
+/* out[b,i,j,:] = (acc[b,i,j,:] + acc[b,j,i,:]) / (2 state[0])  (dist_pred/scheme.py:164-166); as_log: log(. + eps)
+ * (:173).  out != acc. */
+int tgt_probs_finish(const float* acc, int64_t B, int32_t N, int32_t NB, const int32_t* state, int32_t as_log, float eps,
+                     float* out, void* stream);
+/* One sample of the gap loop (gap_pred/scheme.py:88-96): gap (B) of `dtype`; when all B values are finite and
+ * state[0] < S: out[b*S + state[0]] = gap[b] (float32) and state[0]++; state[2]++ either way. */
+int tgt_gap_commit(const void* gap, int32_t dtype, int32_t B, float* out, int32_t S, int32_t* state, void* stream);
+/* `pack_bins_multi` of every graph's real nodes (lib/data/pcqm/bin_ops.py:32-37, dist_pred/scheme.py:221-226):
+ * flat[offsets[b] + s*T_b + k] = bins[b,s,i,j], (i,j) the k-th pair (row-major) of the strict upper triangle of the
+ * n_b = num_nodes[b] real nodes, T_b = n_b(n_b-1)/2.  bins (B,S,N,N) of elem_size bytes; num_nodes (B) and
+ * offsets (B+1, offsets[b] = S * sum_{b' < b} T_b') device int64; total = offsets[B]. */
+int tgt_pack_triu(const void* bins, int32_t elem_size, int32_t B, int32_t S, int32_t N, const int64_t* num_nodes,
+                  const int64_t* offsets, void* flat, int64_t total, void* stream);
+/* `BinsProcessor.bins2dist` (lib/training_schemes/pcqm/commons.py:72-82), the same float32 operations in the same
+ * order: dist[r,i,j] = (u(i,j) + h) * bin_size + (u(j,i) + h) * bin_size, h = 0.5 when shift_half, 0 on the diagonal
+ * when zero_diag.  bins (R,N,N) of `kind`; u = bins, or -- num_nodes != NULL, R = B*S -- bins restricted to
+ * i < j < num_nodes[r / S] (zero elsewhere): what packing the bins and unpacking them into the zero-padded batch
+ * yields (bin_ops.py:39-46), so the two inference stages can be chained on the device. */
+enum { TGT_BINS_U8 = 0, TGT_BINS_U16 = 1, TGT_BINS_I32 = 2, TGT_BINS_I64 = 3, TGT_BINS_F32 = 4 };
+int tgt_bins_to_dist(const void* bins, int32_t kind, int64_t R, int32_t N, const int64_t* num_nodes, int32_t S,
+                     float bin_size, int32_t shift_half, int32_t zero_diag, float* out, void* stream);
 
 #ifdef __cplusplus
 }

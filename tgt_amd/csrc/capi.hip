@@ -55,6 +55,16 @@ int layer_norm_fwd_run(const void* x, int x_dtype, const float* gamma, const flo
 int layer_norm_bwd_run(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, const float* mean,
                        const float* rstd, void* dx, int dx_dtype, float* dgamma, float* dbeta, float* partial,
                        int64_t rows, int C, hipStream_t st);
+int dist_bins_run(const void* x, int dtype, int64_t B, int N, int NB, void* bins, int esz, int64_t ld_b, int S, int* state,
+                  hipStream_t st);
+int sample_commit_run(int* state, int S, hipStream_t st);
+int softmax_accumulate_run(const void* x, int dtype, int64_t rows, int NB, float* acc, int* state, int S, hipStream_t st);
+int probs_finish_run(const float* acc, int64_t B, int N, int NB, const int* state, int as_log, float eps, float* out, hipStream_t st);
+int gap_commit_run(const void* gap, int dtype, int B, float* out, int S, int* state, hipStream_t st);
+int pack_triu_run(const void* bins, int esz, int B, int S, int N, const int64_t* num_nodes, const int64_t* offsets, void* flat,
+                  int64_t total, hipStream_t st);
+int bins_to_dist_run(const void* bins, int kind, int64_t R, int N, const int64_t* num_nodes, int S, float bin_size, int shift_half,
+                     int zero_diag, float* out, hipStream_t st);
 
 }  // namespace tgt
 
@@ -63,7 +73,7 @@ using namespace tgt;
 extern "C" {
 
 const char* tgt_last_error(void) { return g_err; }
-int tgt_abi_version(void) { return 18; }
+int tgt_abi_version(void) { return 19; }
 
 int tgt_triplet_attention_fwd(const tgt_triplet_attention_args* a, void* stream) {
     return triplet_attention_run(a, false, reinterpret_cast<hipStream_t>(stream));
@@ -155,6 +165,31 @@ int tgt_layer_norm_bwd(const void* dy, int32_t dy_dtype, const void* x, int32_t 
                        float* partial, int64_t rows, int32_t C, void* stream) {
     return layer_norm_bwd_run(dy, dy_dtype, x, x_dtype, gamma, mean, rstd, dx, dx_dtype, dgamma, dbeta, partial, rows, C,
                               reinterpret_cast<hipStream_t>(stream));
+}
+
+int tgt_dist_bins_argmax(const void* logits, int32_t dtype, int64_t B, int32_t N, int32_t NB, void* bins, int32_t bins_elem_size,
+                         int64_t ld_b, int32_t S, int32_t* state, void* stream) {
+    return dist_bins_run(logits, dtype, B, N, NB, bins, bins_elem_size, ld_b, S, state, reinterpret_cast<hipStream_t>(stream));
+}
+int tgt_sample_commit(int32_t* state, int32_t S, void* stream) { return sample_commit_run(state, S, reinterpret_cast<hipStream_t>(stream)); }
+int tgt_softmax_accumulate(const void* logits, int32_t dtype, int64_t rows, int32_t NB, float* acc, int32_t* state, int32_t S,
+                           void* stream) {
+    return softmax_accumulate_run(logits, dtype, rows, NB, acc, state, S, reinterpret_cast<hipStream_t>(stream));
+}
+int tgt_probs_finish(const float* acc, int64_t B, int32_t N, int32_t NB, const int32_t* state, int32_t as_log, float eps, float* out,
+                     void* stream) {
+    return probs_finish_run(acc, B, N, NB, state, as_log, eps, out, reinterpret_cast<hipStream_t>(stream));
+}
+int tgt_gap_commit(const void* gap, int32_t dtype, int32_t B, float* out, int32_t S, int32_t* state, void* stream) {
+    return gap_commit_run(gap, dtype, B, out, S, state, reinterpret_cast<hipStream_t>(stream));
+}
+int tgt_pack_triu(const void* bins, int32_t elem_size, int32_t B, int32_t S, int32_t N, const int64_t* num_nodes,
+                  const int64_t* offsets, void* flat, int64_t total, void* stream) {
+    return pack_triu_run(bins, elem_size, B, S, N, num_nodes, offsets, flat, total, reinterpret_cast<hipStream_t>(stream));
+}
+int tgt_bins_to_dist(const void* bins, int32_t kind, int64_t R, int32_t N, const int64_t* num_nodes, int32_t S, float bin_size,
+                     int32_t shift_half, int32_t zero_diag, float* out, void* stream) {
+    return bins_to_dist_run(bins, kind, R, N, num_nodes, S, bin_size, shift_half, zero_diag, out, reinterpret_cast<hipStream_t>(stream));
 }
 
 int tgt_edge_linear_supported(const tgt_edge_linear_args* a) { return edge_linear_supported(a); }
