@@ -1019,6 +1019,382 @@ __global__ void __launch_bounds__(512, 2) edge_slice_kernel(const tgt_edge_linea
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Row-phase kernel: the 256-column Linears of the edge channel whose epilogue works on WHOLE ROWS
+// (residual add [+ LayerNorm of the new row], GELU + dropout, their backward forms, LayerNorm backward).
+//
+// Measured on the slice kernel above (tools/edge_gemm_bench.py with TGT_EG_ABLATE): its epilogue -- every lane storing
+// 16-byte pieces of ITS OWN row, 32 rows per wave instruction -- is what the time goes to: W2+res+LN 0.157 ms, 0.060
+// without the stores; the epilogue alone (no A loads, no MFMA) 0.124 ms for 3 tensor passes that stream in 0.08.
+// Here the accumulators leave through LDS instead: bias add, round to the storage type (what nn.Linear emits under
+// autocast), half-wave exchange, two ds_write_b128 per row block into a row-major staging tile (XOR-swizzled 16-byte
+// slots; it reuses the A buffer the k-loop just finished with when K >= 256).  Then a ROW PHASE with the mapping of the
+// LayerNorm kernels: thread = (row i*16 + tid/32, 16-byte chunk tid%32), so every global access of a wave is two whole
+// 512-byte rows, row reductions are 5 xor-shuffles inside a 32-lane half, the per-column constants (gamma, beta) sit in
+// 8 registers for the whole kernel, and the column sums of the LayerNorm backward (dgamma, dbeta, bias gradient) are
+// per-thread accumulators across ALL tiles of the persistent workgroup, folded once at the end.
+// Weight slice (32 columns x K per wave) resident in registers, A tiles by LDS-DMA into two buffers, as above.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void rp_unpack8(const uint4& raw, float* v) {
+    T t[8];
+    __builtin_memcpy(t, &raw, 16);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = to_f32(t[i]);
+}
+template <typename T>
+__device__ __forceinline__ uint4 rp_pack8(const float* v) {
+    T t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = from_f32<T>(v[i]);
+    uint4 raw;
+    __builtin_memcpy(&raw, t, 16);
+    return raw;
+}
+// sum over the 32 lanes of a half-wave (one row)
+__device__ __forceinline__ float rp_row_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Wave roles.  vmcnt is ONE in-order counter per wave, so a wave that both prefetches and stores can only wait for its
+// prefetch together with every store it issued before (measured on two earlier forms of this kernel: load+MFMA time and
+// row-phase time simply added up, 0.044 + 0.085 ms for W1+GELU; hipcc additionally answers an outstanding LDS-DMA with
+// `s_waitcnt vmcnt(0)` in front of the next LDS read it cannot prove disjoint).  So the two kinds of traffic live in
+// different waves of the workgroup:
+//   waves 0-7   GEMM role: fetch the next 32-row A tile into registers (plain 16-byte loads; these waves never store, so the
+//               compiler's wait before the closing ds_writes counts exactly those loads), k-loop on the current tile, weight
+//               slice (32 columns x K per wave) resident in registers, accumulators out through the staging tile;
+//   waves 8-15  row role: one pipeline stage behind, the row phase of the previous tile -- operand rows prefetched from
+//               global memory a stage ahead into registers, whole-row stores that nobody in this role waits for until
+//               the NEXT stage's operands are needed (a full stage later).
+// 16 waves = 4 per SIMD (128 registers each): every SIMD holds two waves of each role, so the matrix pipe, the VALU work of
+// the row phase and both kinds of memory traffic overlap.  (With 4 + 4 waves the row role ran one wave per SIMD and was
+// latency-bound: 0.096 ms for the GELU row phase alone.)  One s_barrier per stage (32 rows) couples the roles; staging
+// tiles are double-buffered.
+template <typename T, int KS, int EPI>
+__global__ void __launch_bounds__(1024, 4) edge_rows_kernel(const tgt_edge_linear_args a) {
+    using F = frag_t<T>;
+    constexpr int K = KS * 16, N = 256, kBM = 32, kABytes = kBM * K * 2, kSBytes = kBM * N * 2, kPass = 2;
+    constexpr bool kOperand = EPI == EPI_RESID || EPI == EPI_GELU_BWD || EPI == EPI_LN_BWD;
+    constexpr bool kOp2 = EPI == EPI_LN_BWD;
+    constexpr int kOffStage = 2 * kABytes, kOffGB = kOffStage + 2 * kSBytes;      // LDS: A tiles [2] | staging tiles [2] | gamma, beta
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hi = lane >> 5;
+    const EgGeo g(K), gs(N);
+    const int64_t row_tiles = (a.M + kBM - 1) / kBM;
+    const int ablate = a._pad0;
+    float* gb = reinterpret_cast<float*>(smem + kOffGB);
+    if (blockIdx.x >= row_tiles) return;
+    const int n_tiles = (int)((row_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x);       // tiles of this workgroup
+    auto tile_of = [&](int s) { return (int64_t)blockIdx.x + (int64_t)s * gridDim.x; };
+
+    if (wave < 8) {
+        // ------------------------------------------------------------------------------------------------ GEMM role
+        const T* A = reinterpret_cast<const T*>(a.a);
+        const T* W = reinterpret_cast<const T*>(a.w);
+        const int t4 = tid;                                // 0..511
+        const int n0 = wave * 32;
+        constexpr int spr = K >> 3, total = kBM * spr, kNA = (total + 511) / 512;
+        F wr[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wr[ks] = load_frag<T>(W + (int64_t)(n0 + r) * a.ldw + ks * 16 + 8 * hi);
+        uint2 braw[4];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            braw[gq] = make_uint2(0, 0);
+            if (a.bias) braw[gq] = *reinterpret_cast<const uint2*>(reinterpret_cast<const T*>(a.bias) + n0 + 8 * gq + 4 * hi);
+        }
+        uint4 pre[kNA];
+        auto fetch = [&](int64_t tile) {                   // 16-byte pieces (row, slot): consecutive threads = consecutive slots of a row
+#pragma unroll
+            for (int q = 0; q < kNA; ++q) {
+                const int pc = q * 512 + t4;
+                const int row = pc / spr, ps = pc % spr;
+                int64_t m = tile * kBM + row;
+                m = m < a.M ? m : a.M - 1;                 // rows past M re-read row M-1 (never stored)
+                if ((total % 512 == 0 || pc < total) && !(ablate & 4)) pre[q] = *reinterpret_cast<const uint4*>(A + m * a.lda + ps * 8);
+            }
+        };
+        auto commit = [&](int buf) {
+#pragma unroll
+            for (int q = 0; q < kNA; ++q) {
+                const int pc = q * 512 + t4;
+                const int row = pc / spr, ps = pc % spr;
+                if (total % 512 == 0 || pc < total) *reinterpret_cast<uint4*>(smem + buf * kABytes + g.off(row, ps)) = pre[q];
+            }
+        };
+        fetch(tile_of(0));
+        commit(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int s = 0; s <= n_tiles; ++s) {
+            if (s < n_tiles) {
+                const char* xs = smem + (s & 1) * kABytes;
+                char* sg = smem + kOffStage + (s & 1) * kSBytes;
+                if (s + 1 < n_tiles) fetch(tile_of(s + 1));
+                asm volatile("" ::: "memory");            // the prefetch is issued HERE, not sunk towards its use
+                f32x16 acc;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+                if (!(ablate & 8)) {
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        const F xf = load_frag<T>(reinterpret_cast<const T*>(xs + g.off(r, 2 * ks + hi)));
+                        acc = mma32(wr[ks], xf, acc);
+                    }
+                }
+                // accumulators -> staging tile: + bias, rounded to the storage type (what nn.Linear emits under autocast);
+                // lanes (r, hi) of a row exchange halves so that each holds 8 consecutive columns = one 16-byte slot
+                {
+                    float bv[16];
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) unpack4<T>(braw[gq], bv + 4 * gq);
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        uint2 lo = pack4<T>(acc[8 * p] + bv[8 * p], acc[8 * p + 1] + bv[8 * p + 1], acc[8 * p + 2] + bv[8 * p + 2],
+                                            acc[8 * p + 3] + bv[8 * p + 3]);
+                        uint2 up = pack4<T>(acc[8 * p + 4] + bv[8 * p + 4], acc[8 * p + 5] + bv[8 * p + 5], acc[8 * p + 6] + bv[8 * p + 6],
+                                            acc[8 * p + 7] + bv[8 * p + 7]);
+                        swap_halves(lo, up);
+                        *reinterpret_cast<uint4*>(sg + gs.off(r, (n0 >> 3) + 2 * p + hi)) = make_uint4(lo.x, lo.y, up.x, up.y);
+                    }
+                }
+                if (s + 1 < n_tiles) commit((s + 1) & 1);  // (the A buffer of tile s-1: its k-loop ended before the last barrier)
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
+
+    // ------------------------------------------------------------------------------------------------------ row role
+    const int t4 = tid - 512;
+    const int ch = t4 & 31, rsub = t4 >> 5;               // 16-byte chunk (8 columns) and row inside a group of 16
+    if (t4 < N) {
+        gb[t4] = a.gamma ? a.gamma[t4] : 1.f;
+        gb[N + t4] = (a.gamma && a.beta) ? a.beta[t4] : 0.f;
+    }
+    const bool ln_out = EPI == EPI_RESID && a.gamma != nullptr;
+    const uint32_t thresh = a.dropout_p <= 0.f ? 0u : (uint32_t)fminf(65535.f, fmaxf(1.f, rintf(a.dropout_p * 65536.f)));
+    const float inv_keep = a.dropout_p <= 0.f ? 1.f : 1.f / (1.f - a.dropout_p);
+    constexpr int kCs = EPI == EPI_LN_BWD ? 8 : 1;
+    float cs_g[kCs], cs_b[kCs], cs_x[kCs];               // EPI_LN_BWD: column sums over every row this workgroup processes
+#pragma unroll
+    for (int j = 0; j < kCs; ++j) cs_g[j] = cs_b[j] = cs_x[j] = 0.f;
+
+    struct Ops { uint4 o1[kOperand ? kPass : 1]; uint4 o2[kOp2 ? kPass : 1]; float mu[kOp2 ? kPass : 1], rs[kOp2 ? kPass : 1], sc[kPass]; };
+    auto fetch_ops = [&](int64_t tile, Ops& o) {          // the row phase's operands of `tile`: whole rows, straight from global memory
+#pragma unroll
+        for (int i = 0; i < kPass; ++i) {
+            int64_t m = tile * kBM + i * 16 + rsub;
+            m = m < a.M ? m : a.M - 1;
+            if (ablate & 4) continue;
+            if constexpr (kOperand) o.o1[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(a.res) + m * a.ldr + ch * 8);
+            if constexpr (kOp2) {
+                o.o2[i] = a.ds_in ? *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(a.ds_in) + m * a.ld_ds + ch * 8) : make_uint4(0, 0, 0, 0);
+                o.mu[i] = a.mean[m];
+                o.rs[i] = a.rstd[m];
+            }
+            o.sc[i] = 1.f;
+            if (EPI == EPI_GELU_BWD ? a.out_scale != nullptr : a.row_scale != nullptr)
+                o.sc[i] = (EPI == EPI_GELU_BWD ? a.out_scale : a.row_scale)[m / a.rows_per_sample];
+        }
+    };
+    Ops nxt;
+    fetch_ops(tile_of(0), nxt);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    float gam[8], bet[8];                                 // this thread's 8 columns, for the whole kernel
+    {
+        const float4 g0 = *reinterpret_cast<const float4*>(gb + ch * 8), g1 = *reinterpret_cast<const float4*>(gb + ch * 8 + 4);
+        gam[0] = g0.x; gam[1] = g0.y; gam[2] = g0.z; gam[3] = g0.w; gam[4] = g1.x; gam[5] = g1.y; gam[6] = g1.z; gam[7] = g1.w;
+        const float4 b0 = *reinterpret_cast<const float4*>(gb + N + ch * 8), b1 = *reinterpret_cast<const float4*>(gb + N + ch * 8 + 4);
+        bet[0] = b0.x; bet[1] = b0.y; bet[2] = b0.z; bet[3] = b0.w; bet[4] = b1.x; bet[5] = b1.y; bet[6] = b1.z; bet[7] = b1.w;
+    }
+    for (int s = 0; s <= n_tiles; ++s) {
+        if (s >= 1 && !(ablate & 2)) {
+            const Ops cur = nxt;                           // operands of tile s-1 (fetched a stage ago)
+            if (s < n_tiles) fetch_ops(tile_of(s), nxt);
+            asm volatile("" ::: "memory");
+            const char* sg = smem + kOffStage + ((s - 1) & 1) * kSBytes;
+            const int64_t m0 = tile_of(s - 1) * kBM;
+#pragma unroll
+            for (int i = 0; i < kPass; ++i) {
+                const int row = i * 16 + rsub;
+                const int64_t m = m0 + row;
+                const bool ok = m < a.M;
+                const int64_t mc = ok ? m : a.M - 1;
+                float v[8];
+                rp_unpack8<T>(*reinterpret_cast<const uint4*>(sg + gs.off(row, ch)), v);
+                if constexpr (EPI == EPI_GELU) {
+                    T* pre = reinterpret_cast<T*>(a.out2);
+                    T* out = reinterpret_cast<T*>(a.out);
+                    if (ok) *reinterpret_cast<uint4*>(pre + m * a.ldo2 + ch * 8) = rp_pack8<T>(v);
+                    bool keep[8] = {true, true, true, true, true, true, true, true};
+                    if (thresh) keep_vector<8>(a.dropout_seed, (mc * N + ch * 8) >> 3, thresh, keep);
+                    float gl[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float e;
+                        const float cdf = gelu_cdf(v[j], e);
+                        gl[j] = keep[j] ? v[j] * cdf * inv_keep : 0.f;
+                    }
+                    if (ok) *reinterpret_cast<uint4*>(out + m * a.ldo + ch * 8) = rp_pack8<T>(gl);
+                } else if constexpr (EPI == EPI_GELU_BWD) {
+                    const float al = cur.sc[i];
+                    float pv[8], o[8];
+                    rp_unpack8<T>(cur.o1[i], pv);
+                    bool keep[8] = {true, true, true, true, true, true, true, true};
+                    if (thresh) keep_vector<8>(a.dropout_seed, (mc * N + ch * 8) >> 3, thresh, keep);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float e;
+                        const float cdf = gelu_cdf(pv[j], e);
+                        const float dy = a.out_scale ? to_f32(from_f32<T>(v[j] * al)) : v[j];
+                        o[j] = keep[j] ? dy * (cdf + pv[j] * 0.3989422804014327f * e) * inv_keep : 0.f;
+                    }
+                    if (ok) *reinterpret_cast<uint4*>(reinterpret_cast<T*>(a.out) + m * a.ldo + ch * 8) = rp_pack8<T>(o);
+                } else if constexpr (EPI == EPI_RESID) {
+                    const float sc = cur.sc[i];
+                    float rv[8], t[8];
+                    rp_unpack8<T>(cur.o1[i], rv);
+                    float p1 = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        t[j] = to_f32(from_f32<T>(rv[j] + v[j] * sc));      // the stream value as stored: LayerNorm sees that
+                        p1 += t[j];
+                    }
+                    if (ok) *reinterpret_cast<uint4*>(reinterpret_cast<T*>(a.out) + m * a.ldo + ch * 8) = rp_pack8<T>(t);
+                    if (ln_out) {
+                        const float mean = rp_row_sum(p1) * (1.f / N);
+                        float p2 = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            t[j] -= mean;
+                            p2 += t[j] * t[j];
+                        }
+                        const float rstd = rsqrtf(rp_row_sum(p2) * (1.f / N) + a.eps);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) t[j] = t[j] * rstd * gam[j] + bet[j];
+                        if (ok) *reinterpret_cast<uint4*>(reinterpret_cast<T*>(a.y) + m * a.ldy + ch * 8) = rp_pack8<T>(t);
+                        if (ch == 0 && ok) {
+                            if (a.mean) a.mean[m] = mean;
+                            if (a.rstd) a.rstd[m] = rstd;
+                        }
+                    }
+                } else if constexpr (EPI == EPI_LN_BWD) {
+                    // v = dy at the output of LayerNorm(res; gamma); d_res = rstd (g - mean(g) - xhat mean(g xhat)) + ds_in, g = dy gamma
+                    const float mu = cur.mu[i], rs = cur.rs[i], sc = cur.sc[i];
+                    float sv[8], ds[8], xh[8], gg[8];
+                    rp_unpack8<T>(cur.o1[i], sv);
+                    rp_unpack8<T>(cur.o2[i], ds);
+                    float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        xh[j] = ok ? (sv[j] - mu) * rs : 0.f;
+                        const float dy = ok ? v[j] : 0.f;
+                        gg[j] = dy * gam[j];
+                        p1 += gg[j];
+                        p2 += gg[j] * xh[j];
+                        cs_g[j] += dy * xh[j];
+                        cs_b[j] += dy;
+                    }
+                    const float c1 = rp_row_sum(p1) * (1.f / N), c2 = rp_row_sum(p2) * (1.f / N);
+                    float d[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) d[j] = rs * (gg[j] - c1 - xh[j] * c2) + ds[j];
+                    if (ok) *reinterpret_cast<uint4*>(reinterpret_cast<T*>(a.out) + m * a.ldo + ch * 8) = rp_pack8<T>(d);
+                    if (a.out2 || a.colsum_partial) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            // the x-branch gradient as it is stored (rounded), so that its column sums equal a separate pass's
+                            d[j] = to_f32(from_f32<T>(to_f32(from_f32<T>(d[j])) * sc));
+                            cs_x[j] += ok ? d[j] : 0.f;
+                        }
+                        if (a.out2 && ok) *reinterpret_cast<uint4*>(reinterpret_cast<T*>(a.out2) + m * a.ldo2 + ch * 8) = rp_pack8<T>(d);
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    if constexpr (EPI == EPI_LN_BWD) {
+        if (a.colsum_partial) {
+            // fold the 16 row groups, fixed order: [16][3][256] floats in LDS (the A / staging tiles are dead: every wave is past
+            // the last barrier; only the row role takes part from here on -- the GEMM waves have exited, and an exited wave
+            // counts as arrived at a barrier)
+            float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                red[(rsub * 3 + 0) * N + ch * 8 + j] = cs_g[j];
+                red[(rsub * 3 + 1) * N + ch * 8 + j] = cs_b[j];
+                red[(rsub * 3 + 2) * N + ch * 8 + j] = cs_x[j];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            float* part = a.colsum_partial + (int64_t)blockIdx.x * 3 * N;
+            for (int c = t4; c < 3 * N; c += 512) {
+                float t = 0.f;
+#pragma unroll
+                for (int s_ = 0; s_ < 16; ++s_) t += red[s_ * 3 * N + c];
+                part[c] = t;
+            }
+        }
+    }
+}
+
+static int er_grid(int64_t M) {
+    const int64_t row_tiles = (M + 31) / 32;
+    return (int)(row_tiles < eg_num_cus() ? row_tiles : eg_num_cus());
+}
+
+template <typename T, int KS, int EPI>
+static int er_launch(const tgt_edge_linear_args& a, hipStream_t st) {
+    constexpr int K = KS * 16;
+    constexpr int lds0 = 2 * 32 * K * 2 + 2 * 32 * 256 * 2 + 2 * 256 * 4;
+    constexpr int lds = lds0 < 49152 ? 49152 : lds0;                        // the final column-sum fold of LN_BWD needs 48 KB
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_rows_kernel<T, KS, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((edge_rows_kernel<T, KS, EPI>), dim3((unsigned)er_grid(a.M)), dim3(1024), lds, st, a);
+    return check_launch("edge_rows_kernel");
+}
+
+template <typename T, int KS>
+static int er_dispatch(const tgt_edge_linear_args& a, hipStream_t st) {
+    switch (a.epilogue) {
+        case EPI_GELU: return er_launch<T, KS, EPI_GELU>(a, st);
+        case EPI_RESID: return er_launch<T, KS, EPI_RESID>(a, st);
+        case EPI_GELU_BWD: return er_launch<T, KS, EPI_GELU_BWD>(a, st);
+        case EPI_LN_BWD: return er_launch<T, KS, EPI_LN_BWD>(a, st);
+        default: return set_error(TGT_ERR_INVALID, "edge linear (row-phase kernel): bad epilogue %d", a.epilogue);
+    }
+}
+
+// the row-phase kernel takes the 256-column Linears with a whole-row epilogue: K in {64, 128, 256}, contiguous-enough rows
+static bool er_eligible(const tgt_edge_linear_args& a) {
+    if (a.N != 256 || (a.K != 64 && a.K != 128 && a.K != 256) || a.epilogue == EPI_BIAS) return false;
+    if (a.gamma && a.epilogue != EPI_RESID && a.epilogue != EPI_LN_BWD) return false;      // (LayerNorm PROLOGUE: the tile kernel)
+    if (a.gamma && a.epilogue == EPI_RESID && (!a.beta || !a.y)) return false;
+    static const bool off = getenv("TGT_EG_ROWS") && atoi(getenv("TGT_EG_ROWS")) == 0;
+    return !off;
+}
+
+template <typename T>
+static int er_run(const tgt_edge_linear_args& a, hipStream_t st) {
+    switch (a.K) {
+        case 64: return er_dispatch<T, 4>(a, st);
+        case 128: return er_dispatch<T, 8>(a, st);
+        default: return er_dispatch<T, 16>(a, st);
+    }
+}
+
 template <typename T, int KS, int WN, int EPI, int RB>
 static int es_launch(const tgt_edge_linear_args& a, hipStream_t st) {
     constexpr int kBM = 32 * RB;
@@ -1115,9 +1491,12 @@ static int eg_dispatch(const tgt_edge_linear_args& a, hipStream_t st) {
 }
 
 // rows of colsum_partial: one per (128-row tile, row group of waves WM = 8 / WN of the slice kernel)
+// rows of colsum_partial the caller provides (ZERO-FILLED: which kernel runs, and so which rows are written, also depends on K):
+// one per (128-row tile, row group of waves WM = 8 / WN) of the slice / tile kernels -- an upper bound for the row-phase
+// kernel, which writes one row per workgroup
 int edge_linear_parts(int64_t M, int N) {
     const int wn = N <= 64 ? 2 : (N <= 128 ? 4 : 8);
-    return wn == 8 ? (int)((M + 63) / 64) : (int)((M + 127) / 128) * (8 / wn);
+    return wn == 8 ? (int)((M + 31) / 32) : (int)((M + 127) / 128) * (8 / wn);        // (row-phase LN_BWD: 32-row tiles)
 }
 
 int edge_linear_supported(const tgt_edge_linear_args* a) {
@@ -1157,6 +1536,7 @@ int edge_linear_run(const tgt_edge_linear_args* a, hipStream_t st) {
         return set_error(TGT_ERR_INVALID, "edge linear: rows_per_sample missing");
     if (a->gamma && a->epilogue != EPI_LN_BWD && !a->beta) return set_error(TGT_ERR_INVALID, "edge linear: beta missing");
     if (a->dropout_p < 0.f || a->dropout_p >= 1.f) return set_error(TGT_ERR_INVALID, "edge linear: dropout_p outside [0,1)");
+    if (er_eligible(*a)) return a->dtype == TGT_BF16 ? er_run<bf16_t>(*a, st) : er_run<f16_t>(*a, st);
     if (es_eligible(*a)) return a->dtype == TGT_BF16 ? es_run<bf16_t>(*a, st) : es_run<f16_t>(*a, st);
     // narrow outputs: one 32-column block per wave keeps all four waves busy
     const bool narrow = a->N <= 128;
