@@ -187,6 +187,9 @@ typedef struct tgt_node_attention_args {
     const void* d_hhat;
     void*  d_qkv;
     void*  d_eg;
+    void*  w_ws;                      /* backward scratch (may be NULL): (B,N,N,H) of `dtype`.  When given, the row pass leaves the
+                                       * attention weights A[l,m,h] * log(1+sum gates) there and the column pass (dK, dV) reads them
+                                       * and the stored dE instead of re-reading E, G and recomputing softmax and gate per pair */
 } tgt_node_attention_args;
 
 int tgt_node_attention_fwd(const tgt_node_attention_args* a, void* stream);

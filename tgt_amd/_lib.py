@@ -17,7 +17,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 SOURCES = ['capi.hip', 'optimizer.hip', 'edge_gemm.hip', 'params.hip', 'loss.hip', 'predict.hip', 'triplet_attention_proj.hip',
            ('triplet_attention.hip', ['-DTGT_TRI_INST=9'], '.f32'), ('triplet_attention.hip', ['-DTGT_TRI_INST=2'], '.bf16'),
            ('triplet_attention.hip', ['-DTGT_TRI_INST=4'], '.f16'), 'triplet_aggregate.hip', 'node_attention.hip', 'layernorm.hip', 'triangular_update.hip', 'elementwise.hip']
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 TGT_F32, TGT_BF16, TGT_F16 = 0, 1, 2
 TRI_BIASED, TRI_GATED, TRI_MASK_OUT = 1, 2, 4
@@ -62,7 +62,7 @@ class NodeAttentionArgs(C.Structure):
         ('eg', _vp), ('ld_eg', _i64), ('e_off', _i32), ('g_off', _i32),
         ('mask', _vp),
         ('vatt', _vp), ('hhat', _vp), ('lse', _vp), ('gsum', _vp),
-        ('d_vatt', _vp), ('d_hhat', _vp), ('d_qkv', _vp), ('d_eg', _vp),
+        ('d_vatt', _vp), ('d_hhat', _vp), ('d_qkv', _vp), ('d_eg', _vp), ('w_ws', _vp),
     ]
 
 

@@ -461,6 +461,7 @@ __global__ void __launch_bounds__(256) node_att_bwd_row_kernel(const tgt_node_at
                     dA[k] += dvu[d][k] * vb.at(d, k);
                 }
             const float mk = a.mask[lm];
+            float wv[HV];
 #pragma unroll
             for (int k = 0; k < HV; ++k) {
                 const float p = fast_exp(dot[k] + e[k] + mk - lse[k]);
@@ -468,9 +469,11 @@ __global__ void __launch_bounds__(256) node_att_bwd_row_kernel(const tgt_node_at
                 const float dS = p * (dA[k] * gt - delta[k]);
                 dGl[k] = (dA[k] * p + dgsum[k]) * gt * (1.f - gt);
                 dH[k] += dS;
+                wv[k] = p * gt * dsc[k];                       // what the column pass needs of this pair for dV
             }
             stv<T, HV>(deg, lm * a.ld_eg + a.e_off + h, dH);
             stv<T, HV>(deg, lm * a.ld_eg + a.g_off + h, dGl);
+            if (a.w_ws) stv<T, HV>(reinterpret_cast<T*>(a.w_ws), lm * H + h, wv);
 #pragma unroll
             for (int d = 0; d < D; ++d)
 #pragma unroll
@@ -511,6 +514,34 @@ __global__ void __launch_bounds__(256) node_att_bwd_col_kernel(const tgt_node_at
                 kv[d][k] = kb.at(d, k);
                 dk[d][k] = dv[d][k] = 0.f;
             }
+    }
+    if (a.w_ws && !a.logits_only) {
+        // the row pass left dE = dH_hat and the weights A*log(1+sum g) of every pair: two streamed values per query instead of
+        // E, G, the mask, the row statistics and a softmax / gate recomputation
+        const T* wws = reinterpret_cast<const T*>(a.w_ws);
+        for (int l = 0; l < N; ++l) {
+            const int64_t row_l = row0 + l, lm = row_l * N + m;
+            float dH[HV], w[HV];
+            ldv<T, HV>(deg, lm * a.ld_eg + a.e_off + h, dH);
+            ldv<T, HV>(wws, lm * H + h, w);
+            DH<T, D, HV, HM> qb, db;
+            qb.load(qkv, row_l * a.ld_qkv + a.q_off, H, h);
+            db.load(dva, row_l * (int64_t)(D * H), H, h);
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+#pragma unroll
+                for (int k = 0; k < HV; ++k) {
+                    dk[d][k] += dH[k] * qb.at(d, k);
+                    dv[d][k] += w[k] * db.at(d, k);
+                }
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int k = 0; k < HV; ++k) dk[d][k] *= a.scale;
+        DH<T, D, HV, HM>::store(dqkv, row_m * a.ld_qkv + a.k_off, H, h, dk);
+        DH<T, D, HV, HM>::store(dqkv, row_m * a.ld_qkv + a.v_off, H, h, dv);
+        return;
     }
     for (int l = 0; l < N; ++l) {
         const int64_t row_l = row0 + l, lm = row_l * N + m;

@@ -514,6 +514,9 @@ def _node_args(qkv, eg, mask3, H, scale_degree, logits_only):
     return a, W
 
 
+_NODE_W_WS = os.environ.get('TGT_NODE_W_WS', '1') != '0'        # A/B knob: column pass recomputes softmax / gate instead
+
+
 class _NodeAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, eg, mask3, H, scale_degree, want_edges, head_major=False):
@@ -548,6 +551,9 @@ class _NodeAttention(torch.autograd.Function):
         d_qkv, d_eg = torch.empty_like(qkv), torch.empty_like(eg)
         a.lse, a.gsum, a.vatt = lse.data_ptr(), gsum.data_ptr(), vatt.data_ptr()
         a.d_vatt, a.d_hhat, a.d_qkv, a.d_eg = d_vatt.data_ptr(), _ptr(d_hhat), d_qkv.data_ptr(), d_eg.data_ptr()
+        if _NODE_W_WS:      # the pairs' attention weights, handed from the row pass to the column pass (freed on return)
+            w_ws = torch.empty(qkv.shape[0], qkv.shape[1], qkv.shape[1], H, dtype=qkv.dtype, device=qkv.device)
+            a.w_ws = w_ws.data_ptr()
         _call('tgt_node_attention_bwd', _lib.lib().tgt_node_attention_bwd, a)
         return d_qkv, d_eg, None, None, None, None, None
 
