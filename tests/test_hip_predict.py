@@ -180,3 +180,22 @@ def test_cpu_tensors_raise():
         pp.bins2dist(torch.zeros(2, 3, 3), 0.1)
     with pytest.raises(RuntimeError):
         pp.predict_bins(lambda b: torch.zeros(1, 2, 2, 8), {}, 1)
+
+
+def test_hipgraph_replay_of_the_forward_is_bit_identical():
+    """tgt_amd/pcqm/graphed.py: one captured forward replayed on new inputs == the eager forward, bit for bit"""
+    from tgt_amd.pcqm import TGT_Distance
+    from tgt_amd.pcqm.graphed import GraphedForward
+    dk = dict(gu.MODEL_CASES['dist_agx2_tiny'][1])
+    geom = dict(B=3, N=7, num_nodes=[7, 5, 3])
+    model = gu.fill_params(TGT_Distance(**dk), seed=32).cuda().eval()
+    b0 = {k: v.cuda() for k, v in gu.model_batch(geom, seed=41).items()}
+    b1 = {k: v.cuda() for k, v in gu.model_batch(geom, seed=42).items()}
+    for dt in (None, torch.bfloat16):
+        gf = GraphedForward(model, b0, autocast_dtype=dt)
+        for b in (b1, b0):
+            with torch.no_grad(), torch.autocast('cuda', dtype=dt or torch.bfloat16, enabled=dt is not None):
+                want = model(b)
+            assert torch.equal(gf(b), want)
+    with pytest.raises(RuntimeError):
+        gf({k: (v[:2] if k == 'node_mask' else v) for k, v in b0.items()})
