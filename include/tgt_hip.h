@@ -459,6 +459,17 @@ int tgt_pack_triu(const void* bins, int32_t elem_size, int32_t B, int32_t S, int
 enum { TGT_BINS_U8 = 0, TGT_BINS_U16 = 1, TGT_BINS_I32 = 2, TGT_BINS_I64 = 3, TGT_BINS_F32 = 4 };
 int tgt_bins_to_dist(const void* bins, int32_t kind, int64_t R, int32_t N, const int64_t* num_nodes, int32_t S,
                      float bin_size, int32_t shift_half, int32_t zero_diag, float* out, void* stream);
+/* Gaussian basis of the 3-D distance embedding (reference lib/models/pcqm/layers.py:129-157, `gaussian()` +
+ * GaussianLayer.forward): for every node pair p (pairs = B*N*N), t = mul[p]*x[p] + bias[p] (float32: x the pair distance,
+ * mul / bias the summed atom-type embeddings), y[p,k] = exp(-((t - mean[k]) / s_k)^2 / 2) / ((2*3.14159)^0.5 * s_k),
+ * s_k = |std[k]| + 0.01.  y (pairs, K) in `dtype` (the dtype the consuming Linear computes in).  K even, <= 512.
+ * Backward: g = dL/dy (pairs, K) of `dtype`; dt[p] = dL/dt (float32; dmul = dt*x, dbias = dt); partial:
+ * tgt_gaussian_basis_parts(pairs) rows of [dL/dmean (K) | dL/dstd (K)] float32 to be summed over rows (tgt_sum_rows). */
+int tgt_gaussian_basis_parts(int64_t pairs);
+int tgt_gaussian_basis_fwd(const float* x, const float* mul, const float* bias, const float* mean, const float* std,
+                           int64_t pairs, int32_t K, int32_t dtype, void* y, void* stream);
+int tgt_gaussian_basis_bwd(const float* x, const float* mul, const float* bias, const float* mean, const float* std,
+                           int64_t pairs, int32_t K, int32_t dtype, const void* g, float* dt, float* partial, void* stream);
 
 #ifdef __cplusplus
 }

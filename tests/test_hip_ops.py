@@ -923,3 +923,31 @@ def test_cross_entropy_rows(shape, dtype):
     assert abs(float(loss) - float(loss_ref)) < 2e-6 * abs(float(loss_ref))
     assert x.grad.dtype == dtype and rel(x.grad, ref_in.grad) < TOL[dtype] / 4
     assert (x.grad[m == 0] == 0).all()            # masked pairs: exact zeros
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape,K', [((2, 7, 7), 16), ((3, 12, 12), 128), ((1, 5, 5), 258)])
+def test_gaussian_basis(shape, K, dtype):
+    """Gaussian 3-D kernel (reference lib/models/pcqm/layers.py:129-157) forward and backward against the float64 oracle
+    (oracle.core.gaussian_kernel on mul*x + bias)"""
+    from tgt_amd import ops
+    rng = np.random.default_rng(K + shape[1])
+    x = torch.from_numpy(rng.uniform(0.0, 6.0, shape)).float()
+    mul = torch.from_numpy(1.0 + 0.2 * rng.standard_normal(shape + (1,))).float()
+    bias = torch.from_numpy(0.2 * rng.standard_normal(shape + (1,))).float()
+    means = torch.from_numpy(rng.uniform(0.0, 3.0, (1, K))).float()
+    stds = torch.from_numpy(rng.uniform(-3.0, 3.0, (1, K))).float()
+    gy = torch.from_numpy(rng.standard_normal(shape + (K,))).to(dtype)
+    leaves = [t.double().requires_grad_(True) for t in (mul, bias, means, stds)]
+    t64 = leaves[0] * x.double().unsqueeze(-1) + leaves[1]
+    y_ref = core.gaussian_kernel(t64, leaves[2].view(-1), leaves[3].view(-1).abs() + 1e-2)
+    (y_ref * gy.double()).sum().backward()
+    dev = [t.cuda().requires_grad_(True) for t in (mul, bias, means, stds)]
+    with torch.autocast('cuda', dtype=dtype, enabled=dtype != torch.float32):
+        y = ops.gaussian_basis(x.cuda(), *dev)
+    assert y.dtype == dtype
+    y.backward(gy.cuda())
+    tol = TOL[dtype] if dtype != torch.float32 else 1e-5
+    assert rel(y, y_ref) < tol
+    for got, want, name in zip(dev, leaves, ('dmul', 'dbias', 'dmeans', 'dstds')):
+        assert rel(got.grad, want.grad) < 2 * tol + (0 if dtype != torch.float32 else 1e-5), (name, rel(got.grad, want.grad))

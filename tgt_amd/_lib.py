@@ -14,10 +14,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtgt_hip.so')
 CSRC = os.path.join(_HERE, 'csrc')
 # (source, extra flags, object suffix): the triplet attention kernels compile one dtype per translation unit
-SOURCES = ['capi.hip', 'optimizer.hip', 'edge_gemm.hip', 'params.hip', 'loss.hip', 'predict.hip', 'triplet_attention_proj.hip',
+SOURCES = ['capi.hip', 'optimizer.hip', 'edge_gemm.hip', 'params.hip', 'loss.hip', 'predict.hip', 'gaussian.hip', 'triplet_attention_proj.hip',
            ('triplet_attention.hip', ['-DTGT_TRI_INST=9'], '.f32'), ('triplet_attention.hip', ['-DTGT_TRI_INST=2'], '.bf16'),
            ('triplet_attention.hip', ['-DTGT_TRI_INST=4'], '.f16'), 'triplet_aggregate.hip', 'node_attention.hip', 'layernorm.hip', 'triangular_update.hip', 'elementwise.hip']
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 TGT_F32, TGT_BF16, TGT_F16 = 0, 1, 2
 TRI_BIASED, TRI_GATED, TRI_MASK_OUT = 1, 2, 4
@@ -126,6 +126,9 @@ SYMBOLS = {
     'tgt_grad_stats_parts': (C.c_int, []),
     'tgt_grad_scaler_step': (C.c_int, [_vp, _i64, _vp, _vp, _i32, _f32, _f32, _i32, _f32, _f32, _i32, _vp]),
     'tgt_loss_accumulate': (C.c_int, [_vp, _i32, _f32, _vp, _i32, _i32, _vp]),
+    'tgt_gaussian_basis_parts': (C.c_int, [_i64]),
+    'tgt_gaussian_basis_fwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+    'tgt_gaussian_basis_bwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     'tgt_dist_bins_argmax': (C.c_int, [_vp, _i32, _i64, _i32, _i32, _vp, _i32, _i64, _i32, _vp, _vp]),
     'tgt_sample_commit': (C.c_int, [_vp, _i32, _vp]),
     'tgt_softmax_accumulate': (C.c_int, [_vp, _i32, _i64, _i32, _vp, _vp, _i32, _vp]),

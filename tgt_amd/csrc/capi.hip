@@ -55,6 +55,9 @@ int layer_norm_fwd_run(const void* x, int x_dtype, const float* gamma, const flo
 int layer_norm_bwd_run(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, const float* mean,
                        const float* rstd, void* dx, int dx_dtype, float* dgamma, float* dbeta, float* partial,
                        int64_t rows, int C, hipStream_t st);
+int gaussian_parts(int64_t pairs);
+int gaussian_run(const float* x, const float* mul, const float* bias, const float* mean, const float* std_p, int64_t pairs, int K,
+                 int dtype, void* y, const void* g, float* dt, float* partial, hipStream_t st);
 int dist_bins_run(const void* x, int dtype, int64_t B, int N, int NB, void* bins, int esz, int64_t ld_b, int S, int* state,
                   hipStream_t st);
 int sample_commit_run(int* state, int S, hipStream_t st);
@@ -73,7 +76,7 @@ using namespace tgt;
 extern "C" {
 
 const char* tgt_last_error(void) { return g_err; }
-int tgt_abi_version(void) { return 20; }
+int tgt_abi_version(void) { return 21; }
 
 int tgt_triplet_attention_fwd(const tgt_triplet_attention_args* a, void* stream) {
     return triplet_attention_run(a, false, reinterpret_cast<hipStream_t>(stream));
@@ -190,6 +193,17 @@ int tgt_pack_triu(const void* bins, int32_t elem_size, int32_t B, int32_t S, int
 int tgt_bins_to_dist(const void* bins, int32_t kind, int64_t R, int32_t N, const int64_t* num_nodes, int32_t S, float bin_size,
                      int32_t shift_half, int32_t zero_diag, float* out, void* stream) {
     return bins_to_dist_run(bins, kind, R, N, num_nodes, S, bin_size, shift_half, zero_diag, out, reinterpret_cast<hipStream_t>(stream));
+}
+
+int tgt_gaussian_basis_parts(int64_t pairs) { return gaussian_parts(pairs); }
+int tgt_gaussian_basis_fwd(const float* x, const float* mul, const float* bias, const float* mean, const float* std, int64_t pairs,
+                           int32_t K, int32_t dtype, void* y, void* stream) {
+    return gaussian_run(x, mul, bias, mean, std, pairs, K, dtype, y, nullptr, nullptr, nullptr, reinterpret_cast<hipStream_t>(stream));
+}
+int tgt_gaussian_basis_bwd(const float* x, const float* mul, const float* bias, const float* mean, const float* std, int64_t pairs,
+                           int32_t K, int32_t dtype, const void* g, float* dt, float* partial, void* stream) {
+    if (!g) return set_error(TGT_ERR_INVALID, "gaussian basis bwd: null gradient");
+    return gaussian_run(x, mul, bias, mean, std, pairs, K, dtype, nullptr, g, dt, partial, reinterpret_cast<hipStream_t>(stream));
 }
 
 int tgt_edge_linear_supported(const tgt_edge_linear_args* a) { return edge_linear_supported(a); }

@@ -1464,3 +1464,46 @@ def cross_entropy_rows(logits, target):
     """F.cross_entropy(logits, target, reduction='none') for (rows, C) logits in their storage dtype ->
     float32 (rows,), without an fp32 image of the logits (reference commons.py:36-38)."""
     return _CrossEntropyRows.apply(logits, target)
+
+
+# ---------------------------------------------------------------------------
+# Gaussian basis of the 3-D distance embedding (reference lib/models/pcqm/layers.py:129-157)
+# ---------------------------------------------------------------------------
+class _GaussianBasis(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mul, bias, means, stds, out_dtype):
+        _dev(x, mul, bias, means, stds)
+        K = means.numel()
+        xf, mf, bf = (t.detach().reshape(-1).float().contiguous() for t in (x, mul, bias))
+        mw, sw = means.detach().reshape(-1).float().contiguous(), stds.detach().reshape(-1).float().contiguous()
+        y = torch.empty(*x.shape, K, dtype=out_dtype, device=x.device)
+        _lib.check(_lib.lib().tgt_gaussian_basis_fwd(_ptr(xf), _ptr(mf), _ptr(bf), _ptr(mw), _ptr(sw), xf.numel(), K, _DT[out_dtype],
+                                                     _ptr(y), _stream()), 'tgt_gaussian_basis_fwd')
+        ctx.save_for_backward(xf, mf, bf, mw, sw)
+        ctx.meta = (x.shape, mul.shape, bias.shape, means.shape, stds.shape, means.dtype, out_dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        xf, mf, bf, mw, sw = ctx.saved_tensors
+        xs, ms, bs, mws, sws, pdt, out_dtype = ctx.meta
+        K, pairs = mw.numel(), xf.numel()
+        g = g.contiguous()
+        if g.dtype != out_dtype:
+            g = g.to(out_dtype)
+        L = _lib.lib()
+        dt = torch.empty(pairs, dtype=torch.float32, device=g.device)
+        partial = torch.empty(L.tgt_gaussian_basis_parts(pairs), 2 * K, dtype=torch.float32, device=g.device)
+        _lib.check(L.tgt_gaussian_basis_bwd(_ptr(xf), _ptr(mf), _ptr(bf), _ptr(mw), _ptr(sw), pairs, K, _DT[out_dtype], _ptr(g), _ptr(dt),
+                                            _ptr(partial), _stream()), 'tgt_gaussian_basis_bwd')
+        dms = sum_rows(partial)
+        dx = (dt * mf).view(xs) if ctx.needs_input_grad[0] else None
+        return dx, (dt * xf).view(ms), dt.view(bs), dms[:K].view(mws).to(pdt), dms[K:].view(sws).to(pdt), None
+
+
+def gaussian_basis(x, mul, bias, means, stds):
+    """y[..., k] = exp(-((mul*x + bias - means[k]) / (|stds[k]| + 0.01))^2 / 2) / ((2*3.14159)^0.5 (|stds[k]| + 0.01)); x, mul, bias
+    broadcast-free tensors of one shape (mul / bias may carry a trailing 1).  One HIP pass each way; the result comes out
+    in the autocast dtype when autocast is on (the reference's float32 result is cast to it by the Linear that follows)."""
+    cd = torch.get_autocast_dtype('cuda') if (x.is_cuda and torch.is_autocast_enabled('cuda')) else means.dtype
+    return _GaussianBasis.apply(x, mul, bias, means, stds, cd)
