@@ -521,6 +521,9 @@ __global__ void __launch_bounds__(HG * 64, OCC) __attribute__((amdgpu_waves_per_
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
+#ifndef TGT_NT2_OCC
+#define TGT_NT2_OCC 1      // measured: capping the two-tile backward at 256 registers (2 waves per SIMD) spills -- 7.0 ms against 1.6 ms
+#endif
 template <typename T, int D, int HG, int NT>
 static int launch_tri_nt(const tgt_triplet_attention_args& a, bool bwd, hipStream_t st) {
     using G = TriGeo<T, D, HG>;
@@ -565,11 +568,13 @@ static int launch_tri_nt(const tgt_triplet_attention_args& a, bool bwd, hipStrea
                 hipLaunchKernelGGL((tri_att_bwd_kernel<T, D, HG, NT, kOcc, false, -1, false>), dim3(grid),
                                    dim3(G::kThreads), kBwdLds, st, a);
         } else {
+            // two node tiles (N in 33..64): TGT_NT2_OCC waves per SIMD (register cap 512 / TGT_NT2_OCC)
+            constexpr int kOcc2 = NT == 2 ? TGT_NT2_OCC : 1;
             if (cs)
-                hipLaunchKernelGGL((tri_att_bwd_kernel<T, D, HG, NT, 1, true, -1, false>), dim3(grid), dim3(G::kThreads),
+                hipLaunchKernelGGL((tri_att_bwd_kernel<T, D, HG, NT, kOcc2, true, -1, false>), dim3(grid), dim3(G::kThreads),
                                    kBwdLds + kCs, st, a);
             else
-                hipLaunchKernelGGL((tri_att_bwd_kernel<T, D, HG, NT, 1, false, -1, false>), dim3(grid), dim3(G::kThreads),
+                hipLaunchKernelGGL((tri_att_bwd_kernel<T, D, HG, NT, kOcc2, false, -1, false>), dim3(grid), dim3(G::kThreads),
                                    kBwdLds, st, a);
         }
     }
