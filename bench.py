@@ -294,10 +294,17 @@ def main():
                 cand[name] = (sum(times[name]), avg_ms, algorithmic_bytes(kind, args.batch, args.nodes, C, Ht, esz))
         # HBM bytes per launch from the PMC passes (collected offline with rocprofv3 --pmc, see
         # profiles/README.md); only valid for the shape they were measured at
-        traffic = {}
+        traffic, pmc = {}, {}
         tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-        if os.path.exists(tpath) and args.batch == 256 and args.nodes == 32 and args.precision == 'bf16':
-            traffic = json.load(open(tpath))
+        ppath = os.path.join(ROOT, 'profiles', 'r02e_pmc_summary.json')      # tools/pmc_passes.sh: SQ / FETCH / WRITE passes
+        if args.batch == 256 and args.nodes == 32 and args.precision == 'bf16':
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath))
+            if os.path.exists(ppath):
+                pmc = json.load(open(ppath))
+                for short, name in (('tri_att_fwd_kernel', 'tgt_triplet_attention_fwd'), ('tri_att_bwd_kernel', 'tgt_triplet_attention_bwd')):
+                    if short in pmc and 'hbm_bytes_per_launch' in pmc[short]:
+                        traffic[name] = dict(traffic_bytes=pmc[short]['hbm_bytes_per_launch'])
         roofline = None
         if cand:
             name = max(cand, key=lambda k: cand[k][0])
@@ -308,6 +315,9 @@ def main():
                             avg_launch_ms=round(avg_ms, 4), launches=len(times[name]),
                             algorithmic_bytes_per_launch=nbytes,
                             share_of_step=round(tot / (dt * 1e3), 4),
+                            # matrix-core utilisation of this kernel from the SQ counter pass (offline, same shape):
+                            # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs); an HBM-bound core at 15.5 FLOP/B
+                            mfma_util=pmc.get('tri_att_bwd_kernel' if name.endswith('bwd') else 'tri_att_fwd_kernel', {}).get('mfma_util'),
                             other_kernels={k: dict(avg_launch_ms=round(v[1], 4),
                                                    achieved=round(v[2] / (v[1] * 1e-3) / 1e9, 1))
                                            for k, v in cand.items() if k != name})
@@ -317,7 +327,12 @@ def main():
                     avg = sum(times[kname]) / len(times[kname])
                     nb = node_algorithmic_bytes(kind, args.batch, args.nodes, mcfg['node_width'], mcfg['num_heads'], esz)
                     roofline['other_kernels'][kname] = dict(avg_launch_ms=round(avg, 4),
-                                                            achieved=round(nb / (avg * 1e-3) / 1e9, 1))
+                                                            achieved=round(nb / (avg * 1e-3) / 1e9, 1),
+                                                            frac=round(nb / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+                    shorts = ('node_att_fwd_lds_kernel',) if kind == 'fwd' else ('node_att_bwd_row_kernel', 'node_att_bwd_col_kernel')
+                    if all(k in pmc and 'hbm_bytes_per_launch' in pmc[k] for k in shorts):
+                        roofline['other_kernels'][kname]['traffic'] = sum(pmc[k]['hbm_bytes_per_launch'] for k in shorts)
+                        roofline['other_kernels'][kname]['algorithmic_bytes_per_launch'] = nb
         out = dict(
             metric='graphs/sec training step, TGT-At 24L PCQM batch 256, 1/2/4/8 MI355X',
             value=round(args.batch * world * args.steps / dt, 2), unit='graphs/s',
