@@ -365,6 +365,8 @@ NODE_CASES = [  # B, N, num_nodes, W, H
     (3, 32, [32, 17, 32], 768, 64),
     (2, 7, [7, 2], 96, 12),       # H not a power of two
     (1, 40, [33], 64, 8),         # N > 32
+    (2, 9, [9, 5], 128, 16),      # D = 8: matrix-core kernels both ways (16-bit)
+    (2, 12, [12, 7], 256, 16),    # D = 16: matrix-core forward, lane-per-head backward
 ]
 
 

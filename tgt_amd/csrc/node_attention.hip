@@ -677,6 +677,10 @@ static int dispatch_node_d(const tgt_node_attention_args& a, bool bwd, hipStream
     }
 }
 
+// matrix-core kernels for the 16-bit hot shapes (node_attention_mfma.hip)
+bool node_attention_mfma_eligible(const tgt_node_attention_args& a, bool bwd);
+int node_attention_mfma_run(const tgt_node_attention_args& a, bool bwd, hipStream_t st);
+
 int node_attention_run(const tgt_node_attention_args* a, bool bwd, hipStream_t st) {
     if (!a) return set_error(TGT_ERR_INVALID, "node attention: null args");
     if (a->B < 0 || a->N < 0 || a->H <= 0) return set_error(TGT_ERR_INVALID, "node attention: bad sizes B=%d N=%d H=%d", a->B, a->N, a->H);
@@ -698,6 +702,7 @@ int node_attention_run(const tgt_node_attention_args* a, bool bwd, hipStream_t s
         if (!a->d_qkv || !a->d_eg) return set_error(TGT_ERR_INVALID, "node attention bwd: null d_qkv/d_eg");
         if (!a->logits_only && !a->d_vatt) return set_error(TGT_ERR_INVALID, "node attention bwd: null d_vatt");
     }
+    if (node_attention_mfma_eligible(*a, bwd)) return node_attention_mfma_run(*a, bwd, st);
     switch (a->dtype) {
         case TGT_F32: return dispatch_node_d<float>(*a, bwd, st);
         case TGT_BF16: return dispatch_node_d<bf16_t>(*a, bwd, st);
