@@ -181,10 +181,13 @@ def build_library(force=False, verbose=False):
         cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-save-temps=obj', *flags, '-c', s, '-o', o]
         procs.append((cmd, d, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     undefined = {}
+    failed = None
     for cmd, d, p in procs:
         out, _ = p.communicate()
         if p.returncode:
-            raise RuntimeError('hipcc failed: ' + ' '.join(cmd) + '\n' + out.decode(errors='replace'))
+            failed = failed or ('hipcc failed: ' + ' '.join(cmd) + '\n' + out.decode(errors='replace'))
+            shutil.rmtree(d, ignore_errors=True)        # (no stale object, no temporaries left behind)
+            continue
         if verbose and out:
             print(out.decode(errors='replace'))
         # the shipped ISA is linted for registers read but never written (a hipcc spill miscompile this
@@ -197,6 +200,8 @@ def build_library(force=False, verbose=False):
                         undefined[f'{os.path.basename(d)}:{k}'] = regs
             if f != 'unit.o' and not (f.endswith('-gfx950.s') and os.environ.get('TGT_KEEP_ISA')):
                 os.remove(path)
+    if failed:
+        raise RuntimeError(failed)
     if undefined:
         raise RuntimeError('hipcc produced kernels that read vector registers no instruction writes (miscompiled spill?):\n' +
                            '\n'.join(f'  {k}: {v}' for k, v in undefined.items()))

@@ -103,16 +103,6 @@ __device__ __forceinline__ Unit unit_of_block(const tgt_node_attention_args& a) 
     return Unit{u / groups, u % groups};
 }
 
-// Every workgroup runs load -> tile math -> store with nothing of its own overlapping, and workgroups that start
-// together stay in step (the whole chip loads, then computes, then stores: the three phases simply add up).  Holding
-// back every other workgroup of the FIRST round by about half a unit's time de-phases them for the rest of the launch
-// (a successor starts when its predecessor's LDS is free): bits 8.. of the knob = number of ~3.4 us sleeps.
-__device__ __forceinline__ void dephase(int knob) {
-    const int loops = (knob >> 8) & 0xff;
-    if (loops && blockIdx.x < 512 && ((blockIdx.x >> 3) & 1))
-        for (int i = 0; i < loops; ++i) __builtin_amdgcn_s_sleep(127);
-}
-
 // ---- cooperative staging (whole workgroup) ---------------------------------------------------
 // Pair tensors (B,N,N,ld): a pair's record is SUBS 16-byte pieces; chunk c = it * threads + tid is piece
 // c % SUBS of pair c / SUBS, so a thread keeps its key m and piece and walks the queries l = l0 + it * kLStep.
@@ -293,7 +283,6 @@ __global__ void __launch_bounds__(HG * 64, 4) node_att_mfma_fwd_kernel(const tgt
     const int tid = threadIdx.x, lane = tid & 63, hh = tid >> 6, r = lane & 31, hi = lane >> 5;
     const Unit u = unit_of_block<HG>(a);
     const int N = a.N, H = a.H, h = u.hg * HG + hh;
-    dephase(ablate);
     char* rQ = lds + L::off_n(D, false, 0);
     char* rK = lds + L::off_n(D, false, 1);
     char* rV = lds + L::off_n(D, false, 2);
@@ -383,7 +372,6 @@ __global__ void __launch_bounds__(HG * 64, 4) node_att_mfma_bwd_kernel(const tgt
     const int tid = threadIdx.x, lane = tid & 63, hh = tid >> 6, r = lane & 31, hi = lane >> 5;
     const Unit u = unit_of_block<HG>(a);
     const int H = a.H;
-    dephase(ablate);
     char* rQ = lds + L::off_n(D, true, 0);
     char* rK = lds + L::off_n(D, true, 1);
     char* rV = lds + L::off_n(D, true, 2);

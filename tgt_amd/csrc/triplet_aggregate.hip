@@ -18,7 +18,6 @@ namespace tgt {
 
 struct AggCtx {
     int b, dir, g, h, N;
-    SlabSrc v;        // rows k of V[j,k] (inward) / V[k,j] (outward)
     ThirdArm ta;
 };
 
@@ -33,15 +32,26 @@ __device__ __forceinline__ AggCtx agg_ctx(const tgt_triplet_aggregate_args& a, i
     c.b = bid >> 1;
     c.h = c.g * HG + wave;
     c.N = a.N;
-    const int64_t N = a.N, ld = a.ld_v[c.dir], sz = sizeof(T);
-    const char* base = reinterpret_cast<const char*>(a.v[c.dir]) +
-                       ((int64_t)c.b * N * N * ld + a.v_off[c.dir] + c.g * HG * D) * sz;
-    if (c.dir == 0) c.v = {base, ld * sz, N * ld * sz};
-    else            c.v = {base, N * ld * sz, ld * sz};
     const bool use_mask = c.dir == 0 || (a.flags & TGT_TRI_MASK_OUT);
     c.ta = ThirdArm{a.eg[c.dir], a.ld_eg[c.dir], a.e_off[c.dir], a.g_off[c.dir], use_mask ? a.mask : nullptr,
                     true, (a.flags & TGT_TRI_GATED) != 0};
     return c;
+}
+
+// buffer-addressed slabs (triplet_common.hpp): rows k of V[j,k] (inward) / V[k,j] (outward) of this head group
+template <typename T, int D, int HG>
+__device__ __forceinline__ SlabBuf agg_v_slab(const void* tensor, int64_t ld, int off, const AggCtx& c) {
+    const int64_t sz = sizeof(T), N = c.N;
+    const uint32_t ldb = (uint32_t)(ld * sz);
+    return SlabBuf{graph_rsrc(tensor, N * N * ld * sz, c.b), (uint32_t)((off + c.g * HG * D) * sz),
+                   c.dir == 0 ? ldb : (uint32_t)N * ldb, c.dir == 0 ? (uint32_t)N * ldb : ldb};
+}
+// rows i of X[i,j] (the aggregate's output and its gradient)
+template <typename T, int D, int HG>
+__device__ __forceinline__ SlabBuf agg_o_slab(const void* tensor, int64_t ld, int off, const AggCtx& c) {
+    const int64_t sz = sizeof(T), N = c.N;
+    const uint32_t ldb = (uint32_t)(ld * sz);
+    return SlabBuf{graph_rsrc(tensor, N * N * ld * sz, c.b), (uint32_t)((off + c.g * HG * D) * sz), (uint32_t)N * ldb, ldb};
 }
 
 // weights of query tile it / key tile kt in (lane = i) layout: softmax over ALL key tiles
@@ -83,9 +93,10 @@ __global__ void __launch_bounds__(HG * 64) tri_agg_fwd_kernel(const tgt_triplet_
     using G = TriGeo<T, D, HG>;
     using F = frag_t<T>;
     constexpr int KR = 32 * NT;
+    // two LDS sets {V | O}: set j&1 is computed on while slab j+1 lands in the other one -> ONE barrier per j
+    // (hazards as in triplet_attention.hip)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sV = smem;
-    char* sOut = smem + NT * G::kSlabBytes;
+    constexpr int kSet = (NT + 1) * G::kSlabBytes;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hi = lane >> 5;
     const AggCtx c = agg_ctx<T, D, HG>(a, wave);
@@ -94,9 +105,8 @@ __global__ void __launch_bounds__(HG * 64) tri_agg_fwd_kernel(const tgt_triplet_
     make_ident_d<T, G::kDC>(ident_d, r, hi);
     const TriDrop drop = tri_drop(a.dropout_p, a.dropout_seed);
     const uint32_t drop_unit = (uint32_t)((c.b * 2 + c.dir) * a.H + c.h);
-    const int64_t sz = sizeof(T);
-    char* obase = reinterpret_cast<char*>(a.out) + ((int64_t)c.b * N * N * a.ld_out + a.o_off[c.dir] + c.g * HG * D) * sz;
-    const int64_t o_row = (int64_t)N * a.ld_out * sz, o_j = a.ld_out * sz;
+    const SlabBuf bV = agg_v_slab<T, D, HG>(a.v[c.dir], a.ld_v[c.dir], a.v_off[c.dir], c);
+    const SlabBuf bO = agg_o_slab<T, D, HG>(a.out, a.ld_out, a.o_off[c.dir], c);
 
     for (int it = 0; it < NT; ++it) {
         const int i0 = 32 * it;
@@ -120,11 +130,15 @@ __global__ void __launch_bounds__(HG * 64) tri_agg_fwd_kernel(const tgt_triplet_
             }
         }
         uint4 pv[SlabIO<G, KR>::kIters];
-        slab_issue<G, KR>(pv, c.v, 0, 0, N, tid);
-        slab_commit<G, KR>(pv, sV, tid);
+        slab_issue<G, KR>(pv, bV, 0, 0, N, tid);
+        slab_commit<G, KR>(pv, smem, tid);
+        if (N > 1) slab_issue<G, KR>(pv, bV, 1, 0, N, tid);
         __syncthreads();
         for (int j = 0; j < N; ++j) {
-            if (j + 1 < N) slab_issue<G, KR>(pv, c.v, j + 1, 0, N, tid);
+            char* sV = smem + (j & 1) * kSet;
+            char* sOut = sV + NT * G::kSlabBytes;
+            if (j + 1 < N) slab_commit<G, KR>(pv, smem + ((j + 1) & 1) * kSet, tid);
+            if (j + 2 < N) slab_issue<G, KR>(pv, bV, j + 2, 0, N, tid);
             f32x16 o = {0};
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt) {
@@ -138,10 +152,9 @@ __global__ void __launch_bounds__(HG * 64) tri_agg_fwd_kernel(const tgt_triplet_
             }
             write_rows<T, D, HG>(sOut, o, wave, r, hi);
             __syncthreads();
-            slab_store<G, 32>(sOut, obase, o_row, o_j, j, i0, N, tid);
-            if (j + 1 < N) slab_commit<G, KR>(pv, sV, tid);
-            __syncthreads();
+            slab_store<G, 32>(sOut, bO, j, i0, N, tid);
         }
+        __syncthreads();      // the next query-tile pass re-fills the stage and both sets
     }
 }
 
@@ -151,8 +164,7 @@ __global__ void __launch_bounds__(HG * 64) tri_agg_bwd_kernel(const tgt_triplet_
     using F = frag_t<T>;
     constexpr int KR = 32 * NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sO = smem;
-    char* sV = smem + G::kSlabBytes;
+    constexpr int kSet = (NT + 1) * G::kSlabBytes;        // {dO | V}, two sets (see forward)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hi = lane >> 5;
     const AggCtx c = agg_ctx<T, D, HG>(a, wave);
@@ -162,12 +174,9 @@ __global__ void __launch_bounds__(HG * 64) tri_agg_bwd_kernel(const tgt_triplet_
     make_ident_d<T, G::kDC>(ident_d, r, hi);
     const TriDrop drop = tri_drop(a.dropout_p, a.dropout_seed);
     const uint32_t drop_unit = (uint32_t)((c.b * 2 + c.dir) * a.H + c.h);
-    const int64_t sz = sizeof(T), Nl = N;
-    const SlabSrc dO = {reinterpret_cast<const char*>(a.d_out) +
-                            ((int64_t)c.b * Nl * Nl * a.ld_out + a.o_off[c.dir] + c.g * HG * D) * sz,
-                        Nl * a.ld_out * sz, a.ld_out * sz};
-    const int64_t shift = reinterpret_cast<const char*>(a.d_v[c.dir]) - reinterpret_cast<const char*>(a.v[c.dir]);
-    const SlabSrc dV = {c.v.base + shift, c.v.row_stride, c.v.j_stride};
+    const SlabBuf bV = agg_v_slab<T, D, HG>(a.v[c.dir], a.ld_v[c.dir], a.v_off[c.dir], c);
+    const SlabBuf dV = agg_v_slab<T, D, HG>(a.d_v[c.dir], a.ld_v[c.dir], a.v_off[c.dir], c);      // d_v mirrors v
+    const SlabBuf dO = agg_o_slab<T, D, HG>(a.d_out, a.ld_out, a.o_off[c.dir], c);
 
     for (int it = 0; it < NT; ++it) {
         const int i0 = 32 * it;
@@ -202,27 +211,31 @@ __global__ void __launch_bounds__(HG * 64) tri_agg_bwd_kernel(const tgt_triplet_
             for (int q = 0; q < 16; ++q) dacc[kt][q] = 0.f;
 
         uint4 pv[SlabIO<G, KR>::kIters], po[SlabIO<G, 32>::kIters];
-        uint4 prv[NT > 1 ? SlabIO<G, KR>::kIters : 1];
-        slab_issue<G, KR>(pv, c.v, 0, 0, N, tid);
         slab_issue<G, 32>(po, dO, 0, i0, N, tid);
-        if constexpr (NT > 1) {
-            if (it > 0) slab_issue<G, KR>(prv, dV, 0, 0, N, tid);
+        slab_issue<G, KR>(pv, bV, 0, 0, N, tid);
+        slab_commit<G, 32>(po, smem, tid);
+        slab_commit<G, KR>(pv, smem + G::kSlabBytes, tid);
+        if (N > 1) {
+            slab_issue<G, 32>(po, dO, 1, i0, N, tid);
+            slab_issue<G, KR>(pv, bV, 1, 0, N, tid);
         }
-        slab_commit<G, KR>(pv, sV, tid);
-        slab_commit<G, 32>(po, sO, tid);
         __syncthreads();
         for (int j = 0; j < N; ++j) {
+            char* sO = smem + (j & 1) * kSet;
+            char* sV = sO + G::kSlabBytes;
+            if (j + 1 < N) {
+                char* nO = smem + ((j + 1) & 1) * kSet;
+                slab_commit<G, 32>(po, nO, tid);
+                slab_commit<G, KR>(pv, nO + G::kSlabBytes, tid);
+            }
+            if (j + 2 < N) {
+                slab_issue<G, 32>(po, dO, j + 2, i0, N, tid);
+                slab_issue<G, KR>(pv, bV, j + 2, 0, N, tid);
+            }
+            // partial dV the previous query-tile pass stored for THIS j (added at the store below)
             uint4 curv[NT > 1 ? SlabIO<G, KR>::kIters : 1];
             if constexpr (NT > 1) {
-#pragma unroll
-                for (int x = 0; x < SlabIO<G, KR>::kIters; ++x) curv[x] = prv[x];
-            }
-            if (j + 1 < N) {
-                slab_issue<G, KR>(pv, c.v, j + 1, 0, N, tid);
-                slab_issue<G, 32>(po, dO, j + 1, i0, N, tid);
-                if constexpr (NT > 1) {
-                    if (it > 0) slab_issue<G, KR>(prv, dV, j + 1, 0, N, tid);
-                }
+                if (it > 0) slab_issue<G, KR>(curv, dV, j, 0, N, tid);
             }
             F fo[G::kDC];
             read_frags<T, D, HG>(fo, sO, wave, r, hi);
@@ -239,6 +252,7 @@ __global__ void __launch_bounds__(HG * 64) tri_agg_bwd_kernel(const tgt_triplet_
                 f32x16 dv = {0};
 #pragma unroll
                 for (int cc = 0; cc < 2; ++cc) dv = mma32(oTf[cc], a2f[kt][cc], dv);
+                // (in place: this wave only reads its own columns, and only of rows it has not overwritten yet)
                 write_rows<T, D, HG>(sV, dv, wave, 32 * kt + r, hi);
             }
             __syncthreads();
@@ -246,16 +260,12 @@ __global__ void __launch_bounds__(HG * 64) tri_agg_bwd_kernel(const tgt_triplet_
             if constexpr (NT > 1) {
                 if (it > 0) {
                     plain = false;
-                    slab_store_add<G, KR, T>(sV, curv, const_cast<char*>(dV.base), dV.row_stride, dV.j_stride, j, 0, N, tid);
+                    slab_store_add<G, KR, T>(sV, curv, dV, j, 0, N, tid);
                 }
             }
-            if (plain) slab_store<G, KR>(sV, const_cast<char*>(dV.base), dV.row_stride, dV.j_stride, j, 0, N, tid);
-            if (j + 1 < N) {
-                slab_commit<G, KR>(pv, sV, tid);
-                slab_commit<G, 32>(po, sO, tid);
-            }
-            __syncthreads();
+            if (plain) slab_store<G, KR>(sV, dV, j, 0, N, tid);
         }
+        __syncthreads();      // the stage below aliases both sets
 
         // softmax*gate backward on the accumulated dA (recompute P, g)
         float p[NT][16], gate[NT][16];
@@ -297,7 +307,7 @@ static int launch_agg_nt(const tgt_triplet_aggregate_args& a, bool bwd, hipStrea
     using G = TriGeo<T, D, HG>;
     const int grid = a.B * 2 * (a.H / HG);
     constexpr int kArm = ArmStage<T, HG, NT>::kBytes;
-    constexpr int kLds = (NT + 1) * G::kSlabBytes > kArm ? (NT + 1) * G::kSlabBytes : kArm;
+    constexpr int kLds = 2 * (NT + 1) * G::kSlabBytes > kArm ? 2 * (NT + 1) * G::kSlabBytes : kArm;
     if (!bwd) hipLaunchKernelGGL((tri_agg_fwd_kernel<T, D, HG, NT>), dim3(grid), dim3(G::kThreads), kLds, st, a);
     else      hipLaunchKernelGGL((tri_agg_bwd_kernel<T, D, HG, NT>), dim3(grid), dim3(G::kThreads), kLds, st, a);
     return check_launch(bwd ? "tri_agg_bwd_kernel" : "tri_agg_fwd_kernel");

@@ -106,9 +106,14 @@ __device__ __forceinline__ void proj_walk(const tgt_triplet_attention_args& a, c
     F ident_k[2];
     make_ident_k<T>(ident_k, r, hi);
 
-    const int64_t sz = sizeof(T);
-    char* obase = reinterpret_cast<char*>(a.out) + ((int64_t)c.b * N * N * a.ld_out + a.o_off[DIR] + c.g * HG * D) * sz;
-    const int64_t o_row = (int64_t)N * a.ld_out * sz, o_j = a.ld_out * sz;
+    // buffer-addressed result slabs (triplet_common.hpp): Q rows (i,j); K / V partner rows (j,k) inward, (k,j) outward
+    const int64_t sz = sizeof(T), Nl = N;
+    const uint32_t hch = (uint32_t)(c.g * HG * D * sz), lds_ = (uint32_t)(a.ld_qkv[DIR] * sz), ldo_ = (uint32_t)(a.ld_out * sz);
+    const __amdgpu_buffer_rsrc_t r_dst = graph_rsrc(a.qkv[DIR], Nl * Nl * a.ld_qkv[DIR] * sz, c.b);
+    const SlabBuf bQ = {r_dst, (uint32_t)(a.q_off[DIR] * sz) + hch, (uint32_t)N * lds_, lds_};
+    const SlabBuf bK = {r_dst, (uint32_t)(a.k_off[DIR] * sz) + hch, DIR == 0 ? lds_ : (uint32_t)N * lds_, DIR == 0 ? (uint32_t)N * lds_ : lds_};
+    const SlabBuf bV = {r_dst, (uint32_t)(a.v_off[DIR] * sz) + hch, bK.row_stride, bK.j_stride};
+    const SlabBuf bO = {graph_rsrc(a.out, Nl * Nl * a.ld_out * sz, c.b), (uint32_t)(a.o_off[DIR] * sz) + hch, (uint32_t)N * ldo_, ldo_};
 
     float biasM[16], gate[16];
     arm_stage_load<T, HG, 1>(ta, c.b, DIR, c.g, N, 0, smem, tid);
@@ -183,10 +188,10 @@ __device__ __forceinline__ void proj_walk(const tgt_triplet_attention_args& a, c
         for (int cc = 0; cc < 2; ++cc) o = mma32(pack_chunk<T>(vt, cc), pack_chunk<T>(st, cc), o);   // O^T[d][i]
         write_rows<T, D, HG>(sO, o, wave, r, hi);
         __syncthreads();
-        slab_store<G, 32>(sQ, const_cast<char*>(c.q.base), c.q.row_stride, c.q.j_stride, j, 0, N, tid);
-        slab_store<G, 32>(sK, const_cast<char*>(c.k.base), c.k.row_stride, c.k.j_stride, j, 0, N, tid);
-        slab_store<G, 32>(sV, const_cast<char*>(c.v.base), c.v.row_stride, c.v.j_stride, j, 0, N, tid);
-        slab_store<G, 32>(sO, obase, o_row, o_j, j, 0, N, tid);
+        slab_store<G, 32>(sQ, bQ, j, 0, N, tid);
+        slab_store<G, 32>(sK, bK, j, 0, N, tid);
+        slab_store<G, 32>(sV, bV, j, 0, N, tid);
+        slab_store<G, 32>(sO, bO, j, 0, N, tid);
     }
 }
 

@@ -33,12 +33,6 @@ struct TriGeo {
     }
 };
 
-struct SlabSrc {
-    const char* base;      // points at (b, row 0, j 0, this group's first channel)
-    int64_t row_stride;    // bytes between consecutive slab rows
-    int64_t j_stride;      // bytes between consecutive j
-};
-
 // Slab staging.  ROWS = rows of the slab (32 per node tile); slab row `row`
 // is global row `row0 + row` (rows >= N are zero-filled / not stored).
 template <typename G, int ROWS>
@@ -48,19 +42,6 @@ struct SlabIO {
 };
 
 template <typename G, int ROWS, int IT = SlabIO<G, ROWS>::kIters>
-__device__ __forceinline__ void slab_issue(uint4 (&pre)[IT], const SlabSrc& s, int j,
-                                           int row0, int N, int tid) {
-#pragma unroll
-    for (int it = 0; it < SlabIO<G, ROWS>::kIters; ++it) {
-        const int c = it * G::kThreads + tid;
-        const int row = c / G::kSlots, slot = c % G::kSlots;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (c < SlabIO<G, ROWS>::kChunks && row0 + row < N)
-            v = *reinterpret_cast<const uint4*>(s.base + j * s.j_stride + (row0 + row) * s.row_stride + slot * 16);
-        pre[it] = v;
-    }
-}
-template <typename G, int ROWS, int IT = SlabIO<G, ROWS>::kIters>
 __device__ __forceinline__ void slab_commit(const uint4 (&pre)[IT], char* slab, int tid) {
 #pragma unroll
     for (int it = 0; it < SlabIO<G, ROWS>::kIters; ++it) {
@@ -69,87 +50,10 @@ __device__ __forceinline__ void slab_commit(const uint4 (&pre)[IT], char* slab, 
         if (c < SlabIO<G, ROWS>::kChunks) *reinterpret_cast<uint4*>(slab + G::lds_off(row, slot)) = pre[it];
     }
 }
-template <typename G, int ROWS>
-__device__ __forceinline__ void slab_store(const char* slab, char* dst_base, int64_t row_stride, int64_t j_stride,
-                                           int j, int row0, int N, int tid) {
-#pragma unroll
-    for (int it = 0; it < SlabIO<G, ROWS>::kIters; ++it) {
-        const int c = it * G::kThreads + tid;
-        const int row = c / G::kSlots, slot = c % G::kSlots;
-        if (c < SlabIO<G, ROWS>::kChunks && row0 + row < N)
-            *reinterpret_cast<uint4*>(dst_base + j * j_stride + (row0 + row) * row_stride + slot * 16) =
-                *reinterpret_cast<const uint4*>(slab + G::lds_off(row, slot));
-    }
-}
-// store slab + prior (element-wise in T): the second node-tile pass of the
-// backward adds its partial dK/dV to what the first pass stored.
-template <typename G, int ROWS, typename T, int IT = SlabIO<G, ROWS>::kIters>
-__device__ __forceinline__ void slab_store_add(const char* slab, const uint4 (&prior)[IT],
-                                               char* dst_base, int64_t row_stride, int64_t j_stride, int j,
-                                               int row0, int N, int tid) {
-    constexpr int E = 16 / (int)sizeof(T);
-#pragma unroll
-    for (int it = 0; it < SlabIO<G, ROWS>::kIters; ++it) {
-        const int c = it * G::kThreads + tid;
-        const int row = c / G::kSlots, slot = c % G::kSlots;
-        if (c < SlabIO<G, ROWS>::kChunks && row0 + row < N) {
-            uint4 a = *reinterpret_cast<const uint4*>(slab + G::lds_off(row, slot)), b = prior[it], o;
-            T xa[E], xb[E];
-            __builtin_memcpy(xa, &a, 16);
-            __builtin_memcpy(xb, &b, 16);
-#pragma unroll
-            for (int t = 0; t < E; ++t) xa[t] = from_f32<T>(to_f32(xa[t]) + to_f32(xb[t]));
-            __builtin_memcpy(&o, xa, 16);
-            *reinterpret_cast<uint4*>(dst_base + j * j_stride + (row0 + row) * row_stride + slot * 16) = o;
-        }
-    }
-}
-
-// slab_store that also folds the stored values into column sums (the bias gradient of the
-// projection that produced the slab's tensor).  A thread always owns the same 16-byte column
-// chunk (slot = tid % kSlots), so it keeps E private fp32 accumulators -- in LDS, the register
-// file is full -- at cs[tid*E .. +E); the workgroup reduces them once at the end
-// (slab_colsum_finish).  Fixed order -> deterministic.  ADD: the stored value is slab + prior
-// (see slab_store_add) and only the increment is counted.
-template <typename G, int ROWS, typename T, bool ADD, int IT = SlabIO<G, ROWS>::kIters>
-__device__ __forceinline__ void slab_store_sum(const char* slab, const uint4 (&prior)[IT], char* dst_base,
-                                               int64_t row_stride, int64_t j_stride, int j, int row0, int N, int tid,
-                                               float* cs) {
-    constexpr int E = 16 / (int)sizeof(T);
-    static_assert(G::kThreads % G::kSlots == 0, "a thread must own one column chunk");
-    // (plain read-modify-write of this thread's own words: LDS float atomics were 5x slower)
-    float4* mine = reinterpret_cast<float4*>(cs + tid * E);
-    float acc[E];
-#pragma unroll
-    for (int t = 0; t < E / 4; ++t) *reinterpret_cast<float4*>(acc + 4 * t) = mine[t];
-#pragma unroll
-    for (int it = 0; it < SlabIO<G, ROWS>::kIters; ++it) {
-        const int c = it * G::kThreads + tid;
-        const int row = c / G::kSlots, slot = c % G::kSlots;
-        if (c < SlabIO<G, ROWS>::kChunks && row0 + row < N) {
-            uint4 a = *reinterpret_cast<const uint4*>(slab + G::lds_off(row, slot));
-            T xa[E];
-            __builtin_memcpy(xa, &a, 16);
-            if constexpr (ADD) {
-                T xb[E];
-                __builtin_memcpy(xb, &prior[it], 16);
-#pragma unroll
-                for (int t = 0; t < E; ++t) {
-                    const float old = to_f32(xb[t]);
-                    xa[t] = from_f32<T>(to_f32(xa[t]) + old);
-                    acc[t] += to_f32(xa[t]) - old;
-                }
-                __builtin_memcpy(&a, xa, 16);
-            } else {
-#pragma unroll
-                for (int t = 0; t < E; ++t) acc[t] += to_f32(xa[t]);
-            }
-            *reinterpret_cast<uint4*>(dst_base + j * j_stride + (row0 + row) * row_stride + slot * 16) = a;
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < E / 4; ++t) mine[t] = *reinterpret_cast<const float4*>(acc + 4 * t);
-}
+// Column sums folded into the slab stores (the bias gradient of the projection that produced the slab's
+// tensor): a thread always owns the same 16-byte column chunk (slot = tid % kSlots), so it keeps E private
+// fp32 accumulators -- in LDS, the register file is full -- at cs[tid*E .. +E); the workgroup reduces them
+// once at the end (slab_colsum_finish).  Fixed order -> deterministic.
 // floats of one accumulator plane (one of dQ/dK/dV): E per thread
 template <typename G, typename T> constexpr int slab_colsum_plane_floats() { return G::kThreads * (16 / (int)sizeof(T)); }
 // sum the per-thread accumulators of plane `cs` over the threads that share a slot and write the
@@ -553,7 +457,6 @@ __device__ __forceinline__ uint32_t tri_drop_bits(const TriDrop& d, uint32_t uni
 // ---------------------------------------------------------------------------
 struct TriCtx {
     int b, dir, g, h, N;
-    SlabSrc q, k, v;
 };
 
 template <typename T, int D, int HG>
@@ -567,16 +470,6 @@ __device__ __forceinline__ TriCtx tri_ctx(const tgt_triplet_attention_args& a, i
     c.b = bid >> 1;
     c.h = c.g * HG + wave;
     c.N = a.N;
-    const int64_t N = a.N, ld = a.ld_qkv[c.dir], sz = sizeof(T);
-    const char* base = reinterpret_cast<const char*>(a.qkv[c.dir]) + ((int64_t)c.b * N * N * ld + c.g * HG * D) * sz;
-    c.q = {base + (int64_t)a.q_off[c.dir] * sz, N * ld * sz, ld * sz};
-    if (c.dir == 0) {   // partner rows (j,k): contiguous rows of graph row j
-        c.k = {base + (int64_t)a.k_off[c.dir] * sz, ld * sz, N * ld * sz};
-        c.v = {base + (int64_t)a.v_off[c.dir] * sz, ld * sz, N * ld * sz};
-    } else {            // partner rows (k,j): column j
-        c.k = {base + (int64_t)a.k_off[c.dir] * sz, N * ld * sz, ld * sz};
-        c.v = {base + (int64_t)a.v_off[c.dir] * sz, N * ld * sz, ld * sz};
-    }
     return c;
 }
 
