@@ -93,22 +93,13 @@ __device__ __forceinline__ void buf_st16(__amdgpu_buffer_rsrc_t r, uint32_t off,
 }
 
 struct Unit { int b, hg; };
-template <int HG>
-__device__ __forceinline__ Unit unit_of_block(const tgt_node_attention_args& a) {
-    // consecutive units (the head groups of one graph) -> block indices 8 apart = the same XCD, dispatched
-    // back to back: the 128-byte E / G / dH rows they share are fetched from HBM once per XCD
-    const int groups = a.H / HG, total = a.B * groups;
-    int u = blockIdx.x;
-    if (total % 8 == 0) u = (u & 7) * (total >> 3) + (u >> 3);
-    return Unit{u / groups, u % groups};
-}
-
-// ---- cooperative staging (whole workgroup) ---------------------------------------------------
-// Pair tensors (B,N,N,ld): a pair's record is SUBS 16-byte pieces; chunk c = it * threads + tid is piece
+// ---- cooperative staging (NTHR threads) ---------------------------------------------------------
+// Pair tensors (B,N,N,ld): a pair's record is SUBS 16-byte pieces; chunk c = it * NTHR + tid is piece
 // c % SUBS of pair c / SUBS, so a thread keeps its key m and piece and walks the queries l = l0 + it * kLStep.
-template <int HG, int SUBS>
+template <int NTHR, int SUBS>
 struct PairMap {
-    static constexpr int kIters = 1024 * SUBS / (HG * 64), kLStep = HG * 64 / SUBS / 32;
+    static constexpr int kIters = 1024 * SUBS / NTHR, kLStep = NTHR / SUBS / 32;
+    static_assert(1024 * SUBS % NTHR == 0 && NTHR % (SUBS * 32) == 0, "pair chunks must tile the threads");
     int sub, m, l0;
     __device__ __forceinline__ explicit PairMap(int tid) : sub(tid % SUBS), m((tid / SUBS) & 31), l0(tid / SUBS / 32) {}
 };
@@ -118,34 +109,34 @@ __device__ __forceinline__ uint32_t eg_chan(const tgt_node_attention_args& a, co
     constexpr int kE = HG / 8;       // 16-byte pieces of E (8 heads each)
     return (uint32_t)(((sub < kE ? a.e_off + sub * 8 : a.g_off + (sub - kE) * 8) + u.hg * HG) * (int)sizeof(T));
 }
-template <typename T, int HG>
-__device__ __forceinline__ void stage_eg_issue(const tgt_node_attention_args& a, const Unit& u, int tid, uint4 (&v)[4]) {
-    using PM = PairMap<HG, HG / 4>;
-    static_assert(PM::kIters == 4, "E|G record: 4 chunks per thread");
+template <typename T, int HG, int NTHR = HG * 64>
+__device__ __forceinline__ void stage_eg_issue(const tgt_node_attention_args& a, const Unit& u, int tid,
+                                               uint4 (&v)[PairMap<NTHR, HG / 4>::kIters]) {
+    using PM = PairMap<NTHR, HG / 4>;
     const PM pm(tid);
     const int N = a.N;
     const __amdgpu_buffer_rsrc_t rs = graph_rsrc(a.eg, (int64_t)N * N * a.ld_eg * sizeof(T), u.b);
     const uint32_t ldb = (uint32_t)(a.ld_eg * sizeof(T));
     const uint32_t off0 = (uint32_t)(pm.l0 * N + pm.m) * ldb + eg_chan<T, HG>(a, u, pm.sub);
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < PM::kIters; ++it) {
         const bool ok = pm.m < N && pm.l0 + it * PM::kLStep < N;
         v[it] = buf_ld16(rs, ok ? off0 + (uint32_t)(it * PM::kLStep * N) * ldb : kOob);
     }
 }
-template <int HG>
-__device__ __forceinline__ void stage_eg_commit(char* lds, int tid, const uint4 (&v)[4]) {
-    using PM = PairMap<HG, HG / 4>;
+template <int HG, int NTHR = HG * 64>
+__device__ __forceinline__ void stage_eg_commit(char* lds, int tid, const uint4 (&v)[PairMap<NTHR, HG / 4>::kIters]) {
+    using PM = PairMap<NTHR, HG / 4>;
     using L = Lay<HG>;
     const PM pm(tid);
     const int rot = (tid >> 3) & 3;
     char* dst = lds + L::kOffEG + pm.l0 * L::kPitchEG + pm.m * L::kRecEG + pm.sub * 16;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) lds_put16(dst + it * PM::kLStep * L::kPitchEG, v[it], rot);
+    for (int it = 0; it < PM::kIters; ++it) lds_put16(dst + it * PM::kLStep * L::kPitchEG, v[it], rot);
 }
-template <typename T, int HG>
+template <typename T, int HG, int NTHR = HG * 64>
 __device__ __forceinline__ void unstage_eg(const char* lds, void* d_eg, const tgt_node_attention_args& a, const Unit& u, int tid) {
-    using PM = PairMap<HG, HG / 4>;
+    using PM = PairMap<NTHR, HG / 4>;
     using L = Lay<HG>;
     const PM pm(tid);
     const int N = a.N, rot = (tid >> 3) & 3;
@@ -154,41 +145,41 @@ __device__ __forceinline__ void unstage_eg(const char* lds, void* d_eg, const tg
     const uint32_t off0 = (uint32_t)(pm.l0 * N + pm.m) * ldb + eg_chan<T, HG>(a, u, pm.sub);
     const char* src = lds + L::kOffEG + pm.l0 * L::kPitchEG + pm.m * L::kRecEG + pm.sub * 16;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < PM::kIters; ++it) {
         const bool ok = pm.m < N && pm.l0 + it * PM::kLStep < N;
         buf_st16(rs, ok ? off0 + (uint32_t)(it * PM::kLStep * N) * ldb : kOob, lds_get16(src + it * PM::kLStep * L::kPitchEG, rot));
     }
 }
 // (B,N,N,H) tensors (H_hat, dH_hat): HG/8 pieces per pair
-template <typename T, int HG>
-__device__ __forceinline__ void stage_h_issue(const void* x, const tgt_node_attention_args& a, const Unit& u, int tid, uint4 (&v)[2]) {
-    using PM = PairMap<HG, HG / 8>;
-    static_assert(PM::kIters == 2, "dH record: 2 chunks per thread");
+template <typename T, int HG, int NTHR = HG * 64>
+__device__ __forceinline__ void stage_h_issue(const void* x, const tgt_node_attention_args& a, const Unit& u, int tid,
+                                              uint4 (&v)[PairMap<NTHR, HG / 8>::kIters]) {
+    using PM = PairMap<NTHR, HG / 8>;
     const PM pm(tid);
     const int N = a.N;
     const __amdgpu_buffer_rsrc_t rs = graph_rsrc(x, (int64_t)N * N * a.H * sizeof(T), u.b);
     const uint32_t ldb = (uint32_t)(a.H * sizeof(T));
     const uint32_t off0 = (uint32_t)(pm.l0 * N + pm.m) * ldb + (uint32_t)((u.hg * HG + pm.sub * 8) * (int)sizeof(T));
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < PM::kIters; ++it) {
         const bool ok = x && pm.m < N && pm.l0 + it * PM::kLStep < N;
         v[it] = buf_ld16(rs, ok ? off0 + (uint32_t)(it * PM::kLStep * N) * ldb : kOob);
     }
 }
-template <int HG>
-__device__ __forceinline__ void stage_h_commit(char* lds, int tid, const uint4 (&v)[2]) {
-    using PM = PairMap<HG, HG / 8>;
+template <int HG, int NTHR = HG * 64>
+__device__ __forceinline__ void stage_h_commit(char* lds, int tid, const uint4 (&v)[PairMap<NTHR, HG / 8>::kIters]) {
+    using PM = PairMap<NTHR, HG / 8>;
     using L = Lay<HG>;
     const PM pm(tid);
     const int rot = (tid >> 3) & 3;
     char* dst = lds + L::kOffH + pm.l0 * L::kPitchH + pm.m * L::kRecH + pm.sub * 16;
 #pragma unroll
-    for (int it = 0; it < 2; ++it) lds_put16(dst + it * PM::kLStep * L::kPitchH, v[it], rot);
+    for (int it = 0; it < PM::kIters; ++it) lds_put16(dst + it * PM::kLStep * L::kPitchH, v[it], rot);
 }
 // H_hat out of the E slots of the E|G image
-template <typename T, int HG>
+template <typename T, int HG, int NTHR = HG * 64>
 __device__ __forceinline__ void unstage_hhat(const char* lds, void* hhat, const tgt_node_attention_args& a, const Unit& u, int tid) {
-    using PM = PairMap<HG, HG / 8>;
+    using PM = PairMap<NTHR, HG / 8>;
     using L = Lay<HG>;
     const PM pm(tid);
     const int N = a.N, rot = (tid >> 3) & 3;
@@ -197,54 +188,69 @@ __device__ __forceinline__ void unstage_hhat(const char* lds, void* hhat, const 
     const uint32_t off0 = (uint32_t)(pm.l0 * N + pm.m) * ldb + (uint32_t)((u.hg * HG + pm.sub * 8) * (int)sizeof(T));
     const char* src = lds + L::kOffEG + pm.l0 * L::kPitchEG + pm.m * L::kRecEG + pm.sub * 16;
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < PM::kIters; ++it) {
         const bool ok = pm.m < N && pm.l0 + it * PM::kLStep < N;
         buf_st16(rs, ok ? off0 + (uint32_t)(it * PM::kLStep * N) * ldb : kOob, lds_get16(src + it * PM::kLStep * L::kPitchEG, rot));
     }
 }
-// rows of one (B,N,ld) node tensor: the HG-head segment of every (row, d); thread <-> (row, d, piece)
-template <int HG, int D>
+// rows of one (B,N,ld) node tensor: the HG-head segment of every (row, d); chunk c = it * NTHR + tid <-> (row, d, piece)
+template <int HG, int NTHR, int D>
 struct NodeMap {
-    static constexpr int kPer = HG / 8;
-    static_assert(32 * D * kPer <= HG * 64, "one node chunk per thread");
+    static constexpr int kPer = HG / 8, kChunks = 32 * D * kPer, kIters = (kChunks + NTHR - 1) / NTHR;
     int piece, d, row;
     bool in;
-    __device__ __forceinline__ explicit NodeMap(int tid) : piece(tid % kPer), d((tid / kPer) % D), row(tid / kPer / D), in(tid < 32 * D * kPer) {}
+    __device__ __forceinline__ NodeMap(int tid, int it) {
+        const int c = it * NTHR + tid;
+        piece = c % kPer; d = (c / kPer) % D; row = c / kPer / D; in = c < kChunks;
+    }
     __device__ __forceinline__ int lds_off() const { return row * Lay<HG>::pitch_n(D) + d * Lay<HG>::kRecH + piece * 16; }
+    __device__ __forceinline__ uint32_t glb_off(int64_t ld, int off, const tgt_node_attention_args& a, const Unit& u, int esz) const {
+        return (in && row < a.N) ? (uint32_t)((row * ld + off + d * a.H + u.hg * HG + piece * 8) * (int64_t)esz) : kOob;
+    }
 };
-template <typename T, int HG, int D>
-__device__ __forceinline__ uint32_t node_off(const NodeMap<HG, D>& nm, int64_t ld, int off, const tgt_node_attention_args& a, const Unit& u) {
-    return (nm.in && nm.row < a.N) ? (uint32_t)((nm.row * ld + off + nm.d * a.H + u.hg * HG + nm.piece * 8) * (int64_t)sizeof(T)) : kOob;
+template <typename T, int HG, int D, int NTHR = HG * 64>
+__device__ __forceinline__ void stage_node_issue(const void* x, int64_t ld, int off, const tgt_node_attention_args& a, const Unit& u,
+                                                 int tid, uint4 (&v)[NodeMap<HG, NTHR, D>::kIters]) {
+    const __amdgpu_buffer_rsrc_t rs = graph_rsrc(x, (int64_t)a.N * ld * sizeof(T), u.b);
+#pragma unroll
+    for (int it = 0; it < NodeMap<HG, NTHR, D>::kIters; ++it) v[it] = buf_ld16(rs, NodeMap<HG, NTHR, D>(tid, it).glb_off(ld, off, a, u, sizeof(T)));
 }
-template <typename T, int HG, int D>
-__device__ __forceinline__ uint4 stage_node_issue(const void* x, int64_t ld, int off, const tgt_node_attention_args& a, const Unit& u, int tid) {
-    const NodeMap<HG, D> nm(tid);
-    return buf_ld16(graph_rsrc(x, (int64_t)a.N * ld * sizeof(T), u.b), node_off<T, HG, D>(nm, ld, off, a, u));
+template <int HG, int D, int NTHR = HG * 64>
+__device__ __forceinline__ void stage_node_commit(char* region, int tid, const uint4 (&v)[NodeMap<HG, NTHR, D>::kIters]) {
+#pragma unroll
+    for (int it = 0; it < NodeMap<HG, NTHR, D>::kIters; ++it) {
+        const NodeMap<HG, NTHR, D> nm(tid, it);
+        if (nm.in) lds_put16(region + nm.lds_off(), v[it], (tid >> 3) & 3);
+    }
 }
-template <int HG, int D>
-__device__ __forceinline__ void stage_node_commit(char* region, int tid, const uint4& v) {
-    const NodeMap<HG, D> nm(tid);
-    if (nm.in) lds_put16(region + nm.lds_off(), v, (tid >> 3) & 3);
-}
-template <typename T, int HG, int D>
+template <typename T, int HG, int D, int NTHR = HG * 64>
 __device__ __forceinline__ void unstage_node(const char* region, void* x, int64_t ld, int off, const tgt_node_attention_args& a,
                                              const Unit& u, int tid) {
-    const NodeMap<HG, D> nm(tid);
-    if (nm.in)
-        buf_st16(graph_rsrc(x, (int64_t)a.N * ld * sizeof(T), u.b), node_off<T, HG, D>(nm, ld, off, a, u),
-                 lds_get16(region + nm.lds_off(), (tid >> 3) & 3));
+    const __amdgpu_buffer_rsrc_t rs = graph_rsrc(x, (int64_t)a.N * ld * sizeof(T), u.b);
+#pragma unroll
+    for (int it = 0; it < NodeMap<HG, NTHR, D>::kIters; ++it) {
+        const NodeMap<HG, NTHR, D> nm(tid, it);
+        if (nm.in) buf_st16(rs, nm.glb_off(ld, off, a, u, sizeof(T)), lds_get16(region + nm.lds_off(), (tid >> 3) & 3));
+    }
 }
-template <int HG>
-__device__ __forceinline__ void stage_mask(char* lds, const tgt_node_attention_args& a, const Unit& u, int tid) {
-    // pairs past N get -inf: their logits become -inf (weight exactly 0) and their gates sigmoid(-inf) = 0
-    // without a select per tile element
+// mask tile: pairs past N get -inf: their logits become -inf (weight exactly 0) and their gates sigmoid(-inf) = 0
+// without a select per tile element
+template <int NTHR>
+__device__ __forceinline__ void stage_mask_issue(const tgt_node_attention_args& a, const Unit& u, int tid, float (&mk)[1024 / NTHR]) {
     const int N = a.N;
 #pragma unroll
-    for (int idx = tid; idx < 1024; idx += HG * 64) {
-        const int l = idx >> 5, m = idx & 31;
-        float mk = -INFINITY;
-        if (l < N && m < N) mk = a.mask[((int64_t)u.b * N + l) * N + m];
-        *reinterpret_cast<float*>(lds + Lay<HG>::kOffM + l * Lay<HG>::kPitchM + m * 4) = mk;
+    for (int it = 0; it < 1024 / NTHR; ++it) {
+        const int idx = it * NTHR + tid, l = idx >> 5, m = idx & 31;
+        mk[it] = -INFINITY;
+        if (l < N && m < N) mk[it] = a.mask[((int64_t)u.b * N + l) * N + m];
+    }
+}
+template <int HG, int NTHR>
+__device__ __forceinline__ void stage_mask_commit(char* lds, int tid, const float (&mk)[1024 / NTHR]) {
+#pragma unroll
+    for (int it = 0; it < 1024 / NTHR; ++it) {
+        const int idx = it * NTHR + tid, l = idx >> 5, m = idx & 31;
+        *reinterpret_cast<float*>(lds + Lay<HG>::kOffM + l * Lay<HG>::kPitchM + m * 4) = mk[it];
     }
 }
 
@@ -273,35 +279,17 @@ __device__ __forceinline__ void node_put(char* region, const f32x16& acc, int r,
 }
 
 // ---------------------------------------------------------------------------
-// forward
+// forward tile of head hh (one wave): H_hat into the E slots, V_att into the head's Q column
 // ---------------------------------------------------------------------------
 template <typename T, int HG, int D>
-__global__ void __launch_bounds__(HG * 64, 4) node_att_mfma_fwd_kernel(const tgt_node_attention_args a, const int ablate) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
+__device__ __forceinline__ void tile_fwd(char* lds, const tgt_node_attention_args& a, const Unit& u, int r, int hi, int hh) {
     using F = frag_t<T>;
     using L = Lay<HG>;
-    const int tid = threadIdx.x, lane = tid & 63, hh = tid >> 6, r = lane & 31, hi = lane >> 5;
-    const Unit u = unit_of_block<HG>(a);
     const int N = a.N, H = a.H, h = u.hg * HG + hh;
     char* rQ = lds + L::off_n(D, false, 0);
     char* rK = lds + L::off_n(D, false, 1);
     char* rV = lds + L::off_n(D, false, 2);
-
-    if (!(ablate & 2)) {   // stage: every load is issued before the first LDS write
-        uint4 veg[4];
-        stage_eg_issue<T, HG>(a, u, tid, veg);
-        const uint4 vq = stage_node_issue<T, HG, D>(a.qkv, a.ld_qkv, a.q_off, a, u, tid);
-        const uint4 vk = stage_node_issue<T, HG, D>(a.qkv, a.ld_qkv, a.k_off, a, u, tid);
-        const uint4 vv = stage_node_issue<T, HG, D>(a.qkv, a.ld_qkv, a.v_off, a, u, tid);
-        stage_mask<HG>(lds, a, u, tid);
-        stage_eg_commit<HG>(lds, tid, veg);
-        stage_node_commit<HG, D>(rQ, tid, vq);
-        stage_node_commit<HG, D>(rK, tid, vk);
-        stage_node_commit<HG, D>(rV, tid, vv);
-    }
-    __syncthreads();
-
-    if (!(ablate & 1)) {
+    {
         const F fq = node_frag<T, HG, D>(rQ, r, hi, hh), fk = node_frag<T, HG, D>(rK, r, hi, hh), fv = node_frag<T, HG, D>(rV, r, hi, hh);
         F ident_d[1];
         make_ident_d<T, 1>(ident_d, r, hi);
@@ -350,52 +338,25 @@ __global__ void __launch_bounds__(HG * 64, 4) node_att_mfma_fwd_kernel(const tgt
             a.gsum[((int64_t)u.b * N + r) * H + h] = gsum;
         }
     }
-    __syncthreads();
-
-    if (ablate & 4) return;
-    if (a.hhat) unstage_hhat<T, HG>(lds, a.hhat, a, u, tid);
-    unstage_node<T, HG, D>(rQ, a.vatt, (int64_t)D * H, 0, a, u, tid);
 }
 
 // ---------------------------------------------------------------------------
-// backward, one pass: dE, dG, dQ, dK, dV.  Per head, with P, the gates and their sum recomputed:
+// backward tile of head hh (one wave): dE, dG into the E / G slots, dQ, dK, dV into the head's Q, K, V columns.
+// With P, the gates and their sum recomputed:
 //   dA^T[m][l] = dsc_l * V[m,:].dV_att[l,:]      dsc = log(1 + sum_m g)   (1 without the degree scaler)
 //   delta_l = sum_m P dA g        d_dsc = delta / dsc        dgsum = d_dsc / (1 + sum g)
 //   dS = P (dA g - delta)         dG = (dA P + dgsum) g (1 - g)            dE = dH_hat + dS
 //   dQ^T = s K^T dE^T             dK^T = s Q^T dE                          dV^T = dV_att^T (P g dsc)
 // ---------------------------------------------------------------------------
 template <typename T, int HG, int D>
-__global__ void __launch_bounds__(HG * 64, 4) node_att_mfma_bwd_kernel(const tgt_node_attention_args a, const int ablate) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
+__device__ __forceinline__ void tile_bwd(char* lds, const tgt_node_attention_args& a, int r, int hi, int hh) {
     using F = frag_t<T>;
     using L = Lay<HG>;
-    const int tid = threadIdx.x, lane = tid & 63, hh = tid >> 6, r = lane & 31, hi = lane >> 5;
-    const Unit u = unit_of_block<HG>(a);
-    const int H = a.H;
     char* rQ = lds + L::off_n(D, true, 0);
     char* rK = lds + L::off_n(D, true, 1);
     char* rV = lds + L::off_n(D, true, 2);
     char* rO = lds + L::off_n(D, true, 3);
-
-    if (!(ablate & 2)) {
-        uint4 veg[4], vh[2];
-        stage_eg_issue<T, HG>(a, u, tid, veg);
-        stage_h_issue<T, HG>(a.d_hhat, a, u, tid, vh);
-        const uint4 vq = stage_node_issue<T, HG, D>(a.qkv, a.ld_qkv, a.q_off, a, u, tid);
-        const uint4 vk = stage_node_issue<T, HG, D>(a.qkv, a.ld_qkv, a.k_off, a, u, tid);
-        const uint4 vv = stage_node_issue<T, HG, D>(a.qkv, a.ld_qkv, a.v_off, a, u, tid);
-        const uint4 vo = stage_node_issue<T, HG, D>(a.d_vatt, (int64_t)D * H, 0, a, u, tid);
-        stage_mask<HG>(lds, a, u, tid);
-        stage_eg_commit<HG>(lds, tid, veg);
-        stage_h_commit<HG>(lds, tid, vh);
-        stage_node_commit<HG, D>(rQ, tid, vq);
-        stage_node_commit<HG, D>(rK, tid, vk);
-        stage_node_commit<HG, D>(rV, tid, vv);
-        stage_node_commit<HG, D>(rO, tid, vo);
-    }
-    __syncthreads();
-
-    if (!(ablate & 1)) {
+    {
         const F fq = node_frag<T, HG, D>(rQ, r, hi, hh), fk = node_frag<T, HG, D>(rK, r, hi, hh);
         const F fv = node_frag<T, HG, D>(rV, r, hi, hh), fo = node_frag<T, HG, D>(rO, r, hi, hh);
         F ident_d[1];
@@ -520,57 +481,193 @@ __global__ void __launch_bounds__(HG * 64, 4) node_att_mfma_bwd_kernel(const tgt
             node_put<T, HG, D>(rV, dv, r, hi, hh);
         }
     }
-    __syncthreads();
+}
 
-    if (ablate & 4) return;
-    unstage_eg<T, HG>(lds, a.d_eg, a, u, tid);
-    unstage_node<T, HG, D>(rQ, a.d_qkv, a.ld_qkv, a.q_off, a, u, tid);
-    unstage_node<T, HG, D>(rK, a.d_qkv, a.ld_qkv, a.k_off, a, u, tid);
-    unstage_node<T, HG, D>(rV, a.d_qkv, a.ld_qkv, a.v_off, a, u, tid);
+// ---------------------------------------------------------------------------
+// The kernels.  NW waves per workgroup, wave w takes heads w, w + NW, ... of the group's HG heads one after the
+// other.  Shipped form: HG = NW = 16, one workgroup per unit (graph, head group), at most 128 registers.
+// Load, tile math and store of one unit cannot overlap each other (one LDS image), and workgroups that start
+// together stay in step, so the three phases add up on every CU (B=256, N=32, H=64, D=12, bf16, rocprofv3:
+// backward loads alone 30 us + tile math 43 us + stores 24 us; the kernel 88-103 us).  Two things were built
+// against that and measured:
+//   * HG = 8 (two workgroups per CU, TGT_NODE_MFMA_HG=8): no gain -- the two stay in step as well, and a load
+//     request per 16 bytes is too fine for the L2 (loads alone 46 us against 30 us): 117 us;
+//   * a PERSISTENT workgroup of 8 waves x 2 heads that prefetches the NEXT unit's loads into registers under the
+//     tile math (PIPE, TGT_NODE_MFMA_PIPE=1): forward 50.5 -> 48.7 us; the backward needs 78 prefetch registers
+//     on top of the tile's ~130 and hipcc answers by spilling the prefetched chunks to scratch, which puts the
+//     load wait back in front of the tile math (136 us).  Parity-green, not the default.
+// Unit order: XCD x (= block index & 7) owns the graphs b = x mod 8; its workgroups take that list's units
+// (graph-major, head group minor) round-robin, so the head groups of one graph run at the same time on the
+// same XCD and the 128-byte E / G / dH rows they share come from HBM once.
+// ---------------------------------------------------------------------------
+struct Walk {
+    int x, t, step, nt, groups;
+    __device__ __forceinline__ Walk(const tgt_node_attention_args& a, int HG) {
+        groups = a.H / HG;
+        x = blockIdx.x & 7;
+        t = blockIdx.x >> 3;
+        step = gridDim.x >> 3;
+        nt = ((a.B - x + 7) >> 3) * groups;       // units of the graphs b = x, x + 8, ... < B
+    }
+    __device__ __forceinline__ bool live() const { return t < nt; }
+    __device__ __forceinline__ Unit unit() const { return Unit{(t / groups) * 8 + x, t % groups}; }
+    __device__ __forceinline__ void next() { t += step; }
+};
+
+template <typename T, int HG, int NW, int D, bool PIPE>
+__global__ void __launch_bounds__(NW * 64, 1024 / (NW * 64) >= 2 ? 2 : 4)
+node_att_mfma_fwd_kernel(const tgt_node_attention_args a, const int ablate) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    using L = Lay<HG>;
+    constexpr int NTHR = NW * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hi = lane >> 5;
+    char* rQ = lds + L::off_n(D, false, 0);
+    char* rK = lds + L::off_n(D, false, 1);
+    char* rV = lds + L::off_n(D, false, 2);
+    Walk w(a, HG);
+    if (!w.live()) return;
+
+    uint4 veg[PairMap<NTHR, HG / 4>::kIters];
+    uint4 vq[NodeMap<HG, NTHR, D>::kIters], vk[NodeMap<HG, NTHR, D>::kIters], vv[NodeMap<HG, NTHR, D>::kIters];
+    float mk[1024 / NTHR];
+    auto issue = [&](const Unit& u) {
+        stage_eg_issue<T, HG, NTHR>(a, u, tid, veg);
+        stage_node_issue<T, HG, D, NTHR>(a.qkv, a.ld_qkv, a.q_off, a, u, tid, vq);
+        stage_node_issue<T, HG, D, NTHR>(a.qkv, a.ld_qkv, a.k_off, a, u, tid, vk);
+        stage_node_issue<T, HG, D, NTHR>(a.qkv, a.ld_qkv, a.v_off, a, u, tid, vv);
+        stage_mask_issue<NTHR>(a, u, tid, mk);
+    };
+    if (!(ablate & 2)) issue(w.unit());
+    while (true) {
+        const Unit u = w.unit();
+        if (!(ablate & 2)) {
+            stage_eg_commit<HG, NTHR>(lds, tid, veg);
+            stage_node_commit<HG, D, NTHR>(rQ, tid, vq);
+            stage_node_commit<HG, D, NTHR>(rK, tid, vk);
+            stage_node_commit<HG, D, NTHR>(rV, tid, vv);
+            stage_mask_commit<HG, NTHR>(lds, tid, mk);
+        }
+        __syncthreads();
+        w.next();
+        const bool more = PIPE && w.live();
+        if (more && !(ablate & 2)) issue(w.unit());           // in flight under the tile math
+        if (!(ablate & 1)) {
+#pragma unroll 1
+            for (int hh = wave; hh < HG; hh += NW) tile_fwd<T, HG, D>(lds, a, u, r, hi, hh);
+        }
+        __syncthreads();
+        if (!(ablate & 4)) {
+            if (a.hhat) unstage_hhat<T, HG, NTHR>(lds, a.hhat, a, u, tid);
+            unstage_node<T, HG, D, NTHR>(rQ, a.vatt, (int64_t)D * a.H, 0, a, u, tid);
+        }
+        if (!more) break;
+        // (no barrier: a thread overwrites only the chunks it has just read itself -- commit and unstage share the chunk
+        //  map -- and the K / V / mask images were last read before the barrier above)
+    }
+}
+
+template <typename T, int HG, int NW, int D, bool PIPE>
+__global__ void __launch_bounds__(NW * 64, 1024 / (NW * 64) >= 2 ? 2 : 4)
+node_att_mfma_bwd_kernel(const tgt_node_attention_args a, const int ablate) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    using L = Lay<HG>;
+    constexpr int NTHR = NW * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hi = lane >> 5;
+    char* rQ = lds + L::off_n(D, true, 0);
+    char* rK = lds + L::off_n(D, true, 1);
+    char* rV = lds + L::off_n(D, true, 2);
+    char* rO = lds + L::off_n(D, true, 3);
+    Walk w(a, HG);
+    if (!w.live()) return;
+
+    uint4 veg[PairMap<NTHR, HG / 4>::kIters], vh[PairMap<NTHR, HG / 8>::kIters];
+    uint4 vq[NodeMap<HG, NTHR, D>::kIters], vk[NodeMap<HG, NTHR, D>::kIters], vv[NodeMap<HG, NTHR, D>::kIters],
+        vo[NodeMap<HG, NTHR, D>::kIters];
+    float mk[1024 / NTHR];
+    auto issue = [&](const Unit& u) {
+        stage_eg_issue<T, HG, NTHR>(a, u, tid, veg);
+        stage_h_issue<T, HG, NTHR>(a.d_hhat, a, u, tid, vh);
+        stage_node_issue<T, HG, D, NTHR>(a.qkv, a.ld_qkv, a.q_off, a, u, tid, vq);
+        stage_node_issue<T, HG, D, NTHR>(a.qkv, a.ld_qkv, a.k_off, a, u, tid, vk);
+        stage_node_issue<T, HG, D, NTHR>(a.qkv, a.ld_qkv, a.v_off, a, u, tid, vv);
+        stage_node_issue<T, HG, D, NTHR>(a.d_vatt, (int64_t)D * a.H, 0, a, u, tid, vo);
+        stage_mask_issue<NTHR>(a, u, tid, mk);
+    };
+    if (!(ablate & 2)) issue(w.unit());
+    while (true) {
+        const Unit u = w.unit();
+        if (!(ablate & 2)) {
+            stage_eg_commit<HG, NTHR>(lds, tid, veg);
+            stage_h_commit<HG, NTHR>(lds, tid, vh);
+            stage_node_commit<HG, D, NTHR>(rQ, tid, vq);
+            stage_node_commit<HG, D, NTHR>(rK, tid, vk);
+            stage_node_commit<HG, D, NTHR>(rV, tid, vv);
+            stage_node_commit<HG, D, NTHR>(rO, tid, vo);
+            stage_mask_commit<HG, NTHR>(lds, tid, mk);
+        }
+        __syncthreads();
+        w.next();
+        const bool more = PIPE && w.live();
+        if (more && !(ablate & 2)) issue(w.unit());           // in flight under the tile math
+        if (!(ablate & 1)) {
+#pragma unroll 1
+            for (int hh = wave; hh < HG; hh += NW) tile_bwd<T, HG, D>(lds, a, r, hi, hh);
+        }
+        __syncthreads();
+        if (!(ablate & 4)) {
+            unstage_eg<T, HG, NTHR>(lds, a.d_eg, a, u, tid);
+            unstage_node<T, HG, D, NTHR>(rQ, a.d_qkv, a.ld_qkv, a.q_off, a, u, tid);
+            unstage_node<T, HG, D, NTHR>(rK, a.d_qkv, a.ld_qkv, a.k_off, a, u, tid);
+            unstage_node<T, HG, D, NTHR>(rV, a.d_qkv, a.ld_qkv, a.v_off, a, u, tid);
+        }
+        if (!more) break;
+        // (no barrier, as in the forward; the dH / dV_att / mask images were last read before the barrier above)
+    }
 }
 
 constexpr int kLdsMax = 160 * 1024;
 
-template <typename T, int HG, int D>
+template <typename T, int HG, int NW, int D, bool PIPE>
 static int launch(const tgt_node_attention_args& a, bool bwd, hipStream_t st) {
     using L = Lay<HG>;
-    const int grid = a.B * (a.H / HG);
+    // persistent: 256 workgroups (one per CU; idle ones leave at once); one workgroup per unit otherwise, a multiple of 8
+    // so that the XCD lists of Walk cover every unit
+    const int grid = PIPE ? 256 : ((a.B + 7) / 8) * 8 * (a.H / HG);
     static const int ablate = getenv("TGT_NODE_ABLATE") ? atoi(getenv("TGT_NODE_ABLATE")) : 0;    // micro-benchmark only: 1 no tile math, 2 no loads, 4 no stores
     if (!bwd) {
         constexpr int kLds = L::lds_bytes(D, false);
         static_assert(kLds <= kLdsMax, "forward LDS");
-        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&node_att_mfma_fwd_kernel<T, HG, D>),
+        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&node_att_mfma_fwd_kernel<T, HG, NW, D, PIPE>),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLds), true);
         (void)once;
-        hipLaunchKernelGGL((node_att_mfma_fwd_kernel<T, HG, D>), dim3(grid), dim3(HG * 64), kLds, st, a, ablate);
+        hipLaunchKernelGGL((node_att_mfma_fwd_kernel<T, HG, NW, D, PIPE>), dim3(grid), dim3(NW * 64), kLds, st, a, ablate);
         return check_launch("node_att_mfma_fwd_kernel");
     } else {
         constexpr int kLds = L::lds_bytes(D, true);
         if constexpr (kLds <= kLdsMax) {
-            static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&node_att_mfma_bwd_kernel<T, HG, D>),
+            static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&node_att_mfma_bwd_kernel<T, HG, NW, D, PIPE>),
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLds), true);
             (void)once;
-            hipLaunchKernelGGL((node_att_mfma_bwd_kernel<T, HG, D>), dim3(grid), dim3(HG * 64), kLds, st, a, ablate);
+            hipLaunchKernelGGL((node_att_mfma_bwd_kernel<T, HG, NW, D, PIPE>), dim3(grid), dim3(NW * 64), kLds, st, a, ablate);
             return check_launch("node_att_mfma_bwd_kernel");
         }
         return -1;
     }
 }
 
-template <typename T, int HG>
+template <typename T, int HG, int NW, bool PIPE>
 static int dispatch_d(const tgt_node_attention_args& a, bool bwd, hipStream_t st) {
     switch (a.D) {
-        case 8: return launch<T, HG, 8>(a, bwd, st);
-        case 12: return launch<T, HG, 12>(a, bwd, st);
-        case 16: return launch<T, HG, 16>(a, bwd, st);
+        case 8: return launch<T, HG, NW, 8, PIPE>(a, bwd, st);
+        case 12: return launch<T, HG, NW, 12, PIPE>(a, bwd, st);
+        case 16: return launch<T, HG, NW, 16, PIPE>(a, bwd, st);
         default: return -1;
     }
 }
 
-// heads per workgroup.  Measured (B=256, N=32, H=64, D=12, bf16; rocprofv3): 16 heads = one workgroup per CU, 32-byte row
-// segments: forward 51 us, backward 102 us; 8 heads = two workgroups per CU, 16-byte segments: 56 / 117 us (its loads
-// alone take 46 us against 30 us: a request per 16 bytes is too fine for the L2).  The 16-head backward image of D = 16
-// does not fit the LDS, that shape takes the 8-head form.
+// heads per workgroup: 16 (32-byte row segments) unless the shape or TGT_NODE_MFMA_HG says 8 (16-byte segments: a
+// request per 16 bytes is too fine for the L2 -- its loads alone take 46 us against 30 us).  The 16-head backward image
+// of D = 16 does not fit the LDS, that shape takes the 8-head form.
 static int heads_per_group(const tgt_node_attention_args& a, bool bwd) {
     static const int want = getenv("TGT_NODE_MFMA_HG") ? atoi(getenv("TGT_NODE_MFMA_HG")) : 16;
     if (want == 16 && a.H % 16 == 0 && !(bwd && a.D == 16)) return 16;
@@ -579,7 +676,10 @@ static int heads_per_group(const tgt_node_attention_args& a, bool bwd) {
 
 template <typename T>
 static int dispatch(const tgt_node_attention_args& a, bool bwd, hipStream_t st) {
-    return heads_per_group(a, bwd) == 16 ? dispatch_d<T, 16>(a, bwd, st) : dispatch_d<T, 8>(a, bwd, st);
+    static const int pipe = getenv("TGT_NODE_MFMA_PIPE") ? atoi(getenv("TGT_NODE_MFMA_PIPE")) : 0;
+    if (heads_per_group(a, bwd) == 16)
+        return pipe ? dispatch_d<T, 16, 8, true>(a, bwd, st) : dispatch_d<T, 16, 16, false>(a, bwd, st);
+    return dispatch_d<T, 8, 8, false>(a, bwd, st);
 }
 
 }  // namespace nmf
