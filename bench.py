@@ -296,7 +296,7 @@ def main():
         # profiles/README.md); only valid for the shape they were measured at
         traffic, pmc = {}, {}
         tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-        ppath = os.path.join(ROOT, 'profiles', 'r02e_pmc_summary.json')      # tools/pmc_passes.sh: SQ / FETCH / WRITE passes
+        ppath = os.path.join(ROOT, 'profiles', 'r02f_pmc_summary.json')      # tools/pmc_passes.sh: SQ / FETCH / WRITE passes
         if args.batch == 256 and args.nodes == 32 and args.precision == 'bf16':
             if os.path.exists(tpath):
                 traffic = json.load(open(tpath))
@@ -329,7 +329,8 @@ def main():
                     roofline['other_kernels'][kname] = dict(avg_launch_ms=round(avg, 4),
                                                             achieved=round(nb / (avg * 1e-3) / 1e9, 1),
                                                             frac=round(nb / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
-                    shorts = ('node_att_fwd_lds_kernel',) if kind == 'fwd' else ('node_att_bwd_row_kernel', 'node_att_bwd_col_kernel')
+                    # (the matrix-core kernels of csrc/node_attention_mfma.hip: one launch each way)
+                    shorts = ('nmf24node_att_mfma_fwd_kernel',) if kind == 'fwd' else ('nmf24node_att_mfma_bwd_kernel',)
                     if all(k in pmc and 'hbm_bytes_per_launch' in pmc[k] for k in shorts):
                         roofline['other_kernels'][kname]['traffic'] = sum(pmc[k]['hbm_bytes_per_launch'] for k in shorts)
                         roofline['other_kernels'][kname]['algorithmic_bytes_per_launch'] = nb
