@@ -202,6 +202,9 @@ def main():
                     help='CPU baseline over all 256 graphs of one step (16 accumulated micro-batches; minutes)')
     ap.add_argument('--launcher-selftest', action='store_true', help=argparse.SUPPRESS)   # tests/test_bench_launcher.py
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp16', 'fp32'])
+    ap.add_argument('--sync-every', type=int, default=0,
+                    help='read the running mean loss on the host every K steps (K = 1: the reference loop, which pays a '
+                         '.item() per step, tgt_training.py:153-157); 0 = never inside the timed steps (default)')
     ap.add_argument('--no-gemm-tuning', action='store_true', help='library default GEMM heuristics')
     ap.add_argument('--write-gemm-tuning', default='', help='tune online and write the TunableOp file here')
     args = ap.parse_args()
@@ -274,6 +277,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         _, loss = step(args.warmup + i)
+        if args.sync_every and (i + 1) % args.sync_every == 0:
+            trainer.mean_loss()                      # host read of the control block: synchronises this rank
     fence()
     dt = time.perf_counter() - t0
     ops.profile_kernels(False)
@@ -343,7 +348,8 @@ def main():
             config=dict(workload='TGT-At 24L (TGT_Multi, 103.6M params, 512 dist bins) train step; '
                                  f'{args.batch} synthetic N={args.nodes} graphs per GPU; dropouts of tgt_at_tp.yaml on',
                         global_batch=args.batch * world, nodes=args.nodes,
-                        parallelism=f'dp{world}', precision=f'{args.precision} autocast, fp32 params/Adam'),
+                        parallelism=f'dp{world}', precision=f'{args.precision} autocast, fp32 params/Adam',
+                        **({'host_loss_read_every': args.sync_every} if args.sync_every else {})),
             final_loss=round(loss_val, 5),
             roofline=roofline,
         )

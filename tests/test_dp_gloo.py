@@ -41,14 +41,14 @@ def _slice(batch, lo, hi):
     return {k: v[lo:hi] for k, v in batch.items()}
 
 
-def _worker(rank, world, port, kwargs, bucket_mb, result):
+def _worker(rank, world, port, kwargs, bucket_mb, result, comm=None):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from tgt_amd.training.step import Trainer, StepConfig
     torch.set_num_threads(2)
     model = _make(kwargs, seed=11 + rank)            # ranks start DIFFERENT: broadcast must fix it
-    tr = Trainer(model, StepConfig(mixed_precision=None, bucket_mbytes=bucket_mb), loss_fn=_gap_l1)
+    tr = Trainer(model, StepConfig(mixed_precision=None, bucket_mbytes=bucket_mb, grad_comm_dtype=comm), loss_fn=_gap_l1)
     full = _batch(4, 6, seed=5)
     part = _slice(full, 2 * rank, 2 * rank + 2)
     tr.global_step += 1
@@ -84,6 +84,22 @@ def test_two_rank_gradients_equal_single_rank(variant):
         assert result['nbuckets'] > 10
     else:
         assert result['nbuckets'] == -1
+
+
+def test_bf16_gradient_exchange_option():
+    """grad_comm_dtype='bf16' (half the bytes on the links): same gradients up to bfloat16 rounding of
+    each rank's contribution"""
+    kwargs = dict(gu.MODEL_CASES['gap_at_tiny'][1])
+    kwargs['embed_3d_type'] = 'none'
+    mgr = mp.Manager()
+    result = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), kwargs, 0, result, 'bf16'), nprocs=2, join=True)
+    from tgt_amd.training.step import Trainer, StepConfig
+    tr = Trainer(_make(kwargs, seed=11), StepConfig(mixed_precision=None), loss_fn=_gap_l1)
+    tr.compute_gradients(_batch(4, 6, seed=5))
+    ref = tr.flat.grad
+    err = (result['grad'] - ref).norm() / ref.norm()
+    assert 0 < err < 1e-2, err          # not bit-identical (it IS compressed), within bfloat16 rounding
 
 
 def test_flat_state_views_alias_parameters():

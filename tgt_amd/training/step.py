@@ -45,6 +45,9 @@ class StepConfig:
     # precision: None (fp32) | 'bf16' | 'fp16'
     mixed_precision: str = 'bf16'
     bucket_mbytes: int = 64
+    # gradient exchange dtype: None = the float32 flat buffer as it is (reference DDP semantics, bit-exact parity);
+    # 'bf16' = each bucket crosses the links as bfloat16 (half the xGMI bytes, SURVEY 5.8 / 8(e): an option, off by default)
+    grad_comm_dtype: str = None
     # gradient clipping (reference training.py:446-462; None = off, as in the shipped YAMLs)
     clip_grad_value: float = None
     clip_grad_norm: float = None
@@ -259,10 +262,24 @@ class Trainer:
         if self._pending[k] == 0:
             self._reduce_bucket(k)
 
+    def _all_reduce_async(self, g):
+        """all-reduce (sum) of a slice of the flat gradient; returns something with .wait()"""
+        if self.cfg.grad_comm_dtype == 'bf16':
+            wire = g.to(torch.bfloat16)
+            h = dist.all_reduce(wire, group=self.pg, async_op=True)
+
+            class _Done:
+                def wait(_self):
+                    h.wait()
+                    g.copy_(wire)
+            return _Done()
+        assert self.cfg.grad_comm_dtype is None, self.cfg.grad_comm_dtype
+        return dist.all_reduce(g, group=self.pg, async_op=True)
+
     def _reduce_bucket(self, k):
         s, e, n, first = self.buckets[k]
         self.flat.collect_grads(range(first, first + n))
-        self._handles.append(dist.all_reduce(self.flat.grad[s:e], group=self.pg, async_op=True))
+        self._handles.append(self._all_reduce_async(self.flat.grad[s:e]))
 
     def _finish_reduce(self):
         if not self.distributed:
@@ -270,7 +287,7 @@ class Trainer:
             return
         if self.buckets is None:
             self.flat.collect_grads()
-            dist.all_reduce(self.flat.grad, group=self.pg)
+            self._all_reduce_async(self.flat.grad).wait()
             return
         # parameters that received no gradient this step never fire their hook
         for k, left in enumerate(self._pending):
