@@ -30,6 +30,7 @@
 // algorithmic traffic only.  HBM-bound; the workgroups that share a graph's 128-byte E/G
 // rows are given the same XCD (block index -> unit map) so that all but one of them hit in its L2.
 #include <cstdlib>
+#include <type_traits>
 #include "common.hpp"
 #include "triplet_common.hpp"
 
@@ -92,6 +93,34 @@ __device__ __forceinline__ void buf_st16(__amdgpu_buffer_rsrc_t r, uint32_t off,
     __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)off, 0, 0);
 }
 
+// A 16-byte chunk in flight.  uint4: an ordinary buffer load (the compiler tracks it).  AChunk: the load targets
+// ACCUMULATION registers (inline assembly: `buffer_load_dwordx4 a[..]`), where the prefetch of the persistent kernels
+// waits out the tile math -- hipcc would otherwise spill long-lived prefetched VGPRs to scratch, which puts the load
+// wait back in front of the tile math.  The compiler does not see these loads: the kernel waits for them with an
+// explicit s_waitcnt before the first take().
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+struct AChunk { u32x4_t a; };
+struct Rsrc {
+    __amdgpu_buffer_rsrc_t r;
+    i32x4_t w;          // the same descriptor as four dwords (inline assembly operand)
+};
+__device__ __forceinline__ Rsrc make_rsrc(const void* tensor, int64_t graph_bytes, int b) {
+    const uint64_t base = (uint64_t)(reinterpret_cast<const char*>(tensor) + (int64_t)b * graph_bytes);
+    // (readfirstlane: the descriptor must sit in scalar registers, and the inline assembly operand does not force that)
+    return Rsrc{graph_rsrc(tensor, graph_bytes, b),
+                i32x4_t{__builtin_amdgcn_readfirstlane((int)(uint32_t)base), __builtin_amdgcn_readfirstlane((int)((base >> 32) & 0xffffu)),
+                        __builtin_amdgcn_readfirstlane((int)graph_bytes), 0x00020000}};
+}
+__device__ __forceinline__ void ld16(uint4& v, const Rsrc& rs, uint32_t off) { v = buf_ld16(rs.r, off); }
+__device__ __forceinline__ void ld16(AChunk& v, const Rsrc& rs, uint32_t off) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=a"(v.a) : "v"(off), "s"(rs.w) : "memory");
+}
+__device__ __forceinline__ uint4 take(const uint4& v) { return v; }
+__device__ __forceinline__ uint4 take(AChunk& v) {
+    asm volatile("" : "+a"(v.a));          // the value stays in its accumulation registers up to here
+    return make_uint4(v.a.x, v.a.y, v.a.z, v.a.w);
+}
+
 struct Unit { int b, hg; };
 // ---- cooperative staging (NTHR threads) ---------------------------------------------------------
 // Pair tensors (B,N,N,ld): a pair's record is SUBS 16-byte pieces; chunk c = it * NTHR + tid is piece
@@ -109,30 +138,30 @@ __device__ __forceinline__ uint32_t eg_chan(const tgt_node_attention_args& a, co
     constexpr int kE = HG / 8;       // 16-byte pieces of E (8 heads each)
     return (uint32_t)(((sub < kE ? a.e_off + sub * 8 : a.g_off + (sub - kE) * 8) + u.hg * HG) * (int)sizeof(T));
 }
-template <typename T, int HG, int NTHR = HG * 64>
+template <typename T, int HG, int NTHR = HG * 64, typename V = uint4>
 __device__ __forceinline__ void stage_eg_issue(const tgt_node_attention_args& a, const Unit& u, int tid,
-                                               uint4 (&v)[PairMap<NTHR, HG / 4>::kIters]) {
+                                               V (&v)[PairMap<NTHR, HG / 4>::kIters]) {
     using PM = PairMap<NTHR, HG / 4>;
     const PM pm(tid);
     const int N = a.N;
-    const __amdgpu_buffer_rsrc_t rs = graph_rsrc(a.eg, (int64_t)N * N * a.ld_eg * sizeof(T), u.b);
+    const Rsrc rs = make_rsrc(a.eg, (int64_t)N * N * a.ld_eg * sizeof(T), u.b);
     const uint32_t ldb = (uint32_t)(a.ld_eg * sizeof(T));
     const uint32_t off0 = (uint32_t)(pm.l0 * N + pm.m) * ldb + eg_chan<T, HG>(a, u, pm.sub);
 #pragma unroll
     for (int it = 0; it < PM::kIters; ++it) {
         const bool ok = pm.m < N && pm.l0 + it * PM::kLStep < N;
-        v[it] = buf_ld16(rs, ok ? off0 + (uint32_t)(it * PM::kLStep * N) * ldb : kOob);
+        ld16(v[it], rs, ok ? off0 + (uint32_t)(it * PM::kLStep * N) * ldb : kOob);
     }
 }
-template <int HG, int NTHR = HG * 64>
-__device__ __forceinline__ void stage_eg_commit(char* lds, int tid, const uint4 (&v)[PairMap<NTHR, HG / 4>::kIters]) {
+template <int HG, int NTHR = HG * 64, typename V = uint4>
+__device__ __forceinline__ void stage_eg_commit(char* lds, int tid, V (&v)[PairMap<NTHR, HG / 4>::kIters]) {
     using PM = PairMap<NTHR, HG / 4>;
     using L = Lay<HG>;
     const PM pm(tid);
     const int rot = (tid >> 3) & 3;
     char* dst = lds + L::kOffEG + pm.l0 * L::kPitchEG + pm.m * L::kRecEG + pm.sub * 16;
 #pragma unroll
-    for (int it = 0; it < PM::kIters; ++it) lds_put16(dst + it * PM::kLStep * L::kPitchEG, v[it], rot);
+    for (int it = 0; it < PM::kIters; ++it) lds_put16(dst + it * PM::kLStep * L::kPitchEG, take(v[it]), rot);
 }
 template <typename T, int HG, int NTHR = HG * 64>
 __device__ __forceinline__ void unstage_eg(const char* lds, void* d_eg, const tgt_node_attention_args& a, const Unit& u, int tid) {
@@ -151,30 +180,30 @@ __device__ __forceinline__ void unstage_eg(const char* lds, void* d_eg, const tg
     }
 }
 // (B,N,N,H) tensors (H_hat, dH_hat): HG/8 pieces per pair
-template <typename T, int HG, int NTHR = HG * 64>
+template <typename T, int HG, int NTHR = HG * 64, typename V = uint4>
 __device__ __forceinline__ void stage_h_issue(const void* x, const tgt_node_attention_args& a, const Unit& u, int tid,
-                                              uint4 (&v)[PairMap<NTHR, HG / 8>::kIters]) {
+                                              V (&v)[PairMap<NTHR, HG / 8>::kIters]) {
     using PM = PairMap<NTHR, HG / 8>;
     const PM pm(tid);
     const int N = a.N;
-    const __amdgpu_buffer_rsrc_t rs = graph_rsrc(x, (int64_t)N * N * a.H * sizeof(T), u.b);
+    const Rsrc rs = make_rsrc(x, (int64_t)N * N * a.H * sizeof(T), u.b);
     const uint32_t ldb = (uint32_t)(a.H * sizeof(T));
     const uint32_t off0 = (uint32_t)(pm.l0 * N + pm.m) * ldb + (uint32_t)((u.hg * HG + pm.sub * 8) * (int)sizeof(T));
 #pragma unroll
     for (int it = 0; it < PM::kIters; ++it) {
         const bool ok = x && pm.m < N && pm.l0 + it * PM::kLStep < N;
-        v[it] = buf_ld16(rs, ok ? off0 + (uint32_t)(it * PM::kLStep * N) * ldb : kOob);
+        ld16(v[it], rs, ok ? off0 + (uint32_t)(it * PM::kLStep * N) * ldb : kOob);
     }
 }
-template <int HG, int NTHR = HG * 64>
-__device__ __forceinline__ void stage_h_commit(char* lds, int tid, const uint4 (&v)[PairMap<NTHR, HG / 8>::kIters]) {
+template <int HG, int NTHR = HG * 64, typename V = uint4>
+__device__ __forceinline__ void stage_h_commit(char* lds, int tid, V (&v)[PairMap<NTHR, HG / 8>::kIters]) {
     using PM = PairMap<NTHR, HG / 8>;
     using L = Lay<HG>;
     const PM pm(tid);
     const int rot = (tid >> 3) & 3;
     char* dst = lds + L::kOffH + pm.l0 * L::kPitchH + pm.m * L::kRecH + pm.sub * 16;
 #pragma unroll
-    for (int it = 0; it < PM::kIters; ++it) lds_put16(dst + it * PM::kLStep * L::kPitchH, v[it], rot);
+    for (int it = 0; it < PM::kIters; ++it) lds_put16(dst + it * PM::kLStep * L::kPitchH, take(v[it]), rot);
 }
 // H_hat out of the E slots of the E|G image
 template <typename T, int HG, int NTHR = HG * 64>
@@ -208,19 +237,20 @@ struct NodeMap {
         return (in && row < a.N) ? (uint32_t)((row * ld + off + d * a.H + u.hg * HG + piece * 8) * (int64_t)esz) : kOob;
     }
 };
-template <typename T, int HG, int D, int NTHR = HG * 64>
+template <typename T, int HG, int D, int NTHR = HG * 64, typename V = uint4>
 __device__ __forceinline__ void stage_node_issue(const void* x, int64_t ld, int off, const tgt_node_attention_args& a, const Unit& u,
-                                                 int tid, uint4 (&v)[NodeMap<HG, NTHR, D>::kIters]) {
-    const __amdgpu_buffer_rsrc_t rs = graph_rsrc(x, (int64_t)a.N * ld * sizeof(T), u.b);
+                                                 int tid, V (&v)[NodeMap<HG, NTHR, D>::kIters]) {
+    const Rsrc rs = make_rsrc(x, (int64_t)a.N * ld * sizeof(T), u.b);
 #pragma unroll
-    for (int it = 0; it < NodeMap<HG, NTHR, D>::kIters; ++it) v[it] = buf_ld16(rs, NodeMap<HG, NTHR, D>(tid, it).glb_off(ld, off, a, u, sizeof(T)));
+    for (int it = 0; it < NodeMap<HG, NTHR, D>::kIters; ++it) ld16(v[it], rs, NodeMap<HG, NTHR, D>(tid, it).glb_off(ld, off, a, u, sizeof(T)));
 }
-template <int HG, int D, int NTHR = HG * 64>
-__device__ __forceinline__ void stage_node_commit(char* region, int tid, const uint4 (&v)[NodeMap<HG, NTHR, D>::kIters]) {
+template <int HG, int D, int NTHR = HG * 64, typename V = uint4>
+__device__ __forceinline__ void stage_node_commit(char* region, int tid, V (&v)[NodeMap<HG, NTHR, D>::kIters]) {
 #pragma unroll
     for (int it = 0; it < NodeMap<HG, NTHR, D>::kIters; ++it) {
         const NodeMap<HG, NTHR, D> nm(tid, it);
-        if (nm.in) lds_put16(region + nm.lds_off(), v[it], (tid >> 3) & 3);
+        const uint4 x = take(v[it]);
+        if (nm.in) lds_put16(region + nm.lds_off(), x, (tid >> 3) & 3);
     }
 }
 template <typename T, int HG, int D, int NTHR = HG * 64>
@@ -500,6 +530,8 @@ __device__ __forceinline__ void tile_bwd(char* lds, const tgt_node_attention_arg
 // (graph-major, head group minor) round-robin, so the head groups of one graph run at the same time on the
 // same XCD and the 128-byte E / G / dH rows they share come from HBM once.
 // ---------------------------------------------------------------------------
+constexpr int kWaitVm0 = 0x0F70;      // s_waitcnt vmcnt(0) (expcnt / lgkmcnt fields at their maxima = not waited for)
+
 struct Walk {
     int x, t, step, nt, groups;
     __device__ __forceinline__ Walk(const tgt_node_attention_args& a, int HG) {
@@ -527,24 +559,26 @@ node_att_mfma_fwd_kernel(const tgt_node_attention_args a, const int ablate) {
     Walk w(a, HG);
     if (!w.live()) return;
 
-    uint4 veg[PairMap<NTHR, HG / 4>::kIters];
-    uint4 vq[NodeMap<HG, NTHR, D>::kIters], vk[NodeMap<HG, NTHR, D>::kIters], vv[NodeMap<HG, NTHR, D>::kIters];
+    using V = typename std::conditional<PIPE, AChunk, uint4>::type;      // PIPE: the prefetch waits in accumulation registers
+    V veg[PairMap<NTHR, HG / 4>::kIters];
+    V vq[NodeMap<HG, NTHR, D>::kIters], vk[NodeMap<HG, NTHR, D>::kIters], vv[NodeMap<HG, NTHR, D>::kIters];
     float mk[1024 / NTHR];
     auto issue = [&](const Unit& u) {
-        stage_eg_issue<T, HG, NTHR>(a, u, tid, veg);
-        stage_node_issue<T, HG, D, NTHR>(a.qkv, a.ld_qkv, a.q_off, a, u, tid, vq);
-        stage_node_issue<T, HG, D, NTHR>(a.qkv, a.ld_qkv, a.k_off, a, u, tid, vk);
-        stage_node_issue<T, HG, D, NTHR>(a.qkv, a.ld_qkv, a.v_off, a, u, tid, vv);
+        stage_eg_issue<T, HG, NTHR, V>(a, u, tid, veg);
+        stage_node_issue<T, HG, D, NTHR, V>(a.qkv, a.ld_qkv, a.q_off, a, u, tid, vq);
+        stage_node_issue<T, HG, D, NTHR, V>(a.qkv, a.ld_qkv, a.k_off, a, u, tid, vk);
+        stage_node_issue<T, HG, D, NTHR, V>(a.qkv, a.ld_qkv, a.v_off, a, u, tid, vv);
         stage_mask_issue<NTHR>(a, u, tid, mk);
     };
     if (!(ablate & 2)) issue(w.unit());
     while (true) {
         const Unit u = w.unit();
         if (!(ablate & 2)) {
-            stage_eg_commit<HG, NTHR>(lds, tid, veg);
-            stage_node_commit<HG, D, NTHR>(rQ, tid, vq);
-            stage_node_commit<HG, D, NTHR>(rK, tid, vk);
-            stage_node_commit<HG, D, NTHR>(rV, tid, vv);
+            if constexpr (PIPE) __builtin_amdgcn_s_waitcnt(kWaitVm0);      // the assembly loads are invisible to the compiler
+            stage_eg_commit<HG, NTHR, V>(lds, tid, veg);
+            stage_node_commit<HG, D, NTHR, V>(rQ, tid, vq);
+            stage_node_commit<HG, D, NTHR, V>(rK, tid, vk);
+            stage_node_commit<HG, D, NTHR, V>(rV, tid, vv);
             stage_mask_commit<HG, NTHR>(lds, tid, mk);
         }
         __syncthreads();
@@ -580,25 +614,35 @@ node_att_mfma_bwd_kernel(const tgt_node_attention_args a, const int ablate) {
     Walk w(a, HG);
     if (!w.live()) return;
 
-    uint4 veg[PairMap<NTHR, HG / 4>::kIters], vh[PairMap<NTHR, HG / 8>::kIters];
+    // PIPE: the pair tensors of the NEXT unit (E, G, dH_hat: two thirds of the bytes) are fetched under the tile math and
+    // wait in accumulation registers; its node rows and mask follow once the tile math has freed the vector registers,
+    // under the stores of the current unit
+    using V = typename std::conditional<PIPE, AChunk, uint4>::type;
+    V veg[PairMap<NTHR, HG / 4>::kIters], vh[PairMap<NTHR, HG / 8>::kIters];
     uint4 vq[NodeMap<HG, NTHR, D>::kIters], vk[NodeMap<HG, NTHR, D>::kIters], vv[NodeMap<HG, NTHR, D>::kIters],
         vo[NodeMap<HG, NTHR, D>::kIters];
     float mk[1024 / NTHR];
-    auto issue = [&](const Unit& u) {
-        stage_eg_issue<T, HG, NTHR>(a, u, tid, veg);
-        stage_h_issue<T, HG, NTHR>(a.d_hhat, a, u, tid, vh);
+    auto issue_pairs = [&](const Unit& u) {
+        stage_eg_issue<T, HG, NTHR, V>(a, u, tid, veg);
+        stage_h_issue<T, HG, NTHR, V>(a.d_hhat, a, u, tid, vh);
+    };
+    auto issue_rows = [&](const Unit& u) {
         stage_node_issue<T, HG, D, NTHR>(a.qkv, a.ld_qkv, a.q_off, a, u, tid, vq);
         stage_node_issue<T, HG, D, NTHR>(a.qkv, a.ld_qkv, a.k_off, a, u, tid, vk);
         stage_node_issue<T, HG, D, NTHR>(a.qkv, a.ld_qkv, a.v_off, a, u, tid, vv);
         stage_node_issue<T, HG, D, NTHR>(a.d_vatt, (int64_t)D * a.H, 0, a, u, tid, vo);
         stage_mask_issue<NTHR>(a, u, tid, mk);
     };
-    if (!(ablate & 2)) issue(w.unit());
+    if (!(ablate & 2)) {
+        issue_pairs(w.unit());
+        issue_rows(w.unit());
+    }
     while (true) {
         const Unit u = w.unit();
         if (!(ablate & 2)) {
-            stage_eg_commit<HG, NTHR>(lds, tid, veg);
-            stage_h_commit<HG, NTHR>(lds, tid, vh);
+            if constexpr (PIPE) __builtin_amdgcn_s_waitcnt(kWaitVm0);      // the assembly loads are invisible to the compiler
+            stage_eg_commit<HG, NTHR, V>(lds, tid, veg);
+            stage_h_commit<HG, NTHR, V>(lds, tid, vh);
             stage_node_commit<HG, D, NTHR>(rQ, tid, vq);
             stage_node_commit<HG, D, NTHR>(rK, tid, vk);
             stage_node_commit<HG, D, NTHR>(rV, tid, vv);
@@ -608,12 +652,13 @@ node_att_mfma_bwd_kernel(const tgt_node_attention_args a, const int ablate) {
         __syncthreads();
         w.next();
         const bool more = PIPE && w.live();
-        if (more && !(ablate & 2)) issue(w.unit());           // in flight under the tile math
+        if (more && !(ablate & 2)) issue_pairs(w.unit());     // in flight under the tile math
         if (!(ablate & 1)) {
 #pragma unroll 1
             for (int hh = wave; hh < HG; hh += NW) tile_bwd<T, HG, D>(lds, a, r, hi, hh);
         }
         __syncthreads();
+        if (more && !(ablate & 2)) issue_rows(w.unit());      // in flight under the stores
         if (!(ablate & 4)) {
             unstage_eg<T, HG, NTHR>(lds, a.d_eg, a, u, tid);
             unstage_node<T, HG, D, NTHR>(rQ, a.d_qkv, a.ld_qkv, a.q_off, a, u, tid);
