@@ -12,8 +12,8 @@
 // passes (rows: dE, dG, dQ; columns: dK, dV) that together move 2.17x the algorithmic bytes
 // (profiles/r02_pmc_summary.json).  Per (graph, head) the op is ONE 32x32 attention tile with a
 // depth-D contraction: exactly the tile of the triplet kernels (triplet_attention.hip).  Here:
-//   workgroup = (graph b, group of HG heads), HG waves, wave = head (HG = 8: two workgroups share a CU and
-//   one loads / stores while the other computes; HG = 16: one workgroup per CU, 32-byte row segments).
+//   workgroup = (graph b, group of HG heads), HG waves, wave = head (HG = 16: one workgroup per CU, 32-byte row
+//   segments; HG = 8 for the shape whose 16-head image does not fit the LDS).
 //   1. the workgroup pulls everything it needs through LDS ONCE with 16-byte accesses: the 2*HG-byte
 //      segments (HG heads) of every E / G / dH_hat row of the graph, the mask, and the HG-head
 //      segments of the Q / K / V / dV_att rows;
@@ -30,7 +30,6 @@
 // algorithmic traffic only.  HBM-bound; the workgroups that share a graph's 128-byte E/G
 // rows are given the same XCD (block index -> unit map) so that all but one of them hit in its L2.
 #include <cstdlib>
-#include <type_traits>
 #include "common.hpp"
 #include "triplet_common.hpp"
 
@@ -93,34 +92,6 @@ __device__ __forceinline__ void buf_st16(__amdgpu_buffer_rsrc_t r, uint32_t off,
     __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)off, 0, 0);
 }
 
-// A 16-byte chunk in flight.  uint4: an ordinary buffer load (the compiler tracks it).  AChunk: the load targets
-// ACCUMULATION registers (inline assembly: `buffer_load_dwordx4 a[..]`), where the prefetch of the persistent kernels
-// waits out the tile math -- hipcc would otherwise spill long-lived prefetched VGPRs to scratch, which puts the load
-// wait back in front of the tile math.  The compiler does not see these loads: the kernel waits for them with an
-// explicit s_waitcnt before the first take().
-typedef int i32x4_t __attribute__((ext_vector_type(4)));
-struct AChunk { u32x4_t a; };
-struct Rsrc {
-    __amdgpu_buffer_rsrc_t r;
-    i32x4_t w;          // the same descriptor as four dwords (inline assembly operand)
-};
-__device__ __forceinline__ Rsrc make_rsrc(const void* tensor, int64_t graph_bytes, int b) {
-    const uint64_t base = (uint64_t)(reinterpret_cast<const char*>(tensor) + (int64_t)b * graph_bytes);
-    // (readfirstlane: the descriptor must sit in scalar registers, and the inline assembly operand does not force that)
-    return Rsrc{graph_rsrc(tensor, graph_bytes, b),
-                i32x4_t{__builtin_amdgcn_readfirstlane((int)(uint32_t)base), __builtin_amdgcn_readfirstlane((int)((base >> 32) & 0xffffu)),
-                        __builtin_amdgcn_readfirstlane((int)graph_bytes), 0x00020000}};
-}
-__device__ __forceinline__ void ld16(uint4& v, const Rsrc& rs, uint32_t off) { v = buf_ld16(rs.r, off); }
-__device__ __forceinline__ void ld16(AChunk& v, const Rsrc& rs, uint32_t off) {
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=a"(v.a) : "v"(off), "s"(rs.w) : "memory");
-}
-__device__ __forceinline__ uint4 take(const uint4& v) { return v; }
-__device__ __forceinline__ uint4 take(AChunk& v) {
-    asm volatile("" : "+a"(v.a));          // the value stays in its accumulation registers up to here
-    return make_uint4(v.a.x, v.a.y, v.a.z, v.a.w);
-}
-
 struct Unit { int b, hg; };
 // ---- cooperative staging (NTHR threads) ---------------------------------------------------------
 // Pair tensors (B,N,N,ld): a pair's record is SUBS 16-byte pieces; chunk c = it * NTHR + tid is piece
@@ -138,30 +109,30 @@ __device__ __forceinline__ uint32_t eg_chan(const tgt_node_attention_args& a, co
     constexpr int kE = HG / 8;       // 16-byte pieces of E (8 heads each)
     return (uint32_t)(((sub < kE ? a.e_off + sub * 8 : a.g_off + (sub - kE) * 8) + u.hg * HG) * (int)sizeof(T));
 }
-template <typename T, int HG, int NTHR = HG * 64, typename V = uint4>
+template <typename T, int HG, int NTHR = HG * 64>
 __device__ __forceinline__ void stage_eg_issue(const tgt_node_attention_args& a, const Unit& u, int tid,
-                                               V (&v)[PairMap<NTHR, HG / 4>::kIters]) {
+                                               uint4 (&v)[PairMap<NTHR, HG / 4>::kIters]) {
     using PM = PairMap<NTHR, HG / 4>;
     const PM pm(tid);
     const int N = a.N;
-    const Rsrc rs = make_rsrc(a.eg, (int64_t)N * N * a.ld_eg * sizeof(T), u.b);
+    const __amdgpu_buffer_rsrc_t rs = graph_rsrc(a.eg, (int64_t)N * N * a.ld_eg * sizeof(T), u.b);
     const uint32_t ldb = (uint32_t)(a.ld_eg * sizeof(T));
     const uint32_t off0 = (uint32_t)(pm.l0 * N + pm.m) * ldb + eg_chan<T, HG>(a, u, pm.sub);
 #pragma unroll
     for (int it = 0; it < PM::kIters; ++it) {
         const bool ok = pm.m < N && pm.l0 + it * PM::kLStep < N;
-        ld16(v[it], rs, ok ? off0 + (uint32_t)(it * PM::kLStep * N) * ldb : kOob);
+        v[it] = buf_ld16(rs, ok ? off0 + (uint32_t)(it * PM::kLStep * N) * ldb : kOob);
     }
 }
-template <int HG, int NTHR = HG * 64, typename V = uint4>
-__device__ __forceinline__ void stage_eg_commit(char* lds, int tid, V (&v)[PairMap<NTHR, HG / 4>::kIters]) {
+template <int HG, int NTHR = HG * 64>
+__device__ __forceinline__ void stage_eg_commit(char* lds, int tid, uint4 (&v)[PairMap<NTHR, HG / 4>::kIters]) {
     using PM = PairMap<NTHR, HG / 4>;
     using L = Lay<HG>;
     const PM pm(tid);
     const int rot = (tid >> 3) & 3;
     char* dst = lds + L::kOffEG + pm.l0 * L::kPitchEG + pm.m * L::kRecEG + pm.sub * 16;
 #pragma unroll
-    for (int it = 0; it < PM::kIters; ++it) lds_put16(dst + it * PM::kLStep * L::kPitchEG, take(v[it]), rot);
+    for (int it = 0; it < PM::kIters; ++it) lds_put16(dst + it * PM::kLStep * L::kPitchEG, v[it], rot);
 }
 template <typename T, int HG, int NTHR = HG * 64>
 __device__ __forceinline__ void unstage_eg(const char* lds, void* d_eg, const tgt_node_attention_args& a, const Unit& u, int tid) {
@@ -180,30 +151,30 @@ __device__ __forceinline__ void unstage_eg(const char* lds, void* d_eg, const tg
     }
 }
 // (B,N,N,H) tensors (H_hat, dH_hat): HG/8 pieces per pair
-template <typename T, int HG, int NTHR = HG * 64, typename V = uint4>
+template <typename T, int HG, int NTHR = HG * 64>
 __device__ __forceinline__ void stage_h_issue(const void* x, const tgt_node_attention_args& a, const Unit& u, int tid,
-                                              V (&v)[PairMap<NTHR, HG / 8>::kIters]) {
+                                              uint4 (&v)[PairMap<NTHR, HG / 8>::kIters]) {
     using PM = PairMap<NTHR, HG / 8>;
     const PM pm(tid);
     const int N = a.N;
-    const Rsrc rs = make_rsrc(x, (int64_t)N * N * a.H * sizeof(T), u.b);
+    const __amdgpu_buffer_rsrc_t rs = graph_rsrc(x, (int64_t)N * N * a.H * sizeof(T), u.b);
     const uint32_t ldb = (uint32_t)(a.H * sizeof(T));
     const uint32_t off0 = (uint32_t)(pm.l0 * N + pm.m) * ldb + (uint32_t)((u.hg * HG + pm.sub * 8) * (int)sizeof(T));
 #pragma unroll
     for (int it = 0; it < PM::kIters; ++it) {
         const bool ok = x && pm.m < N && pm.l0 + it * PM::kLStep < N;
-        ld16(v[it], rs, ok ? off0 + (uint32_t)(it * PM::kLStep * N) * ldb : kOob);
+        v[it] = buf_ld16(rs, ok ? off0 + (uint32_t)(it * PM::kLStep * N) * ldb : kOob);
     }
 }
-template <int HG, int NTHR = HG * 64, typename V = uint4>
-__device__ __forceinline__ void stage_h_commit(char* lds, int tid, V (&v)[PairMap<NTHR, HG / 8>::kIters]) {
+template <int HG, int NTHR = HG * 64>
+__device__ __forceinline__ void stage_h_commit(char* lds, int tid, uint4 (&v)[PairMap<NTHR, HG / 8>::kIters]) {
     using PM = PairMap<NTHR, HG / 8>;
     using L = Lay<HG>;
     const PM pm(tid);
     const int rot = (tid >> 3) & 3;
     char* dst = lds + L::kOffH + pm.l0 * L::kPitchH + pm.m * L::kRecH + pm.sub * 16;
 #pragma unroll
-    for (int it = 0; it < PM::kIters; ++it) lds_put16(dst + it * PM::kLStep * L::kPitchH, take(v[it]), rot);
+    for (int it = 0; it < PM::kIters; ++it) lds_put16(dst + it * PM::kLStep * L::kPitchH, v[it], rot);
 }
 // H_hat out of the E slots of the E|G image
 template <typename T, int HG, int NTHR = HG * 64>
@@ -237,20 +208,19 @@ struct NodeMap {
         return (in && row < a.N) ? (uint32_t)((row * ld + off + d * a.H + u.hg * HG + piece * 8) * (int64_t)esz) : kOob;
     }
 };
-template <typename T, int HG, int D, int NTHR = HG * 64, typename V = uint4>
+template <typename T, int HG, int D, int NTHR = HG * 64>
 __device__ __forceinline__ void stage_node_issue(const void* x, int64_t ld, int off, const tgt_node_attention_args& a, const Unit& u,
-                                                 int tid, V (&v)[NodeMap<HG, NTHR, D>::kIters]) {
-    const Rsrc rs = make_rsrc(x, (int64_t)a.N * ld * sizeof(T), u.b);
+                                                 int tid, uint4 (&v)[NodeMap<HG, NTHR, D>::kIters]) {
+    const __amdgpu_buffer_rsrc_t rs = graph_rsrc(x, (int64_t)a.N * ld * sizeof(T), u.b);
 #pragma unroll
-    for (int it = 0; it < NodeMap<HG, NTHR, D>::kIters; ++it) ld16(v[it], rs, NodeMap<HG, NTHR, D>(tid, it).glb_off(ld, off, a, u, sizeof(T)));
+    for (int it = 0; it < NodeMap<HG, NTHR, D>::kIters; ++it) v[it] = buf_ld16(rs, NodeMap<HG, NTHR, D>(tid, it).glb_off(ld, off, a, u, sizeof(T)));
 }
-template <int HG, int D, int NTHR = HG * 64, typename V = uint4>
-__device__ __forceinline__ void stage_node_commit(char* region, int tid, V (&v)[NodeMap<HG, NTHR, D>::kIters]) {
+template <int HG, int D, int NTHR = HG * 64>
+__device__ __forceinline__ void stage_node_commit(char* region, int tid, uint4 (&v)[NodeMap<HG, NTHR, D>::kIters]) {
 #pragma unroll
     for (int it = 0; it < NodeMap<HG, NTHR, D>::kIters; ++it) {
         const NodeMap<HG, NTHR, D> nm(tid, it);
-        const uint4 x = take(v[it]);
-        if (nm.in) lds_put16(region + nm.lds_off(), x, (tid >> 3) & 3);
+        if (nm.in) lds_put16(region + nm.lds_off(), v[it], (tid >> 3) & 3);
     }
 }
 template <typename T, int HG, int D, int NTHR = HG * 64>
@@ -514,205 +484,145 @@ __device__ __forceinline__ void tile_bwd(char* lds, const tgt_node_attention_arg
 }
 
 // ---------------------------------------------------------------------------
-// The kernels.  NW waves per workgroup, wave w takes heads w, w + NW, ... of the group's HG heads one after the
-// other.  Shipped form: HG = NW = 16, one workgroup per unit (graph, head group), at most 128 registers.
-// Load, tile math and store of one unit cannot overlap each other (one LDS image), and workgroups that start
-// together stay in step, so the three phases add up on every CU (B=256, N=32, H=64, D=12, bf16, rocprofv3:
-// backward loads alone 30 us + tile math 43 us + stores 24 us; the kernel 88-103 us).  Two things were built
-// against that and measured:
-//   * HG = 8 (two workgroups per CU, TGT_NODE_MFMA_HG=8): no gain -- the two stay in step as well, and a load
-//     request per 16 bytes is too fine for the L2 (loads alone 46 us against 30 us): 117 us;
-//   * a PERSISTENT workgroup of 8 waves x 2 heads that prefetches the NEXT unit's loads into registers under the
-//     tile math (PIPE, TGT_NODE_MFMA_PIPE=1): forward 50.5 -> 48.7 us; the backward needs 78 prefetch registers
-//     on top of the tile's ~130 and hipcc answers by spilling the prefetched chunks to scratch, which puts the
-//     load wait back in front of the tile math (136 us).  Parity-green, not the default.
+// The kernels: one workgroup per unit (graph, head group), NW = HG waves, wave = head.
 // Unit order: XCD x (= block index & 7) owns the graphs b = x mod 8; its workgroups take that list's units
-// (graph-major, head group minor) round-robin, so the head groups of one graph run at the same time on the
-// same XCD and the 128-byte E / G / dH rows they share come from HBM once.
+// (graph-major, head group minor) in order, so the head groups of one graph run at the same time on the same XCD
+// and the 128-byte E / G / dH rows they share come from HBM once.
+// What bounds them (B=256, N=32, H=64, D=12, bf16, rocprofv3; TGT_NODE_ABLATE): load, tile math and store of a
+// unit cannot overlap (one LDS image) and workgroups that start together stay in step, so the phases add up --
+// backward: loads alone 30 us + tile math 43 us + stores 24 us, the kernel 86-103 us.  Built against that,
+// measured and removed again (git history): 8-head workgroups, two per CU (they stay in step too, and a load
+// request per 16 bytes is too fine for the L2: 117 us; the form remains for D = 16, whose 16-head backward image
+// does not fit the LDS); a delayed start for every other first-round workgroup (slower by the delay); a persistent
+// 8-wave workgroup prefetching the NEXT unit's loads into registers, then into accumulation registers by inline
+// assembly, under the tile math (forward 48.7-51.0 us against 50.0-50.5; the backward's tile math spills under the
+// 128 + 128 register split hipcc applies once accumulation registers are in use: 136-153 us).
 // ---------------------------------------------------------------------------
-constexpr int kWaitVm0 = 0x0F70;      // s_waitcnt vmcnt(0) (expcnt / lgkmcnt fields at their maxima = not waited for)
+__device__ __forceinline__ bool unit_of_block(const tgt_node_attention_args& a, int HG, Unit& u) {
+    const int groups = a.H / HG, x = blockIdx.x & 7, t = blockIdx.x >> 3;
+    const int nt = ((a.B - x + 7) >> 3) * groups;       // units of the graphs b = x, x + 8, ... < B
+    u = Unit{(t / groups) * 8 + x, t % groups};
+    return t < nt;
+}
 
-struct Walk {
-    int x, t, step, nt, groups;
-    __device__ __forceinline__ Walk(const tgt_node_attention_args& a, int HG) {
-        groups = a.H / HG;
-        x = blockIdx.x & 7;
-        t = blockIdx.x >> 3;
-        step = gridDim.x >> 3;
-        nt = ((a.B - x + 7) >> 3) * groups;       // units of the graphs b = x, x + 8, ... < B
-    }
-    __device__ __forceinline__ bool live() const { return t < nt; }
-    __device__ __forceinline__ Unit unit() const { return Unit{(t / groups) * 8 + x, t % groups}; }
-    __device__ __forceinline__ void next() { t += step; }
-};
-
-template <typename T, int HG, int NW, int D, bool PIPE>
-__global__ void __launch_bounds__(NW * 64, 1024 / (NW * 64) >= 2 ? 2 : 4)
-node_att_mfma_fwd_kernel(const tgt_node_attention_args a, const int ablate) {
+template <typename T, int HG, int D>
+__global__ void __launch_bounds__(HG * 64, 4) node_att_mfma_fwd_kernel(const tgt_node_attention_args a, const int ablate) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     using L = Lay<HG>;
-    constexpr int NTHR = NW * 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hi = lane >> 5;
+    constexpr int NTHR = HG * 64;
+    const int tid = threadIdx.x, lane = tid & 63, hh = tid >> 6, r = lane & 31, hi = lane >> 5;
     char* rQ = lds + L::off_n(D, false, 0);
     char* rK = lds + L::off_n(D, false, 1);
     char* rV = lds + L::off_n(D, false, 2);
-    Walk w(a, HG);
-    if (!w.live()) return;
+    Unit u;
+    if (!unit_of_block(a, HG, u)) return;
 
-    using V = typename std::conditional<PIPE, AChunk, uint4>::type;      // PIPE: the prefetch waits in accumulation registers
-    V veg[PairMap<NTHR, HG / 4>::kIters];
-    V vq[NodeMap<HG, NTHR, D>::kIters], vk[NodeMap<HG, NTHR, D>::kIters], vv[NodeMap<HG, NTHR, D>::kIters];
-    float mk[1024 / NTHR];
-    auto issue = [&](const Unit& u) {
-        stage_eg_issue<T, HG, NTHR, V>(a, u, tid, veg);
-        stage_node_issue<T, HG, D, NTHR, V>(a.qkv, a.ld_qkv, a.q_off, a, u, tid, vq);
-        stage_node_issue<T, HG, D, NTHR, V>(a.qkv, a.ld_qkv, a.k_off, a, u, tid, vk);
-        stage_node_issue<T, HG, D, NTHR, V>(a.qkv, a.ld_qkv, a.v_off, a, u, tid, vv);
+    if (!(ablate & 2)) {   // stage: every load is issued before the first LDS write
+        uint4 veg[PairMap<NTHR, HG / 4>::kIters];
+        uint4 vq[NodeMap<HG, NTHR, D>::kIters], vk[NodeMap<HG, NTHR, D>::kIters], vv[NodeMap<HG, NTHR, D>::kIters];
+        float mk[1024 / NTHR];
+        stage_eg_issue<T, HG>(a, u, tid, veg);
+        stage_node_issue<T, HG, D>(a.qkv, a.ld_qkv, a.q_off, a, u, tid, vq);
+        stage_node_issue<T, HG, D>(a.qkv, a.ld_qkv, a.k_off, a, u, tid, vk);
+        stage_node_issue<T, HG, D>(a.qkv, a.ld_qkv, a.v_off, a, u, tid, vv);
         stage_mask_issue<NTHR>(a, u, tid, mk);
-    };
-    if (!(ablate & 2)) issue(w.unit());
-    while (true) {
-        const Unit u = w.unit();
-        if (!(ablate & 2)) {
-            if constexpr (PIPE) __builtin_amdgcn_s_waitcnt(kWaitVm0);      // the assembly loads are invisible to the compiler
-            stage_eg_commit<HG, NTHR, V>(lds, tid, veg);
-            stage_node_commit<HG, D, NTHR, V>(rQ, tid, vq);
-            stage_node_commit<HG, D, NTHR, V>(rK, tid, vk);
-            stage_node_commit<HG, D, NTHR, V>(rV, tid, vv);
-            stage_mask_commit<HG, NTHR>(lds, tid, mk);
-        }
-        __syncthreads();
-        w.next();
-        const bool more = PIPE && w.live();
-        if (more && !(ablate & 2)) issue(w.unit());           // in flight under the tile math
-        if (!(ablate & 1)) {
-#pragma unroll 1
-            for (int hh = wave; hh < HG; hh += NW) tile_fwd<T, HG, D>(lds, a, u, r, hi, hh);
-        }
-        __syncthreads();
-        if (!(ablate & 4)) {
-            if (a.hhat) unstage_hhat<T, HG, NTHR>(lds, a.hhat, a, u, tid);
-            unstage_node<T, HG, D, NTHR>(rQ, a.vatt, (int64_t)D * a.H, 0, a, u, tid);
-        }
-        if (!more) break;
-        // (no barrier: a thread overwrites only the chunks it has just read itself -- commit and unstage share the chunk
-        //  map -- and the K / V / mask images were last read before the barrier above)
+        stage_eg_commit<HG>(lds, tid, veg);
+        stage_node_commit<HG, D>(rQ, tid, vq);
+        stage_node_commit<HG, D>(rK, tid, vk);
+        stage_node_commit<HG, D>(rV, tid, vv);
+        stage_mask_commit<HG, NTHR>(lds, tid, mk);
     }
+    __syncthreads();
+    if (!(ablate & 1)) tile_fwd<T, HG, D>(lds, a, u, r, hi, hh);
+    __syncthreads();
+    if (ablate & 4) return;
+    if (a.hhat) unstage_hhat<T, HG>(lds, a.hhat, a, u, tid);
+    unstage_node<T, HG, D>(rQ, a.vatt, (int64_t)D * a.H, 0, a, u, tid);
 }
 
-template <typename T, int HG, int NW, int D, bool PIPE>
-__global__ void __launch_bounds__(NW * 64, 1024 / (NW * 64) >= 2 ? 2 : 4)
-node_att_mfma_bwd_kernel(const tgt_node_attention_args a, const int ablate) {
+template <typename T, int HG, int D>
+__global__ void __launch_bounds__(HG * 64, 4) node_att_mfma_bwd_kernel(const tgt_node_attention_args a, const int ablate) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     using L = Lay<HG>;
-    constexpr int NTHR = NW * 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hi = lane >> 5;
+    constexpr int NTHR = HG * 64;
+    const int tid = threadIdx.x, lane = tid & 63, hh = tid >> 6, r = lane & 31, hi = lane >> 5;
     char* rQ = lds + L::off_n(D, true, 0);
     char* rK = lds + L::off_n(D, true, 1);
     char* rV = lds + L::off_n(D, true, 2);
     char* rO = lds + L::off_n(D, true, 3);
-    Walk w(a, HG);
-    if (!w.live()) return;
+    Unit u;
+    if (!unit_of_block(a, HG, u)) return;
 
-    // PIPE: the pair tensors of the NEXT unit (E, G, dH_hat: two thirds of the bytes) are fetched under the tile math and
-    // wait in accumulation registers; its node rows and mask follow once the tile math has freed the vector registers,
-    // under the stores of the current unit
-    using V = typename std::conditional<PIPE, AChunk, uint4>::type;
-    V veg[PairMap<NTHR, HG / 4>::kIters], vh[PairMap<NTHR, HG / 8>::kIters];
-    uint4 vq[NodeMap<HG, NTHR, D>::kIters], vk[NodeMap<HG, NTHR, D>::kIters], vv[NodeMap<HG, NTHR, D>::kIters],
-        vo[NodeMap<HG, NTHR, D>::kIters];
-    float mk[1024 / NTHR];
-    auto issue_pairs = [&](const Unit& u) {
-        stage_eg_issue<T, HG, NTHR, V>(a, u, tid, veg);
-        stage_h_issue<T, HG, NTHR, V>(a.d_hhat, a, u, tid, vh);
-    };
-    auto issue_rows = [&](const Unit& u) {
-        stage_node_issue<T, HG, D, NTHR>(a.qkv, a.ld_qkv, a.q_off, a, u, tid, vq);
-        stage_node_issue<T, HG, D, NTHR>(a.qkv, a.ld_qkv, a.k_off, a, u, tid, vk);
-        stage_node_issue<T, HG, D, NTHR>(a.qkv, a.ld_qkv, a.v_off, a, u, tid, vv);
-        stage_node_issue<T, HG, D, NTHR>(a.d_vatt, (int64_t)D * a.H, 0, a, u, tid, vo);
-        stage_mask_issue<NTHR>(a, u, tid, mk);
-    };
     if (!(ablate & 2)) {
-        issue_pairs(w.unit());
-        issue_rows(w.unit());
+        uint4 veg[PairMap<NTHR, HG / 4>::kIters], vh[PairMap<NTHR, HG / 8>::kIters];
+        uint4 vq[NodeMap<HG, NTHR, D>::kIters], vk[NodeMap<HG, NTHR, D>::kIters], vv[NodeMap<HG, NTHR, D>::kIters],
+            vo[NodeMap<HG, NTHR, D>::kIters];
+        float mk[1024 / NTHR];
+        stage_eg_issue<T, HG>(a, u, tid, veg);
+        stage_h_issue<T, HG>(a.d_hhat, a, u, tid, vh);
+        stage_node_issue<T, HG, D>(a.qkv, a.ld_qkv, a.q_off, a, u, tid, vq);
+        stage_node_issue<T, HG, D>(a.qkv, a.ld_qkv, a.k_off, a, u, tid, vk);
+        stage_node_issue<T, HG, D>(a.qkv, a.ld_qkv, a.v_off, a, u, tid, vv);
+        stage_node_issue<T, HG, D>(a.d_vatt, (int64_t)D * a.H, 0, a, u, tid, vo);
+        stage_mask_issue<NTHR>(a, u, tid, mk);
+        stage_eg_commit<HG>(lds, tid, veg);
+        stage_h_commit<HG>(lds, tid, vh);
+        stage_node_commit<HG, D>(rQ, tid, vq);
+        stage_node_commit<HG, D>(rK, tid, vk);
+        stage_node_commit<HG, D>(rV, tid, vv);
+        stage_node_commit<HG, D>(rO, tid, vo);
+        stage_mask_commit<HG, NTHR>(lds, tid, mk);
     }
-    while (true) {
-        const Unit u = w.unit();
-        if (!(ablate & 2)) {
-            if constexpr (PIPE) __builtin_amdgcn_s_waitcnt(kWaitVm0);      // the assembly loads are invisible to the compiler
-            stage_eg_commit<HG, NTHR, V>(lds, tid, veg);
-            stage_h_commit<HG, NTHR, V>(lds, tid, vh);
-            stage_node_commit<HG, D, NTHR>(rQ, tid, vq);
-            stage_node_commit<HG, D, NTHR>(rK, tid, vk);
-            stage_node_commit<HG, D, NTHR>(rV, tid, vv);
-            stage_node_commit<HG, D, NTHR>(rO, tid, vo);
-            stage_mask_commit<HG, NTHR>(lds, tid, mk);
-        }
-        __syncthreads();
-        w.next();
-        const bool more = PIPE && w.live();
-        if (more && !(ablate & 2)) issue_pairs(w.unit());     // in flight under the tile math
-        if (!(ablate & 1)) {
-#pragma unroll 1
-            for (int hh = wave; hh < HG; hh += NW) tile_bwd<T, HG, D>(lds, a, r, hi, hh);
-        }
-        __syncthreads();
-        if (more && !(ablate & 2)) issue_rows(w.unit());      // in flight under the stores
-        if (!(ablate & 4)) {
-            unstage_eg<T, HG, NTHR>(lds, a.d_eg, a, u, tid);
-            unstage_node<T, HG, D, NTHR>(rQ, a.d_qkv, a.ld_qkv, a.q_off, a, u, tid);
-            unstage_node<T, HG, D, NTHR>(rK, a.d_qkv, a.ld_qkv, a.k_off, a, u, tid);
-            unstage_node<T, HG, D, NTHR>(rV, a.d_qkv, a.ld_qkv, a.v_off, a, u, tid);
-        }
-        if (!more) break;
-        // (no barrier, as in the forward; the dH / dV_att / mask images were last read before the barrier above)
-    }
+    __syncthreads();
+    if (!(ablate & 1)) tile_bwd<T, HG, D>(lds, a, r, hi, hh);
+    __syncthreads();
+    if (ablate & 4) return;
+    unstage_eg<T, HG>(lds, a.d_eg, a, u, tid);
+    unstage_node<T, HG, D>(rQ, a.d_qkv, a.ld_qkv, a.q_off, a, u, tid);
+    unstage_node<T, HG, D>(rK, a.d_qkv, a.ld_qkv, a.k_off, a, u, tid);
+    unstage_node<T, HG, D>(rV, a.d_qkv, a.ld_qkv, a.v_off, a, u, tid);
 }
 
 constexpr int kLdsMax = 160 * 1024;
 
-template <typename T, int HG, int NW, int D, bool PIPE>
+template <typename T, int HG, int D>
 static int launch(const tgt_node_attention_args& a, bool bwd, hipStream_t st) {
     using L = Lay<HG>;
-    // persistent: 256 workgroups (one per CU; idle ones leave at once); one workgroup per unit otherwise, a multiple of 8
-    // so that the XCD lists of Walk cover every unit
-    const int grid = PIPE ? 256 : ((a.B + 7) / 8) * 8 * (a.H / HG);
+    const int grid = ((a.B + 7) / 8) * 8 * (a.H / HG);       // a multiple of 8: the XCD lists of unit_of_block cover every unit
     static const int ablate = getenv("TGT_NODE_ABLATE") ? atoi(getenv("TGT_NODE_ABLATE")) : 0;    // micro-benchmark only: 1 no tile math, 2 no loads, 4 no stores
     if (!bwd) {
         constexpr int kLds = L::lds_bytes(D, false);
         static_assert(kLds <= kLdsMax, "forward LDS");
-        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&node_att_mfma_fwd_kernel<T, HG, NW, D, PIPE>),
+        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&node_att_mfma_fwd_kernel<T, HG, D>),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLds), true);
         (void)once;
-        hipLaunchKernelGGL((node_att_mfma_fwd_kernel<T, HG, NW, D, PIPE>), dim3(grid), dim3(NW * 64), kLds, st, a, ablate);
+        hipLaunchKernelGGL((node_att_mfma_fwd_kernel<T, HG, D>), dim3(grid), dim3(HG * 64), kLds, st, a, ablate);
         return check_launch("node_att_mfma_fwd_kernel");
     } else {
         constexpr int kLds = L::lds_bytes(D, true);
         if constexpr (kLds <= kLdsMax) {
-            static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&node_att_mfma_bwd_kernel<T, HG, NW, D, PIPE>),
+            static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&node_att_mfma_bwd_kernel<T, HG, D>),
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLds), true);
             (void)once;
-            hipLaunchKernelGGL((node_att_mfma_bwd_kernel<T, HG, NW, D, PIPE>), dim3(grid), dim3(NW * 64), kLds, st, a, ablate);
+            hipLaunchKernelGGL((node_att_mfma_bwd_kernel<T, HG, D>), dim3(grid), dim3(HG * 64), kLds, st, a, ablate);
             return check_launch("node_att_mfma_bwd_kernel");
         }
         return -1;
     }
 }
 
-template <typename T, int HG, int NW, bool PIPE>
+template <typename T, int HG>
 static int dispatch_d(const tgt_node_attention_args& a, bool bwd, hipStream_t st) {
     switch (a.D) {
-        case 8: return launch<T, HG, NW, 8, PIPE>(a, bwd, st);
-        case 12: return launch<T, HG, NW, 12, PIPE>(a, bwd, st);
-        case 16: return launch<T, HG, NW, 16, PIPE>(a, bwd, st);
+        case 8: return launch<T, HG, 8>(a, bwd, st);
+        case 12: return launch<T, HG, 12>(a, bwd, st);
+        case 16: return launch<T, HG, 16>(a, bwd, st);
         default: return -1;
     }
 }
 
-// heads per workgroup: 16 (32-byte row segments) unless the shape or TGT_NODE_MFMA_HG says 8 (16-byte segments: a
-// request per 16 bytes is too fine for the L2 -- its loads alone take 46 us against 30 us).  The 16-head backward image
-// of D = 16 does not fit the LDS, that shape takes the 8-head form.
+// heads per workgroup: 16 (32-byte row segments) unless the shape or TGT_NODE_MFMA_HG says 8 (16-byte segments; the
+// 16-head backward image of D = 16 does not fit the LDS, that shape takes the 8-head form)
 static int heads_per_group(const tgt_node_attention_args& a, bool bwd) {
     static const int want = getenv("TGT_NODE_MFMA_HG") ? atoi(getenv("TGT_NODE_MFMA_HG")) : 16;
     if (want == 16 && a.H % 16 == 0 && !(bwd && a.D == 16)) return 16;
@@ -721,10 +631,7 @@ static int heads_per_group(const tgt_node_attention_args& a, bool bwd) {
 
 template <typename T>
 static int dispatch(const tgt_node_attention_args& a, bool bwd, hipStream_t st) {
-    static const int pipe = getenv("TGT_NODE_MFMA_PIPE") ? atoi(getenv("TGT_NODE_MFMA_PIPE")) : 0;
-    if (heads_per_group(a, bwd) == 16)
-        return pipe ? dispatch_d<T, 16, 8, true>(a, bwd, st) : dispatch_d<T, 16, 16, false>(a, bwd, st);
-    return dispatch_d<T, 8, 8, false>(a, bwd, st);
+    return heads_per_group(a, bwd) == 16 ? dispatch_d<T, 16>(a, bwd, st) : dispatch_d<T, 8>(a, bwd, st);
 }
 
 }  // namespace nmf
