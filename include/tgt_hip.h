@@ -190,6 +190,10 @@ typedef struct tgt_node_attention_args {
     void*  w_ws;                      /* backward scratch (may be NULL): (B,N,N,H) of `dtype`.  When given, the row pass leaves the
                                        * attention weights A[l,m,h] * log(1+sum gates) there and the column pass (dK, dV) reads them
                                        * and the stored dE instead of re-reading E, G and recomputing softmax and gate per pair */
+    const float* hhat_scale;          /* optional (B) float32: H_hat is WRITTEN as hhat_scale[b] * H_hat (the softmax still sees the
+                                       * unscaled logits) and the backward reads d_hhat as the gradient of that scaled tensor.  The
+                                       * DropPath factors of the edge branch lin_O_e(H_hat) feeds (reference layers.py:270-272),
+                                       * folded in here: see TGT_EDGE_BIAS_SCALED */
 } tgt_node_attention_args;
 
 int tgt_node_attention_fwd(const tgt_node_attention_args* a, void* stream);
@@ -277,6 +281,11 @@ int tgt_loss_accumulate(const void* loss, int32_t loss_is_f64, float samples, fl
  * caller's library GEMM + tgt_layer_norm_* path.
  * ---------------------------------------------------------------------- */
 enum { TGT_EPI_BIAS = 0, TGT_EPI_GELU = 1, TGT_EPI_RESID = 2, TGT_EPI_GELU_BWD = 3, TGT_EPI_LN_BWD = 4 };
+/* flags.  TGT_EDGE_BIAS_SCALED (TGT_EPI_RESID, N = 256, K in {64,128,256}): a arrives PRE-SCALED by row_scale (its producer
+ * folded the DropPath factor in: tgt_gelu_dropout_scaled_fwd, tgt_node_attention_args.hhat_scale), so
+ *     out = res + a W^T + row_scale[row / rows_per_sample] * bias
+ * and the backward of the block needs no scaled copy of the stream gradient (tgt_add_layer_norm_bwd with scale and d_x = NULL). */
+enum { TGT_EDGE_BIAS_SCALED = 1 };
 typedef struct tgt_edge_linear_args {
     int64_t M;
     int32_t K, N, dtype, epilogue;
@@ -291,7 +300,7 @@ typedef struct tgt_edge_linear_args {
     const void* res;    int64_t ldr;
     const void* ds_in;  int64_t ld_ds;
     const float* row_scale; const float* out_scale; int64_t rows_per_sample;
-    float dropout_p;    uint32_t _pad1;  uint64_t dropout_seed;
+    float dropout_p;    uint32_t flags;  uint64_t dropout_seed;      /* flags: TGT_EDGE_* */
     float* colsum_partial;
 } tgt_edge_linear_args;
 int tgt_edge_linear_supported(const tgt_edge_linear_args* a);
@@ -339,6 +348,15 @@ int tgt_add_layer_norm_bwd(const void* dy, int32_t dy_dtype, const void* s, int3
 int tgt_gelu_dropout_fwd(const void* x, void* y, int64_t n, int32_t dtype, float p, uint64_t seed, void* stream);
 int tgt_gelu_dropout_bwd(const void* x, const void* dy, void* dx, int64_t n, int32_t dtype, float p,
                          uint64_t seed, void* stream);
+/* The same with a per-sample factor folded in: y = sample_scale[i / elems_per_sample] * dropout(gelu(x)) and the matching
+ * backward (dx = sample_scale[...] * ...).  sample_scale: the DropPath factors (0 or 1/keep) of the residual branch this
+ * activation feeds (reference layers.py:169-174, :288-290): with the activation pre-scaled, the branch's closing Linear
+ * computes  s = res + x' W^T + sample_scale * b  (TGT_EDGE_BIAS_SCALED) and the backward needs no scaled copy of the
+ * stream gradient.  elems_per_sample: a multiple of 8. */
+int tgt_gelu_dropout_scaled_fwd(const void* x, void* y, int64_t n, int32_t dtype, float p, uint64_t seed,
+                                const float* sample_scale, int64_t elems_per_sample, void* stream);
+int tgt_gelu_dropout_scaled_bwd(const void* x, const void* dy, void* dx, int64_t n, int32_t dtype, float p, uint64_t seed,
+                                const float* sample_scale, int64_t elems_per_sample, void* stream);
 
 /* Column sums of a (rows, C) tensor into float32 (C): the bias gradient of a Linear layer
  * (the `grad_output.sum(0)` ATen reduction behind nn.Linear, e.g. reference

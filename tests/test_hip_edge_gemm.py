@@ -235,3 +235,59 @@ def test_linear_residual_layer_norm_op_matches_the_two_launch_composition(B, N, 
     for name, a, b_ in zip(names, *outs):
         tol = 3 * TOL[dtype] if name.startswith('d') else TOL[dtype]
         assert rel(a, b_) < tol, (name, rel(a, b_))
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('B,N,K', [(3, 10, 64), (4, 12, 256)])
+def test_prescaled_residual_matches_the_scaled_composition(B, N, K, dtype, monkeypatch):
+    """DropPath folded into the producer (TGT_EDGE_BIAS_SCALED + tgt_add_layer_norm_bwd without d_x): feeding x * scale with
+    prescaled=True must give the outputs and EVERY gradient of the plain op on x (the gradient of x through the product rule:
+    d x = scale * d x')"""
+    C = 256
+    monkeypatch.setattr(ops, '_EDGE_MIN_ROWS', 1)
+    g = torch.Generator(device='cuda').manual_seed(23)
+    mk = lambda *shape, scale=1.0: torch.randn(*shape, device='cuda', generator=g) * scale
+    x0, res0 = mk(B, N, N, K).to(dtype), mk(B, N, N, C).to(dtype)
+    w0, b0 = mk(C, K, scale=K ** -0.5), mk(C, scale=0.3)
+    lw0, lb0 = torch.rand(C, device='cuda', generator=g) + 0.5, mk(C, scale=0.2)
+    sc = (torch.rand(B, device='cuda', generator=g) > 0.3).float() / 0.7
+    sc[0] = 0.0                                            # a dropped graph
+    gs, gy = mk(B, N, N, C).to(dtype), mk(B, N, N, C).to(dtype)
+    outs = []
+    for pres in (True, False):
+        leaves = [t.clone().requires_grad_(True) for t in (x0, res0, w0, b0, lw0, lb0)]
+        x, res, w, b, lw, lb = leaves
+        with torch.autocast('cuda', dtype=dtype):
+            if pres:
+                xs = x * sc.view(-1, 1, 1, 1).to(dtype)    # (exact: the factors are 0 or 1/0.7 rounded once either way)
+                s, y = ops.linear_residual_layer_norm(xs, w, b, res, sc, lw, lb, 1e-5, prescaled=True)
+                assert type(s.grad_fn).__name__ == '_LinearResidualLNBackward'
+            else:
+                s, y = ops.linear_residual_layer_norm(x, w, b, res, sc, lw, lb, 1e-5)
+        ((s.float() * gs.float()).sum() + (y.float() * gy.float()).sum()).backward()
+        outs.append([s, y] + [t.grad for t in leaves])
+    names = ['s', 'y', 'dx', 'dres', 'dW', 'db', 'dln_w', 'dln_b']
+    for name, a, b_ in zip(names, *outs):
+        tol = 3 * TOL[dtype] if name.startswith('d') else TOL[dtype]
+        assert rel(a, b_) < tol, (name, rel(a, b_))
+    assert float(outs[0][2][0].abs().max()) == 0.0        # the dropped graph's input gets no gradient
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+def test_gelu_dropout_sample_scale(dtype):
+    """tgt_gelu_dropout_scaled_*: y = scale[b] * dropout(gelu(x)) and its backward, same drop pattern as the unscaled op"""
+    B, R, C = 3, 50, 64
+    g = torch.Generator(device='cuda').manual_seed(5)
+    x0 = torch.randn(B, R, C, device='cuda', generator=g).to(dtype)
+    dy = torch.randn(B, R, C, device='cuda', generator=g).to(dtype)
+    sc = torch.tensor([0.0, 1.25, 1.25], device='cuda')
+    for p in (0.0, 0.2):
+        xa, xb = x0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
+        ya = ops._GeluDropout.apply(xa, p, 1234, sc)
+        yb = ops._GeluDropout.apply(xb, p, 1234, None)
+        ya.backward(dy)
+        yb.backward(dy)
+        ref, gref = yb.float() * sc.view(-1, 1, 1), xb.grad.float() * sc.view(-1, 1, 1)
+        tol = {torch.float32: 1e-6, torch.bfloat16: 8e-3, torch.float16: 1e-3}[dtype]
+        assert rel(ya, ref) < tol and rel(xa.grad, gref) < tol
+        assert float(ya[0].abs().max()) == 0.0 and float(xa.grad[0].abs().max()) == 0.0

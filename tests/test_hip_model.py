@@ -360,3 +360,40 @@ def test_full_width_24L_training_gradients_vs_oracle():
             tol = tol_grad if tol_grad is not None else 2.0 * drift['pgrad.' + k]      # bf16: 2x the reference's drift
             assert rel(pm[k].grad, pr[k].grad) < tol, (mode, k, rel(pm[k].grad, pr[k].grad), tol)
         del model
+
+
+def test_drop_path_folded_into_producers_matches_the_plain_wiring(monkeypatch):
+    """Three TGT layers with DropPath on: the factor folded into the node attention's H_hat and the FFN's activation
+    (ops.can_prescale -> linear_residual_layer_norm(prescaled=True)) against the plain wiring (scale applied by the residual
+    entry, scaled gradient copy in its backward) on the SAME drop masks: outputs and every parameter gradient."""
+    from tgt_amd import ops
+    from tgt_amd.tgt import Graph, TGT_Encoder
+    monkeypatch.setattr(ops, '_EDGE_MIN_ROWS', 1)
+    B, N, W, C, H = 6, 8, 256, 256, 64
+    kw = dict(node_width=W, edge_width=C, num_heads=H, activation='gelu', scale_degree=True, node_update=True, edge_update=True,
+              triplet_heads=16, triplet_type='attention', triplet_dropout=0, node_ffn_multiplier=1., edge_ffn_multiplier=1.,
+              source_dropout=0., drop_path=0.4, node_act_dropout=0., edge_act_dropout=0.)
+    g = torch.Generator(device='cuda').manual_seed(3)
+    h0 = torch.randn(B, N, W, device='cuda', generator=g)
+    e0 = torch.randn(B, N, N, C, device='cuda', generator=g)
+    mask = gu.additive_mask([8, 5, 8, 3, 8, 6], N, torch.float32).cuda()
+    gh, ge = torch.randn(B, N, W, device='cuda', generator=g), torch.randn(B, N, N, C, device='cuda', generator=g)
+    runs = []
+    for fold in (True, False):
+        monkeypatch.setattr(ops, '_PRESCALE', fold)
+        layer = gu.fill_params(TGT_Encoder(model_height=3, **kw), seed=9).cuda().train()      # (layers hand their closing residual on)
+        torch.manual_seed(123)
+        ops.reset_random_pools()
+        h, e = h0.clone().requires_grad_(True), e0.clone().requires_grad_(True)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            out = layer(Graph(h=h, e=e, mask=mask))
+        ((out.h.float() * gh).sum() + (out.e.float() * ge).sum()).backward()
+        torch.cuda.synchronize()
+        runs.append((out.h.detach(), out.e.detach(), h.grad, e.grad, {k: p.grad for k, p in layer.named_parameters()}))
+    a, b = runs
+    for i, name in enumerate(('h', 'e', 'dh', 'de')):
+        assert rel(a[i], b[i]) < (2e-2 if i < 2 else 4e-2), (name, rel(a[i], b[i]))
+    for k in b[4]:
+        assert (a[4][k] is None) == (b[4][k] is None), k
+        if b[4][k] is not None and float(b[4][k].abs().max()) > 0:
+            assert rel(a[4][k], b[4][k]) < 6e-2, (k, rel(a[4][k], b[4][k]))

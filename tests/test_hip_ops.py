@@ -416,6 +416,33 @@ def test_node_attention(case, dtype, scale_degree, want_edges, head_major):
     assert rel(ex.grad, e64.grad) < 2 * tol, ('deg', rel(ex.grad, e64.grad))
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('case', [NODE_CASES[1], NODE_CASES[4], NODE_CASES[5]])
+def test_node_attention_hhat_scale(case, dtype):
+    """hhat_scale (the DropPath factor of the edge branch folded into the kernel): H_hat comes back times scale[b], V_att is
+    untouched, and the backward treats d_hhat as the gradient of the scaled tensor -- both kernel families"""
+    from tgt_amd import ops
+    B, N, nn_, W, H = case
+    rng = np.random.default_rng(3)
+    qkv, eg = rnd(rng, B, N, 3 * W).to(dtype).cuda(), rnd(rng, B, N, N, 2 * H).to(dtype).cuda()
+    gv, gh = rnd(rng, B, N, W).to(dtype).cuda(), rnd(rng, B, N, N, H).to(dtype).cuda()
+    mask = gu.additive_mask(nn_, N, torch.float32).reshape(B, N, N).cuda()
+    sc = torch.tensor(([0.0, 1.25, 1.25] * B)[:B], device='cuda')
+    if B == 1:
+        sc[0] = 1.25
+    sc4 = sc.view(-1, 1, 1, 1)
+    qa, ea = qkv.clone().requires_grad_(True), eg.clone().requires_grad_(True)
+    va, ha = ops.node_attention(qa, ea, mask, H, True, True, hhat_scale=sc)
+    torch.autograd.backward([va, ha], [gv, gh])
+    qb, eb = qkv.clone().requires_grad_(True), eg.clone().requires_grad_(True)
+    vb, hb = ops.node_attention(qb, eb, mask, H, True, True)
+    torch.autograd.backward([vb, hb], [gv, (gh.float() * sc4).to(dtype)])
+    tol = max(TOL[dtype], 1e-6)
+    assert torch.equal(va, vb)
+    assert rel(ha, hb.float() * sc4) < tol
+    assert rel(qa.grad, qb.grad) < 2 * tol and rel(ea.grad, eb.grad) < 2 * tol
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_edge_logits(dtype):
     from tgt_amd import ops

@@ -17,7 +17,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 SOURCES = ['capi.hip', 'optimizer.hip', 'edge_gemm.hip', 'params.hip', 'loss.hip', 'predict.hip', 'gaussian.hip', 'triplet_attention_proj.hip',
            ('triplet_attention.hip', ['-DTGT_TRI_INST=9'], '.f32'), ('triplet_attention.hip', ['-DTGT_TRI_INST=2'], '.bf16'),
            ('triplet_attention.hip', ['-DTGT_TRI_INST=4'], '.f16'), 'triplet_aggregate.hip', 'node_attention.hip', 'node_attention_mfma.hip', 'layernorm.hip', 'triangular_update.hip', 'elementwise.hip']
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 TGT_F32, TGT_BF16, TGT_F16 = 0, 1, 2
 TRI_BIASED, TRI_GATED, TRI_MASK_OUT = 1, 2, 4
@@ -62,7 +62,7 @@ class NodeAttentionArgs(C.Structure):
         ('eg', _vp), ('ld_eg', _i64), ('e_off', _i32), ('g_off', _i32),
         ('mask', _vp),
         ('vatt', _vp), ('hhat', _vp), ('lse', _vp), ('gsum', _vp),
-        ('d_vatt', _vp), ('d_hhat', _vp), ('d_qkv', _vp), ('d_eg', _vp), ('w_ws', _vp),
+        ('d_vatt', _vp), ('d_hhat', _vp), ('d_qkv', _vp), ('d_eg', _vp), ('w_ws', _vp), ('hhat_scale', _vp),
     ]
 
 
@@ -82,12 +82,13 @@ class EdgeLinearArgs(C.Structure):
         ('out', _vp), ('ldo', _i64), ('out2', _vp), ('ldo2', _i64),
         ('res', _vp), ('ldr', _i64), ('ds_in', _vp), ('ld_ds', _i64),
         ('row_scale', _vp), ('out_scale', _vp), ('rows_per_sample', _i64),
-        ('dropout_p', _f32), ('_pad1', C.c_uint32), ('dropout_seed', C.c_uint64),
+        ('dropout_p', _f32), ('flags', C.c_uint32), ('dropout_seed', C.c_uint64),
         ('colsum_partial', _vp),
     ]
 
 
 EPI_BIAS, EPI_GELU, EPI_RESID, EPI_GELU_BWD, EPI_LN_BWD = range(5)
+EDGE_BIAS_SCALED = 1
 
 
 # symbol -> (restype, argtypes); every symbol include/tgt_hip.h declares
@@ -106,6 +107,8 @@ SYMBOLS = {
     'tgt_triangular_update_bwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     'tgt_gelu_dropout_fwd': (C.c_int, [_vp, _vp, _i64, _i32, _f32, C.c_uint64, _vp]),
     'tgt_gelu_dropout_bwd': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, C.c_uint64, _vp]),
+    'tgt_gelu_dropout_scaled_fwd': (C.c_int, [_vp, _vp, _i64, _i32, _f32, C.c_uint64, _vp, _i64, _vp]),
+    'tgt_gelu_dropout_scaled_bwd': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, C.c_uint64, _vp, _i64, _vp]),
     'tgt_add_layer_norm_fwd': (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _f32, _vp]),
     'tgt_add_layer_norm_bwd': (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     'tgt_layer_norm_parts': (C.c_int, []),

@@ -34,7 +34,7 @@ int add_layer_norm_bwd_run(const void* dy, int dy_dtype, const void* s, int s_dt
                            const float* rstd, void* d_res, void* d_x, int d_dtype, float* dgamma, float* dbeta,
                            float* d_x_colsum, float* partial, int64_t rows, int C, hipStream_t st);
 int gelu_dropout_run(const void* x, const void* dy, void* out, int64_t n, int dtype, float p, uint64_t seed, bool bwd,
-                     hipStream_t st);
+                     const float* row_scale, int64_t elems_per_sample, hipStream_t st);
 int triangular_update_run(const void* e4, const void* v4, const float* mask, void* out, const void* d_out, void* d_e4,
                           void* d_v4, int B, int N, int H, int dtype, bool bwd, hipStream_t st);
 int colsum_run(const void* x, int x_dtype, int64_t rows, int C, float* out, float* partial, hipStream_t st);
@@ -76,7 +76,7 @@ using namespace tgt;
 extern "C" {
 
 const char* tgt_last_error(void) { return g_err; }
-int tgt_abi_version(void) { return 21; }
+int tgt_abi_version(void) { return 22; }
 
 int tgt_triplet_attention_fwd(const tgt_triplet_attention_args* a, void* stream) {
     return triplet_attention_run(a, false, reinterpret_cast<hipStream_t>(stream));
@@ -108,11 +108,19 @@ int tgt_triangular_update_bwd(const void* e4, const void* v4, const float* mask,
                                  reinterpret_cast<hipStream_t>(stream));
 }
 int tgt_gelu_dropout_fwd(const void* x, void* y, int64_t n, int32_t dtype, float p, uint64_t seed, void* stream) {
-    return gelu_dropout_run(x, nullptr, y, n, dtype, p, seed, false, reinterpret_cast<hipStream_t>(stream));
+    return gelu_dropout_run(x, nullptr, y, n, dtype, p, seed, false, nullptr, 0, reinterpret_cast<hipStream_t>(stream));
 }
 int tgt_gelu_dropout_bwd(const void* x, const void* dy, void* dx, int64_t n, int32_t dtype, float p, uint64_t seed,
                          void* stream) {
-    return gelu_dropout_run(x, dy, dx, n, dtype, p, seed, true, reinterpret_cast<hipStream_t>(stream));
+    return gelu_dropout_run(x, dy, dx, n, dtype, p, seed, true, nullptr, 0, reinterpret_cast<hipStream_t>(stream));
+}
+int tgt_gelu_dropout_scaled_fwd(const void* x, void* y, int64_t n, int32_t dtype, float p, uint64_t seed, const float* sample_scale,
+                                int64_t elems_per_sample, void* stream) {
+    return gelu_dropout_run(x, nullptr, y, n, dtype, p, seed, false, sample_scale, elems_per_sample, reinterpret_cast<hipStream_t>(stream));
+}
+int tgt_gelu_dropout_scaled_bwd(const void* x, const void* dy, void* dx, int64_t n, int32_t dtype, float p, uint64_t seed,
+                                const float* sample_scale, int64_t elems_per_sample, void* stream) {
+    return gelu_dropout_run(x, dy, dx, n, dtype, p, seed, true, sample_scale, elems_per_sample, reinterpret_cast<hipStream_t>(stream));
 }
 int tgt_add_layer_norm_fwd(const void* x, int32_t x_dtype, const void* res, int32_t res_dtype, const float* scale,
                            int64_t rows_per_sample, void* s_out, const float* gamma, const float* beta, void* y,

@@ -1104,7 +1104,8 @@ __global__ void __launch_bounds__(1024, 4) edge_rows_kernel(const tgt_edge_linea
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             braw[gq] = make_uint2(0, 0);
-            if (a.bias) braw[gq] = *reinterpret_cast<const uint2*>(reinterpret_cast<const T*>(a.bias) + n0 + 8 * gq + 4 * hi);
+            if (a.bias && !(EPI == EPI_RESID && (a.flags & TGT_EDGE_BIAS_SCALED)))      // (BIAS_SCALED: the row phase adds scale * bias)
+                braw[gq] = *reinterpret_cast<const uint2*>(reinterpret_cast<const T*>(a.bias) + n0 + 8 * gq + 4 * hi);
         }
         uint4 pre[kNA];
         auto fetch = [&](int64_t tile) {                   // 16-byte pieces (row, slot): consecutive threads = consecutive slots of a row
@@ -1207,6 +1208,10 @@ __global__ void __launch_bounds__(1024, 4) edge_rows_kernel(const tgt_edge_linea
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     float gam[8], bet[8];                                 // this thread's 8 columns, for the whole kernel
+    float bsc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};    // EPI_RESID + BIAS_SCALED: the bias, added as row_scale * bias
+    if constexpr (EPI == EPI_RESID) {
+        if ((a.flags & TGT_EDGE_BIAS_SCALED) && a.bias) rp_unpack8<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(a.bias) + ch * 8), bsc);
+    }
     {
         const float4 g0 = *reinterpret_cast<const float4*>(gb + ch * 8), g1 = *reinterpret_cast<const float4*>(gb + ch * 8 + 4);
         gam[0] = g0.x; gam[1] = g0.y; gam[2] = g0.z; gam[3] = g0.w; gam[4] = g1.x; gam[5] = g1.y; gam[6] = g1.z; gam[7] = g1.w;
@@ -1261,9 +1266,10 @@ __global__ void __launch_bounds__(1024, 4) edge_rows_kernel(const tgt_edge_linea
                     float rv[8], t[8];
                     rp_unpack8<T>(cur.o1[i], rv);
                     float p1 = 0.f;
+                    const bool pres = (a.flags & TGT_EDGE_BIAS_SCALED) != 0;     // x arrived pre-scaled: res + x W^T + scale * bias
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        t[j] = to_f32(from_f32<T>(rv[j] + v[j] * sc));      // the stream value as stored: LayerNorm sees that
+                        t[j] = to_f32(from_f32<T>(pres ? rv[j] + v[j] + sc * bsc[j] : rv[j] + v[j] * sc));      // the stream value as stored: LayerNorm sees that
                         p1 += t[j];
                     }
                     if (ok) *reinterpret_cast<uint4*>(reinterpret_cast<T*>(a.out) + m * a.ldo + ch * 8) = rp_pack8<T>(t);
@@ -1510,6 +1516,8 @@ int edge_linear_supported(const tgt_edge_linear_args* a) {
     if (a->gamma && a->epilogue == EPI_RESID && (N > 256 || (K != 64 && K != 128 && K != 256))) return 0;
     if (a->gamma && a->epilogue != EPI_LN_BWD && chunks > 1) return 0;
     if (a->epilogue == EPI_LN_BWD && (N > 256 || !a->gamma || !a->mean || !a->rstd || !a->res)) return 0;
+    // row_scale on the bias only (the input arrived pre-scaled): the row-phase kernel's residual epilogue
+    if ((a->flags & TGT_EDGE_BIAS_SCALED) && (a->epilogue != EPI_RESID || !er_eligible(*a))) return 0;
     return 1;
 }
 

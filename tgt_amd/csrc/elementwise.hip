@@ -14,7 +14,8 @@ namespace tgt {
 template <typename T, bool BWD>
 __global__ void __launch_bounds__(256) gelu_dropout_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                           T* __restrict__ out, int64_t n, uint64_t seed,
-                                                          uint32_t thresh, float inv_keep) {
+                                                          uint32_t thresh, float inv_keep, const float* __restrict__ row_scale,
+                                                          int64_t elems_per_sample) {
     constexpr int V = 16 / (int)sizeof(T);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x * V;
     for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * V; i < n; i += stride) {
@@ -34,6 +35,9 @@ __global__ void __launch_bounds__(256) gelu_dropout_kernel(const T* __restrict__
         }
         bool keep[V];
         if (thresh != 0u) keep_vector<V>(seed, i / V, thresh, keep);
+        // per-sample factor (DropPath of the residual branch this activation feeds, folded in here so that the
+        // branch's Linear + residual add need no scaled copy of their gradient); a vector never straddles samples
+        const float ik = row_scale ? inv_keep * row_scale[i / elems_per_sample] : inv_keep;
 #pragma unroll
         for (int t = 0; t < V; ++t) {
             const float v = to_f32(xv[t]);
@@ -42,7 +46,7 @@ __global__ void __launch_bounds__(256) gelu_dropout_kernel(const T* __restrict__
             float r;
             if (!BWD) r = v * cdf;
             else r = to_f32(gv[t]) * (cdf + v * 0.3989422804014327f * e);
-            ov[t] = from_f32<T>((thresh == 0u || keep[t]) ? r * inv_keep : 0.f);
+            ov[t] = from_f32<T>((thresh == 0u || keep[t]) ? r * ik : 0.f);
         }
         if (i + V <= n) {
             uint4 raw;
@@ -56,7 +60,7 @@ __global__ void __launch_bounds__(256) gelu_dropout_kernel(const T* __restrict__
 
 template <typename T>
 static int gd_launch(const void* x, const void* dy, void* out, int64_t n, float p, uint64_t seed, bool bwd,
-                     hipStream_t st) {
+                     const float* row_scale, int64_t eps_, hipStream_t st) {
     const uint32_t thresh = p <= 0.f ? 0u : (uint32_t)fmin(65535.0, fmax(1.0, nearbyint((double)p * 65536.0)));   // 16-bit
     const float inv_keep = p <= 0.f ? 1.f : 1.f / (1.f - p);
     constexpr int V = 16 / (int)sizeof(T);
@@ -68,24 +72,26 @@ static int gd_launch(const void* x, const void* dy, void* out, int64_t n, float 
     if (blocks < 1) blocks = 1;
     if (!bwd)
         hipLaunchKernelGGL((gelu_dropout_kernel<T, false>), dim3((unsigned)blocks), dim3(256), 0, st,
-                           reinterpret_cast<const T*>(x), nullptr, reinterpret_cast<T*>(out), n, seed, thresh, inv_keep);
+                           reinterpret_cast<const T*>(x), nullptr, reinterpret_cast<T*>(out), n, seed, thresh, inv_keep, row_scale, eps_);
     else
         hipLaunchKernelGGL((gelu_dropout_kernel<T, true>), dim3((unsigned)blocks), dim3(256), 0, st,
                            reinterpret_cast<const T*>(x), reinterpret_cast<const T*>(dy), reinterpret_cast<T*>(out), n,
-                           seed, thresh, inv_keep);
+                           seed, thresh, inv_keep, row_scale, eps_);
     return check_launch(bwd ? "gelu_dropout_bwd_kernel" : "gelu_dropout_fwd_kernel");
 }
 
 int gelu_dropout_run(const void* x, const void* dy, void* out, int64_t n, int dtype, float p, uint64_t seed, bool bwd,
-                     hipStream_t st) {
+                     const float* row_scale, int64_t elems_per_sample, hipStream_t st) {
     if (!x || !out || n < 0 || (bwd && !dy)) return set_error(TGT_ERR_INVALID, "gelu_dropout: null tensor");
     if (p < 0.f || p >= 1.f) return set_error(TGT_ERR_INVALID, "gelu_dropout: p=%f outside [0,1)", p);
     if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)dy) % 16) return set_error(TGT_ERR_INVALID, "gelu_dropout: tensors must be 16-byte aligned");
     if (n == 0) return TGT_OK;
+    if (row_scale && (elems_per_sample <= 0 || elems_per_sample % 8))
+        return set_error(TGT_ERR_INVALID, "gelu_dropout: row_scale needs elems_per_sample, a multiple of 8");
     switch (dtype) {
-        case TGT_F32: return gd_launch<float>(x, dy, out, n, p, seed, bwd, st);
-        case TGT_BF16: return gd_launch<bf16_t>(x, dy, out, n, p, seed, bwd, st);
-        case TGT_F16: return gd_launch<f16_t>(x, dy, out, n, p, seed, bwd, st);
+        case TGT_F32: return gd_launch<float>(x, dy, out, n, p, seed, bwd, row_scale, elems_per_sample, st);
+        case TGT_BF16: return gd_launch<bf16_t>(x, dy, out, n, p, seed, bwd, row_scale, elems_per_sample, st);
+        case TGT_F16: return gd_launch<f16_t>(x, dy, out, n, p, seed, bwd, row_scale, elems_per_sample, st);
         default: return set_error(TGT_ERR_INVALID, "gelu_dropout: bad dtype %d", dtype);
     }
 }

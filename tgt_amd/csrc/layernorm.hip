@@ -224,11 +224,13 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const LnArgs a) {
                     for (int i = 0; i < 8; ++i) dx[i] += dd[i];
                 }
                 ln_store8(a.dx, a.dx_dtype, row * a.C + col, dx);
-                if (a.dx2) {
+                if (a.dx2 || a.scale) {
+                    // (scale without dx2: the x branch was pre-scaled by its producer -- its gradient IS d_total, only the
+                    //  bias gradient of the Linear in between carries the factor: column sums of d_total * scale)
                     const float sc = a.scale ? a.scale[row / a.rows_per_sample] : 1.f;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) dx[i] *= sc;
-                    ln_store8(a.dx2, a.dx_dtype, row * a.C + col, dx);
+                    if (a.dx2) ln_store8(a.dx2, a.dx_dtype, row * a.C + col, dx);
                 }
                 if constexpr (CS) {
 #pragma unroll
@@ -414,7 +416,8 @@ int add_layer_norm_bwd_run(const void* dy, int dy_dtype, const void* s, int s_dt
         return set_error(TGT_ERR_INVALID, "add_layer_norm bwd: null tensor");
     if (bad_dtype(s_dtype) || bad_dtype(dy_dtype) || bad_dtype(d_dtype) || (ds_in && bad_dtype(ds_dtype)))
         return set_error(TGT_ERR_INVALID, "add_layer_norm bwd: bad dtype");
-    if (scale && (rows_per_sample <= 0 || !d_x)) return set_error(TGT_ERR_INVALID, "add_layer_norm bwd: scale needs d_x and rows_per_sample");
+    if (scale && rows_per_sample <= 0) return set_error(TGT_ERR_INVALID, "add_layer_norm bwd: scale needs rows_per_sample");
+    if (scale && !d_x && !d_x_colsum) return set_error(TGT_ERR_INVALID, "add_layer_norm bwd: scale without d_x only shapes d_x_colsum");
     if (d_x_colsum && d_x_colsum != dbeta + C)
         return set_error(TGT_ERR_INVALID, "add_layer_norm bwd: d_x_colsum must directly follow dbeta (one 2C buffer)");
     if (((uintptr_t)s | (uintptr_t)dy | (uintptr_t)d_res | (uintptr_t)d_x | (uintptr_t)ds_in) % 16)

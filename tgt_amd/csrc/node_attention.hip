@@ -155,6 +155,7 @@ __global__ void __launch_bounds__(256) node_att_fwd_kernel(const tgt_node_attent
     const T* qkv = reinterpret_cast<const T*>(a.qkv);
     const T* eg = reinterpret_cast<const T*>(a.eg);
     T* hhat = reinterpret_cast<T*>(a.hhat);
+    const float hs = a.hhat_scale ? a.hhat_scale[n.b] : 1.f;       // H_hat is written times the branch's DropPath factor
     const int64_t row0 = (int64_t)n.b * N, row_l = row0 + n.x;
 
     float q[D][HV], acc[D][HV], mx[HV], sum[HV], gsum[HV];
@@ -189,7 +190,12 @@ __global__ void __launch_bounds__(256) node_att_fwd_kernel(const tgt_node_attent
 #pragma unroll
                 for (int k = 0; k < HV; ++k) s[k] += q[d][k] * kb.at(d, k);
         }
-        if (hhat) stv<T, HV>(hhat, lm * H + h, s);
+        if (hhat) {
+                        float so[HV];
+#pragma unroll
+                        for (int k = 0; k < HV; ++k) so[k] = s[k] * hs;
+                        stv<T, HV>(hhat, lm * H + h, so);
+                    }
         if (a.logits_only) continue;
         const float mk = a.mask[lm];
         float corr[HV], w[HV];
@@ -256,6 +262,7 @@ __global__ void __launch_bounds__(512) node_att_fwd_lds_kernel(const tgt_node_at
     const T* qkv = reinterpret_cast<const T*>(a.qkv);
     const T* eg = reinterpret_cast<const T*>(a.eg);
     T* hhat = reinterpret_cast<T*>(a.hhat);
+    const float hs = a.hhat_scale ? a.hhat_scale[b] : 1.f;         // H_hat is written times the branch's DropPath factor
     const int64_t row0 = (int64_t)b * N, row_l = row0 + (active ? l : 0);
 
     float q[D][HV], acc[D][HV], mx[HV], sum[HV], gsum[HV];
@@ -320,7 +327,12 @@ __global__ void __launch_bounds__(512) node_att_fwd_lds_kernel(const tgt_node_at
 #pragma unroll
                             for (int k = 0; k < HV; ++k) s[k] += q[d][k] * kb.at(d, k);
                     }
-                    if (hhat) stv<T, HV>(hhat, lm * H + h, s);
+                    if (hhat) {
+                        float so[HV];
+#pragma unroll
+                        for (int k = 0; k < HV; ++k) so[k] = s[k] * hs;
+                        stv<T, HV>(hhat, lm * H + h, so);
+                    }
                     if (!a.logits_only) {
                         const float mk = mr[kk];
                         float corr[HV], w[HV];
@@ -380,6 +392,7 @@ __global__ void __launch_bounds__(256) node_att_bwd_row_kernel(const tgt_node_at
     const T* dhh = reinterpret_cast<const T*>(a.d_hhat);
     T* dqkv = reinterpret_cast<T*>(a.d_qkv);
     T* deg = reinterpret_cast<T*>(a.d_eg);
+    const float hs = a.hhat_scale ? a.hhat_scale[n.b] : 1.f;       // d_hhat is the gradient of hhat_scale * H_hat
     const int64_t row0 = (int64_t)n.b * N, row_l = row0 + n.x;
 
     float q[D][HV], dq[D][HV];
@@ -401,7 +414,11 @@ __global__ void __launch_bounds__(256) node_att_bwd_row_kernel(const tgt_node_at
             float dH[HV];
 #pragma unroll
             for (int k = 0; k < HV; ++k) dH[k] = 0.f;
-            if (dhh) ldv<T, HV>(dhh, lm * H + h, dH);
+            if (dhh) {
+                ldv<T, HV>(dhh, lm * H + h, dH);
+#pragma unroll
+                for (int k = 0; k < HV; ++k) dH[k] *= hs;
+            }
             stv<T, HV>(deg, lm * a.ld_eg + a.e_off + h, dH);
             DH<T, D, HV, HM> kb;
             kb.load(qkv, (row0 + m) * a.ld_qkv + a.k_off, H, h);
@@ -447,7 +464,11 @@ __global__ void __launch_bounds__(256) node_att_bwd_row_kernel(const tgt_node_at
             ldv<T, HV>(eg, lm * a.ld_eg + a.g_off + h, g);
 #pragma unroll
             for (int k = 0; k < HV; ++k) dH[k] = 0.f;
-            if (dhh) ldv<T, HV>(dhh, lm * H + h, dH);
+            if (dhh) {
+                ldv<T, HV>(dhh, lm * H + h, dH);
+#pragma unroll
+                for (int k = 0; k < HV; ++k) dH[k] *= hs;
+            }
 #pragma unroll
             for (int k = 0; k < HV; ++k) dot[k] = dA[k] = 0.f;
             DH<T, D, HV, HM> kb, vb;

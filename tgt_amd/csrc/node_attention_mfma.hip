@@ -299,6 +299,7 @@ __device__ __forceinline__ void tile_fwd(char* lds, const tgt_node_attention_arg
         float gt[16], mx = -INFINITY;
         char* pe0 = lds + L::kOffEG + r * L::kPitchEG + hh * 2;
         const char* pm0 = lds + L::kOffM + r * L::kPitchM;
+        const float hs = a.hhat_scale ? a.hhat_scale[u.b] : 1.f;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int m = acc_row(q, hi);
@@ -306,7 +307,7 @@ __device__ __forceinline__ void tile_fwd(char* lds, const tgt_node_attention_arg
             const float e = to_f32(*reinterpret_cast<const T*>(pe)), g = to_f32(*reinterpret_cast<const T*>(pe + L::kRecH));
             const float mk = *reinterpret_cast<const float*>(pm0 + m * 4);
             const float sv = s[q] * a.scale + e;
-            *reinterpret_cast<T*>(pe) = from_f32<T>(sv);          // H_hat leaves through the E slot this lane just read
+            *reinterpret_cast<T*>(pe) = from_f32<T>(sv * hs);     // H_hat (times the branch's DropPath factor, if given) leaves through the E slot this lane just read
             const float x = sv + mk;                              // (mk = -inf past N)
             gt[q] = fast_sigmoid(g + mk);
             s[q] = x;
@@ -349,7 +350,7 @@ __device__ __forceinline__ void tile_fwd(char* lds, const tgt_node_attention_arg
 //   dQ^T = s K^T dE^T             dK^T = s Q^T dE                          dV^T = dV_att^T (P g dsc)
 // ---------------------------------------------------------------------------
 template <typename T, int HG, int D>
-__device__ __forceinline__ void tile_bwd(char* lds, const tgt_node_attention_args& a, int r, int hi, int hh) {
+__device__ __forceinline__ void tile_bwd(char* lds, const tgt_node_attention_args& a, const Unit& u, int r, int hi, int hh) {
     using F = frag_t<T>;
     using L = Lay<HG>;
     char* rQ = lds + L::off_n(D, true, 0);
@@ -406,11 +407,12 @@ __device__ __forceinline__ void tile_bwd(char* lds, const tgt_node_attention_arg
 
         F dsf[2], af[2];
         float tile_unscale = 1.f;
+        const float hs = a.hhat_scale ? a.hhat_scale[u.b] : 1.f;       // d_hhat is the gradient of hhat_scale * H_hat
         {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int m = acc_row(q, hi);
-                const float dh = to_f32(*reinterpret_cast<const T*>(ph0 + m * L::kRecH));
+                const float dh = to_f32(*reinterpret_cast<const T*>(ph0 + m * L::kRecH)) * hs;
                 const float p = s[q], g = gt[q];
                 const float dS = p * (da[q] * g - delta);
                 const float dGl = (da[q] * p + dgsum) * g * (1.f - g);
@@ -574,7 +576,7 @@ __global__ void __launch_bounds__(HG * 64, 4) node_att_mfma_bwd_kernel(const tgt
         stage_mask_commit<HG, NTHR>(lds, tid, mk);
     }
     __syncthreads();
-    if (!(ablate & 1)) tile_bwd<T, HG, D>(lds, a, r, hi, hh);
+    if (!(ablate & 1)) tile_bwd<T, HG, D>(lds, a, u, r, hi, hh);
     __syncthreads();
     if (ablate & 4) return;
     unstage_eg<T, HG>(lds, a.d_eg, a, u, tid);

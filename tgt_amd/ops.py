@@ -519,8 +519,8 @@ _NODE_W_WS = os.environ.get('TGT_NODE_W_WS', '0') == '1'        # opt-in: row pa
 
 class _NodeAttention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, eg, mask3, H, scale_degree, want_edges, head_major=False):
-        _dev(qkv, eg, mask3)
+    def forward(ctx, qkv, eg, mask3, H, scale_degree, want_edges, head_major=False, hhat_scale=None):
+        _dev(qkv, eg, mask3, hhat_scale)
         qkv, eg = qkv.contiguous(), eg.contiguous()
         if eg.dtype != qkv.dtype:
             eg = eg.to(qkv.dtype)
@@ -532,8 +532,9 @@ class _NodeAttention(torch.autograd.Function):
         lse = torch.empty(B, N, H, dtype=torch.float32, device=qkv.device)
         gsum = torch.empty(B, N, H, dtype=torch.float32, device=qkv.device)
         a.vatt, a.hhat, a.lse, a.gsum = vatt.data_ptr(), _ptr(hhat), lse.data_ptr(), gsum.data_ptr()
+        a.hhat_scale = _ptr(hhat_scale)
         _call('tgt_node_attention_fwd', _lib.lib().tgt_node_attention_fwd, a)
-        ctx.save_for_backward(qkv, eg, mask3, lse, gsum, vatt)
+        ctx.save_for_backward(qkv, eg, mask3, lse, gsum, vatt, hhat_scale)
         ctx.cfg = (H, scale_degree, want_edges, bool(head_major))
         if want_edges:
             return vatt, hhat
@@ -541,7 +542,7 @@ class _NodeAttention(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_vatt, d_hhat):
-        qkv, eg, mask3, lse, gsum, vatt = ctx.saved_tensors
+        qkv, eg, mask3, lse, gsum, vatt, hhat_scale = ctx.saved_tensors
         H, scale_degree, want_edges, head_major = ctx.cfg
         a, W = _node_args(qkv, eg, mask3, H, scale_degree, False)
         a.head_major = int(head_major)
@@ -551,22 +552,25 @@ class _NodeAttention(torch.autograd.Function):
         d_qkv, d_eg = torch.empty_like(qkv), torch.empty_like(eg)
         a.lse, a.gsum, a.vatt = lse.data_ptr(), gsum.data_ptr(), vatt.data_ptr()
         a.d_vatt, a.d_hhat, a.d_qkv, a.d_eg = d_vatt.data_ptr(), _ptr(d_hhat), d_qkv.data_ptr(), d_eg.data_ptr()
+        a.hhat_scale = _ptr(hhat_scale)
         if _NODE_W_WS:      # the pairs' attention weights, handed from the row pass to the column pass (freed on return)
             w_ws = torch.empty(qkv.shape[0], qkv.shape[1], qkv.shape[1], H, dtype=qkv.dtype, device=qkv.device)
             a.w_ws = w_ws.data_ptr()
         _call('tgt_node_attention_bwd', _lib.lib().tgt_node_attention_bwd, a)
-        return d_qkv, d_eg, None, None, None, None, None
+        return d_qkv, d_eg, None, None, None, None, None, None
 
 
-def node_attention(qkv, eg, mask3, num_heads, scale_degree=True, want_edges=True, head_major=False):
+def node_attention(qkv, eg, mask3, num_heads, scale_degree=True, want_edges=True, head_major=False, hhat_scale=None):
     """qkv (B,N,3W) and eg (B,N,N,2H) in the reference's head-minor layout (channel = d*H + h);
     returns V_att (B,N,W) and H_hat (B,N,N,H) (or None).
     head_major: Q, K, V and V_att use channel = h*D + d instead (a caller would permute the rows
     of lin_QKV and the columns of lin_O_h) -- same arithmetic, a lane's D values in one block.
     Measured SLOWER at the BASELINE shape (0.112 / 0.210 ms against 0.074 / 0.179 ms forward /
     backward), so the modules do not use it.
+    hhat_scale (B,) float32: H_hat is returned multiplied by hhat_scale[b] (the DropPath factor of the edge branch it
+    feeds, folded in: linear_residual_layer_norm(prescaled=True)).
     Reference arithmetic: lib/tgt/layers/layers.py:62-77."""
-    return _NodeAttention.apply(qkv, eg, mask3, num_heads, scale_degree, want_edges, head_major)
+    return _NodeAttention.apply(qkv, eg, mask3, num_heads, scale_degree, want_edges, head_major, hhat_scale)
 
 
 class _EdgeLogits(torch.autograd.Function):
@@ -820,36 +824,41 @@ def drop_path_add_(x, residual, drop_prob, training):
 
 class _GeluDropout(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, p, seed):
-        _dev(x)
+    def forward(ctx, x, p, seed, sample_scale):
+        _dev(x, sample_scale)
         x = x.contiguous()
         y = torch.empty_like(x)
+        eps_ = x.numel() // x.shape[0] if sample_scale is not None else 0
         s, e = _prof_begin()
-        _lib.check(_lib.lib().tgt_gelu_dropout_fwd(_ptr(x), _ptr(y), x.numel(), _DT[x.dtype], float(p), seed, _stream()),
-                   'tgt_gelu_dropout_fwd')
+        _lib.check(_lib.lib().tgt_gelu_dropout_scaled_fwd(_ptr(x), _ptr(y), x.numel(), _DT[x.dtype], float(p), seed,
+                                                          _ptr(sample_scale), eps_, _stream()), 'tgt_gelu_dropout_fwd')
         _prof_end('tgt_gelu_dropout_fwd', s, e)
-        ctx.save_for_backward(x)
-        ctx.p, ctx.seed = float(p), seed
+        ctx.save_for_backward(x, sample_scale)
+        ctx.p, ctx.seed, ctx.eps_ = float(p), seed, eps_
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, = ctx.saved_tensors
+        x, sample_scale = ctx.saved_tensors
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         s, e = _prof_begin()
-        _lib.check(_lib.lib().tgt_gelu_dropout_bwd(_ptr(x), _ptr(dy), _ptr(dx), x.numel(), _DT[x.dtype], ctx.p, ctx.seed,
-                                                   _stream()), 'tgt_gelu_dropout_bwd')
+        _lib.check(_lib.lib().tgt_gelu_dropout_scaled_bwd(_ptr(x), _ptr(dy), _ptr(dx), x.numel(), _DT[x.dtype], ctx.p, ctx.seed,
+                                                          _ptr(sample_scale), ctx.eps_, _stream()), 'tgt_gelu_dropout_bwd')
         _prof_end('tgt_gelu_dropout_bwd', s, e)
-        return dx, None, None
+        return dx, None, None, None
 
 
-def gelu_dropout(x, p, training):
+def gelu_dropout(x, p, training, sample_scale=None):
     """dropout(gelu(x), p) in one pass each way (reference FFN, lib/tgt/layers/layers.py:157-158).
-    The drop pattern comes from a per-call seed drawn from torch's CPU generator (no device sync)."""
+    The drop pattern comes from a per-call seed drawn from torch's CPU generator (no device sync).
+    sample_scale (B,) float32: the result is multiplied by sample_scale[b] -- the DropPath factor of the residual
+    branch, folded in here (see linear_residual_layer_norm(prescaled=True))."""
     p = float(p) if training else 0.0
     seed = int(torch.empty((), dtype=torch.int64).random_().item()) if p > 0 else 0
-    return _GeluDropout.apply(x, p, seed)
+    if sample_scale is not None and (x.numel() // x.shape[0]) % 8:
+        raise RuntimeError('gelu_dropout: sample_scale needs a multiple of 8 elements per sample')
+    return _GeluDropout.apply(x, p, seed, sample_scale)
 
 
 class _MultiHotEmbed(torch.autograd.Function):
@@ -1135,7 +1144,8 @@ def linear(x, weight, bias=None):
 # edge-channel Linear with fused LayerNorm prologue / GELU / residual / backward epilogues
 # ---------------------------------------------------------------------------
 def edge_linear_raw(a, w, bias=None, epilogue=_lib.EPI_BIAS, *, ln=None, y=None, out=None, out2=None, res=None, ds_in=None,
-                    row_scale=None, out_scale=None, rows_per_sample=0, dropout=(0.0, 0), stats=None, colsum_partial=None):
+                    row_scale=None, out_scale=None, rows_per_sample=0, dropout=(0.0, 0), stats=None, colsum_partial=None,
+                    flags=0):
     """One launch of tgt_edge_linear on 2-D operands (rows may be strided views with a contiguous last axis).
     a (M,K), w (N,K), bias (N) in one 16-bit dtype; ln = (gamma, beta, eps) float32 for the LayerNorm prologue /
     the LN_BWD epilogue; stats = (mean, rstd) float32 (M) (written by the prologue, read by LN_BWD).
@@ -1184,6 +1194,7 @@ def edge_linear_raw(a, w, bias=None, epilogue=_lib.EPI_BIAS, *, ln=None, y=None,
         g.out_scale = out_scale.data_ptr()
     g.rows_per_sample = int(rows_per_sample)
     g.dropout_p, g.dropout_seed = float(dropout[0]), int(dropout[1]) & 0xFFFFFFFFFFFFFFFF
+    g.flags = int(flags)
     if colsum_partial is not None:
         g.colsum_partial = colsum_partial.data_ptr()
     _call('tgt_edge_linear', _lib.lib().tgt_edge_linear, g)
@@ -1267,7 +1278,7 @@ class _LinearResidualLN(torch.autograd.Function):
     Backward: the add+LN backward kernel (it also yields the bias gradient), then the Linear's gradients."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, res, scale, ln_w, ln_b, eps, cd, out_dtype):
+    def forward(ctx, x, weight, bias, res, scale, ln_w, ln_b, eps, cd, out_dtype, prescaled=False):
         _dev(x, weight, res, ln_w, ln_b)
         xs = x.shape
         x2 = x.reshape(-1, xs[-1])
@@ -1286,9 +1297,11 @@ class _LinearResidualLN(torch.autograd.Function):
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
         rps = rows // xs[0]
         edge_linear_raw(x2, w, b, _lib.EPI_RESID, out=s.view(rows, N), res=res2, row_scale=scale, rows_per_sample=rps,
-                        ln=(g, be, eps), stats=(mean, rstd), y=y.view(rows, N))
+                        ln=(g, be, eps), stats=(mean, rstd), y=y.view(rows, N),
+                        flags=_lib.EDGE_BIAS_SCALED if (prescaled and scale is not None) else 0)
         ctx.save_for_backward(x2, w, s, g, mean, rstd, scale)
         ctx.meta = (xs, x.dtype, weight.dtype, None if bias is None else bias.dtype, ln_w.dtype, res.dtype, rps)
+        ctx.prescaled = bool(prescaled and scale is not None)
         return s, y
 
     @staticmethod
@@ -1298,16 +1311,19 @@ class _LinearResidualLN(torch.autograd.Function):
         N = s.shape[-1]
         rows = s.numel() // N
         L = _lib.lib()
+        pres = ctx.prescaled       # x arrived pre-scaled: the gradient of x W^T IS the stream gradient, only the bias carries the factor
         if dy is None:                                  # the LayerNorm branch was not used
             d_res = ds
-            d_z = ds if scale is None else ds * scale.view(-1, *([1] * (ds.ndim - 1))).to(ds.dtype)
+            d_z = ds if (scale is None or pres) else ds * scale.view(-1, *([1] * (ds.ndim - 1))).to(ds.dtype)
             dg = dbeta = None
             cs = None
+            if pres and bdt is not None and ctx.needs_input_grad[2]:
+                cs = (ds.reshape(scale.numel(), -1, N).float().sum(1) * scale.view(-1, 1)).sum(0)
         else:
             dy = dy.contiguous()
             ds = None if ds is None else ds.contiguous()
             d_res = torch.empty_like(s)
-            d_z = torch.empty_like(s) if scale is not None else None
+            d_z = torch.empty_like(s) if (scale is not None and not pres) else None
             dg = torch.empty(N, dtype=torch.float32, device=s.device)
             db_cs = torch.empty(2 * N, dtype=torch.float32, device=s.device)
             partial = torch.empty(L.tgt_layer_norm_parts() * 3 * N, dtype=torch.float32, device=s.device)
@@ -1327,18 +1343,43 @@ class _LinearResidualLN(torch.autograd.Function):
         if need_db and cs is not None:
             db = cs.to(bdt)
         return (dx, dw, db, d_res if rdt == d_res.dtype else d_res.to(rdt), None,
-                None if dg is None else dg.to(lndt), None if dbeta is None else dbeta.to(lndt), None, None, None)
+                None if dg is None else dg.to(lndt), None if dbeta is None else dbeta.to(lndt), None, None, None, None)
 
 
-def linear_residual_layer_norm(x, weight, bias, res, scale, ln_weight, ln_bias, eps=1e-5):
+def _residual_fusable(x, weight, res, cd):
+    N = weight.shape[0]
+    x2 = x.reshape(-1, x.shape[-1])
+    return N <= 256 and res.is_cuda and _edge_kernel_ok(x2, N, cd) and res.dtype in (cd,) and res.is_contiguous()
+
+
+_PRESCALE = os.environ.get('TGT_PRESCALE', '1') != '0'       # A/B knob: DropPath factor folded into the branch's producer
+
+
+def can_prescale(rows, in_features, out_features, dtype):
+    """Will linear_residual_layer_norm(prescaled=True) on (rows, in_features) -> out_features rows of `dtype` (the compute
+    dtype) run as the ONE fused launch that implements it?  (The callers decide before they run the producer.)"""
+    return (_PRESCALE and _EDGE_GEMM and dtype in (torch.bfloat16, torch.float16) and out_features == 256 and
+            in_features in (64, 128, 256) and rows >= _EDGE_MIN_ROWS)
+
+
+def linear_residual_layer_norm(x, weight, bias, res, scale, ln_weight, ln_bias, eps=1e-5, prescaled=False):
     """(s, y): s = res + scale[graph] * linear(x, weight, bias) (scale: per-sample DropPath factors or None),
     y = LayerNorm(s).  One fused launch on the MI355X slice kernel when the shape qualifies (16-bit compute dtype,
     in_features in {64,128,256}, out_features <= 256 and a multiple of 8, >= 65536 rows); otherwise the composition of
-    ops.linear and ops.add_layer_norm (same arithmetic, two launches + one more pass over the rows)."""
+    ops.linear and ops.add_layer_norm (same arithmetic, two launches + one more pass over the rows).
+    prescaled: x already carries the factor (its producer folded it in: gelu_dropout(sample_scale=), node_attention(
+    hhat_scale=)), so s = res + x W^T + scale[graph] * bias -- the same value, and the backward hands the stream gradient
+    itself to the Linear's gradient GEMMs instead of writing a scaled copy of it (one pass over the rows less)."""
     cd = torch.get_autocast_dtype('cuda') if (x.is_cuda and torch.is_autocast_enabled('cuda')) else x.dtype
-    N = weight.shape[0]
-    x2 = x.reshape(-1, x.shape[-1])
-    if N <= 256 and res.is_cuda and _edge_kernel_ok(x2, N, cd) and res.dtype in (cd,) and res.is_contiguous():
+    if prescaled and scale is not None:
+        if _residual_fusable(x, weight, res, cd) and weight.shape[0] == 256:
+            return _LinearResidualLN.apply(x, weight, bias, res, scale, ln_weight, ln_bias, eps, cd, cd, True)
+        # composition with the same arithmetic (shapes the fused launch does not take)
+        z = linear(x, weight, None)
+        if bias is not None:
+            z = z + scale.view([-1] + [1] * (z.ndim - 1)).to(z.dtype) * bias.to(z.dtype)
+        return add_layer_norm(z, res, None, ln_weight, ln_bias, eps)
+    if _residual_fusable(x, weight, res, cd):
         return _LinearResidualLN.apply(x, weight, bias, res, scale, ln_weight, ln_bias, eps, cd, cd)
     return add_layer_norm(linear(x, weight, bias), res, scale, ln_weight, ln_bias, eps)
 

@@ -42,16 +42,22 @@ class PendingResidual:
     residual add and the LayerNorm that opens the next layer are ONE launch (ops.linear_residual_layer_norm).
     Only TGT_Encoder asks layers for this (defer_edge=True) and resolves the last one."""
 
-    def __init__(self, x, lin, res, scale):
+    def __init__(self, x, lin, res, scale, prescaled=False):
         self.x, self.lin, self.res, self.scale = x, lin, res, scale
+        self.prescaled = prescaled and scale is not None      # x already carries the DropPath factor (FFN.hidden(sample_scale=))
 
     def materialize(self):
+        if self.prescaled:                                    # res + x' W^T + scale * b
+            z = ops.linear(self.x, self.lin.weight, None)
+            if self.lin.bias is not None:
+                z = z + self.scale.view([-1] + [1] * (z.ndim - 1)).to(z.dtype) * self.lin.bias.to(z.dtype)
+            return z.add_(self.res)
         return ops.scaled_add_(self.lin(self.x), self.res, self.scale)
 
     def enter(self, ln):
         """(res + lin(x)*scale, LayerNorm of it)"""
         return ops.linear_residual_layer_norm(self.x, self.lin.weight, self.lin.bias, self.res, self.scale,
-                                              ln.weight, ln.bias, ln.eps)
+                                              ln.weight, ln.bias, ln.eps, prescaled=self.prescaled)
 
 
 class EGT_Attention(nn.Module):
@@ -90,10 +96,11 @@ class EGT_Attention(nn.Module):
         v_att, e = self.attend(h, e_hat, mask, e, qkv)
         return self.lin_O_h(v_att), e
 
-    def attend(self, h, e_hat, mask, e=None, qkv=None, project_edges=True):
+    def attend(self, h, e_hat, mask, e=None, qkv=None, project_edges=True, hhat_scale=None):
         """(V_att before lin_O_h, updated edge channels): forward_normed without the node output
         projection, which TGT_Layer runs on the node stream together with the node FFN.
-        project_edges=False: return H_hat itself; the caller fuses lin_O_e with what follows it"""
+        project_edges=False: return H_hat itself; the caller fuses lin_O_e with what follows it (hhat_scale: H_hat
+        comes back multiplied by that per-graph factor, the DropPath of the branch it feeds)"""
         B, N = h.shape[0], h.shape[1]
         if qkv is None:
             qkv = self.project_nodes(h)
@@ -104,7 +111,7 @@ class EGT_Attention(nn.Module):
             # caller's mask is left untouched (the triplet module sees it un-dropped)
             mask3 = mask3 + ops.source_drop_mask(B, N, self.source_dropout, torch.finfo(mask.dtype).min, h.device)
         v_att, h_hat = ops.node_attention(qkv, eg, mask3, self.num_heads,
-                                          self.scale_degree, self.edge_update)
+                                          self.scale_degree, self.edge_update, hhat_scale=hhat_scale)
         if self.edge_update:
             e = self.lin_O_e(h_hat) if project_edges else h_hat
         return v_att, e
@@ -179,13 +186,17 @@ class FFN(nn.Module):
         """the block after ffn_ln (TGT_Layer fuses that LayerNorm with the residual add before it)"""
         return self.lin_W2(self.hidden(x))
 
-    def hidden(self, x):
+    def hidden(self, x, sample_scale=None):
         """activation(lin_W1(x)) with dropout: the input of lin_W2 (TGT_Layer fuses lin_W2 with the residual add and
-        the next LayerNorm)"""
+        the next LayerNorm).  sample_scale (B,): the result times that per-graph factor (the branch's DropPath, folded in)"""
         x = self.lin_W1(x)
         if self.activation == 'gelu' and x.dtype in (torch.float32, torch.bfloat16, torch.float16):
-            return ops.gelu_dropout(x, self.act_dropout, self.training)      # one pass each way, no mask tensor
-        return self.dropout(self.ffn_fn(x))
+            return ops.gelu_dropout(x, self.act_dropout, self.training, sample_scale)      # one pass each way, no mask tensor
+        x = self.dropout(self.ffn_fn(x))
+        return x if sample_scale is None else x * sample_scale.view([-1] + [1] * (x.ndim - 1)).to(x.dtype)
+
+    def can_fold_scale(self):
+        return self.activation == 'gelu'
 
 
 class DropPath(nn.Module):
@@ -262,19 +273,29 @@ class TGT_Layer(nn.Module):
             side.join(h, qkv)
         h_in, e_in = h, e
         fuse_oe = self.node_update and self.edge_update          # lin_O_e joins the entry of the next edge sub-block
+        dp, tr = self.drop_path.drop_path, self.training
+        # DropPath folded into the branch's PRODUCER where that is free (H_hat out of the node attention kernel, the FFN's
+        # activation): the factor is drawn before the branch runs and the closing Linear + residual add then need no scaled
+        # copy of the stream gradient in the backward (ops.linear_residual_layer_norm(prescaled=True))
+        cd = torch.get_autocast_dtype('cuda') if (e_hat.is_cuda and torch.is_autocast_enabled('cuda')) else e_hat.dtype
+        pair_rows = e_hat.numel() // e_hat.shape[-1]
+        sc_oe = ops.drop_path_scale(e_hat, dp, tr) if fuse_oe else None      # (drawn here whether it is folded or not)
+        fold_oe = sc_oe is not None and ops.can_prescale(pair_rows, self.update.num_heads, e_hat.shape[-1], cd)
         if self.node_update:
-            v_att, e = self.update.attend(h, e_hat, mask, e, qkv, project_edges=not fuse_oe)   # lin_O_h follows on the node stream
+            v_att, e = self.update.attend(h, e_hat, mask, e, qkv, project_edges=not fuse_oe,
+                                          hhat_scale=sc_oe if fold_oe else None)   # lin_O_h follows on the node stream
         else:
             h, e = self.update.forward_normed(h, e_hat, mask, e, qkv)
         # Each residual add is fused with the LayerNorm that opens the next sub-block
         # (s = res + DropPath(x); y = LN(s) in one pass, and one pass in the backward).
-        dp, tr = self.drop_path.drop_path, self.training
 
-        def enter(x, res, ln, lin=None):
-            """(s, LayerNorm(s)) with s = res + DropPath(x), or res + DropPath(lin(x)) in one launch"""
+        def enter(x, res, ln, lin=None, scale=None, folded=False):
+            """(s, LayerNorm(s)) with s = res + DropPath(x), or res + DropPath(lin(x)) in one launch
+            (scale: the factor when it was drawn earlier; folded: x already carries it)"""
             if lin is not None:
-                return ops.linear_residual_layer_norm(x, lin.weight, lin.bias, res, ops.drop_path_scale(x, dp, tr),
-                                                      ln.weight, ln.bias, ln.eps)
+                sc = scale if scale is not None else ops.drop_path_scale(x, dp, tr)
+                return ops.linear_residual_layer_norm(x, lin.weight, lin.bias, res, sc, ln.weight, ln.bias, ln.eps,
+                                                      prescaled=folded)
             return ops.add_layer_norm(x, res, ops.drop_path_scale(x, dp, tr), ln.weight, ln.bias, ln.eps)
 
         node_side = None
@@ -289,11 +310,14 @@ class TGT_Layer(nn.Module):
         if self.edge_update:
             lin_oe = self.update.lin_O_e if fuse_oe else None        # then `e` is still H_hat
             if self._triplet_update:
-                e, x = enter(e, e_in, self.tria.tri_ln_e, lin_oe)
+                e, x = enter(e, e_in, self.tria.tri_ln_e, lin_oe, sc_oe, fold_oe)
                 e, x = enter(self.tria.forward_normed(x, mask), e, self.edge_ffn.ffn_ln)
             else:
-                e, x = enter(e, e_in, self.edge_ffn.ffn_ln, lin_oe)
-            closing = PendingResidual(self.edge_ffn.hidden(x), self.edge_ffn.lin_W2, e, ops.drop_path_scale(x, dp, tr))
+                e, x = enter(e, e_in, self.edge_ffn.ffn_ln, lin_oe, sc_oe, fold_oe)
+            sc_ffn = ops.drop_path_scale(x, dp, tr)
+            fold = (sc_ffn is not None and self.edge_ffn.can_fold_scale() and
+                    ops.can_prescale(pair_rows, self.edge_ffn.lin_W2.weight.shape[1], self.edge_ffn.lin_W2.weight.shape[0], cd))
+            closing = PendingResidual(self.edge_ffn.hidden(x, sc_ffn if fold else None), self.edge_ffn.lin_W2, e, sc_ffn, prescaled=fold)
             e = closing if defer_edge else closing.materialize()
         g = g.copy()
         g.pop('node_side', None)
