@@ -103,7 +103,7 @@ def test_projected_triplet_attention_bias_gradient(case, dtype, variant, proj_ke
     gated, biased = variant == 'gated', variant != 'axial'
     L = ops.TripletLayout(C, H, gated=gated, biased=biased)
     # proj_kernel: the Q/K/V projection runs INSIDE the attention forward kernel (opt-in path)
-    monkeypatch.setenv('TGT_TRI_PROJ', '1' if proj_kernel else '0')
+    monkeypatch.setattr(ops, '_TRI_PROJ', bool(proj_kernel))
     if proj_kernel and not ops._proj_fused_ok(torch.empty(0), N, L, dtype):
         pytest.skip('shape not covered by the projection-fused kernel')
     rng = np.random.default_rng(7 + hash((B, N, C, H)) % 1000)
@@ -150,7 +150,7 @@ def test_projection_fused_triplet_attention_vs_oracle(case, dtype, variant, monk
     B, N, nn_, C, H = case
     gated, biased = variant == 'gated', variant != 'axial'
     L = ops.TripletLayout(C, H, gated=gated, biased=biased)
-    monkeypatch.setenv('TGT_TRI_PROJ', '1')
+    monkeypatch.setattr(ops, '_TRI_PROJ', True)
     assert ops._proj_fused_ok(torch.empty(0), N, L, dtype), 'shape must be one the projection-fused kernel takes'
     rng = np.random.default_rng(11 + hash((B, N, C, H)) % 1000)
     x = rnd(rng, B, N, N, C).to(dtype)

@@ -37,7 +37,8 @@ __global__ void __launch_bounds__(256) gelu_dropout_kernel(const T* __restrict__
         if (thresh != 0u) keep_vector<V>(seed, i / V, thresh, keep);
         // per-sample factor (DropPath of the residual branch this activation feeds, folded in here so that the
         // branch's Linear + residual add need no scaled copy of their gradient); a vector never straddles samples
-        const float ik = row_scale ? inv_keep * row_scale[i / elems_per_sample] : inv_keep;
+        // (32-bit division in vector units: a 64-bit one per vector costs as much as the rest of the loop body)
+        const float ik = row_scale ? inv_keep * row_scale[(uint32_t)(i / V) / (uint32_t)(elems_per_sample / V)] : inv_keep;
 #pragma unroll
         for (int t = 0; t < V; ++t) {
             const float v = to_f32(xv[t]);
@@ -86,8 +87,8 @@ int gelu_dropout_run(const void* x, const void* dy, void* out, int64_t n, int dt
     if (p < 0.f || p >= 1.f) return set_error(TGT_ERR_INVALID, "gelu_dropout: p=%f outside [0,1)", p);
     if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)dy) % 16) return set_error(TGT_ERR_INVALID, "gelu_dropout: tensors must be 16-byte aligned");
     if (n == 0) return TGT_OK;
-    if (row_scale && (elems_per_sample <= 0 || elems_per_sample % 8))
-        return set_error(TGT_ERR_INVALID, "gelu_dropout: row_scale needs elems_per_sample, a multiple of 8");
+    if (row_scale && (elems_per_sample <= 0 || elems_per_sample % 8 || n / 4 > 0xffffffffLL))
+        return set_error(TGT_ERR_INVALID, "gelu_dropout: row_scale needs elems_per_sample, a multiple of 8 (and n < 2^34)");
     switch (dtype) {
         case TGT_F32: return gd_launch<float>(x, dy, out, n, p, seed, bwd, row_scale, elems_per_sample, st);
         case TGT_BF16: return gd_launch<bf16_t>(x, dy, out, n, p, seed, bwd, row_scale, elems_per_sample, st);

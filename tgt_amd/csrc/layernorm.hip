@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const LnArgs a) {
                 if (a.res) {
                     float rr[8];
                     ln_load8(a.res, a.res_dtype, row * a.C + col, rr);
-                    const float sc = a.scale ? a.scale[row / a.rows_per_sample] : 1.f;
+                    const float sc = a.scale ? a.scale[(uint32_t)row / (uint32_t)a.rows_per_sample] : 1.f;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) x[v][i] = rr[i] + x[v][i] * sc;
                     ln_store8(a.s_out, a.x_dtype, row * a.C + col, x[v]);
@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const LnArgs a) {
                 if (a.dx2 || a.scale) {
                     // (scale without dx2: the x branch was pre-scaled by its producer -- its gradient IS d_total, only the
                     //  bias gradient of the Linear in between carries the factor: column sums of d_total * scale)
-                    const float sc = a.scale ? a.scale[row / a.rows_per_sample] : 1.f;
+                    const float sc = a.scale ? a.scale[(uint32_t)row / (uint32_t)a.rows_per_sample] : 1.f;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) dx[i] *= sc;
                     if (a.dx2) ln_store8(a.dx2, a.dx_dtype, row * a.C + col, dx);
@@ -398,7 +398,7 @@ int add_layer_norm_fwd_run(const void* x, int x_dtype, const void* res, int res_
     if (!x || !res || !s_out || !gamma || !beta || !y || !mean || !rstd || rows < 0)
         return set_error(TGT_ERR_INVALID, "add_layer_norm fwd: null tensor");
     if (bad_dtype(x_dtype) || bad_dtype(y_dtype) || bad_dtype(res_dtype)) return set_error(TGT_ERR_INVALID, "add_layer_norm fwd: bad dtype");
-    if (scale && rows_per_sample <= 0) return set_error(TGT_ERR_INVALID, "add_layer_norm fwd: rows_per_sample");
+    if (scale && (rows_per_sample <= 0 || rows > 0xffffffffLL)) return set_error(TGT_ERR_INVALID, "add_layer_norm fwd: rows_per_sample (and rows < 2^32)");
     if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)res | (uintptr_t)s_out) % 16) return set_error(TGT_ERR_INVALID, "add_layer_norm fwd: tensors must be 16-byte aligned");
     if (rows == 0) return TGT_OK;
     LnArgs a = {};
@@ -416,7 +416,7 @@ int add_layer_norm_bwd_run(const void* dy, int dy_dtype, const void* s, int s_dt
         return set_error(TGT_ERR_INVALID, "add_layer_norm bwd: null tensor");
     if (bad_dtype(s_dtype) || bad_dtype(dy_dtype) || bad_dtype(d_dtype) || (ds_in && bad_dtype(ds_dtype)))
         return set_error(TGT_ERR_INVALID, "add_layer_norm bwd: bad dtype");
-    if (scale && rows_per_sample <= 0) return set_error(TGT_ERR_INVALID, "add_layer_norm bwd: scale needs rows_per_sample");
+    if (scale && (rows_per_sample <= 0 || rows > 0xffffffffLL)) return set_error(TGT_ERR_INVALID, "add_layer_norm bwd: scale needs rows_per_sample (and rows < 2^32)");
     if (scale && !d_x && !d_x_colsum) return set_error(TGT_ERR_INVALID, "add_layer_norm bwd: scale without d_x only shapes d_x_colsum");
     if (d_x_colsum && d_x_colsum != dbeta + C)
         return set_error(TGT_ERR_INVALID, "add_layer_norm bwd: d_x_colsum must directly follow dbeta (one 2C buffer)");
