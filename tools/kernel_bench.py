@@ -133,6 +133,14 @@ def main():
         sc = torch.ones(B, device=dev)
         t = timeit(lambda: ops.add_layer_norm(x4, res, sc, w, b, 1e-5, dt), a.iters)
         out['add_ln_fwd_edge'] = dict(ms=round(t, 4), GBs=round(4 * x.numel() * esz / t / 1e6, 1))
+        xr, rr = x4.clone().requires_grad_(True), res.clone().requires_grad_(True)
+        g4 = g.view(B, N, N, C)
+
+        def add_ln_fb():
+            s_, y_ = ops.add_layer_norm(xr, rr, sc, w, b, 1e-5, dt)
+            return torch.autograd.grad([s_, y_], [xr, rr], [g4, g4])
+        t2 = timeit(add_ln_fb, a.iters)
+        out['add_ln_bwd_edge'] = dict(ms=round(t2 - t, 4), GBs=round(5 * x.numel() * esz / (t2 - t) / 1e6, 1))
         t = timeit(lambda: ops.gelu_dropout(x4, 0.1, True), a.iters)
         out['gelu_dropout_fwd'] = dict(ms=round(t, 4), GBs=round(2 * x.numel() * esz / t / 1e6, 1))
     print(json.dumps(out))
