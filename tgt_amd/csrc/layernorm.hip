@@ -20,7 +20,7 @@
 
 namespace tgt {
 
-constexpr int kLnParts = 1024;
+constexpr int kLnParts = 1536;
 
 __device__ __forceinline__ void ln_load8(const void* p, int dtype, int64_t idx, float (&v)[8]) {
     if (dtype == TGT_F32) {
@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const LnArgs a) {
 // CS: also accumulate the column sums of the x-branch gradient (d_total * scale) -- the bias
 // gradient of the Linear that produced x -- as a third column plane of the partial buffer.
 template <int LPR, int VPL, bool CS>
-__global__ void __launch_bounds__(256) ln_bwd_kernel(const LnArgs a) {
+__global__ void __launch_bounds__(256, VPL == 1 ? 5 : 1) ln_bwd_kernel(const LnArgs a) {
     constexpr int RPW = 64 / LPR, NP = CS ? 3 : 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem);        // [4 waves][RPW][NP][VPL*LPR*8]
@@ -174,6 +174,12 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const LnArgs a) {
     const int64_t wave = (int64_t)blockIdx.x * 4 + w, nwaves = (int64_t)gridDim.x * 4;
     const float invC = 1.f / a.C;
     float gam[VPL][8], dgam[VPL][8], dbet[VPL][8], dxs[CS ? VPL : 1][8];
+    // CS, one vector per lane: the column sums of the x-branch gradient accumulate in LDS (this thread's own 32 bytes, plain
+    // read-modify-write) instead of 8 more registers -- the kernel then fits 96 registers = 5 waves per SIMD, and occupancy
+    // is what this load-latency-bound pass runs on (plain backward 105 -> 81 us at 5 waves)
+    constexpr bool kLdsAcc = CS && VPL == 1;
+    float4* accx = reinterpret_cast<float4*>(smem) + 4 * threadIdx.x;      // [column sums of dx | dbeta]; ALIASES `red` (used after the walk only)
+    if constexpr (kLdsAcc) accx[0] = accx[1] = accx[2] = accx[3] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
         const int col = (v * LPR + gl) * 8;
@@ -200,9 +206,15 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const LnArgs a) {
                     xh[v][i] = (xh[v][i] - mean) * rstd;
                     g[v][i] = dy[i] * gam[v][i];
                     dgam[v][i] += dy[i] * xh[v][i];
-                    dbet[v][i] += dy[i];
+                    if constexpr (!kLdsAcc) dbet[v][i] += dy[i];
                     s1 += g[v][i];
                     s2 += g[v][i] * xh[v][i];
+                }
+                if constexpr (kLdsAcc) {
+                    float4 b0 = accx[2], b1 = accx[3];
+                    b0.x += dy[0]; b0.y += dy[1]; b0.z += dy[2]; b0.w += dy[3];
+                    b1.x += dy[4]; b1.y += dy[5]; b1.z += dy[6]; b1.w += dy[7];
+                    accx[2] = b0; accx[3] = b1;
                 }
             } else {
 #pragma unroll
@@ -232,12 +244,26 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const LnArgs a) {
                     for (int i = 0; i < 8; ++i) dx[i] *= sc;
                     if (a.dx2) ln_store8(a.dx2, a.dx_dtype, row * a.C + col, dx);
                 }
-                if constexpr (CS) {
+                if constexpr (kLdsAcc) {
+                    float4 a0 = accx[0], a1 = accx[1];
+                    a0.x += dx[0]; a0.y += dx[1]; a0.z += dx[2]; a0.w += dx[3];
+                    a1.x += dx[4]; a1.y += dx[5]; a1.z += dx[6]; a1.w += dx[7];
+                    accx[0] = a0; accx[1] = a1;
+                } else if constexpr (CS) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) dxs[v][i] += dx[i];
                 }
             }
         }
+    }
+    if constexpr (kLdsAcc) {
+        const float4 a0 = accx[0], a1 = accx[1];
+        dxs[0][0] = a0.x; dxs[0][1] = a0.y; dxs[0][2] = a0.z; dxs[0][3] = a0.w;
+        dxs[0][4] = a1.x; dxs[0][5] = a1.y; dxs[0][6] = a1.z; dxs[0][7] = a1.w;
+        const float4 b0 = accx[2], b1 = accx[3];
+        dbet[0][0] = b0.x; dbet[0][1] = b0.y; dbet[0][2] = b0.z; dbet[0][3] = b0.w;
+        dbet[0][4] = b1.x; dbet[0][5] = b1.y; dbet[0][6] = b1.z; dbet[0][7] = b1.w;
+        __syncthreads();          // every thread has its sums in registers before `red` overwrites the accumulators
     }
     // fold the 4*RPW row-groups of this workgroup, fixed order
     constexpr int CW = VPL * LPR * 8;
@@ -341,10 +367,15 @@ static int ln_launch(const LnArgs& a, bool bwd, float* dgamma, float* dbeta, hip
         hipLaunchKernelGGL((ln_fwd_kernel<LPR, VPL>), dim3((unsigned)blocks), dim3(256), 0, st, a);
         return check_launch("ln_fwd_kernel");
     }
-    const int parts = kLnParts;          // fixed grid: the partial buffer has exactly kLnParts rows
+    static const int grid_env = getenv("TGT_LN_BWD_GRID") ? atoi(getenv("TGT_LN_BWD_GRID")) : 0;
+    // grid = rows of the partial buffer that get written.  One vector per lane: 96 registers = 5 waves per SIMD, 1280 workgroups of
+    // 4 waves are exactly one round on 256 CUs (measured: 1024 and 1536 are both slower)
+    const int dflt = VPL == 1 ? 1280 : 1024;
+    const int parts = grid_env > 0 && grid_env <= kLnParts ? grid_env : dflt;
     const bool cs = a.x_colsum != nullptr;     // then dbeta and x_colsum are ONE buffer [dbeta | x_colsum] (checked by the caller)
     const int np = cs ? 3 : 2;
-    const size_t lds = (size_t)4 * RPW * np * VPL * LPR * 8 * sizeof(float);
+    size_t lds = (size_t)4 * RPW * np * VPL * LPR * 8 * sizeof(float);
+    if (cs && VPL == 1 && lds < 256 * 64) lds = 256 * 64;          // the in-LDS accumulators alias the fold buffer
     if (cs) hipLaunchKernelGGL((ln_bwd_kernel<LPR, VPL, true>), dim3(parts), dim3(256), lds, st, a);
     else hipLaunchKernelGGL((ln_bwd_kernel<LPR, VPL, false>), dim3(parts), dim3(256), lds, st, a);
     if (int e = check_launch("ln_bwd_kernel")) return e;
