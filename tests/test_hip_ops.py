@@ -46,6 +46,8 @@ CASES = [  # B, N, num_nodes, C, H
     (2, 48, [48, 37], 64, 4),     # two node tiles (BASELINE cfg 4: N up to 48)
     (1, 64, [64], 32, 4),         # N = 64, D = 8
     (2, 33, [33, 20], 256, 16),   # one node past a tile, BASELINE width
+    (2, 64, [64, 50], 64, 4),     # N = 64, D = 16: four 16-wide blocks (the 16-wide forward kernel)
+    (1, 57, [57], 128, 8),        # ragged last block, two head groups
 ]
 
 

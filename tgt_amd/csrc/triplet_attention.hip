@@ -627,6 +627,9 @@ int tri_att_run_f16(const tgt_triplet_attention_args& a, bool bwd, hipStream_t s
 #endif
 
 #if TGT_TRI_INST & 8
+bool tri_att16_fwd_eligible(const tgt_triplet_attention_args& a);
+int tri_att16_fwd_run(const tgt_triplet_attention_args& a, hipStream_t st);
+
 int triplet_attention_run(const tgt_triplet_attention_args* a, bool bwd, hipStream_t st) {
     if (!a) return set_error(TGT_ERR_INVALID, "triplet attention: null args");
     if (a->B < 0 || a->N < 0 || a->H <= 0) return set_error(TGT_ERR_INVALID, "triplet attention: bad sizes B=%d N=%d H=%d", a->B, a->N, a->H);
@@ -652,6 +655,7 @@ int triplet_attention_run(const tgt_triplet_attention_args* a, bool bwd, hipStre
             if ((a->flags & (TGT_TRI_BIASED | TGT_TRI_GATED)) && !a->d_eg[dir]) return set_error(TGT_ERR_INVALID, "triplet attention bwd: d_eg missing");
         }
     }
+    if (!bwd && tri_att16_fwd_eligible(*a)) return tri_att16_fwd_run(*a, st);      // 33 <= N <= 64: 16-wide tiles (triplet_attention16.hip)
     switch (a->dtype) {
         case TGT_F32: return tri_att_run_f32(*a, bwd, st);
         case TGT_BF16: return tri_att_run_bf16(*a, bwd, st);

@@ -1,0 +1,266 @@
+// Triplet attention FORWARD on 16-wide node tiles (v_mfma_f32_16x16x16) for 33 <= N <= 64 -- BASELINE config 4.
+//
+// Replaces the einsum -> +bias -> +mask -> softmax -> *gate -> einsum chains of reference
+// lib/tgt/layers/triplet.py:213-246 for graphs padded to more than 32 nodes.  Same arithmetic and the same
+// decomposition as triplet_attention.hip (workgroup = (graph, direction, group of HG heads), walk over the shared
+// node j, slabs of Q rows [i,j] and partner K / V rows through two LDS sets, one barrier per j); what changes is
+// the tile: 32-wide tiles pad a 48-node graph to 64 x 64 (two query-tile passes over the walk, each against two key
+// tiles: 4 tile pairs for 2.25 tile pairs of work, K / V slabs streamed twice, 128 registers of third-arm state per
+// wave).  Here a WAVE owns (head, block of 16 queries) and all NQ = ceil(N/16) key blocks:
+//   S^T[key][query] per key block = one 16x16x16 MFMA (K rows x Q rows, depth D = 16): lane (query = l & 15,
+//   g = l >> 4) holds keys 4g..4g+3 of the block -- softmax over keys = in-lane values + two lane exchanges
+//   (l ^ 16, l ^ 32); V^T = V . I through the matrix core; O^T[d][query] = sum_blocks V^T P^T.  With 16x16x16
+//   the accumulator layout (lane = column, rows 4g+q) IS the operand layout (lane = row or column, k = 4g+t): no
+//   permuted k-order, no shuffles.
+// One pass over the walk whatever N <= 64 is: HG * NQ waves, every lane works on real elements (N = 48: 9 key-block
+// products per (head, j) against 16 for the padded 32-wide tiles), third-arm state 2 * NQ * 4 registers per wave.
+// The backward stays on the two-tile kernel of triplet_attention.hip for now.
+#include <cstdlib>
+#include "triplet_common.hpp"
+
+namespace tgt {
+namespace t16 {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct F4;
+template <> struct F4<bf16_t> { typedef s16x4 type; };
+template <> struct F4<f16_t> { typedef h16x4 type; };
+template <typename T> using frag4_t = typename F4<T>::type;
+
+// C[m][n] += sum_kk A[m][kk] B[kk][n], kk in [0,16): lane l = (x = l & 15, g = l >> 4) supplies A[m = x][kk = 4g + t] /
+// B[kk = 4g + t][n = x], t = 0..3, and holds C[m = 4g + q][n = x], q = 0..3
+__device__ __forceinline__ f32x4 mma16(s16x4 a, s16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mma16(h16x4 a, h16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
+
+template <typename T>
+__device__ __forceinline__ frag4_t<T> pack4(const f32x4& v) {
+    T t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = from_f32<T>(v[i]);
+    frag4_t<T> f;
+    __builtin_memcpy(&f, t, 8);
+    return f;
+}
+template <typename T>
+__device__ __forceinline__ frag4_t<T> ident4(int x, int g) {     // B[kk][n] = (kk == n)
+    T t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = from_f32<T>(4 * g + i == x ? 1.f : 0.f);
+    frag4_t<T> f;
+    __builtin_memcpy(&f, t, 8);
+    return f;
+}
+
+// slab geometry: 16 * NQ rows of HG heads x 16 channels; the slab_* templates of triplet_common.hpp take it as they take TriGeo
+template <typename T, int HG, int NQ>
+struct Geo16 {
+    static constexpr int kThreads = HG * NQ * 64;
+    static constexpr int kRows = 16 * NQ;
+    static constexpr int kRowBytes = HG * 16 * (int)sizeof(T);
+    static constexpr int kSlots = kRowBytes / 16;
+    static constexpr int kSlabBytes = kRows * kRowBytes;
+    static constexpr int kRowsPerBankRow = kRowBytes >= 256 ? 1 : 256 / kRowBytes;
+    static constexpr int kSwzMask = (kSlots < 16 ? kSlots : 16) - 1;
+    __device__ static __forceinline__ int lds_off(int row, int slot) {
+        const int f = (row / kRowsPerBankRow) & kSwzMask;
+        return row * kRowBytes + ((slot ^ f) << 4);
+    }
+    __device__ static __forceinline__ int lds_elem(int row, int col) {
+        const int bo = col * (int)sizeof(T);
+        return lds_off(row, bo >> 4) + (bo & 15);
+    }
+};
+
+// operand fragment of head hw for slab row `row`: channels 4g .. 4g+3
+template <typename T, typename G>
+__device__ __forceinline__ frag4_t<T> frag_of(const char* slab, int row, int hw, int g) {
+    frag4_t<T> f;
+    const uint2 raw = *reinterpret_cast<const uint2*>(slab + G::lds_elem(row, hw * 16 + 4 * g));
+    __builtin_memcpy(&f, &raw, 8);
+    return f;
+}
+
+// third-arm stage: the (x, y) pair records [E of the HG heads | G of the HG heads] of the whole graph + the mask, in memory
+// order (x, y); element (query i, key k) of direction 0 sits at (x, y) = (i, k), of direction 1 at (k, i)
+template <typename T, int HG, int NQ>
+struct Arm16 {
+    static constexpr int R = 16 * NQ, kVals = 2 * HG, kRec = kVals * (int)sizeof(T);
+    static constexpr int kPitch = R * kRec + 4, kMPitch = R * 4 + 4;
+    static constexpr int kOffM = ((R * kPitch + 15) / 16) * 16;
+    static constexpr int kBytes = kOffM + R * kMPitch;
+};
+
+template <typename T, int HG, int NQ>
+__global__ void __launch_bounds__(HG * NQ * 64) tri_att16_fwd_kernel(const tgt_triplet_attention_args a) {
+    using G = Geo16<T, HG, NQ>;
+    using A = Arm16<T, HG, NQ>;
+    using F = frag4_t<T>;
+    constexpr int R = G::kRows, kSet = 3 * G::kSlabBytes;        // {Q | K | V}, two sets
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x16 = lane & 15, g = lane >> 4, hw = wave % HG, qb = wave / HG;
+    const int ngroups = a.H / HG;
+    int bid = blockIdx.x;
+    const int grp = bid % ngroups;
+    bid /= ngroups;
+    const int dir = bid & 1, b = bid >> 1, N = a.N;
+    const bool biased = (a.flags & TGT_TRI_BIASED) != 0, gated = (a.flags & TGT_TRI_GATED) != 0;
+
+    // ---- third arm of this wave: bias + mask and gate for (query 16 qb + x16, keys 16 kb + 4 g + q) ----
+    float biasM[NQ][4], gate[NQ][4];
+    {
+        const T* eg = reinterpret_cast<const T*>(a.eg[dir]);
+        const int64_t ld = a.ld_eg[dir];
+        for (int idx = tid; idx < R * R * A::kVals; idx += G::kThreads) {
+            const int v = idx % A::kVals, p = idx / A::kVals, y = p % R, x = p / R;
+            T val = from_f32<T>(0.f);
+            if (x < N && y < N) {
+                const bool is_e = v < HG;
+                if (is_e ? biased : gated)
+                    val = eg[(((int64_t)b * N + x) * N + y) * ld + (is_e ? a.e_off[dir] + grp * HG + v : a.g_off[dir] + grp * HG + v - HG)];
+            }
+            *reinterpret_cast<T*>(smem + x * A::kPitch + y * A::kRec + v * (int)sizeof(T)) = val;
+        }
+        for (int idx = tid; idx < R * R; idx += G::kThreads) {
+            const int y = idx % R, x = idx / R;
+            float m = 0.f;
+            if (x < N && y < N && a.mask) m = a.mask[((int64_t)b * N + x) * N + y];
+            *reinterpret_cast<float*>(smem + A::kOffM + x * A::kMPitch + y * 4) = m;
+        }
+        __syncthreads();
+        const int i = 16 * qb + x16;
+#pragma unroll
+        for (int kb = 0; kb < NQ; ++kb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = 16 * kb + 4 * g + q;
+                const int xx = dir == 0 ? i : k, yy = dir == 0 ? k : i;
+                const char* pp = smem + xx * A::kPitch + yy * A::kRec;
+                const float e = to_f32(*reinterpret_cast<const T*>(pp + hw * (int)sizeof(T)));
+                const float gl = to_f32(*reinterpret_cast<const T*>(pp + (HG + hw) * (int)sizeof(T)));
+                const float m = *reinterpret_cast<const float*>(smem + A::kOffM + xx * A::kMPitch + yy * 4);
+                biasM[kb][q] = k < N ? e + m : -INFINITY;
+                gate[kb][q] = (i < N && k < N) ? (gated ? fast_sigmoid(gl + m) : 1.f) : 0.f;
+            }
+        __syncthreads();
+    }
+
+    // ---- slabs (buffer-addressed, triplet_common.hpp) ----
+    const int64_t sz = sizeof(T), Nl = N;
+    const uint32_t hch = (uint32_t)(grp * HG * 16 * sz), lds_ = (uint32_t)(a.ld_qkv[dir] * sz), ldo_ = (uint32_t)(a.ld_out * sz);
+    const __amdgpu_buffer_rsrc_t r_src = graph_rsrc(a.qkv[dir], Nl * Nl * a.ld_qkv[dir] * sz, b);
+    const SlabBuf bQ = {r_src, (uint32_t)(a.q_off[dir] * sz) + hch, (uint32_t)N * lds_, lds_};
+    const SlabBuf bK = {r_src, (uint32_t)(a.k_off[dir] * sz) + hch, dir == 0 ? lds_ : (uint32_t)N * lds_, dir == 0 ? (uint32_t)N * lds_ : lds_};
+    const SlabBuf bV = {r_src, (uint32_t)(a.v_off[dir] * sz) + hch, bK.row_stride, bK.j_stride};
+    const SlabBuf bO = {graph_rsrc(a.out, Nl * Nl * a.ld_out * sz, b), (uint32_t)(a.o_off[dir] * sz) + hch, (uint32_t)N * ldo_, ldo_};
+
+    uint4 pq[SlabIO<G, R>::kIters], pk[SlabIO<G, R>::kIters], pv[SlabIO<G, R>::kIters];
+    slab_issue<G, R>(pq, bQ, 0, 0, N, tid);
+    slab_issue<G, R>(pk, bK, 0, 0, N, tid);
+    slab_issue<G, R>(pv, bV, 0, 0, N, tid);
+    slab_commit<G, R>(pq, smem, tid);
+    slab_commit<G, R>(pk, smem + G::kSlabBytes, tid);
+    slab_commit<G, R>(pv, smem + 2 * G::kSlabBytes, tid);
+    if (N > 1) {
+        slab_issue<G, R>(pq, bQ, 1, 0, N, tid);
+        slab_issue<G, R>(pk, bK, 1, 0, N, tid);
+        slab_issue<G, R>(pv, bV, 1, 0, N, tid);
+    }
+    __syncthreads();
+
+    const F ident = ident4<T>(x16, g);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    // one barrier per j: hazards as in triplet_attention.hip (the other set is rewritten at the top of the iteration by the
+    // thread that last read those chunks; O goes into this wave's own rows / columns of the Q slab)
+    for (int j = 0; j < N; ++j) {
+        char* sQ = smem + (j & 1) * kSet;
+        char* sK = sQ + G::kSlabBytes;
+        char* sV = sK + G::kSlabBytes;
+        if (j + 1 < N) {
+            char* nQ = smem + ((j + 1) & 1) * kSet;
+            slab_commit<G, R>(pq, nQ, tid);
+            slab_commit<G, R>(pk, nQ + G::kSlabBytes, tid);
+            slab_commit<G, R>(pv, nQ + 2 * G::kSlabBytes, tid);
+        }
+        if (j + 2 < N) {
+            slab_issue<G, R>(pq, bQ, j + 2, 0, N, tid);
+            slab_issue<G, R>(pk, bK, j + 2, 0, N, tid);
+            slab_issue<G, R>(pv, bV, j + 2, 0, N, tid);
+        }
+        const F fq = frag_of<T, G>(sQ, 16 * qb + x16, hw, g);
+        f32x4 s[NQ], vt[NQ];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < NQ; ++kb) {
+            const F fk = frag_of<T, G>(sK, 16 * kb + x16, hw, g), fv = frag_of<T, G>(sV, 16 * kb + x16, hw, g);
+            s[kb] = mma16(fk, fq, z);             // S^T[key][query]
+            vt[kb] = mma16(fv, ident, z);         // V[key][d] -> lane d
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                s[kb][q] = s[kb][q] * a.scale + biasM[kb][q];
+                mx = fmaxf(mx, s[kb][q]);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, xhalf(mx));
+        float sum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NQ; ++kb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                s[kb][q] = fast_exp(s[kb][q] - mx);
+                sum += s[kb][q];
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += xhalf(sum);
+        const float inv = fast_rcp(sum);
+        f32x4 o = z;
+#pragma unroll
+        for (int kb = 0; kb < NQ; ++kb) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s[kb][q] = s[kb][q] * inv * gate[kb][q];
+            o = mma16(pack4<T>(vt[kb]), pack4<T>(s[kb]), o);          // O^T[d][query]
+        }
+        {   // lane (query, g) holds channels 4g .. 4g+3 of its query: 8 bytes into the head's columns of the Q slab
+            const F of = pack4<T>(o);
+            uint2 raw;
+            __builtin_memcpy(&raw, &of, 8);
+            *reinterpret_cast<uint2*>(sQ + G::lds_elem(16 * qb + x16, hw * 16 + 4 * g)) = raw;
+        }
+        __syncthreads();
+        slab_store<G, R>(sQ, bO, j, 0, N, tid);
+    }
+}
+
+template <typename T, int HG, int NQ>
+static int launch(const tgt_triplet_attention_args& a, hipStream_t st) {
+    using G = Geo16<T, HG, NQ>;
+    constexpr int kArm = Arm16<T, HG, NQ>::kBytes, kSlabs = 2 * 3 * G::kSlabBytes;
+    constexpr int kLds = kArm > kSlabs ? kArm : kSlabs;
+    static_assert(kLds <= 160 * 1024, "LDS");
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tri_att16_fwd_kernel<T, HG, NQ>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, kLds), true);
+    (void)once;
+    hipLaunchKernelGGL((tri_att16_fwd_kernel<T, HG, NQ>), dim3(a.B * 2 * (a.H / HG)), dim3(G::kThreads), kLds, st, a);
+    return check_launch("tri_att16_fwd_kernel");
+}
+
+template <typename T>
+static int run(const tgt_triplet_attention_args& a, hipStream_t st) {
+    return a.N <= 48 ? launch<T, 4, 3>(a, st) : launch<T, 4, 4>(a, st);
+}
+
+}  // namespace t16
+
+// forward on 16-wide tiles: 16-bit, D = 16, 33 <= N <= 64, H a multiple of 4, no attention dropout
+bool tri_att16_fwd_eligible(const tgt_triplet_attention_args& a) {
+    static const int on = getenv("TGT_TRI16") ? atoi(getenv("TGT_TRI16")) : 1;
+    return on && (a.dtype == TGT_BF16 || a.dtype == TGT_F16) && a.D == 16 && a.N > 32 && a.N <= 64 && a.H % 4 == 0 && !(a.dropout_p > 0.f);
+}
+int tri_att16_fwd_run(const tgt_triplet_attention_args& a, hipStream_t st) {
+    return a.dtype == TGT_BF16 ? t16::run<bf16_t>(a, st) : t16::run<f16_t>(a, st);
+}
+
+}  // namespace tgt
