@@ -64,3 +64,28 @@ def test_packed_broadcast_reads_one_half():
 def test_kernels_are_separate():
     both = lint.lint_text(GOOD + BAD.replace('_Z4goodv', '_Z3badv'))
     assert both == {'_Z3badv': ['a11']}
+
+
+# the store-data hazard met on MI355X (csrc/triplet_attention16.hip, fp16 column-sum variant): a 128-bit store whose first
+# data register a VALU instruction rewrites in the very next slot
+STORE_HAZARD = """
+_Z5storev:
+	ds_read_b128 v[114:117], v48
+	s_waitcnt lgkmcnt(0)
+	buffer_store_dwordx4 v[114:117], v72, s[12:15], s28 offen
+	v_cvt_f32_f16_e32 v114, v108
+	s_endpgm
+.Lfunc_end2:
+"""
+
+
+def test_store_data_overwritten_behind_a_wide_store_is_flagged():
+    bad = lint.lint_store_hazard(STORE_HAZARD)
+    assert list(bad) == ['_Z5storev'] and 'v114' in bad['_Z5storev'][0]
+    assert '_Z5storev' in lint.lint_all(STORE_HAZARD)
+    padded = STORE_HAZARD.replace('\tv_cvt_f32_f16_e32 v114, v108\n', '\ts_nop 0\n\tv_cvt_f32_f16_e32 v114, v108\n')
+    assert lint.lint_store_hazard(padded) == {}
+    other = STORE_HAZARD.replace('v_cvt_f32_f16_e32 v114, v108', 'v_cvt_f32_f16_e32 v120, v108')      # not a data register
+    assert lint.lint_store_hazard(other) == {}
+    narrow = STORE_HAZARD.replace('buffer_store_dwordx4 v[114:117]', 'buffer_store_dwordx2 v[114:115]')  # 64-bit stores are safe
+    assert lint.lint_store_hazard(narrow) == {}

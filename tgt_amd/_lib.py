@@ -199,7 +199,7 @@ def build_library(force=False, verbose=False):
             path = os.path.join(d, f)
             if f.endswith('-gfx950.s'):
                 with open(path) as fh:
-                    for k, regs in isa_lint().lint_text(fh.read()).items():
+                    for k, regs in isa_lint().lint_all(fh.read()).items():
                         undefined[f'{os.path.basename(d)}:{k}'] = regs
             if f != 'unit.o' and not (f.endswith('-gfx950.s') and os.environ.get('TGT_KEEP_ISA')):
                 os.remove(path)

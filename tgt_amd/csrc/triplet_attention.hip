@@ -629,6 +629,8 @@ int tri_att_run_f16(const tgt_triplet_attention_args& a, bool bwd, hipStream_t s
 #if TGT_TRI_INST & 8
 bool tri_att16_fwd_eligible(const tgt_triplet_attention_args& a);
 int tri_att16_fwd_run(const tgt_triplet_attention_args& a, hipStream_t st);
+bool tri_att16_bwd_eligible(const tgt_triplet_attention_args& a);
+int tri_att16_bwd_run(const tgt_triplet_attention_args& a, hipStream_t st);
 
 int triplet_attention_run(const tgt_triplet_attention_args* a, bool bwd, hipStream_t st) {
     if (!a) return set_error(TGT_ERR_INVALID, "triplet attention: null args");
@@ -656,6 +658,7 @@ int triplet_attention_run(const tgt_triplet_attention_args* a, bool bwd, hipStre
         }
     }
     if (!bwd && tri_att16_fwd_eligible(*a)) return tri_att16_fwd_run(*a, st);      // 33 <= N <= 64: 16-wide tiles (triplet_attention16.hip)
+    if (bwd && tri_att16_bwd_eligible(*a)) return tri_att16_bwd_run(*a, st);
     switch (a->dtype) {
         case TGT_F32: return tri_att_run_f32(*a, bwd, st);
         case TGT_BF16: return tri_att_run_bf16(*a, bwd, st);

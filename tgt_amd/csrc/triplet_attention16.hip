@@ -234,6 +234,363 @@ __global__ void __launch_bounds__(HG * NQ * 64) tri_att16_fwd_kernel(const tgt_t
     }
 }
 
+// ---------------------------------------------------------------------------
+// backward on the same tiles, N <= 48 (NQ = 3: 12 waves, up to 170 registers).
+// Per j, two phases with a barrier between them:
+//   phase 1, wave = (head, QUERY block): S, dA for every key block, softmax recomputed, dS = P (dA g - delta), A = P g;
+//            dE / dG accumulate in registers; dQ^T = s sum_blocks K^T dS^T goes into the head's columns of the Q slab;
+//            the wave leaves Q^T, dO^T (operand layout) and its dS / A blocks (transposed on the way: 2-byte stores)
+//            in an LDS exchange area;
+//   phase 2, wave = (head, KEY block): dK^T = s sum_query-blocks Q^T dS, dV^T = sum dO^T A from the exchange area --
+//            complete sums over all queries, no partial tiles -- into the head's columns of the K / V slabs.
+// Stores, fused gradient row (ld_dqkv / ld_deg) and the in-kernel bias-gradient column sums as in triplet_attention.hip;
+// the per-thread column accumulators live in registers here (24 of them: this kernel has the room).
+// ---------------------------------------------------------------------------
+template <typename T, int HG, int NQ, bool CS>
+__global__ void __launch_bounds__(HG * NQ * 64) tri_att16_bwd_kernel(const tgt_triplet_attention_args a) {
+    using G = Geo16<T, HG, NQ>;
+    using A = Arm16<T, HG, NQ>;
+    using F = frag4_t<T>;
+    constexpr int R = G::kRows, kSet = 4 * G::kSlabBytes;        // {Q | dO | K | V}, two sets
+    constexpr int kBlk = 16 * 16 * (int)sizeof(T);               // one 16x16 exchange block
+    constexpr int kXWave = (2 + 2 * NQ) * kBlk;                  // per (head, query block): Q^T, dO^T, dS[kb], A[kb]
+    constexpr int kOffX = 2 * kSet;
+    constexpr int E = 16 / (int)sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x16 = lane & 15, g = lane >> 4, hw = wave % HG, qb = wave / HG;
+    const int ngroups = a.H / HG;
+    int bid = blockIdx.x;
+    const int grp = bid % ngroups;
+    bid /= ngroups;
+    const int dir = bid & 1, b = bid >> 1, N = a.N;
+    const bool biased = (a.flags & TGT_TRI_BIASED) != 0, gated = (a.flags & TGT_TRI_GATED) != 0;
+
+    float biasM[NQ][4], gate[NQ][4], dE[NQ][4], dG[NQ][4];
+    {
+        const T* eg = reinterpret_cast<const T*>(a.eg[dir]);
+        const int64_t ld = a.ld_eg[dir];
+        for (int idx = tid; idx < R * R * A::kVals; idx += G::kThreads) {
+            const int v = idx % A::kVals, p = idx / A::kVals, y = p % R, x = p / R;
+            T val = from_f32<T>(0.f);
+            if (x < N && y < N) {
+                const bool is_e = v < HG;
+                if (is_e ? biased : gated)
+                    val = eg[(((int64_t)b * N + x) * N + y) * ld + (is_e ? a.e_off[dir] + grp * HG + v : a.g_off[dir] + grp * HG + v - HG)];
+            }
+            *reinterpret_cast<T*>(smem + x * A::kPitch + y * A::kRec + v * (int)sizeof(T)) = val;
+        }
+        for (int idx = tid; idx < R * R; idx += G::kThreads) {
+            const int y = idx % R, x = idx / R;
+            float m = 0.f;
+            if (x < N && y < N && a.mask) m = a.mask[((int64_t)b * N + x) * N + y];
+            *reinterpret_cast<float*>(smem + A::kOffM + x * A::kMPitch + y * 4) = m;
+        }
+        __syncthreads();
+        const int i = 16 * qb + x16;
+#pragma unroll
+        for (int kb = 0; kb < NQ; ++kb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = 16 * kb + 4 * g + q;
+                const int xx = dir == 0 ? i : k, yy = dir == 0 ? k : i;
+                const char* pp = smem + xx * A::kPitch + yy * A::kRec;
+                const float e = to_f32(*reinterpret_cast<const T*>(pp + hw * (int)sizeof(T)));
+                const float gl = to_f32(*reinterpret_cast<const T*>(pp + (HG + hw) * (int)sizeof(T)));
+                const float m = *reinterpret_cast<const float*>(smem + A::kOffM + xx * A::kMPitch + yy * 4);
+                const bool valid = i < N && k < N;
+                biasM[kb][q] = valid ? e + m : -INFINITY;          // padding queries get weight exactly 0: they feed sums over queries
+                gate[kb][q] = valid ? (gated ? fast_sigmoid(gl + m) : 1.f) : 0.f;
+                dE[kb][q] = dG[kb][q] = 0.f;
+            }
+        __syncthreads();
+    }
+
+    const int64_t sz = sizeof(T), Nl = N;
+    const int64_t ldq = a.ld_dqkv[dir] ? a.ld_dqkv[dir] : a.ld_qkv[dir];
+    const int64_t lde = a.ld_deg[dir] ? a.ld_deg[dir] : a.ld_eg[dir];
+    const uint32_t hch = (uint32_t)(grp * HG * 16 * sz);
+    const uint32_t lds_ = (uint32_t)(a.ld_qkv[dir] * sz), ldg_ = (uint32_t)(ldq * sz), ldo_ = (uint32_t)(a.ld_out * sz);
+    const __amdgpu_buffer_rsrc_t r_src = graph_rsrc(a.qkv[dir], Nl * Nl * a.ld_qkv[dir] * sz, b);
+    const __amdgpu_buffer_rsrc_t r_grd = graph_rsrc(a.d_qkv[dir], Nl * Nl * ldq * sz, b);
+    const __amdgpu_buffer_rsrc_t r_do = graph_rsrc(a.d_out, Nl * Nl * a.ld_out * sz, b);
+    const uint32_t qo = (uint32_t)(a.q_off[dir] * sz) + hch, ko = (uint32_t)(a.k_off[dir] * sz) + hch, vo = (uint32_t)(a.v_off[dir] * sz) + hch;
+    const SlabBuf bQ = {r_src, qo, (uint32_t)N * lds_, lds_};
+    const SlabBuf bK = {r_src, ko, dir == 0 ? lds_ : (uint32_t)N * lds_, dir == 0 ? (uint32_t)N * lds_ : lds_};
+    const SlabBuf bV = {r_src, vo, bK.row_stride, bK.j_stride};
+    const SlabBuf bO = {r_do, (uint32_t)(a.o_off[dir] * sz) + hch, (uint32_t)N * ldo_, ldo_};
+    const SlabBuf gQ = {r_grd, qo, (uint32_t)N * ldg_, ldg_};
+    const SlabBuf gK = {r_grd, ko, dir == 0 ? ldg_ : (uint32_t)N * ldg_, dir == 0 ? (uint32_t)N * ldg_ : ldg_};
+    const SlabBuf gV = {r_grd, vo, gK.row_stride, gK.j_stride};
+
+    static_assert(SlabIO<G, R>::kIters == 1, "one chunk per thread");
+    const bool has_chunk = tid < SlabIO<G, R>::kChunks;
+    const int crow = tid / G::kSlots, cslot = tid % G::kSlots;
+    // column sums of dQ, dK, dV over this thread's chunk column: fp32 accumulators in LDS behind the exchange area (this thread's
+    // own 96 bytes, plain read-modify-write; 24 more registers would push the tile math into scratch)
+    float* csl = reinterpret_cast<float*>(smem + kOffX + HG * NQ * kXWave) + tid * 3 * E;
+    if constexpr (CS) {
+        if (has_chunk)
+#pragma unroll
+            for (int e = 0; e < 3 * E; ++e) csl[e] = 0.f;
+    }
+
+    uint4 pq[1], po[1], pk[1], pv[1];
+    slab_issue<G, R>(pq, bQ, 0, 0, N, tid);
+    slab_issue<G, R>(po, bO, 0, 0, N, tid);
+    slab_issue<G, R>(pk, bK, 0, 0, N, tid);
+    slab_issue<G, R>(pv, bV, 0, 0, N, tid);
+    slab_commit<G, R>(pq, smem, tid);
+    slab_commit<G, R>(po, smem + G::kSlabBytes, tid);
+    slab_commit<G, R>(pk, smem + 2 * G::kSlabBytes, tid);
+    slab_commit<G, R>(pv, smem + 3 * G::kSlabBytes, tid);
+    if (N > 1) {
+        slab_issue<G, R>(pq, bQ, 1, 0, N, tid);
+        slab_issue<G, R>(po, bO, 1, 0, N, tid);
+        slab_issue<G, R>(pk, bK, 1, 0, N, tid);
+        slab_issue<G, R>(pv, bV, 1, 0, N, tid);
+    }
+    __syncthreads();
+
+    const F ident = ident4<T>(x16, g);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    char* xw = smem + kOffX + (hw * NQ + qb) * kXWave;          // this wave's exchange blocks (phase 1)
+    for (int j = 0; j < N; ++j) {
+        char* sQ = smem + (j & 1) * kSet;
+        char* sO = sQ + G::kSlabBytes;
+        char* sK = sQ + 2 * G::kSlabBytes;
+        char* sV = sQ + 3 * G::kSlabBytes;
+        if (j + 1 < N) {
+            char* nQ = smem + ((j + 1) & 1) * kSet;
+            slab_commit<G, R>(pq, nQ, tid);
+            slab_commit<G, R>(po, nQ + G::kSlabBytes, tid);
+            slab_commit<G, R>(pk, nQ + 2 * G::kSlabBytes, tid);
+            slab_commit<G, R>(pv, nQ + 3 * G::kSlabBytes, tid);
+        }
+        if (j + 2 < N) {
+            slab_issue<G, R>(pq, bQ, j + 2, 0, N, tid);
+            slab_issue<G, R>(po, bO, j + 2, 0, N, tid);
+            slab_issue<G, R>(pk, bK, j + 2, 0, N, tid);
+            slab_issue<G, R>(pv, bV, j + 2, 0, N, tid);
+        }
+        // ---- phase 1: (head, query block) ----
+        {
+            const F fq = frag_of<T, G>(sQ, 16 * qb + x16, hw, g), fo = frag_of<T, G>(sO, 16 * qb + x16, hw, g);
+            f32x4 s[NQ], da[NQ];
+            F kTf[NQ];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < NQ; ++kb) {
+                const F fk = frag_of<T, G>(sK, 16 * kb + x16, hw, g), fv = frag_of<T, G>(sV, 16 * kb + x16, hw, g);
+                s[kb] = mma16(fk, fq, z);                 // S^T[key][query]
+                da[kb] = mma16(fv, fo, z);                // dA^T[key][query]
+                kTf[kb] = pack4<T>(mma16(fk, ident, z));  // K^T: lane d, keys 4g..4g+3
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    s[kb][q] = s[kb][q] * a.scale + biasM[kb][q];
+                    mx = fmaxf(mx, s[kb][q]);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, xhalf(mx));
+            if (mx == -INFINITY) mx = 0.f;                // padding query: every weight is exactly 0
+            float sum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < NQ; ++kb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    s[kb][q] = fast_exp(s[kb][q] - mx);
+                    sum += s[kb][q];
+                }
+            sum += __shfl_xor(sum, 16);
+            sum += xhalf(sum);
+            const float inv = sum > 0.f ? fast_rcp(sum) : 0.f;
+            float delta = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < NQ; ++kb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float p = s[kb][q] * inv, dp = da[kb][q] * gate[kb][q];
+                    delta += p * dp;
+                    if (gated) dG[kb][q] += da[kb][q] * p;
+                    s[kb][q] = p;
+                    da[kb][q] = dp;
+                }
+            delta += __shfl_xor(delta, 16);
+            delta += xhalf(delta);
+            // Q^T, dO^T in operand layout (lane d, queries 4g..4g+3) for phase 2
+            {
+                const F qTf = pack4<T>(mma16(fq, ident, z)), oTf = pack4<T>(mma16(fo, ident, z));
+                uint2 r0, r1;
+                __builtin_memcpy(&r0, &qTf, 8);
+                __builtin_memcpy(&r1, &oTf, 8);
+                *reinterpret_cast<uint2*>(xw + (x16 * 16 + 4 * g) * (int)sizeof(T)) = r0;
+                *reinterpret_cast<uint2*>(xw + kBlk + (x16 * 16 + 4 * g) * (int)sizeof(T)) = r1;
+            }
+            f32x4 dq = z;
+#pragma unroll
+            for (int kb = 0; kb < NQ; ++kb) {
+                f32x4 dsv;
+                char* xs = xw + (2 + kb) * kBlk;
+                char* xa = xw + (2 + NQ + kb) * kBlk;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float ds = s[kb][q] * (da[kb][q] - delta);
+                    if (biased) dE[kb][q] += ds;
+                    dsv[q] = ds * a.scale;
+                    // transposed on the way out: block[key][query]
+                    *reinterpret_cast<T*>(xs + ((4 * g + q) * 16 + x16) * (int)sizeof(T)) = from_f32<T>(dsv[q]);
+                    *reinterpret_cast<T*>(xa + ((4 * g + q) * 16 + x16) * (int)sizeof(T)) = from_f32<T>(s[kb][q] * gate[kb][q]);
+                }
+                dq = mma16(kTf[kb], pack4<T>(dsv), dq);          // dQ^T[d][query]
+            }
+            const F dqf = pack4<T>(dq);
+            uint2 raw;
+            __builtin_memcpy(&raw, &dqf, 8);
+            *reinterpret_cast<uint2*>(sQ + G::lds_elem(16 * qb + x16, hw * 16 + 4 * g)) = raw;
+        }
+        __syncthreads();
+        // ---- phase 2: (head, KEY block = this wave's block index) ----
+        {
+            const int kb = qb;
+            f32x4 dk = z, dv = z;
+#pragma unroll
+            for (int q2 = 0; q2 < NQ; ++q2) {
+                const char* xo = smem + kOffX + (hw * NQ + q2) * kXWave;
+                F qTf, oTf, dsb, ab;
+                const uint2 r0 = *reinterpret_cast<const uint2*>(xo + (x16 * 16 + 4 * g) * (int)sizeof(T));
+                const uint2 r1 = *reinterpret_cast<const uint2*>(xo + kBlk + (x16 * 16 + 4 * g) * (int)sizeof(T));
+                const uint2 r2 = *reinterpret_cast<const uint2*>(xo + (2 + kb) * kBlk + (x16 * 16 + 4 * g) * (int)sizeof(T));
+                const uint2 r3 = *reinterpret_cast<const uint2*>(xo + (2 + NQ + kb) * kBlk + (x16 * 16 + 4 * g) * (int)sizeof(T));
+                __builtin_memcpy(&qTf, &r0, 8);
+                __builtin_memcpy(&oTf, &r1, 8);
+                __builtin_memcpy(&dsb, &r2, 8);
+                __builtin_memcpy(&ab, &r3, 8);
+                dk = mma16(qTf, dsb, dk);                 // dK^T[d][key] += Q^T[d][queries] dS[queries][key]
+                dv = mma16(oTf, ab, dv);                  // dV^T[d][key] += dO^T[d][queries] A[queries][key]
+            }
+            const F dkf = pack4<T>(dk), dvf = pack4<T>(dv);
+            uint2 r0, r1;
+            __builtin_memcpy(&r0, &dkf, 8);
+            __builtin_memcpy(&r1, &dvf, 8);
+            *reinterpret_cast<uint2*>(sK + G::lds_elem(16 * kb + x16, hw * 16 + 4 * g)) = r0;
+            *reinterpret_cast<uint2*>(sV + G::lds_elem(16 * kb + x16, hw * 16 + 4 * g)) = r1;
+        }
+        __syncthreads();
+        if (has_chunk && crow < N) {
+            const char* slabs[3] = {sQ, sK, sV};
+            const SlabBuf* dst[3] = {&gQ, &gK, &gV};
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const uint4 v = *reinterpret_cast<const uint4*>(slabs[p] + G::lds_off(crow, cslot));
+                if constexpr (CS) {
+                    T xa[E];
+                    __builtin_memcpy(xa, &v, 16);
+                    float4* acc = reinterpret_cast<float4*>(csl + p * E);
+#pragma unroll
+                    for (int e4 = 0; e4 < E / 4; ++e4) {
+                        float4 t = acc[e4];
+                        t.x += to_f32(xa[4 * e4]); t.y += to_f32(xa[4 * e4 + 1]); t.z += to_f32(xa[4 * e4 + 2]); t.w += to_f32(xa[4 * e4 + 3]);
+                        acc[e4] = t;
+                    }
+                }
+                const uint32_t so = dst[p]->chan + (uint32_t)j * dst[p]->j_stride;
+                buf_store16(*dst[p], v, (uint32_t)crow * dst[p]->row_stride + (uint32_t)cslot * 16u, so);
+                // A 128-bit store reads its data registers a cycle or two AFTER it issues; hipcc pads that hazard only for
+                // stores without a scalar offset, and here the fp16 column-sum code that follows wrote a conversion result
+                // into the first data register right behind the store (seen: the first dword of stored chunks replaced by
+                // fp32 bit patterns, tools/probes/dbg_tri16.py).  Two wait states, fenced against the scheduler:
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 1" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- third-arm gradients: through the stage image, then 2-byte scatter (as arm_stage_store_grad) ----
+    {
+        const int i = 16 * qb + x16;
+#pragma unroll
+        for (int kb = 0; kb < NQ; ++kb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = 16 * kb + 4 * g + q;
+                const int xx = dir == 0 ? i : k, yy = dir == 0 ? k : i;
+                char* pp = smem + xx * A::kPitch + yy * A::kRec;
+                const float gq = gate[kb][q];
+                *reinterpret_cast<T*>(pp + hw * (int)sizeof(T)) = from_f32<T>(dE[kb][q]);
+                *reinterpret_cast<T*>(pp + (HG + hw) * (int)sizeof(T)) = from_f32<T>(dG[kb][q] * gq * (1.f - gq));
+            }
+    }
+    __syncthreads();
+    float part = 0.f;
+    if (biased || gated) {
+        static_assert(G::kThreads % A::kVals == 0, "a thread must own one E/G column");
+        T* deg = reinterpret_cast<T*>(a.d_eg[dir]);
+        for (int idx = tid; idx < R * R * A::kVals; idx += G::kThreads) {
+            const int v = idx % A::kVals, p = idx / A::kVals, y = p % R, x = p / R;
+            const bool is_e = v < HG;
+            if (x < N && y < N && (is_e ? biased : gated)) {
+                const T val = *reinterpret_cast<const T*>(smem + x * A::kPitch + y * A::kRec + v * (int)sizeof(T));
+                deg[(((int64_t)b * N + x) * N + y) * lde + (is_e ? a.e_off[dir] + grp * HG + v : a.g_off[dir] + grp * HG + v - HG)] = val;
+                part += to_f32(val);
+            }
+        }
+    }
+    if constexpr (CS) {
+        float csum[3][E];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int e = 0; e < E; ++e) csum[p][e] = has_chunk ? csl[p * E + e] : 0.f;
+        __syncthreads();                                         // the stage image and the accumulators are dead: their space takes the fold
+        constexpr int kPlane = G::kThreads * E;
+        float* cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int e = 0; e < E; ++e) cs[p * kPlane + tid * E + e] = csum[p][e];
+        cs[3 * kPlane + tid] = part;
+        __syncthreads();
+        float* row = a.d_qkv_colsum[dir] + (int64_t)b * ldq + grp * HG * 16;
+        slab_colsum_finish<G, T>(cs, row + a.q_off[dir], tid);
+        slab_colsum_finish<G, T>(cs + kPlane, row + a.k_off[dir], tid);
+        slab_colsum_finish<G, T>(cs + 2 * kPlane, row + a.v_off[dir], tid);
+        if ((biased || gated) && tid < A::kVals) {
+            float v = 0.f;
+            for (int t = tid; t < G::kThreads; t += A::kVals) v += cs[3 * kPlane + t];
+            float* erow = a.d_eg_colsum[dir] + (int64_t)b * lde;
+            if (tid < HG) { if (biased) erow[a.e_off[dir] + grp * HG + tid] = v; }
+            else if (gated) erow[a.g_off[dir] + grp * HG + tid - HG] = v;
+        }
+    }
+}
+
+template <typename T, int HG, int NQ>
+static int launch_bwd(const tgt_triplet_attention_args& a, hipStream_t st) {
+    using G = Geo16<T, HG, NQ>;
+    constexpr int E = 16 / (int)sizeof(T);
+    constexpr int kArm = Arm16<T, HG, NQ>::kBytes;
+    constexpr int kWalk = 2 * 4 * G::kSlabBytes + HG * NQ * (2 + 2 * NQ) * 16 * 16 * (int)sizeof(T) + SlabIO<G, G::kRows>::kChunks * 3 * E * 4;      // (+ the column-sum accumulators of the chunk-owning threads)
+    constexpr int kCs = (3 * G::kThreads * E + G::kThreads) * 4;
+    constexpr int kLds = (kArm > kWalk ? kArm : kWalk) > kCs ? (kArm > kWalk ? kArm : kWalk) : kCs;
+    static_assert(kLds <= 160 * 1024, "LDS");
+    const bool cs = a.d_qkv_colsum[0] != nullptr;
+    const int grid = a.B * 2 * (a.H / HG);
+    if (cs) {
+        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tri_att16_bwd_kernel<T, HG, NQ, true>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLds), true);
+        (void)once;
+        hipLaunchKernelGGL((tri_att16_bwd_kernel<T, HG, NQ, true>), dim3(grid), dim3(G::kThreads), kLds, st, a);
+    } else {
+        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tri_att16_bwd_kernel<T, HG, NQ, false>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLds), true);
+        (void)once;
+        hipLaunchKernelGGL((tri_att16_bwd_kernel<T, HG, NQ, false>), dim3(grid), dim3(G::kThreads), kLds, st, a);
+    }
+    return check_launch("tri_att16_bwd_kernel");
+}
+
 template <typename T, int HG, int NQ>
 static int launch(const tgt_triplet_attention_args& a, hipStream_t st) {
     using G = Geo16<T, HG, NQ>;
@@ -253,6 +610,15 @@ static int run(const tgt_triplet_attention_args& a, hipStream_t st) {
 }
 
 }  // namespace t16
+
+// backward on 16-wide tiles: as the forward, N <= 48 (three blocks)
+bool tri_att16_bwd_eligible(const tgt_triplet_attention_args& a) {
+    static const int on = getenv("TGT_TRI16_BWD") ? atoi(getenv("TGT_TRI16_BWD")) : 1;
+    return on && (a.dtype == TGT_BF16 || a.dtype == TGT_F16) && a.D == 16 && a.N > 32 && a.N <= 48 && a.H % 4 == 0 && !(a.dropout_p > 0.f);
+}
+int tri_att16_bwd_run(const tgt_triplet_attention_args& a, hipStream_t st) {
+    return a.dtype == TGT_BF16 ? t16::launch_bwd<bf16_t, 4, 3>(a, st) : t16::launch_bwd<f16_t, 4, 3>(a, st);
+}
 
 // forward on 16-wide tiles: 16-bit, D = 16, 33 <= N <= 64, H a multiple of 4, no attention dropout
 bool tri_att16_fwd_eligible(const tgt_triplet_attention_args& a) {

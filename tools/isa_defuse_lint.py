@@ -1,4 +1,5 @@
-"""Lint gfx950 assembly for vector registers (AGPRs and VGPRs) that are read but never written.
+"""Lint gfx950 assembly for (1) vector registers (AGPRs and VGPRs) that are read but never written and (2) wide vector
+stores whose data registers are overwritten before the store has read them (lint_store_hazard).
 
 Why: hipcc (ROCm 7.2) miscompiled one triplet-attention backward instantiation -- a 128-bit
 loop-invariant MFMA operand was spilled as 3 dwords to scratch + 1 dword parked in an AGPR
@@ -89,6 +90,60 @@ def lint_text(text):
     return bad
 
 
+_WIDE_STORE = re.compile(r'^(buffer|global|flat|scratch)_store_dwordx[34]$')
+
+
+def lint_store_hazard(text, states=1):
+    """-> {kernel: ['v114 <- v_cvt_f32_f16_e32 @line N', ...]}: a 96/128-bit vector store whose DATA registers a VALU
+    instruction overwrites within `states` wait states of the store.
+
+    Why: the store reads its data registers after it has issued.  hipcc pads that hazard only for stores without a scalar
+    offset; on MI355X a `buffer_store_dwordx4 v[114:117], v72, s[12:15], s28 offen` directly followed by
+    `v_cvt_f32_f16 v114, ...` stored the conversion result in place of the first dword (the fp16 column-sum variant of
+    csrc/triplet_attention16.hip: DESIGN.md section 4.1b).  `s_nop N` between the two counts as N + 1 states.
+    states = 1: the distance at which corruption was observed; the same overwrite one instruction later (129 places in
+    this library, all in kernels that pass their parity tests) has never shown it."""
+    bad = {}
+    kernel, pending = None, []          # pending: [(remaining states, frozenset of data regs, store text)]
+    for ln, line in enumerate(text.splitlines(), 1):
+        s = line.split(';')[0].strip()
+        if not s:
+            continue
+        m = _LABEL.match(s)
+        if m:
+            name = m.group(1)
+            if name.startswith('.Lfunc_end'):
+                kernel, pending = None, []
+            elif not name.startswith(('.', 'BB')):
+                kernel, pending = name, []
+            continue
+        if s.startswith('.') or kernel is None:
+            continue
+        parts = s.split(None, 1)
+        op = parts[0]
+        ops = [t.strip().split()[0] for t in parts[1].split(',') if t.strip()] if len(parts) > 1 else []
+        cost = 1
+        if op == 's_nop' and ops:
+            try:
+                cost = int(ops[0], 0) + 1
+            except ValueError:
+                cost = 1
+        elif op.startswith('v_') and ops and pending:
+            file, regs = _regs(ops[0])
+            if file == 'v' and not op.startswith(('v_cmp', 'v_readlane', 'v_readfirstlane')):
+                for left, data, what in pending:
+                    hit = sorted(set(regs) & data)
+                    if hit:
+                        bad.setdefault(kernel, []).append(f'v{hit[0]} <- {op} @line {ln} ({what})')
+        pending = [(left - cost, data, what) for left, data, what in pending if left - cost > 0]
+        if _WIDE_STORE.match(op) and ops:
+            data_tok = ops[0] if op.startswith('buffer') else (ops[1] if len(ops) > 1 else '')
+            file, regs = _regs(data_tok)
+            if file == 'v':
+                pending.append((states, frozenset(regs), s[:60]))
+    return bad
+
+
 def emit_asm(out_dir):
     """Device-only asm of every translation unit of libtgt_hip.so -> [paths]."""
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -110,11 +165,19 @@ def emit_asm(out_dir):
     return outs
 
 
+def lint_all(text):
+    """both checks: {kernel: [findings]}"""
+    bad = {k: list(v) for k, v in lint_text(text).items()}
+    for k, v in lint_store_hazard(text).items():
+        bad.setdefault(k, []).extend(v)
+    return bad
+
+
 def lint_files(paths):
     bad = {}
     for p in paths:
         with open(p) as f:
-            for k, regs in lint_text(f.read()).items():
+            for k, regs in lint_all(f.read()).items():
                 bad[f'{os.path.basename(p)}:{k}'] = regs
     return bad
 
@@ -125,8 +188,8 @@ def main(argv):
         paths += emit_asm(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tgt_amd', 'build', 'isa'))
     bad = lint_files(paths)
     for k, regs in bad.items():
-        print(f'UNDEFINED REGISTER READ  {k}: {regs}')
-    print(f'{len(paths)} files, {len(bad)} kernels with undefined vector-register reads')
+        print(f'ISA LINT  {k}: {regs}')
+    print(f'{len(paths)} files, {len(bad)} kernels with findings (undefined vector-register reads / store-data hazards)')
     return 1 if bad else 0
 
 
