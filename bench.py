@@ -196,6 +196,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=256, help='graphs per GPU')
     ap.add_argument('--nodes', type=int, default=32)
+    ap.add_argument('--ragged', action='store_true',
+                    help='SURVEY 8(d) secondary: num_nodes ~ U{nodes/2..nodes} with the first graph at `nodes` (padded batch)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-worker', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--cpu-baseline-full', action='store_true',
@@ -253,7 +255,7 @@ def main():
     trainer = Trainer(model, cfg)
 
     # synthetic batches, resident in HBM before timing (4 distinct ones, cycled)
-    pool = [{k: v.to(dev) for k, v in make_batch(args.batch, args.nodes, batch_seed(s, rank)).items()}
+    pool = [{k: v.to(dev) for k, v in make_batch(args.batch, args.nodes, batch_seed(s, rank), ragged=args.ragged).items()}
             for s in range(4)]
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
@@ -301,7 +303,7 @@ def main():
         # profiles/README.md); only valid for the shape they were measured at
         traffic, pmc = {}, {}
         tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-        ppath = os.path.join(ROOT, 'profiles', 'r02i_pmc_summary.json')      # tools/pmc_passes.sh: SQ / FETCH / WRITE passes
+        ppath = os.path.join(ROOT, 'profiles', 'r02j_pmc_summary.json')      # tools/pmc_passes.sh: SQ / FETCH / WRITE passes
         if args.batch == 256 and args.nodes == 32 and args.precision == 'bf16':
             if os.path.exists(tpath):
                 traffic = json.load(open(tpath))
@@ -346,7 +348,8 @@ def main():
             ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling='weak',
             vs_baseline=None, dtype=args.precision, data='synthetic',
             config=dict(workload='TGT-At 24L (TGT_Multi, 103.6M params, 512 dist bins) train step; '
-                                 f'{args.batch} synthetic N={args.nodes} graphs per GPU; dropouts of tgt_at_tp.yaml on',
+                                 f'{args.batch} synthetic N={args.nodes} graphs per GPU' + (f' (ragged: num_nodes ~ U{{{max(1, args.nodes // 2)}..{args.nodes}}}, padded)' if args.ragged else '') +
+                                 '; dropouts of tgt_at_tp.yaml on',
                         global_batch=args.batch * world, nodes=args.nodes,
                         parallelism=f'dp{world}', precision=f'{args.precision} autocast, fp32 params/Adam',
                         **({'host_loss_read_every': args.sync_every} if args.sync_every else {})),

@@ -542,6 +542,24 @@ def test_multi_hot_embed_matches_embedding_sum():
     assert wg.grad[0].abs().max() == 0
 
 
+def test_multi_hot_embed_chunked_weight_gradient():
+    """>= 2048 pair rows: the weight gradient is computed as row-chunk partial products + a fixed-order sum"""
+    from tgt_amd import ops
+    rng = np.random.default_rng(4)
+    V, C = 59, 64
+    w = rnd(rng, V, C).float()
+    idx = torch.from_numpy(rng.integers(0, V, size=(4, 32, 32, 3)))
+    g = rnd(rng, 4, 32, 32, C).float()
+    emb = torch.nn.Embedding(V, C, padding_idx=0)
+    emb.weight.data.copy_(w)
+    emb(idx).sum(-2).backward(g)
+    assert ops._wgrad_chunks(4 * 32 * 32) > 1
+    wg = w.cuda().requires_grad_(True)
+    ops.multi_hot_embed(idx.cuda(), wg, padding_idx=0).backward(g.cuda())
+    assert rel(wg.grad, emb.weight.grad) < 1e-5
+    assert wg.grad[0].abs().max() == 0
+
+
 def test_drop_path_add():
     from tgt_amd import ops
     torch.manual_seed(0)

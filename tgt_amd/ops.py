@@ -890,7 +890,15 @@ class _MultiHotEmbed(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         counts, = ctx.saved_tensors
-        gw = counts.t() @ g.reshape(counts.shape[0], -1).to(counts.dtype)
+        g2 = g.reshape(counts.shape[0], -1).to(counts.dtype)
+        P = _wgrad_chunks(counts.shape[0]) if (g2.is_cuda and g2.dtype == torch.float32 and g2.is_contiguous()) else 1
+        if P > 1:
+            # the contraction runs over all B*N*N pair rows into a (59, C) result: as ONE GEMM the library puts it on a
+            # handful of workgroups (0.33 ms at the BASELINE batch); row chunks + a fixed-order sum are byte-bound
+            gw = torch.empty(counts.shape[1], g2.shape[1], dtype=torch.float32, device=g2.device)
+            _wgrad_into(gw, counts, g2, P)
+        else:
+            gw = counts.t() @ g2
         if ctx.padding_idx is not None:
             gw[ctx.padding_idx] = 0
         return None, gw.to(ctx.wdtype), None, None
