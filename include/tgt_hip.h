@@ -101,6 +101,13 @@ typedef struct tgt_triplet_attention_args {
      * Q/K/V (1536 channels: six full 256-wide GEMM tile columns) and E/G in two tensors while the
      * backward writes ONE fused gradient row for a single data/weight-gradient GEMM. */
     int64_t  ld_dqkv[2], ld_deg[2];
+    /* optional (ABI 23): per-graph DropPath factor (B) float32 of the residual branch this call belongs to (reference
+     * lib/tgt/layers/layers.py:169-174: Bernoulli(keep)/keep per graph, multiplied onto the branch output at the residual
+     * add).  A graph whose factor is exactly 0 contributes nothing to the stream and receives an all-zero d_out, so the
+     * kernels do not read or compute it: the forward writes zeros to its `out` rows, the backward zeros to its d_qkv / d_eg
+     * rows and column sums -- equal (up to the sign of a zero) to the full computation followed by the multiplication.  The factor itself
+     * is NOT applied here.  NULL = every graph is computed.  (The 16-wide kernels for N > 32 ignore it.) */
+    const float* graph_scale;
 } tgt_triplet_attention_args;
 
 int tgt_triplet_attention_fwd(const tgt_triplet_attention_args* a, void* stream);

@@ -92,6 +92,60 @@ def test_triplet_attention(case, dtype, variant):
         assert rel(g[..., 6 * C:L.used], gr[..., 6 * C:L.used]) < 2 * tol, ('deg', rel(g[..., 6 * C:L.used], gr[..., 6 * C:L.used]))
 
 
+SKIP_CASES = [  # B, N, num_nodes, C, H  (8-head workgroups, 4-head workgroups, one-head workgroups, two node tiles)
+    (5, 32, [32, 17, 32, 9, 32], 256, 16),
+    (5, 20, [20, 13, 20, 1, 7], 64, 4),
+    (4, 5, [5, 1, 5, 3], 48, 3),
+    (3, 40, [40, 33, 36], 64, 4),
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('case', SKIP_CASES)
+@pytest.mark.parametrize('variant', ['gated', 'axial'])
+@pytest.mark.parametrize('projected', [False, True])
+def test_triplet_attention_skips_droppath_dropped_graphs(case, dtype, variant, projected):
+    """tgt_triplet_attention_args.graph_scale (ABI 23): a graph whose DropPath factor is 0 is not computed -- zeros out,
+    zero gradients (its incoming gradient is zero behind the residual add's multiplication, reference layers.py:169-174,
+    286-287) -- and every other graph, every parameter gradient and the in-kernel bias-gradient sums are EQUAL to the full
+    computation's."""
+    from tgt_amd import ops
+    B, N, nn_, C, H = case
+    gated, biased = variant == 'gated', variant != 'axial'
+    L = ops.TripletLayout(C, H, gated=gated, biased=biased)
+    rng = np.random.default_rng(11 + hash((B, N, C, H)) % 1000)
+    mask = gu.additive_mask(nn_, N, torch.float32).reshape(B, N, N).cuda()
+    sc = torch.tensor([0.0 if b % 2 else 1.25 for b in range(B)], dtype=torch.float32, device='cuda')
+    live = (sc != 0).view(B, 1, 1, 1)
+    d_out = rnd(rng, B, N, N, 2 * C).to(dtype).cuda() * live.to(dtype)           # what the dropped graphs receive: zeros
+    if projected:
+        x = rnd(rng, B, N, N, C).to(dtype).cuda()
+        w = (rnd(rng, L.width, C) * C ** -0.5).to(dtype).cuda()
+        b = (rnd(rng, L.width) * 0.1).to(dtype).cuda()
+        if L.width > L.used:
+            w[L.used:] = 0
+            b[L.used:] = 0
+        base = (x, w, b)
+        run = lambda ins, gs: ops.projected_triplet_attention(*ins, mask, L, graph_scale=gs)
+    else:
+        base = (rnd(rng, B, N, N, L.width).to(dtype).cuda(),)
+        run = lambda ins, gs: ops.triplet_attention(*ins, mask, L, graph_scale=gs)
+    full_in = [t.clone().requires_grad_(True) for t in base]
+    skip_in = [t.clone().requires_grad_(True) for t in base]
+    va_full = run(full_in, None)
+    va_full.backward(d_out)
+    va_skip = run(skip_in, sc)
+    va_skip.backward(d_out)
+    torch.cuda.synchronize()
+    assert torch.equal(va_skip * live.to(dtype), va_full * live.to(dtype))
+    assert float(va_full[1].abs().max()) > 0
+    if N <= 32:                   # (the 16-wide kernels of N > 32 compute every graph: the factor is optional information)
+        assert float(va_skip[1].abs().max()) == 0
+    for got, want in zip(skip_in, full_in):
+        assert torch.isfinite(got.grad).all()
+        assert torch.equal(got.grad, want.grad), float((got.grad.float() - want.grad.float()).abs().max())
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('case', CASES + [(2, 17, [17, 9], 128, 8), (2, 32, [32, 30], 128, 8)])
 @pytest.mark.parametrize('variant', ['gated', 'ungated', 'axial'])

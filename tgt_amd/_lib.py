@@ -17,7 +17,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 SOURCES = ['capi.hip', 'optimizer.hip', 'edge_gemm.hip', 'params.hip', 'loss.hip', 'predict.hip', 'gaussian.hip', 'triplet_attention_proj.hip',
            ('triplet_attention.hip', ['-DTGT_TRI_INST=9'], '.f32'), ('triplet_attention.hip', ['-DTGT_TRI_INST=2'], '.bf16'),
            ('triplet_attention.hip', ['-DTGT_TRI_INST=4'], '.f16'), 'triplet_attention16.hip', 'triplet_aggregate.hip', 'node_attention.hip', 'node_attention_mfma.hip', 'layernorm.hip', 'triangular_update.hip', 'elementwise.hip']
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 TGT_F32, TGT_BF16, TGT_F16 = 0, 1, 2
 TRI_BIASED, TRI_GATED, TRI_MASK_OUT = 1, 2, 4
@@ -37,6 +37,7 @@ class TripletAttentionArgs(C.Structure):
         ('d_qkv_colsum', _vp * 2), ('d_eg_colsum', _vp * 2),
         ('dropout_p', _f32), ('_pad1', C.c_uint32), ('dropout_seed', C.c_uint64),
         ('ld_dqkv', _i64 * 2), ('ld_deg', _i64 * 2),
+        ('graph_scale', _vp),
     ]
 
 

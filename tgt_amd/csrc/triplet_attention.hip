@@ -69,6 +69,14 @@ __global__ void __launch_bounds__(HG * 64, (NT == 1 && sizeof(T) == 2) ? 4 : (si
     const SlabBuf bV = {r_src, (uint32_t)(a.v_off[c.dir] * sz) + hch, bK.row_stride, bK.j_stride};
     const SlabBuf bO = {graph_rsrc(a.out, Nl * Nl * a.ld_out * sz, c.b), (uint32_t)(a.o_off[c.dir] * sz) + hch, (uint32_t)N * ldo_, ldo_};
 
+    // a graph DropPath dropped (graph_scale[b] == 0): the residual add multiplies this branch by zero, so nothing is
+    // read or computed; the rows get the zeros that product would give (workgroup-uniform branch)
+    if (a.graph_scale && a.graph_scale[c.b] == 0.f) {
+        for (int i0 = 0; i0 < N; i0 += 32)
+            for (int j = 0; j < N; ++j) slab_store_zero<G, 32>(bO, j, i0, N, tid);
+        return;
+    }
+
     for (int it = 0; it < NT; ++it) {
         const int i0 = 32 * it;
         if (i0 >= N) break;
@@ -255,6 +263,29 @@ __global__ void __launch_bounds__(HG * 64, OCC) __attribute__((amdgpu_waves_per_
     if constexpr (CS)
         for (int t = tid; t < 3 * kPlane + HG * 64; t += HG * 64) cs[t] = 0.f;     // + one dE/dG partial per thread
 
+    // a graph DropPath dropped (graph_scale[b] == 0) receives an all-zero d_out: every gradient of it is exactly zero.
+    // Nothing is read or computed; zeros go to its dQ / dK / dV / dE / dG rows, and the column sums below stay zero.
+    const bool dead = a.graph_scale && a.graph_scale[c.b] == 0.f;          // workgroup-uniform
+    if (dead) {
+        for (int it = 0; it < NT; ++it) {
+            const int i0 = 32 * it;
+            if (i0 >= N) break;
+            for (int j = 0; j < N; ++j) {
+                slab_store_zero<G, 32>(gQ, j, i0, N, tid);
+                if (it == 0) {
+                    slab_store_zero<G, KR>(dK, j, 0, N, tid);
+                    slab_store_zero<G, KR>(dV, j, 0, N, tid);
+                }
+            }
+            const float zero16[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            __syncthreads();
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) arm_stage_put_grad<T, HG, NT>(smem, c.dir, wave, r, hi, kt, zero16, zero16);
+            __syncthreads();
+            arm_stage_store_grad<T, HG, NT>(dta, a.d_eg[c.dir], c.b, c.dir, c.g, N, i0, smem, tid);
+            __syncthreads();
+        }
+    } else
     for (int it = 0; it < NT; ++it) {
         const int i0 = 32 * it;
         if (i0 >= N) break;

@@ -117,6 +117,18 @@ __device__ __forceinline__ void slab_store(const char* slab, const SlabBuf& s, i
                         (uint32_t)row * s.row_stride + (uint32_t)slot * 16u, so);
     }
 }
+// zeros to the slab's rows (a DropPath-dropped graph: tgt_triplet_attention_args.graph_scale)
+template <typename G, int ROWS>
+__device__ __forceinline__ void slab_store_zero(const SlabBuf& s, int j, int row0, int N, int tid) {
+    const uint32_t so = s.chan + (uint32_t)j * s.j_stride + (uint32_t)row0 * s.row_stride;
+#pragma unroll
+    for (int it = 0; it < SlabIO<G, ROWS>::kIters; ++it) {
+        const int c = it * G::kThreads + tid;
+        const int row = c / G::kSlots, slot = c % G::kSlots;
+        if (c < SlabIO<G, ROWS>::kChunks && row0 + row < N)
+            buf_store16(s, make_uint4(0, 0, 0, 0), (uint32_t)row * s.row_stride + (uint32_t)slot * 16u, so);
+    }
+}
 template <typename G, int ROWS, typename T, int IT = SlabIO<G, ROWS>::kIters>
 __device__ __forceinline__ void slab_store_add(const char* slab, const uint4 (&prior)[IT], const SlabBuf& s, int j,
                                                int row0, int N, int tid) {

@@ -107,7 +107,7 @@ class TripletLayout:
         self.flags = (_lib.TRI_BIASED if biased else 0) | (_lib.TRI_GATED if gated else 0)
 
 
-def _tri_args(fused, mask3, out, L, d_out=None, d_fused=None, colsum=None, dropout=(0.0, 0), eg=None):
+def _tri_args(fused, mask3, out, L, d_out=None, d_fused=None, colsum=None, dropout=(0.0, 0), eg=None, graph_scale=None):
     """eg given: `fused` holds only the Q/K/V channels (rows of 6C) and `eg` the third-arm E/G channels
     (rows of L.used - 6C); d_fused / colsum stay ONE fused row of L.width (ld_dqkv / ld_deg)."""
     B, N = fused.shape[0], fused.shape[1]
@@ -129,6 +129,10 @@ def _tri_args(fused, mask3, out, L, d_out=None, d_fused=None, colsum=None, dropo
     a.out, a.ld_out = out.data_ptr(), 2 * L.C
     a.o_off = _pair(C.c_int32, 0, L.C)
     a.dropout_p, a.dropout_seed = float(dropout[0]), int(dropout[1]) & 0xFFFFFFFFFFFFFFFF
+    if graph_scale is not None:           # per-graph DropPath factor of the branch: graphs at exactly 0 are not computed
+        if graph_scale.dtype != torch.float32 or graph_scale.numel() != B or not graph_scale.is_contiguous() or not graph_scale.is_cuda:
+            raise RuntimeError('triplet attention: graph_scale must be a contiguous float32 device tensor with one value per graph')
+        a.graph_scale = graph_scale.data_ptr()
     if d_out is not None:
         a.d_out = d_out.data_ptr()
         dp = d_fused.data_ptr()
@@ -155,16 +159,16 @@ def draw_dropout(p, training):
 
 class _TripletAttention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, fused, mask3, L, dropout=(0.0, 0)):
+    def forward(ctx, fused, mask3, L, dropout=(0.0, 0), graph_scale=None):
         _dev(fused, mask3)
         fused = fused.contiguous()
         B, N = fused.shape[0], fused.shape[1]
         assert fused.shape == (B, N, N, L.width), (fused.shape, L.width)
         out = torch.empty(B, N, N, 2 * L.C, dtype=fused.dtype, device=fused.device)
-        a = _tri_args(fused, mask3, out, L, dropout=dropout)
+        a = _tri_args(fused, mask3, out, L, dropout=dropout, graph_scale=graph_scale)
         _call('tgt_triplet_attention_fwd', _lib.lib().tgt_triplet_attention_fwd, a)
         ctx.save_for_backward(fused, mask3, out)
-        ctx.L, ctx.dropout = L, dropout
+        ctx.L, ctx.dropout, ctx.graph_scale = L, dropout, graph_scale
         return out
 
     @staticmethod
@@ -174,17 +178,20 @@ class _TripletAttention(torch.autograd.Function):
         d_fused = torch.empty_like(fused)          # every used column is written by the kernel
         if ctx.L.width > ctx.L.used:
             d_fused[..., ctx.L.used:] = 0
-        a = _tri_args(fused, mask3, out, ctx.L, d_out, d_fused, dropout=ctx.dropout)
+        a = _tri_args(fused, mask3, out, ctx.L, d_out, d_fused, dropout=ctx.dropout, graph_scale=ctx.graph_scale)
         _call('tgt_triplet_attention_bwd', _lib.lib().tgt_triplet_attention_bwd, a)
-        return d_fused, None, None, None
+        return d_fused, None, None, None, None
 
 
-def triplet_attention(fused, mask3, layout, dropout=(0.0, 0)):
+def triplet_attention(fused, mask3, layout, dropout=(0.0, 0), graph_scale=None):
     """fused: (B,N,N,layout.width) fused projections (head-major Q/K/V), mask3:
     (B,N,N) float32.  Returns Va (B,N,N,2C) with channel = dir*C + h*D + d.
     dropout: (p, seed) of the attention dropout on the gated weights (draw_dropout).
+    graph_scale (B,) float32: the DropPath factor of the residual branch the result feeds (drawn by the caller, applied by
+    the caller): graphs whose factor is exactly 0 are skipped -- zeros out, zero gradients -- which equals computing them
+    and multiplying by that zero (the incoming gradient of such a graph MUST be zero, as it is behind that multiplication).
     Reference arithmetic: lib/tgt/layers/triplet.py:213-246."""
-    return _TripletAttention.apply(fused, mask3, layout, dropout)
+    return _TripletAttention.apply(fused, mask3, layout, dropout, graph_scale)
 
 
 def _colsum_workspace(B, width, used, device):
@@ -303,7 +310,7 @@ class _ProjectedTripletAttention(torch.autograd.Function):
     parameters (w0, b0, w1, b1, ...), fused/unfused here with one launch each way."""
 
     @staticmethod
-    def forward(ctx, x, mask3, L, cd, table, dropout, *wb):
+    def forward(ctx, x, mask3, L, cd, table, dropout, graph_scale, *wb):
         _dev(x, mask3)
         B, N = x.shape[0], x.shape[1]
         weight, bias = wb if table is None else _fuse_params(table, wb, cd)
@@ -333,15 +340,15 @@ class _ProjectedTripletAttention(torch.autograd.Function):
             w, b = _as_dtype(weight, cd), _as_dtype(bias, cd)
             fused = torch.addmm(b[:6 * L.C], x2, w[:6 * L.C].t()).view(B, N, N, 6 * L.C)
             eg = torch.addmm(b[6 * L.C:L.used], x2, w[6 * L.C:L.used].t()).view(B, N, N, L.used - 6 * L.C)
-            a = _tri_args(fused, mask3, out, L, dropout=dropout, eg=eg)
+            a = _tri_args(fused, mask3, out, L, dropout=dropout, eg=eg, graph_scale=graph_scale)
             _call('tgt_triplet_attention_fwd', _lib.lib().tgt_triplet_attention_fwd, a)
         else:
             x2, w, fused = _linear_forward(x, weight, bias, cd)
-            a = _tri_args(fused, mask3, out, L, dropout=dropout)
+            a = _tri_args(fused, mask3, out, L, dropout=dropout, graph_scale=graph_scale)
             _call('tgt_triplet_attention_fwd', _lib.lib().tgt_triplet_attention_fwd, a)
         ctx.save_for_backward(x2, w, fused, mask3, out, eg if eg is not None else fused.new_empty(0),
                               *(wb if table is not None else ()))
-        ctx.L, ctx.table, ctx.dropout = L, table, dropout
+        ctx.L, ctx.table, ctx.dropout, ctx.graph_scale = L, table, dropout, graph_scale
         ctx.meta = (x.shape, x.dtype, weight.dtype, bias.dtype)
         return out
 
@@ -357,9 +364,9 @@ class _ProjectedTripletAttention(torch.autograd.Function):
         if L.width > L.used:
             d_fused[..., L.used:] = 0
         colsum = _colsum_workspace(fused.shape[0], L.width, L.used, fused.device)
-        a = _tri_args(fused, mask3, out, L, d_out, d_fused, colsum, dropout=ctx.dropout, eg=eg)
+        a = _tri_args(fused, mask3, out, L, d_out, d_fused, colsum, dropout=ctx.dropout, eg=eg, graph_scale=ctx.graph_scale)
         _call('tgt_triplet_attention_bwd', _lib.lib().tgt_triplet_attention_bwd, a)
-        need_p = any(ctx.needs_input_grad[6:])
+        need_p = any(ctx.needs_input_grad[7:])
         db = sum_rows(colsum) if need_p else None
         d2 = d_fused.view(-1, L.width)
         if eg is not None and need_p:
@@ -374,22 +381,22 @@ class _ProjectedTripletAttention(torch.autograd.Function):
             dx, dw, _ = _linear_backward(x2, w, d2, xs, xdt, torch.float32, None,
                                          ctx.needs_input_grad[0], need_p, False)
         if not need_p:
-            return (dx, None, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 6)
+            return (dx, None, None, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 7)
         if table is None:
-            return dx, None, None, None, None, None, dw.to(wdt), db.to(bdt)
-        return (dx, None, None, None, None, None, *_unfuse_grads(table, params, dw, db))
+            return dx, None, None, None, None, None, None, dw.to(wdt), db.to(bdt)
+        return (dx, None, None, None, None, None, None, *_unfuse_grads(table, params, dw, db))
 
 
-def projected_triplet_attention(x, weight, bias, mask3, layout, table=None, dropout=(0.0, 0)):
+def projected_triplet_attention(x, weight, bias, mask3, layout, table=None, dropout=(0.0, 0), graph_scale=None):
     """triplet_attention(linear(x, weight, bias), mask3, layout) with the bias gradient of the
     projection produced inside the backward kernel.  weight/bias: the fused (layout.width, C)
     projection in kernel order (see TripletLayout) -- or, with a ParamTable, `weight` is the
     tuple of the module's nn.Linear parameters (w0, b0, w1, b1, ...) and bias is None."""
     if not _TRI_COLSUM and table is None:      # A/B knob: separate bias-gradient pass
-        return triplet_attention(linear(x, weight, bias), mask3, layout, dropout)
+        return triplet_attention(linear(x, weight, bias), mask3, layout, dropout, graph_scale)
     cd = torch.get_autocast_dtype('cuda') if (x.is_cuda and torch.is_autocast_enabled('cuda')) else x.dtype
     wb = (weight, bias) if table is None else tuple(weight)
-    return _ProjectedTripletAttention.apply(x, mask3, layout, cd, table, dropout, *wb)
+    return _ProjectedTripletAttention.apply(x, mask3, layout, cd, table, dropout, graph_scale, *wb)
 
 
 # ---------------------------------------------------------------------------

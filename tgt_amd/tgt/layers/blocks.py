@@ -13,6 +13,7 @@ from .triplet import get_triplet_layer
 
 
 _CHAIN_NODE_STREAM = __import__('os').environ.get('TGT_NODE_CHAIN', '1') != '0'      # A/B knob
+_TRI_SKIP = __import__('os').environ.get('TGT_TRI_SKIP', '1') != '0'      # A/B knob: triplet kernels skip DropPath-dropped graphs
 
 
 def _keep(module, **kw):
@@ -296,7 +297,7 @@ class TGT_Layer(nn.Module):
                 sc = scale if scale is not None else ops.drop_path_scale(x, dp, tr)
                 return ops.linear_residual_layer_norm(x, lin.weight, lin.bias, res, sc, ln.weight, ln.bias, ln.eps,
                                                       prescaled=folded)
-            return ops.add_layer_norm(x, res, ops.drop_path_scale(x, dp, tr), ln.weight, ln.bias, ln.eps)
+            return ops.add_layer_norm(x, res, scale if scale is not None else ops.drop_path_scale(x, dp, tr), ln.weight, ln.bias, ln.eps)
 
         node_side = None
         if self.node_update:
@@ -311,7 +312,13 @@ class TGT_Layer(nn.Module):
             lin_oe = self.update.lin_O_e if fuse_oe else None        # then `e` is still H_hat
             if self._triplet_update:
                 e, x = enter(e, e_in, self.tria.tri_ln_e, lin_oe, sc_oe, fold_oe)
-                e, x = enter(self.tria.forward_normed(x, mask), e, self.edge_ffn.ffn_ln)
+                # the triplet branch's DropPath factor is drawn BEFORE the branch runs: the attention kernels skip the
+                # graphs it drops (zeros out, zero gradients -- what the multiplication at the residual add gives anyway)
+                sc_tri = ops.drop_path_scale(x, dp, tr) if (_TRI_SKIP and getattr(self.tria, 'takes_graph_scale', False)) else None
+                if sc_tri is not None:
+                    e, x = enter(self.tria.forward_normed(x, mask, graph_scale=sc_tri), e, self.edge_ffn.ffn_ln, scale=sc_tri)
+                else:
+                    e, x = enter(self.tria.forward_normed(x, mask), e, self.edge_ffn.ffn_ln)
             else:
                 e, x = enter(e, e_in, self.edge_ffn.ffn_ln, lin_oe, sc_oe, fold_oe)
             sc_ffn = ops.drop_path_scale(x, dp, tr)

@@ -110,12 +110,17 @@ class TripletAttention(_TripletBase):
     def forward(self, e, mask):
         return self.forward_normed(self.tri_ln_e(e), mask)
 
-    def forward_normed(self, x, mask):
-        """the block after tri_ln_e (TGT_Layer fuses that LayerNorm with the residual add before it)"""
+    takes_graph_scale = True          # forward_normed(..., graph_scale=): DropPath-dropped graphs are not computed
+
+    def forward_normed(self, x, mask, graph_scale=None):
+        """the block after tri_ln_e (TGT_Layer fuses that LayerNorm with the residual add before it).
+        graph_scale (B,) float32: the DropPath factor the CALLER multiplies this block's result with at the residual add
+        (reference layers.py:286-287); graphs whose factor is 0 are skipped by the attention kernels"""
         B, N = x.shape[0], x.shape[1]
         va = ops.projected_triplet_attention(x, self._projection_params(), None, ops.as_mask3(mask, B, N),
                                              self._layout, table=self._table,
-                                             dropout=ops.draw_dropout(self.attention_dropout, self.training))
+                                             dropout=ops.draw_dropout(self.attention_dropout, self.training),
+                                             graph_scale=graph_scale)
         return self._out_proj(va)
 
 
