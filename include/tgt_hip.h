@@ -106,7 +106,7 @@ typedef struct tgt_triplet_attention_args {
      * add).  A graph whose factor is exactly 0 contributes nothing to the stream and receives an all-zero d_out, so the
      * kernels do not read or compute it: the forward writes zeros to its `out` rows, the backward zeros to its d_qkv / d_eg
      * rows and column sums -- equal (up to the sign of a zero) to the full computation followed by the multiplication.  The factor itself
-     * is NOT applied here.  NULL = every graph is computed.  (The 16-wide kernels for N > 32 ignore it.) */
+     * is NOT applied here.  NULL = every graph is computed. */
     const float* graph_scale;
 } tgt_triplet_attention_args;
 

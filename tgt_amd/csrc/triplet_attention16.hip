@@ -108,6 +108,16 @@ __global__ void __launch_bounds__(HG * NQ * 64) tri_att16_fwd_kernel(const tgt_t
     const int dir = bid & 1, b = bid >> 1, N = a.N;
     const bool biased = (a.flags & TGT_TRI_BIASED) != 0, gated = (a.flags & TGT_TRI_GATED) != 0;
 
+    // a graph DropPath dropped (graph_scale[b] == 0, see tgt_hip.h): nothing is read or computed, its rows get zeros
+    if (a.graph_scale && a.graph_scale[b] == 0.f) {
+        const int64_t sz0 = sizeof(T);
+        const uint32_t ld0 = (uint32_t)(a.ld_out * sz0);
+        const SlabBuf zO = {graph_rsrc(a.out, (int64_t)N * N * a.ld_out * sz0, b), (uint32_t)(a.o_off[dir] * sz0) + (uint32_t)(grp * HG * 16 * sz0),
+                            (uint32_t)N * ld0, ld0};
+        for (int j = 0; j < N; ++j) slab_store_zero<G, R>(zO, j, 0, N, tid);
+        return;
+    }
+
     // ---- third arm of this wave: bias + mask and gate for (query 16 qb + x16, keys 16 kb + 4 g + q) ----
     float biasM[NQ][4], gate[NQ][4];
     {
@@ -335,6 +345,16 @@ __global__ void __launch_bounds__(HG * NQ * 64) tri_att16_bwd_kernel(const tgt_t
             for (int e = 0; e < 3 * E; ++e) csl[e] = 0.f;
     }
 
+    // a graph DropPath dropped (graph_scale[b] == 0) receives an all-zero d_out: zeros to its gradient rows, nothing read or
+    // computed; dE / dG (zero-initialised above) and the column sums leave through the common tail below
+    const bool dead = a.graph_scale && a.graph_scale[b] == 0.f;          // workgroup-uniform
+    if (dead) {
+        for (int j = 0; j < N; ++j) {
+            slab_store_zero<G, R>(gQ, j, 0, N, tid);
+            slab_store_zero<G, R>(gK, j, 0, N, tid);
+            slab_store_zero<G, R>(gV, j, 0, N, tid);
+        }
+    } else {
     uint4 pq[1], po[1], pk[1], pv[1];
     slab_issue<G, R>(pq, bQ, 0, 0, N, tid);
     slab_issue<G, R>(po, bO, 0, 0, N, tid);
@@ -506,6 +526,7 @@ __global__ void __launch_bounds__(HG * NQ * 64) tri_att16_bwd_kernel(const tgt_t
             }
         }
     }
+    }      // (!dead)
     __syncthreads();
     // ---- third-arm gradients: through the stage image, then 2-byte scatter (as arm_stage_store_grad) ----
     {
