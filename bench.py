@@ -43,6 +43,18 @@ def node_algorithmic_bytes(kind, B, N, W, Hn, esz=2):
     return B * per_graph
 
 
+def dropped_graph_discount(kind, N, C, Ht, drop_frac, esz=2):
+    """factor on algorithmic_bytes for launches in which a fraction `drop_frac` of the graphs is DropPath-dropped and
+    skipped by the kernel (tgt_triplet_attention_args.graph_scale): such a graph only has its zeros written
+    (fwd: O = N^2 C of the 4 N^2 C + 2 N^2 Ht elements; bwd: dQ,dK,dV,dE,dG = 3 N^2 C + 2 N^2 Ht of 7 N^2 C + 4 N^2 Ht)"""
+    n2 = N * N
+    if kind == 'fwd':
+        full, moved = 2 * (4 * n2 * C + 2 * n2 * Ht) * esz + n2 * 4, 2 * (n2 * C) * esz
+    else:
+        full, moved = 2 * (7 * n2 * C + 4 * n2 * Ht) * esz + n2 * 4, 2 * (3 * n2 * C + 2 * n2 * Ht) * esz
+    return 1.0 - drop_frac * (1.0 - moved / full)
+
+
 def algorithmic_bytes(kind, B, N, C, Ht, esz=2):
     """HBM bytes one launch must move (both directions), SURVEY §8(d):
     fwd: 2 dirs x (Q,K,V in + O out = 4 N^2 C, E,G = 2 N^2 Ht) elements + mask
@@ -294,16 +306,25 @@ def main():
         times = ops.kernel_times_ms(prof)
         C, Ht = mcfg['edge_width'], mcfg['triplet_heads']
         esz = 4 if args.precision == 'fp32' else 2
+        # DropPath ramps linearly 0 .. drop_path over the layers (tgt_amd/tgt/stack.py): the mean fraction of graphs a triplet launch
+        # skips when the kernels are given the factors (TGT_TRI_SKIP: 1 = forward only, the default; 2 = backward too; 0 = off)
+        skip_mode = os.environ.get('TGT_TRI_SKIP', '1')
+        skip_mode = skip_mode if skip_mode in ('1', '2') else ''
+        drop_frac = 0.5 * float(mcfg.get('drop_path', 0.0))
         cand = {}
         for name, kind in (('tgt_triplet_attention_bwd', 'bwd'), ('tgt_triplet_attention_fwd', 'fwd')):
             if name in times and times[name]:
                 avg_ms = sum(times[name]) / len(times[name])
-                cand[name] = (sum(times[name]), avg_ms, algorithmic_bytes(kind, args.batch, args.nodes, C, Ht, esz))
+                nbytes_k = algorithmic_bytes(kind, args.batch, args.nodes, C, Ht, esz)
+                if skip_mode and (kind == 'fwd' or skip_mode == '2'):
+                    # the kernel does not move the bytes of the graphs DropPath drops: count what it moves (expected fraction)
+                    nbytes_k = int(nbytes_k * dropped_graph_discount(kind, args.nodes, C, Ht, drop_frac, esz))
+                cand[name] = (sum(times[name]), avg_ms, nbytes_k)
         # HBM bytes per launch from the PMC passes (collected offline with rocprofv3 --pmc, see
         # profiles/README.md); only valid for the shape they were measured at
         traffic, pmc = {}, {}
         tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-        ppath = os.path.join(ROOT, 'profiles', 'r02j_pmc_summary.json')      # tools/pmc_passes.sh: SQ / FETCH / WRITE passes
+        ppath = os.path.join(ROOT, 'profiles', 'r02k_pmc_summary.json')      # tools/pmc_passes.sh: SQ / FETCH / WRITE passes
         if args.batch == 256 and args.nodes == 32 and args.precision == 'bf16':
             if os.path.exists(tpath):
                 traffic = json.load(open(tpath))
@@ -328,6 +349,10 @@ def main():
                             other_kernels={k: dict(avg_launch_ms=round(v[1], 4),
                                                    achieved=round(v[2] / (v[1] * 1e-3) / 1e9, 1))
                                            for k, v in cand.items() if k != name})
+            if skip_mode and drop_frac > 0:
+                roofline['droppath_skip'] = dict(kernels='forward' if skip_mode == '1' else 'forward+backward',
+                                                 expected_dropped_fraction=drop_frac,
+                                                 note='algorithmic bytes of the skipping kernels count only what they move for a dropped graph')
             # the bias/softmax path (node attention with edge bias and gate), same accounting
             for kname, kind in (('tgt_node_attention_fwd', 'fwd'), ('tgt_node_attention_bwd', 'bwd')):
                 if times.get(kname):

@@ -105,12 +105,14 @@ SKIP_CASES = [  # B, N, num_nodes, C, H  (8-head workgroups, 4-head workgroups, 
 @pytest.mark.parametrize('case', SKIP_CASES)
 @pytest.mark.parametrize('variant', ['gated', 'axial'])
 @pytest.mark.parametrize('projected', [False, True])
-def test_triplet_attention_skips_droppath_dropped_graphs(case, dtype, variant, projected):
+@pytest.mark.parametrize('skip_backward', [True, False])
+def test_triplet_attention_skips_droppath_dropped_graphs(case, dtype, variant, projected, skip_backward, monkeypatch):
     """tgt_triplet_attention_args.graph_scale (ABI 23): a graph whose DropPath factor is 0 is not computed -- zeros out,
     zero gradients (its incoming gradient is zero behind the residual add's multiplication, reference layers.py:169-174,
     286-287) -- and every other graph, every parameter gradient and the in-kernel bias-gradient sums are EQUAL to the full
     computation's."""
     from tgt_amd import ops
+    monkeypatch.setattr(ops, '_TRI_SKIP_BWD', skip_backward)      # (TGT_TRI_SKIP=2; the default hands the factors to the forward only)
     B, N, nn_, C, H = case
     gated, biased = variant == 'gated', variant != 'axial'
     L = ops.TripletLayout(C, H, gated=gated, biased=biased)

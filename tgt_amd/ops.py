@@ -22,6 +22,11 @@ _PROFILE = None
 _TRI_SPLIT = os.environ.get('TGT_TRI_SPLIT', '1') != '0'        # A/B knobs, read once
 _TRI_PROJ = os.environ.get('TGT_TRI_PROJ', '0') == '1'
 _TRI_COLSUM = os.environ.get('TGT_TRI_COLSUM', '1') != '0'
+# graph_scale (DropPath-dropped graphs skipped by the triplet kernels) reaches the BACKWARD kernel only with TGT_TRI_SKIP=2: at the
+# BASELINE shapes the backward is 1024 workgroups in exactly four rounds on 256 CUs (one workgroup per CU), and with ~10 % of them
+# finishing early the last round is still a round -- measured 0.474 vs 0.476 ms -- so by default it keeps computing every graph (the
+# forward, two workgroups per CU, gains 4 %)
+_TRI_SKIP_BWD = os.environ.get('TGT_TRI_SKIP', '1') == '2'
 
 
 def profile_kernels(enable=True):
@@ -168,7 +173,7 @@ class _TripletAttention(torch.autograd.Function):
         a = _tri_args(fused, mask3, out, L, dropout=dropout, graph_scale=graph_scale)
         _call('tgt_triplet_attention_fwd', _lib.lib().tgt_triplet_attention_fwd, a)
         ctx.save_for_backward(fused, mask3, out)
-        ctx.L, ctx.dropout, ctx.graph_scale = L, dropout, graph_scale
+        ctx.L, ctx.dropout, ctx.graph_scale = L, dropout, (graph_scale if _TRI_SKIP_BWD else None)
         return out
 
     @staticmethod
@@ -348,7 +353,7 @@ class _ProjectedTripletAttention(torch.autograd.Function):
             _call('tgt_triplet_attention_fwd', _lib.lib().tgt_triplet_attention_fwd, a)
         ctx.save_for_backward(x2, w, fused, mask3, out, eg if eg is not None else fused.new_empty(0),
                               *(wb if table is not None else ()))
-        ctx.L, ctx.table, ctx.dropout, ctx.graph_scale = L, table, dropout, graph_scale
+        ctx.L, ctx.table, ctx.dropout, ctx.graph_scale = L, table, dropout, (graph_scale if _TRI_SKIP_BWD else None)
         ctx.meta = (x.shape, x.dtype, weight.dtype, bias.dtype)
         return out
 
