@@ -274,6 +274,7 @@ int tgt_loss_accumulate(const void* loss, int32_t loss_is_f64, float samples, fl
  *       mean / rstd (M) float32 written when given; y (M, K) = the normalised rows when given.
  *   TGT_EPI_BIAS     out = z * out_scale[row / rows_per_sample]        (out_scale may be NULL)
  *   TGT_EPI_GELU     out2 = z (pre-activation);  out = dropout(gelu(z), dropout_p, dropout_seed)
+ *                    (* row_scale[m / rows_per_sample] when given: N = 256, K in {64,128,256} only -- tgt_gelu_dropout_scaled_fwd's factor)
  *                    (generator of tgt_gelu_dropout_fwd on the (M, N) index space)
  *   TGT_EPI_RESID    out = res + row_scale[row / rows_per_sample] * z   (row_scale may be NULL)
  *   TGT_EPI_GELU_BWD out = z' * gelu'(res) * keep / (1-p), z' = z * out_scale[..]; res = the forward's pre-activation

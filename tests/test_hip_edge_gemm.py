@@ -291,3 +291,42 @@ def test_gelu_dropout_sample_scale(dtype):
         tol = {torch.float32: 1e-6, torch.bfloat16: 8e-3, torch.float16: 1e-3}[dtype]
         assert rel(ya, ref) < tol and rel(xa.grad, gref) < tol
         assert float(ya[0].abs().max()) == 0.0 and float(xa.grad[0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('p', [0.0, 0.1])
+@pytest.mark.parametrize('with_scale', [False, True])
+def test_linear_gelu_dropout_node_equals_the_unfused_chain(dtype, p, with_scale, monkeypatch):
+    """lin_W1 + GELU + dropout (+ the folded DropPath factor) as one launch and one autograd node (the FFN's hidden
+    activation on the edge rows, reference layers.py:155-158) against Linear -> tgt_gelu_dropout: same drop pattern (same
+    seed draw), outputs and every gradient within the GEMM's rounding"""
+    monkeypatch.setattr(ops, '_EDGE_MIN_ROWS', 1)
+    g = torch.Generator(device='cuda').manual_seed(13)
+    B, n, K, N = 4, 9, 256, 256
+    x = torch.randn(B, n, n, K, device='cuda', generator=g)
+    w = torch.randn(N, K, device='cuda', generator=g) * K ** -0.5
+    b = torch.randn(N, device='cuda', generator=g) * 0.1
+    dy = torch.randn(B, n, n, N, device='cuda', generator=g).to(dtype)
+    sc = torch.tensor([1.25, 0.0, 1.25, 1.25], device='cuda') if with_scale else None
+    outs = []
+    for fused in (True, False):
+        ins = [t.clone().requires_grad_(True) for t in (x, w, b)]
+        torch.manual_seed(77)                      # both draw ONE seed from the CPU generator
+        with torch.autocast('cuda', dtype=dtype):
+            if fused:
+                assert ops.linear_gelu_dropout_ok(ins[0], ins[1], sc)
+                y = ops.linear_gelu_dropout(ins[0], ins[1], ins[2], p, True, sc)
+            else:
+                y = ops.gelu_dropout(ops.linear(ins[0], ins[1], ins[2]), p, True, sc)
+        y.backward(dy)
+        outs.append((y, [t.grad for t in ins]))
+    torch.cuda.synchronize()
+    (y1, g1), (y0, g0) = outs
+    assert y1.dtype == dtype and torch.isfinite(y1).all()
+    assert rel(y1, y0) < TOL[dtype]
+    # the same elements are dropped (up to pre-activations that round across zero ... none at these sizes: compare the patterns)
+    assert float(((y1 == 0) != (y0 == 0)).float().mean()) < 2e-3
+    if with_scale:
+        assert float(y1[1].abs().max()) == 0
+    for a_, b_, name in zip(g1, g0, ('dx', 'dw', 'db')):
+        assert rel(a_, b_) < 2 * TOL[dtype], (name, rel(a_, b_))

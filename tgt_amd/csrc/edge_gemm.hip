@@ -1240,11 +1240,12 @@ __global__ void __launch_bounds__(1024, 4) edge_rows_kernel(const tgt_edge_linea
                     bool keep[8] = {true, true, true, true, true, true, true, true};
                     if (thresh) keep_vector<8>(a.dropout_seed, (mc * N + ch * 8) >> 3, thresh, keep);
                     float gl[8];
+                    const float ik = inv_keep * cur.sc[i];       // (row_scale: the DropPath factor of the branch, folded into the activation)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         float e;
                         const float cdf = gelu_cdf(v[j], e);
-                        gl[j] = keep[j] ? v[j] * cdf * inv_keep : 0.f;
+                        gl[j] = keep[j] ? v[j] * cdf * ik : 0.f;
                     }
                     if (ok) *reinterpret_cast<uint4*>(out + m * a.ldo + ch * 8) = rp_pack8<T>(gl);
                 } else if constexpr (EPI == EPI_GELU_BWD) {
@@ -1518,6 +1519,8 @@ int edge_linear_supported(const tgt_edge_linear_args* a) {
     if (a->epilogue == EPI_LN_BWD && (N > 256 || !a->gamma || !a->mean || !a->rstd || !a->res)) return 0;
     // row_scale on the bias only (the input arrived pre-scaled): the row-phase kernel's residual epilogue
     if ((a->flags & TGT_EDGE_BIAS_SCALED) && (a->epilogue != EPI_RESID || !er_eligible(*a))) return 0;
+    // row_scale on the activation (tgt_gelu_dropout_scaled_fwd's per-sample factor): the row-phase kernel's GELU epilogue only
+    if (a->epilogue == EPI_GELU && a->row_scale && !er_eligible(*a)) return 0;
     return 1;
 }
 

@@ -344,7 +344,12 @@ class _ProjectedTripletAttention(torch.autograd.Function):
             x2 = x2 if x2.dtype == cd else x2.to(cd)
             w, b = _as_dtype(weight, cd), _as_dtype(bias, cd)
             fused = torch.addmm(b[:6 * L.C], x2, w[:6 * L.C].t()).view(B, N, N, 6 * L.C)
-            eg = torch.addmm(b[6 * L.C:L.used], x2, w[6 * L.C:L.used].t()).view(B, N, N, L.used - 6 * L.C)
+            we, be = w[6 * L.C:L.used], b[6 * L.C:L.used]
+            if we.shape[0] <= 128 and we.is_contiguous() and _edge_kernel_ok(x2, we.shape[0], cd):
+                # the narrow third-arm projection on the weight-resident slice kernel (29 vs 37 us against the tuned library GEMM)
+                eg = edge_linear_raw(x2, we, be.contiguous()).view(B, N, N, L.used - 6 * L.C)
+            else:
+                eg = torch.addmm(be, x2, we.t()).view(B, N, N, L.used - 6 * L.C)
             a = _tri_args(fused, mask3, out, L, dropout=dropout, eg=eg, graph_scale=graph_scale)
             _call('tgt_triplet_attention_fwd', _lib.lib().tgt_triplet_attention_fwd, a)
         else:
@@ -1229,15 +1234,81 @@ def edge_linear_raw(a, w, bias=None, epilogue=_lib.EPI_BIAS, *, ln=None, y=None,
     return out
 
 
-def edge_linear_supported(K, N, dtype, epilogue=_lib.EPI_BIAS, ln=False):
+def edge_linear_supported(K, N, dtype, epilogue=_lib.EPI_BIAS, ln=False, row_scale=False):
     if dtype not in (torch.bfloat16, torch.float16):
         return False
     g = _lib.EdgeLinearArgs()
     g.M, g.K, g.N, g.dtype, g.epilogue = 128, K, N, _DT[dtype], epilogue
     one = C.c_void_p(16)
+    if row_scale:
+        g.row_scale, g.rows_per_sample = one, 1
     if ln or epilogue == _lib.EPI_LN_BWD:
         g.gamma = g.beta = g.mean = g.rstd = g.res = one
     return bool(_lib.lib().tgt_edge_linear_supported(C.byref(g)))
+
+
+_FFN_GELU_EPI = os.environ.get('TGT_FFN_GELU_EPI', '1') != '0'     # A/B knob: lin_W1 + GELU + dropout as one launch on the edge rows
+
+
+class _LinearGeluDropout(torch.autograd.Function):
+    """act = dropout(gelu(x W^T + b), p) * sample_scale[b] as ONE launch (tgt_edge_linear, TGT_EPI_GELU on the row-phase
+    kernel): the pre-activation is written once for the backward and never re-read by a separate activation pass
+    (reference FFN, lib/tgt/layers/layers.py:155-158).  Same drop pattern and arithmetic as tgt_gelu_dropout_scaled_fwd on
+    the stored pre-activation; the backward is that kernel's backward followed by the Linear's."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cd, p, seed, sample_scale):
+        _dev(x, weight, sample_scale)
+        xs = x.shape
+        x2 = x.reshape(-1, xs[-1])
+        if x2.dtype != cd:
+            x2 = x2.to(cd)
+        w = _as_dtype(weight, cd)
+        b = None if bias is None else _as_dtype(bias, cd)
+        N = weight.shape[0]
+        pre = torch.empty(*xs[:-1], N, dtype=cd, device=x.device)
+        act = torch.empty_like(pre)
+        rps = (x2.shape[0] // sample_scale.numel()) if sample_scale is not None else 0
+        edge_linear_raw(x2, w, b, _lib.EPI_GELU, out=act.view(-1, N), out2=pre.view(-1, N), dropout=(p, seed),
+                        row_scale=sample_scale, rows_per_sample=rps)
+        ctx.save_for_backward(x2, w, pre, sample_scale)
+        ctx.meta = (xs, x.dtype, weight.dtype, None if bias is None else bias.dtype, float(p), seed, rps * N)
+        return act
+
+    @staticmethod
+    def backward(ctx, d_act):
+        x2, w, pre, sample_scale = ctx.saved_tensors
+        xs, xdt, wdt, bdt, p, seed, eps_ = ctx.meta
+        d_act = d_act.contiguous()
+        d_pre = torch.empty_like(pre)
+        s, e = _prof_begin()
+        _lib.check(_lib.lib().tgt_gelu_dropout_scaled_bwd(_ptr(pre), _ptr(d_act), _ptr(d_pre), pre.numel(), _DT[pre.dtype], p, seed,
+                                                          _ptr(sample_scale), eps_, _stream()), 'tgt_gelu_dropout_bwd')
+        _prof_end('tgt_gelu_dropout_bwd', s, e)
+        need_db = bdt is not None and ctx.needs_input_grad[2]
+        dx, dw, db = _linear_backward(x2, w, d_pre.view(-1, d_pre.shape[-1]), xs, xdt, wdt, bdt, ctx.needs_input_grad[0],
+                                      ctx.needs_input_grad[1], need_db)
+        return dx, dw, db, None, None, None, None
+
+
+def linear_gelu_dropout_ok(x, weight, sample_scale=None):
+    """whether linear_gelu_dropout takes this call: edge rows (many of them), 16-bit compute dtype, 256 outputs, K in {64,128,256}"""
+    if not (_FFN_GELU_EPI and x.is_cuda):
+        return False
+    cd = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled('cuda') else x.dtype
+    rows = x.numel() // x.shape[-1]
+    if sample_scale is not None and (rows % sample_scale.numel() or sample_scale.dtype != torch.float32):
+        return False
+    return weight.shape[0] == 256 and _edge_kernel_ok(x.reshape(-1, x.shape[-1]), 256, cd) and \
+        edge_linear_supported(x.shape[-1], 256, cd, _lib.EPI_GELU, row_scale=sample_scale is not None)
+
+
+def linear_gelu_dropout(x, weight, bias, p, training, sample_scale=None):
+    """dropout(gelu(linear(x, weight, bias)), p) [* sample_scale per graph] in one launch; see linear_gelu_dropout_ok"""
+    cd = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled('cuda') else x.dtype
+    p = float(p) if training else 0.0
+    seed = int(torch.empty((), dtype=torch.int64).random_().item()) if p > 0 else 0
+    return _LinearGeluDropout.apply(x, weight, bias, cd, p, seed, sample_scale)
 
 
 # ---------------------------------------------------------------------------

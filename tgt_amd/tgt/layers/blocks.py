@@ -190,6 +190,8 @@ class FFN(nn.Module):
     def hidden(self, x, sample_scale=None):
         """activation(lin_W1(x)) with dropout: the input of lin_W2 (TGT_Layer fuses lin_W2 with the residual add and
         the next LayerNorm).  sample_scale (B,): the result times that per-graph factor (the branch's DropPath, folded in)"""
+        if self.activation == 'gelu' and ops.linear_gelu_dropout_ok(x, self.lin_W1.weight, sample_scale):
+            return ops.linear_gelu_dropout(x, self.lin_W1.weight, self.lin_W1.bias, self.act_dropout, self.training, sample_scale)
         x = self.lin_W1(x)
         if self.activation == 'gelu' and x.dtype in (torch.float32, torch.bfloat16, torch.float16):
             return ops.gelu_dropout(x, self.act_dropout, self.training, sample_scale)      # one pass each way, no mask tensor
