@@ -330,3 +330,49 @@ def test_linear_gelu_dropout_node_equals_the_unfused_chain(dtype, p, with_scale,
         assert float(y1[1].abs().max()) == 0
     for a_, b_, name in zip(g1, g0, ('dx', 'dw', 'db')):
         assert rel(a_, b_) < 2 * TOL[dtype], (name, rel(a_, b_))
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('p', [0.0, 0.1])
+@pytest.mark.parametrize('prescaled', [False, True])
+def test_ffn_block_with_fused_activation_both_ways(dtype, p, prescaled, monkeypatch):
+    """the edge FFN as the layer runs it (reference layers.py:155-160, 284-290): lin_W1 + GELU + dropout as one launch, and in
+    the backward the activation's derivative as the epilogue of lin_W2's data-gradient GEMM (the closing node receives the
+    activation detached and returns the gradient of the PRE-activation) -- against the unfused chain with the same seed draw:
+    stream, normalised rows and every gradient within the GEMMs' rounding"""
+    monkeypatch.setattr(ops, '_EDGE_MIN_ROWS', 1)
+    g = torch.Generator(device='cuda').manual_seed(21)
+    B, n, C = 4, 9, 256
+    x = torch.randn(B, n, n, C, device='cuda', generator=g)
+    res = torch.randn(B, n, n, C, device='cuda', generator=g).to(dtype)
+    w1 = torch.randn(C, C, device='cuda', generator=g) * C ** -0.5
+    b1 = torch.randn(C, device='cuda', generator=g) * 0.1
+    w2 = torch.randn(C, C, device='cuda', generator=g) * C ** -0.5
+    b2 = torch.randn(C, device='cuda', generator=g) * 0.1
+    lw = torch.rand(C, device='cuda', generator=g) + 0.5
+    lb = torch.randn(C, device='cuda', generator=g) * 0.2
+    d_s = torch.randn(B, n, n, C, device='cuda', generator=g).to(dtype)
+    d_y = torch.randn(B, n, n, C, device='cuda', generator=g).to(dtype)
+    sc = torch.tensor([1.25, 0.0, 1.25, 1.25], device='cuda')
+    runs = []
+    for fused in (True, False):
+        monkeypatch.setattr(ops, '_FFN_GELU_EPI', fused)
+        monkeypatch.setattr(ops, '_FFN_GELU_BWD_EPI', fused)
+        ins = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2, res, lw, lb)]
+        torch.manual_seed(5)
+        with torch.autocast('cuda', dtype=dtype):
+            fold = sc if prescaled else None
+            if fused:
+                act = ops.linear_gelu_dropout(ins[0], ins[1], ins[2], p, True, fold)
+                assert hasattr(act, '_tgt_gelu')
+            else:
+                act = ops.gelu_dropout(ops.linear(ins[0], ins[1], ins[2]), p, True, fold)
+            s, y = ops.linear_residual_layer_norm(act, ins[3], ins[4], ins[5], sc, ins[6], ins[7], 1e-5, prescaled=prescaled)
+        torch.autograd.backward([s, y], [d_s, d_y])
+        runs.append((s, y, [t.grad for t in ins]))
+    torch.cuda.synchronize()
+    (s1, y1, g1), (s0, y0, g0) = runs
+    assert rel(s1, s0) < TOL[dtype] and rel(y1, y0) < TOL[dtype]
+    for a_, b_, name in zip(g1, g0, ('dx', 'dw1', 'db1', 'dw2', 'db2', 'dres', 'dgamma', 'dbeta')):
+        assert a_ is not None and torch.isfinite(a_).all(), name
+        assert rel(a_, b_) < 3 * TOL[dtype], (name, rel(a_, b_))

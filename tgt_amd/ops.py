@@ -1248,6 +1248,10 @@ def edge_linear_supported(K, N, dtype, epilogue=_lib.EPI_BIAS, ln=False, row_sca
 
 
 _FFN_GELU_EPI = os.environ.get('TGT_FFN_GELU_EPI', '1') != '0'     # A/B knob: lin_W1 + GELU + dropout as one launch on the edge rows
+# A/B knob: GELU backward as the epilogue of lin_W2's data-gradient GEMM (the closing node takes the activation detached and returns the
+# gradient of the pre-activation).  Parity-green, measured NEUTRAL in the step (2506.0 vs 2506.8 graphs/s over three same-box pairs: the
+# row phase of that epilogue is instruction-bound, 0.122 ms against 0.068 + 0.072 for GEMM + activation pass): off by default
+_FFN_GELU_BWD_EPI = os.environ.get('TGT_FFN_GELU_BWD_EPI', '0') == '1'
 
 
 class _LinearGeluDropout(torch.autograd.Function):
@@ -1273,18 +1277,28 @@ class _LinearGeluDropout(torch.autograd.Function):
                         row_scale=sample_scale, rows_per_sample=rps)
         ctx.save_for_backward(x2, w, pre, sample_scale)
         ctx.meta = (xs, x.dtype, weight.dtype, None if bias is None else bias.dtype, float(p), seed, rps * N)
-        return act
+        ctx.set_materialize_grads(False)
+        # TWO outputs: the activation, and the pre-activation as a differentiable value of its own -- a consumer that owns the
+        # activation's derivative (linear_residual_layer_norm: GELU backward as the epilogue of its data-gradient GEMM) reads
+        # the activation detached and sends its gradient to `pre` directly
+        return act, pre
 
     @staticmethod
-    def backward(ctx, d_act):
+    def backward(ctx, d_act, d_pre_in):
         x2, w, pre, sample_scale = ctx.saved_tensors
         xs, xdt, wdt, bdt, p, seed, eps_ = ctx.meta
-        d_act = d_act.contiguous()
-        d_pre = torch.empty_like(pre)
-        s, e = _prof_begin()
-        _lib.check(_lib.lib().tgt_gelu_dropout_scaled_bwd(_ptr(pre), _ptr(d_act), _ptr(d_pre), pre.numel(), _DT[pre.dtype], p, seed,
-                                                          _ptr(sample_scale), eps_, _stream()), 'tgt_gelu_dropout_bwd')
-        _prof_end('tgt_gelu_dropout_bwd', s, e)
+        d_pre = None
+        if d_act is not None:
+            d_act = d_act.contiguous()
+            d_pre = torch.empty_like(pre)
+            s, e = _prof_begin()
+            _lib.check(_lib.lib().tgt_gelu_dropout_scaled_bwd(_ptr(pre), _ptr(d_act), _ptr(d_pre), pre.numel(), _DT[pre.dtype], p, seed,
+                                                              _ptr(sample_scale), eps_, _stream()), 'tgt_gelu_dropout_bwd')
+            _prof_end('tgt_gelu_dropout_bwd', s, e)
+        if d_pre_in is not None:
+            d_pre = d_pre_in.contiguous() if d_pre is None else d_pre + d_pre_in
+        if d_pre is None:
+            return None, None, None, None, None, None, None
         need_db = bdt is not None and ctx.needs_input_grad[2]
         dx, dw, db = _linear_backward(x2, w, d_pre.view(-1, d_pre.shape[-1]), xs, xdt, wdt, bdt, ctx.needs_input_grad[0],
                                       ctx.needs_input_grad[1], need_db)
@@ -1308,7 +1322,10 @@ def linear_gelu_dropout(x, weight, bias, p, training, sample_scale=None):
     cd = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled('cuda') else x.dtype
     p = float(p) if training else 0.0
     seed = int(torch.empty((), dtype=torch.int64).random_().item()) if p > 0 else 0
-    return _LinearGeluDropout.apply(x, weight, bias, cd, p, seed, sample_scale)
+    act, pre = _LinearGeluDropout.apply(x, weight, bias, cd, p, seed, sample_scale)
+    # rides on the tensor object (as _tgt_colsum does): what a consumer needs to take over the activation's backward
+    act._tgt_gelu = (pre, p, seed, sample_scale)
+    return act
 
 
 # ---------------------------------------------------------------------------
@@ -1377,7 +1394,9 @@ class _LinearResidualLN(torch.autograd.Function):
     Backward: the add+LN backward kernel (it also yields the bias gradient), then the Linear's gradients."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, res, scale, ln_w, ln_b, eps, cd, out_dtype, prescaled=False):
+    def forward(ctx, x, weight, bias, res, scale, ln_w, ln_b, eps, cd, out_dtype, prescaled=False, pre=None, gelu=None):
+        # pre / gelu = (p, seed, sample_scale): x is dropout(gelu(pre)) * sample_scale, handed in DETACHED; this node then owns the
+        # activation's derivative and returns the gradient of `pre` (GELU backward as the epilogue of the data-gradient GEMM)
         _dev(x, weight, res, ln_w, ln_b)
         xs = x.shape
         x2 = x.reshape(-1, xs[-1])
@@ -1398,14 +1417,19 @@ class _LinearResidualLN(torch.autograd.Function):
         edge_linear_raw(x2, w, b, _lib.EPI_RESID, out=s.view(rows, N), res=res2, row_scale=scale, rows_per_sample=rps,
                         ln=(g, be, eps), stats=(mean, rstd), y=y.view(rows, N),
                         flags=_lib.EDGE_BIAS_SCALED if (prescaled and scale is not None) else 0)
-        ctx.save_for_backward(x2, w, s, g, mean, rstd, scale)
+        ctx.gelu = None
+        if pre is not None:
+            ctx.gelu = (float(gelu[0]), gelu[1], gelu[2] is not None)
+            ctx.save_for_backward(x2, w, s, g, mean, rstd, scale, pre, gelu[2])
+        else:
+            ctx.save_for_backward(x2, w, s, g, mean, rstd, scale)
         ctx.meta = (xs, x.dtype, weight.dtype, None if bias is None else bias.dtype, ln_w.dtype, res.dtype, rps)
         ctx.prescaled = bool(prescaled and scale is not None)
         return s, y
 
     @staticmethod
     def backward(ctx, ds, dy):
-        x2, w, s, g, mean, rstd, scale = ctx.saved_tensors
+        x2, w, s, g, mean, rstd, scale = ctx.saved_tensors[:7]
         xs, xdt, wdt, bdt, lndt, rdt, rps = ctx.meta
         N = s.shape[-1]
         rows = s.numel() // N
@@ -1437,12 +1461,23 @@ class _LinearResidualLN(torch.autograd.Function):
                 d_z = d_res
             dbeta, cs = db_cs[:N], db_cs[N:]
         need_db = bdt is not None and ctx.needs_input_grad[2]
-        dx, dw, db = _linear_backward(x2, w, d_z.reshape(rows, N), xs, xdt, wdt, bdt, ctx.needs_input_grad[0],
+        d_pre = None
+        need_dx = ctx.needs_input_grad[0]
+        if ctx.gelu is not None:
+            # d_pre = ((d_z W) * sample_scale) * gelu'(pre) * keep / (1 - p): the data gradient and the activation's backward in
+            # one launch (TGT_EPI_GELU_BWD); x was handed in detached, its slot gets no gradient
+            pre, g_scale = ctx.saved_tensors[7], (ctx.saved_tensors[8] if ctx.gelu[2] else None)
+            need_dx = False
+            if ctx.needs_input_grad[11]:
+                d_pre = torch.empty_like(pre)
+                edge_linear_raw(d_z.reshape(rows, N), w.t().contiguous(), None, _lib.EPI_GELU_BWD, out=d_pre.view(rows, -1),
+                                res=pre.view(rows, -1), out_scale=g_scale, rows_per_sample=rps, dropout=(ctx.gelu[0], ctx.gelu[1]))
+        dx, dw, db = _linear_backward(x2, w, d_z.reshape(rows, N), xs, xdt, wdt, bdt, need_dx,
                                       ctx.needs_input_grad[1], need_db and cs is None)
         if need_db and cs is not None:
             db = cs.to(bdt)
         return (dx, dw, db, d_res if rdt == d_res.dtype else d_res.to(rdt), None,
-                None if dg is None else dg.to(lndt), None if dbeta is None else dbeta.to(lndt), None, None, None, None)
+                None if dg is None else dg.to(lndt), None if dbeta is None else dbeta.to(lndt), None, None, None, None, d_pre, None)
 
 
 def _residual_fusable(x, weight, res, cd):
@@ -1470,16 +1505,24 @@ def linear_residual_layer_norm(x, weight, bias, res, scale, ln_weight, ln_bias, 
     hhat_scale=)), so s = res + x W^T + scale[graph] * bias -- the same value, and the backward hands the stream gradient
     itself to the Linear's gradient GEMMs instead of writing a scaled copy of it (one pass over the rows less)."""
     cd = torch.get_autocast_dtype('cuda') if (x.is_cuda and torch.is_autocast_enabled('cuda')) else x.dtype
+    # x = the FFN's activation out of linear_gelu_dropout: take over its backward when the data gradient runs on the row-phase kernel
+    gelu = getattr(x, '_tgt_gelu', None) if _FFN_GELU_BWD_EPI else None
+    if gelu is not None and not (weight.shape[0] == 256 and weight.shape[1] == 256 and gelu[0].dtype == cd and
+                                 _residual_fusable(x, weight, res, cd) and edge_linear_supported(256, 256, cd, _lib.EPI_GELU_BWD)):
+        gelu = None
+    extra = () if gelu is None else (gelu[0], gelu[1:])
+    if gelu is not None:
+        x = x.detach()
     if prescaled and scale is not None:
         if _residual_fusable(x, weight, res, cd) and weight.shape[0] == 256:
-            return _LinearResidualLN.apply(x, weight, bias, res, scale, ln_weight, ln_bias, eps, cd, cd, True)
+            return _LinearResidualLN.apply(x, weight, bias, res, scale, ln_weight, ln_bias, eps, cd, cd, True, *extra)
         # composition with the same arithmetic (shapes the fused launch does not take)
         z = linear(x, weight, None)
         if bias is not None:
             z = z + scale.view([-1] + [1] * (z.ndim - 1)).to(z.dtype) * bias.to(z.dtype)
         return add_layer_norm(z, res, None, ln_weight, ln_bias, eps)
     if _residual_fusable(x, weight, res, cd):
-        return _LinearResidualLN.apply(x, weight, bias, res, scale, ln_weight, ln_bias, eps, cd, cd)
+        return _LinearResidualLN.apply(x, weight, bias, res, scale, ln_weight, ln_bias, eps, cd, cd, False, *extra)
     return add_layer_norm(linear(x, weight, bias), res, scale, ln_weight, ln_bias, eps)
 
 
