@@ -324,7 +324,7 @@ def main():
         # profiles/README.md); only valid for the shape they were measured at
         traffic, pmc = {}, {}
         tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-        ppath = os.path.join(ROOT, 'profiles', 'r02k_pmc_summary.json')      # tools/pmc_passes.sh: SQ / FETCH / WRITE passes
+        ppath = os.path.join(ROOT, 'profiles', 'r02l_pmc_summary.json')      # tools/pmc_passes.sh: SQ / FETCH / WRITE passes
         if args.batch == 256 and args.nodes == 32 and args.precision == 'bf16':
             if os.path.exists(tpath):
                 traffic = json.load(open(tpath))
