@@ -969,12 +969,15 @@ def _take_colsum(grad, C_):
     return tag[0]
 
 
+_WGRAD_MAXP = int(os.environ.get('TGT_WGRAD_MAXP', '128'))      # A/B knob: cap on the row chunks of a weight gradient
+
+
 def _wgrad_chunks(M, out_in=0):
     """number of row chunks for dW = sum_c dY_c^T X_c (rows per chunk >= 1024, <= 128 chunks; 64
     for the 1600x256 fused projection, whose fp32 partials are 1.6 MB each:
     tools/wgrad_chunk_probe.py)"""
-    for P in ((64, 32, 16, 8, 4, 2) if out_in >= 262144 else (128, 64, 32, 16, 8, 4, 2)):
-        if M % P == 0 and M // P >= 1024:
+    for P in ((64, 32, 16, 8, 4, 2) if out_in >= 262144 else (256, 128, 64, 32, 16, 8, 4, 2)):
+        if P <= _WGRAD_MAXP and M % P == 0 and M // P >= 1024:
             return P
     return 1
 
