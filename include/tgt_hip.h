@@ -365,6 +365,14 @@ int tgt_gelu_dropout_scaled_fwd(const void* x, void* y, int64_t n, int32_t dtype
                                 const float* sample_scale, int64_t elems_per_sample, void* stream);
 int tgt_gelu_dropout_scaled_bwd(const void* x, const void* dy, void* dx, int64_t n, int32_t dtype, float p, uint64_t seed,
                                 const float* sample_scale, int64_t elems_per_sample, void* stream);
+/* (ABI 24) tgt_gelu_dropout_scaled_bwd that also returns colsum (cols) float32 = the column sums of dx seen as (n / cols, cols)
+ * rows, i.e. the bias gradient of the nn.Linear in front of the activation (reference layers.py:156-157, `grad.sum(0)` of
+ * lin_W1) without a separate pass over dx.  sample_scale may be NULL.  cols: a multiple of 16/sizeof(T) that divides
+ * 256 * 16/sizeof(T) (64 .. 2048 for 16-bit) and n.  partial: scratch of tgt_gelu_colsum_parts() * cols floats.  Fixed summation order. */
+int tgt_gelu_colsum_parts(void);
+int tgt_gelu_dropout_bwd_colsum(const void* x, const void* dy, void* dx, int64_t n, int32_t dtype, float p, uint64_t seed,
+                                const float* sample_scale, int64_t elems_per_sample, int32_t cols, float* partial, float* colsum,
+                                void* stream);
 
 /* Column sums of a (rows, C) tensor into float32 (C): the bias gradient of a Linear layer
  * (the `grad_output.sum(0)` ATen reduction behind nn.Linear, e.g. reference

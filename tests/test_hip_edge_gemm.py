@@ -296,11 +296,13 @@ def test_gelu_dropout_sample_scale(dtype):
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('p', [0.0, 0.1])
 @pytest.mark.parametrize('with_scale', [False, True])
-def test_linear_gelu_dropout_node_equals_the_unfused_chain(dtype, p, with_scale, monkeypatch):
+@pytest.mark.parametrize('colsum', [True, False])
+def test_linear_gelu_dropout_node_equals_the_unfused_chain(dtype, p, with_scale, colsum, monkeypatch):
     """lin_W1 + GELU + dropout (+ the folded DropPath factor) as one launch and one autograd node (the FFN's hidden
     activation on the edge rows, reference layers.py:155-158) against Linear -> tgt_gelu_dropout: same drop pattern (same
     seed draw), outputs and every gradient within the GEMM's rounding"""
     monkeypatch.setattr(ops, '_EDGE_MIN_ROWS', 1)
+    monkeypatch.setattr(ops, '_GELU_BWD_COLSUM', colsum)        # lin_W1's bias gradient from the activation's backward pass (ABI 24) or a separate pass
     g = torch.Generator(device='cuda').manual_seed(13)
     B, n, K, N = 4, 9, 256, 256
     x = torch.randn(B, n, n, K, device='cuda', generator=g)
@@ -376,3 +378,25 @@ def test_ffn_block_with_fused_activation_both_ways(dtype, p, prescaled, monkeypa
     for a_, b_, name in zip(g1, g0, ('dx', 'dw1', 'db1', 'dw2', 'db2', 'dres', 'dgamma', 'dbeta')):
         assert a_ is not None and torch.isfinite(a_).all(), name
         assert rel(a_, b_) < 3 * TOL[dtype], (name, rel(a_, b_))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('rows,cols', [(4100, 256), (333, 64), (9000, 512), (77, 128)])
+@pytest.mark.parametrize('p', [0.0, 0.2])
+def test_gelu_backward_with_bias_gradient_column_sums(dtype, rows, cols, p):
+    """tgt_gelu_dropout_bwd_colsum: dx bit-equal to tgt_gelu_dropout_scaled_bwd, colsum = float64 column sums of the STORED dx"""
+    g = torch.Generator(device='cuda').manual_seed(3)
+    x = torch.randn(rows, cols, device='cuda', generator=g).to(dtype)
+    dy = torch.randn(rows, cols, device='cuda', generator=g).to(dtype)
+    L = _lib.lib()
+    seed = 0x51ed if p else 0
+    dx0, dx1 = torch.empty_like(x), torch.empty_like(x)
+    _lib.check(L.tgt_gelu_dropout_scaled_bwd(x.data_ptr(), dy.data_ptr(), dx0.data_ptr(), x.numel(), ops._DT[dtype], p, seed, None, 0, None), 'a')
+    cs = torch.empty(cols, device='cuda')
+    partial = torch.empty(L.tgt_gelu_colsum_parts() * cols, device='cuda')
+    _lib.check(L.tgt_gelu_dropout_bwd_colsum(x.data_ptr(), dy.data_ptr(), dx1.data_ptr(), x.numel(), ops._DT[dtype], p, seed, None, 0,
+                                             cols, partial.data_ptr(), cs.data_ptr(), None), 'b')
+    torch.cuda.synchronize()
+    assert torch.equal(dx0, dx1)
+    want = dx0.double().sum(0)
+    assert float((cs.double() - want).abs().max()) <= 1e-5 * float(want.abs().max()) + 1e-6

@@ -17,7 +17,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 SOURCES = ['capi.hip', 'optimizer.hip', 'edge_gemm.hip', 'params.hip', 'loss.hip', 'predict.hip', 'gaussian.hip', 'triplet_attention_proj.hip',
            ('triplet_attention.hip', ['-DTGT_TRI_INST=9'], '.f32'), ('triplet_attention.hip', ['-DTGT_TRI_INST=2'], '.bf16'),
            ('triplet_attention.hip', ['-DTGT_TRI_INST=4'], '.f16'), 'triplet_attention16.hip', 'triplet_aggregate.hip', 'node_attention.hip', 'node_attention_mfma.hip', 'layernorm.hip', 'triangular_update.hip', 'elementwise.hip']
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 TGT_F32, TGT_BF16, TGT_F16 = 0, 1, 2
 TRI_BIASED, TRI_GATED, TRI_MASK_OUT = 1, 2, 4
@@ -110,6 +110,8 @@ SYMBOLS = {
     'tgt_gelu_dropout_bwd': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, C.c_uint64, _vp]),
     'tgt_gelu_dropout_scaled_fwd': (C.c_int, [_vp, _vp, _i64, _i32, _f32, C.c_uint64, _vp, _i64, _vp]),
     'tgt_gelu_dropout_scaled_bwd': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, C.c_uint64, _vp, _i64, _vp]),
+    'tgt_gelu_colsum_parts': (C.c_int, []),
+    'tgt_gelu_dropout_bwd_colsum': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, C.c_uint64, _vp, _i64, _i32, _vp, _vp, _vp]),
     'tgt_add_layer_norm_fwd': (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _f32, _vp]),
     'tgt_add_layer_norm_bwd': (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     'tgt_layer_norm_parts': (C.c_int, []),

@@ -39,6 +39,10 @@ int triangular_update_run(const void* e4, const void* v4, const float* mask, voi
                           void* d_v4, int B, int N, int H, int dtype, bool bwd, hipStream_t st);
 int colsum_run(const void* x, int x_dtype, int64_t rows, int C, float* out, float* partial, hipStream_t st);
 int sum_rows_run(const float* x, int rows, int C, float* out, hipStream_t st);
+int gelu_dropout_bwd_colsum_run(const void* x, const void* dy, void* out, int64_t n, int dtype, float p, uint64_t seed,
+                                const float* row_scale, int64_t elems_per_sample, int cols, float* partial, float* colsum,
+                                hipStream_t st);
+int gelu_colsum_parts();
 int triplet_attention_proj_supported(const tgt_triplet_attention_args* a, int C);
 int triplet_attention_proj_run(const tgt_triplet_attention_args* a, const void* x, int C, const void* w, const void* bias,
                                hipStream_t st);
@@ -76,7 +80,7 @@ using namespace tgt;
 extern "C" {
 
 const char* tgt_last_error(void) { return g_err; }
-int tgt_abi_version(void) { return 23; }
+int tgt_abi_version(void) { return 24; }
 
 int tgt_triplet_attention_fwd(const tgt_triplet_attention_args* a, void* stream) {
     return triplet_attention_run(a, false, reinterpret_cast<hipStream_t>(stream));
@@ -113,6 +117,13 @@ int tgt_gelu_dropout_fwd(const void* x, void* y, int64_t n, int32_t dtype, float
 int tgt_gelu_dropout_bwd(const void* x, const void* dy, void* dx, int64_t n, int32_t dtype, float p, uint64_t seed,
                          void* stream) {
     return gelu_dropout_run(x, dy, dx, n, dtype, p, seed, true, nullptr, 0, reinterpret_cast<hipStream_t>(stream));
+}
+int tgt_gelu_colsum_parts(void) { return gelu_colsum_parts(); }
+int tgt_gelu_dropout_bwd_colsum(const void* x, const void* dy, void* dx, int64_t n, int32_t dtype, float p, uint64_t seed,
+                                const float* sample_scale, int64_t elems_per_sample, int32_t cols, float* partial, float* colsum,
+                                void* stream) {
+    return gelu_dropout_bwd_colsum_run(x, dy, dx, n, dtype, p, seed, sample_scale, elems_per_sample, cols, partial, colsum,
+                                       reinterpret_cast<hipStream_t>(stream));
 }
 int tgt_gelu_dropout_scaled_fwd(const void* x, void* y, int64_t n, int32_t dtype, float p, uint64_t seed, const float* sample_scale,
                                 int64_t elems_per_sample, void* stream) {

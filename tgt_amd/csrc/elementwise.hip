@@ -11,12 +11,19 @@
 
 namespace tgt {
 
-template <typename T, bool BWD>
+// CS (backward only): also the column sums of `out` seen as (n / cols, cols) rows -- the bias gradient of the Linear in front of
+// the activation -- as one partial row per workgroup in cs_partial (gridDim.x, cols).  A thread's vectors all start at the same
+// column (the grid stride is a multiple of cols: host-checked), so it keeps 16/sizeof(T) float accumulators; the 256 / (cols/V)
+// threads of a workgroup that share a column group are folded through LDS.
+template <typename T, bool BWD, bool CS = false>
 __global__ void __launch_bounds__(256) gelu_dropout_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                           T* __restrict__ out, int64_t n, uint64_t seed,
                                                           uint32_t thresh, float inv_keep, const float* __restrict__ row_scale,
-                                                          int64_t elems_per_sample) {
+                                                          int64_t elems_per_sample, int cols = 0, float* __restrict__ cs_partial = nullptr) {
     constexpr int V = 16 / (int)sizeof(T);
+    float csum[CS ? V : 1];
+    if constexpr (CS)
+        for (int t = 0; t < V; ++t) csum[t] = 0.f;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x * V;
     for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * V; i < n; i += stride) {
         T xv[V], gv[V], ov[V];
@@ -48,6 +55,7 @@ __global__ void __launch_bounds__(256) gelu_dropout_kernel(const T* __restrict__
             if (!BWD) r = v * cdf;
             else r = to_f32(gv[t]) * (cdf + v * 0.3989422804014327f * e);
             ov[t] = from_f32<T>((thresh == 0u || keep[t]) ? r * ik : 0.f);
+            if constexpr (CS) csum[t] += (i + t < n) ? to_f32(ov[t]) : 0.f;        // of the value as stored
         }
         if (i + V <= n) {
             uint4 raw;
@@ -55,6 +63,20 @@ __global__ void __launch_bounds__(256) gelu_dropout_kernel(const T* __restrict__
             *reinterpret_cast<uint4*>(out + i) = raw;
         } else {
             for (int t = 0; t < V && i + t < n; ++t) out[i + t] = ov[t];
+        }
+    }
+    if constexpr (CS) {
+        __shared__ float fold[256 * V];
+#pragma unroll
+        for (int t = 0; t < V; ++t) fold[threadIdx.x * V + t] = csum[t];
+        __syncthreads();
+        const int groups = cols / V;                         // threads per row of vectors; 256 % groups == 0 (host-checked)
+        // thread tid starts at column ((blockIdx*256 + tid) * V) % cols = ((tid % groups) * V): (256 * V) % cols == 0
+        for (int c = threadIdx.x; c < cols; c += 256) {
+            const int gidx = c / V, e = c % V;
+            float v = 0.f;
+            for (int t = gidx; t < 256; t += groups) v += fold[t * V + e];
+            cs_partial[(int64_t)blockIdx.x * cols + c] = v;
         }
     }
 }
@@ -79,6 +101,44 @@ static int gd_launch(const void* x, const void* dy, void* out, int64_t n, float 
                            reinterpret_cast<const T*>(x), reinterpret_cast<const T*>(dy), reinterpret_cast<T*>(out), n,
                            seed, thresh, inv_keep, row_scale, eps_);
     return check_launch(bwd ? "gelu_dropout_bwd_kernel" : "gelu_dropout_fwd_kernel");
+}
+
+int sum_rows_run(const float* x, int rows, int C, float* out, hipStream_t st);      // layernorm.hip: fixed-order sum over rows
+
+static constexpr int kGdColsumParts = 4096;        // workgroups (= partial rows) of the column-sum variant: a grid-stride grid
+int gelu_colsum_parts() { return kGdColsumParts; }
+
+template <typename T>
+static int gd_colsum_launch(const void* x, const void* dy, void* out, int64_t n, float p, uint64_t seed, const float* row_scale,
+                            int64_t eps_, int cols, float* partial, float* colsum, hipStream_t st) {
+    const uint32_t thresh = p <= 0.f ? 0u : (uint32_t)fmin(65535.0, fmax(1.0, nearbyint((double)p * 65536.0)));
+    const float inv_keep = p <= 0.f ? 1.f : 1.f / (1.f - p);
+    constexpr int V = 16 / (int)sizeof(T);
+    if (cols % V || cols < V || (256 * V) % cols || n % cols)
+        return set_error(TGT_ERR_UNSUPPORTED, "gelu_dropout colsum: cols=%d must divide %d and n", cols, 256 * V);
+    int64_t blocks = (n / V + 255) / 256;
+    if (blocks > kGdColsumParts) blocks = kGdColsumParts;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((gelu_dropout_kernel<T, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const T*>(x),
+                       reinterpret_cast<const T*>(dy), reinterpret_cast<T*>(out), n, seed, thresh, inv_keep, row_scale, eps_, cols, partial);
+    if (int e = check_launch("gelu_dropout_bwd_colsum_kernel")) return e;
+    return sum_rows_run(partial, (int)blocks, cols, colsum, st);
+}
+
+int gelu_dropout_bwd_colsum_run(const void* x, const void* dy, void* out, int64_t n, int dtype, float p, uint64_t seed,
+                                const float* row_scale, int64_t elems_per_sample, int cols, float* partial, float* colsum,
+                                hipStream_t st) {
+    if (!x || !out || !dy || !partial || !colsum || n <= 0 || cols <= 0) return set_error(TGT_ERR_INVALID, "gelu_dropout colsum: bad argument");
+    if (p < 0.f || p >= 1.f) return set_error(TGT_ERR_INVALID, "gelu_dropout: p=%f outside [0,1)", p);
+    if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)dy) % 16) return set_error(TGT_ERR_INVALID, "gelu_dropout: tensors must be 16-byte aligned");
+    if (row_scale && (elems_per_sample <= 0 || elems_per_sample % 8 || n / 4 > 0xffffffffLL))
+        return set_error(TGT_ERR_INVALID, "gelu_dropout: row_scale needs elems_per_sample, a multiple of 8 (and n < 2^34)");
+    switch (dtype) {
+        case TGT_F32: return gd_colsum_launch<float>(x, dy, out, n, p, seed, row_scale, elems_per_sample, cols, partial, colsum, st);
+        case TGT_BF16: return gd_colsum_launch<bf16_t>(x, dy, out, n, p, seed, row_scale, elems_per_sample, cols, partial, colsum, st);
+        case TGT_F16: return gd_colsum_launch<f16_t>(x, dy, out, n, p, seed, row_scale, elems_per_sample, cols, partial, colsum, st);
+        default: return set_error(TGT_ERR_INVALID, "gelu_dropout: bad dtype %d", dtype);
+    }
 }
 
 int gelu_dropout_run(const void* x, const void* dy, void* out, int64_t n, int dtype, float p, uint64_t seed, bool bwd,

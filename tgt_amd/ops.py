@@ -1250,6 +1250,10 @@ def edge_linear_supported(K, N, dtype, epilogue=_lib.EPI_BIAS, ln=False, row_sca
     return bool(_lib.lib().tgt_edge_linear_supported(C.byref(g)))
 
 
+# A/B knob: lin_W1's bias gradient out of the activation's backward pass (tgt_gelu_dropout_bwd_colsum, ABI 24).  Parity-green; in the step
+# it LOSES 0.25 % (2496 / 2498 vs 2501 / 2505 graphs/s same-box): the 4096-workgroup grid-stride form and the eight accumulators per
+# vector cost the streaming kernel more than the 22 us column-sum pass they replace.  Off by default.
+_GELU_BWD_COLSUM = os.environ.get('TGT_GELU_BWD_COLSUM', '0') == '1'
 _FFN_GELU_EPI = os.environ.get('TGT_FFN_GELU_EPI', '1') != '0'     # A/B knob: lin_W1 + GELU + dropout as one launch on the edge rows
 # A/B knob: GELU backward as the epilogue of lin_W2's data-gradient GEMM (the closing node takes the activation detached and returns the
 # gradient of the pre-activation).  Parity-green, measured NEUTRAL in the step (2506.0 vs 2506.8 graphs/s over three same-box pairs: the
@@ -1291,20 +1295,35 @@ class _LinearGeluDropout(torch.autograd.Function):
         x2, w, pre, sample_scale = ctx.saved_tensors
         xs, xdt, wdt, bdt, p, seed, eps_ = ctx.meta
         d_pre = None
+        need_db = bdt is not None and ctx.needs_input_grad[2]
+        cs = None
         if d_act is not None:
             d_act = d_act.contiguous()
             d_pre = torch.empty_like(pre)
+            L = _lib.lib()
+            N = pre.shape[-1]
+            vec = 16 // pre.element_size()
             s, e = _prof_begin()
-            _lib.check(_lib.lib().tgt_gelu_dropout_scaled_bwd(_ptr(pre), _ptr(d_act), _ptr(d_pre), pre.numel(), _DT[pre.dtype], p, seed,
-                                                              _ptr(sample_scale), eps_, _stream()), 'tgt_gelu_dropout_bwd')
+            if _GELU_BWD_COLSUM and need_db and d_pre_in is None and N % vec == 0 and (256 * vec) % N == 0:
+                # the bias gradient of lin_W1 (column sums of d_pre) rides on the activation's backward pass: no separate
+                # reduction pass over the 134 MB gradient
+                cs = torch.empty(N, dtype=torch.float32, device=pre.device)
+                partial = torch.empty(L.tgt_gelu_colsum_parts() * N, dtype=torch.float32, device=pre.device)
+                _lib.check(L.tgt_gelu_dropout_bwd_colsum(_ptr(pre), _ptr(d_act), _ptr(d_pre), pre.numel(), _DT[pre.dtype], p, seed,
+                                                         _ptr(sample_scale), eps_, N, _ptr(partial), _ptr(cs), _stream()),
+                           'tgt_gelu_dropout_bwd_colsum')
+            else:
+                _lib.check(L.tgt_gelu_dropout_scaled_bwd(_ptr(pre), _ptr(d_act), _ptr(d_pre), pre.numel(), _DT[pre.dtype], p, seed,
+                                                         _ptr(sample_scale), eps_, _stream()), 'tgt_gelu_dropout_bwd')
             _prof_end('tgt_gelu_dropout_bwd', s, e)
         if d_pre_in is not None:
             d_pre = d_pre_in.contiguous() if d_pre is None else d_pre + d_pre_in
         if d_pre is None:
             return None, None, None, None, None, None, None
-        need_db = bdt is not None and ctx.needs_input_grad[2]
         dx, dw, db = _linear_backward(x2, w, d_pre.view(-1, d_pre.shape[-1]), xs, xdt, wdt, bdt, ctx.needs_input_grad[0],
-                                      ctx.needs_input_grad[1], need_db)
+                                      ctx.needs_input_grad[1], need_db and cs is None)
+        if need_db and cs is not None:
+            db = cs.to(bdt)
         return dx, dw, db, None, None, None, None
 
 
