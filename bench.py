@@ -322,17 +322,26 @@ def main():
                 cand[name] = (sum(times[name]), avg_ms, nbytes_k)
         # HBM bytes per launch from the PMC passes (collected offline with rocprofv3 --pmc, see
         # profiles/README.md); only valid for the shape they were measured at
-        traffic, pmc = {}, {}
-        tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-        ppath = os.path.join(ROOT, 'profiles', 'r02l_pmc_summary.json')      # tools/pmc_passes.sh: SQ / FETCH / WRITE passes
+        # The counters cannot be collected inside this run (rocprofv3 --pmc wraps the process), so `traffic` / `mfma_util` come
+        # from a tracked summary -- but ONLY from one measured on exactly these kernel sources (`_kernel_src_sha`, written by
+        # tools/pmc_summary.py) at this shape; anything else is reported as stale, not as a measurement.
+        traffic, pmc, pmc_note = {}, {}, None
         if args.batch == 256 and args.nodes == 32 and args.precision == 'bf16':
-            if os.path.exists(tpath):
-                traffic = json.load(open(tpath))
-            if os.path.exists(ppath):
-                pmc = json.load(open(ppath))
-                for short, name in (('tri_att_fwd_kernel', 'tgt_triplet_attention_fwd'), ('tri_att_bwd_kernel', 'tgt_triplet_attention_bwd')):
-                    if short in pmc and 'hbm_bytes_per_launch' in pmc[short]:
-                        traffic[name] = dict(traffic_bytes=pmc[short]['hbm_bytes_per_launch'])
+            sys.path.insert(0, os.path.join(ROOT, 'tools'))
+            from pmc_summary import kernel_source_sha
+            sha = kernel_source_sha(ROOT)
+            summaries = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_pmc_summary.json'))
+            for f in reversed(summaries):
+                cand_pmc = json.load(open(os.path.join(ROOT, 'profiles', f)))
+                if cand_pmc.get('_kernel_src_sha') == sha:
+                    pmc, pmc_note = cand_pmc, dict(file='profiles/' + f, kernel_src_sha=sha, match=True)
+                    break
+            if not pmc and summaries:
+                pmc_note = dict(file='profiles/' + summaries[-1], kernel_src_sha=sha, match=False,
+                                note='kernel sources changed since the last counter pass: traffic / mfma_util not quoted')
+            for short, name in (('tri_att_fwd_kernel', 'tgt_triplet_attention_fwd'), ('tri_att_bwd_kernel', 'tgt_triplet_attention_bwd')):
+                if short in pmc and 'hbm_bytes_per_launch' in pmc[short]:
+                    traffic[name] = dict(traffic_bytes=pmc[short]['hbm_bytes_per_launch'])
         roofline = None
         if cand:
             name = max(cand, key=lambda k: cand[k][0])
@@ -349,6 +358,7 @@ def main():
                             other_kernels={k: dict(avg_launch_ms=round(v[1], 4),
                                                    achieved=round(v[2] / (v[1] * 1e-3) / 1e9, 1))
                                            for k, v in cand.items() if k != name})
+            roofline['offline_pmc'] = pmc_note
             if skip_mode and drop_frac > 0:
                 roofline['droppath_skip'] = dict(kernels='forward' if skip_mode == '1' else 'forward+backward',
                                                  expected_dropped_fraction=drop_frac,
@@ -370,6 +380,9 @@ def main():
             metric='graphs/sec training step, TGT-At 24L PCQM batch 256, 1/2/4/8 MI355X',
             value=round(args.batch * world * args.steps / dt, 2), unit='graphs/s',
             n_gpus=world, steps=args.steps, warmup=args.warmup,
+            # what actually ran: the process group's size and backend as torch.distributed reports them (1 / None without one)
+            world=dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1,
+            rccl_ranks=dist.get_world_size() if (dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl') else 0,
             ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling='weak',
             vs_baseline=None, dtype=args.precision, data='synthetic',
             config=dict(workload='TGT-At 24L (TGT_Multi, 103.6M params, 512 dist bins) train step; '

@@ -247,7 +247,10 @@ int tgt_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
  * ---------------------------------------------------------------------- */
 enum { TGT_CTL_SCALE = 0, TGT_CTL_TRACKER = 1, TGT_CTL_FOUND_INF = 2, TGT_CTL_STEPS = 3, TGT_CTL_MULT = 4,
        TGT_CTL_COEF = 5, TGT_CTL_NORM = 6, TGT_CTL_SKIPPED = 7, TGT_CTL_LOSS = 8, TGT_CTL_SAMPLES = 9,
-       TGT_CTL_NAN = 10, TGT_CTL_PAIR = 12, TGT_CTL_SIZE = 16 };
+       TGT_CTL_NAN = 10, TGT_CTL_LOSS_LO = 11, TGT_CTL_PAIR = 12, TGT_CTL_SAMPLES_LO = 14, TGT_CTL_SIZE = 16 };
+/* TGT_CTL_LOSS / TGT_CTL_SAMPLES are (value, low-order part) float pairs with TGT_CTL_LOSS_LO / TGT_CTL_SAMPLES_LO: the running sums
+ * are value + low part (read both, add in float64).  TGT_CTL_STEPS is an exact float32 count up to 2^24 optimizer steps (the
+ * reference's longest schedule is 3e5).  TGT_CTL_COEF follows torch's clip_grad_norm_: NaN when the gradient norm is NaN. */
 int tgt_grad_stats_parts(void);
 int tgt_grad_scaler_step(const float* grad, int64_t n, float* ctl, float* partial, int32_t world,
                          float clip_value, float clip_norm, int32_t dynamic, float growth_factor,
@@ -265,13 +268,11 @@ int tgt_loss_accumulate(const void* loss, int32_t loss_is_f64, float samples, fl
 
 /* ------------------------------------------------------------------------
  * Edge-channel Linear with the neighbouring passes fused in (csrc/edge_gemm.hip):
- *     out[M, N] = epilogue( prologue(a[M, K]) . w[N, K]^T + bias )
- * Replaces, on the (B*N*N, C) edge rows, the nn.LayerNorm -> nn.Linear -> GELU/Dropout -> nn.Linear ->
- * residual add_ chains of reference lib/tgt/layers/layers.py:37-38,:62-80 (mha_ln_e, lin_EG, lin_O_e),
- * :155-160 (FFN), :270-290 (residual wiring) and lib/tgt/layers/triplet.py:207-211,:248-249
- * (tri_ln_e, lin_QKV/lin_EG projections, lin_O), forward and data-gradient.
- *   prologue (gamma != NULL and epilogue != LN_BWD): x = LayerNorm(a) over K (K <= 256), gamma/beta float32;
- *       mean / rstd (M) float32 written when given; y (M, K) = the normalised rows when given.
+ *     out[M, N] = epilogue( a[M, K] . w[N, K]^T + bias ),   K in {64, 128, 256}
+ * Replaces, on the (B*N*N, C) edge rows, the nn.Linear -> GELU/Dropout -> nn.Linear -> residual add_ -> nn.LayerNorm
+ * chains of reference lib/tgt/layers/layers.py:37-38,:62-80 (mha_ln_e, lin_EG, lin_O_e),
+ * :155-160 (FFN), :270-290 (residual wiring) and lib/tgt/layers/triplet.py:207-211 (tri_ln_e, lin_EG projections),
+ * forward and data-gradient.
  *   TGT_EPI_BIAS     out = z * out_scale[row / rows_per_sample]        (out_scale may be NULL)
  *   TGT_EPI_GELU     out2 = z (pre-activation);  out = dropout(gelu(z), dropout_p, dropout_seed)
  *                    (* row_scale[m / rows_per_sample] when given: N = 256, K in {64,128,256} only -- tgt_gelu_dropout_scaled_fwd's factor)
@@ -284,9 +285,12 @@ int tgt_loss_accumulate(const void* loss, int32_t loss_is_f64, float samples, fl
  *                    colsum_partial (tgt_edge_linear_parts(M, N), 3N) float32, ZERO-FILLED by the caller, when given: per row tile
  *                    [sum dy*xhat | sum dy | sum out2-or-out]: dgamma, dbeta and the bias gradient of the Linear
  *                    that produced the branch, to be summed over the tiles (tgt_sum_planes)
- * Element type 16-bit (TGT_BF16 / TGT_F16; bias in the same type); N % 8 == 0; K in {16,32,64,128} or a multiple
- * of 16 >= 256; not both K > 256 and N > 256.  tgt_edge_linear_supported() tells; anything else is the
- * caller's library GEMM + tgt_layer_norm_* path.
+ *   TGT_EPI_RESID with gamma / beta / y: additionally y = LayerNorm(out as stored; gamma, beta, eps), mean / rstd (M)
+ *                    float32 written when given (N <= 256): the fused entry of the next pre-norm sub-block.
+ * Element type 16-bit (TGT_BF16 / TGT_F16; bias in the same type); N % 8 == 0; K in {64, 128, 256}.
+ * tgt_edge_linear_supported() tells; anything else is the caller's library GEMM + tgt_layer_norm_* path.
+ * tgt_edge_linear_set_grid_cap(cap): TEST HOOK -- at most `cap` persistent workgroups per launch (0 = no cap), so that small
+ * problems walk several row tiles per workgroup the way the BASELINE-size launches do.
  * ---------------------------------------------------------------------- */
 enum { TGT_EPI_BIAS = 0, TGT_EPI_GELU = 1, TGT_EPI_RESID = 2, TGT_EPI_GELU_BWD = 3, TGT_EPI_LN_BWD = 4 };
 /* flags.  TGT_EDGE_BIAS_SCALED (TGT_EPI_RESID, N = 256, K in {64,128,256}): a arrives PRE-SCALED by row_scale (its producer
@@ -314,6 +318,7 @@ typedef struct tgt_edge_linear_args {
 int tgt_edge_linear_supported(const tgt_edge_linear_args* a);
 int tgt_edge_linear_parts(int64_t M, int32_t N);
 int tgt_edge_linear(const tgt_edge_linear_args* a, void* stream);
+void tgt_edge_linear_set_grid_cap(int32_t cap);
 
 /* ------------------------------------------------------------------------
  * LayerNorm over the last axis (the five per-layer norms of the TGT layer:

@@ -41,14 +41,15 @@ def _slice(batch, lo, hi):
     return {k: v[lo:hi] for k, v in batch.items()}
 
 
-def _worker(rank, world, port, kwargs, bucket_mb, result, comm=None):
+def _worker(rank, world, port, kwargs, bucket_mb, result, comm=None, exchange='all_reduce'):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from tgt_amd.training.step import Trainer, StepConfig
     torch.set_num_threads(2)
     model = _make(kwargs, seed=11 + rank)            # ranks start DIFFERENT: broadcast must fix it
-    tr = Trainer(model, StepConfig(mixed_precision=None, bucket_mbytes=bucket_mb, grad_comm_dtype=comm), loss_fn=_gap_l1)
+    tr = Trainer(model, StepConfig(mixed_precision=None, bucket_mbytes=bucket_mb, grad_comm_dtype=comm, grad_exchange=exchange),
+                 loss_fn=_gap_l1)
     full = _batch(4, 6, seed=5)
     part = _slice(full, 2 * rank, 2 * rank + 2)
     tr.global_step += 1
@@ -100,6 +101,32 @@ def test_bf16_gradient_exchange_option():
     ref = tr.flat.grad
     err = (result['grad'] - ref).norm() / ref.norm()
     assert 0 < err < 1e-2, err          # not bit-identical (it IS compressed), within bfloat16 rounding
+
+
+@pytest.mark.parametrize('variant', ['bucketed', 'shared_weights', 'bf16_wire'])
+def test_reduce_scatter_all_gather_exchange_option(variant):
+    """grad_exchange='reduce_scatter' (reduce-scatter + all-gather per bucket, the form that uses all xGMI
+    links of the mesh at once): the same averaged gradients as the single-rank run, bucketed, for weight-shared models (one
+    exchange after backward) and with the bfloat16 wire format."""
+    kwargs = dict(gu.MODEL_CASES['gap_at_tiny'][1])
+    kwargs['embed_3d_type'] = 'none'
+    if variant == 'shared_weights':
+        kwargs['layer_multiplier'] = 2
+    mgr = mp.Manager()
+    result = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), kwargs, 64 if variant == 'shared_weights' else 0, result,
+                            'bf16' if variant == 'bf16_wire' else None, 'reduce_scatter'), nprocs=2, join=True)
+    from tgt_amd.training.step import Trainer, StepConfig
+    tr = Trainer(_make(kwargs, seed=11), StepConfig(mixed_precision=None), loss_fn=_gap_l1)
+    assert torch.equal(result['param'], tr.flat.param)
+    tr.compute_gradients(_batch(4, 6, seed=5))
+    ref = tr.flat.grad
+    if variant == 'bf16_wire':
+        err = (result['grad'] - ref).norm() / ref.norm()
+        assert 0 < err < 1e-2, err
+    else:
+        err = (result['grad'] - ref).abs().max() / ref.abs().max()
+        assert err < 1e-5, err
 
 
 def test_flat_state_views_alias_parameters():

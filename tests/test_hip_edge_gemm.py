@@ -37,8 +37,8 @@ def _ln64(x, gamma, beta, eps):
     return (x - mu) * rstd * gamma.double() + beta.double(), mu.squeeze(-1), rstd.squeeze(-1)
 
 
-SHAPES = [(300, 16, 8), (300, 32, 24), (257, 64, 256), (1000, 128, 128), (1024, 256, 128), (513, 256, 256),
-          (640, 256, 1600), (384, 512, 256), (200, 1600, 256), (130, 272, 64), (128, 256, 64)]
+SHAPES = [(300, 64, 8), (300, 64, 24), (257, 64, 256), (1000, 128, 128), (1024, 256, 128), (513, 256, 256),
+          (640, 256, 1600), (384, 128, 256), (130, 256, 32), (128, 256, 64)]
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
@@ -57,28 +57,6 @@ def test_plain_linear_matches_float64(M, K, N, dtype):
     ref = (av.double() @ w.double().t()) * sc.double().repeat_interleave(100)[:M, None]
     assert rel(dst[:, :N], ref) < TOL[dtype]
     assert torch.all(dst[:, N:] == 7.0)                 # nothing written past the N columns
-
-
-@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize('M,K,N', [s for s in SHAPES if s[1] <= 256 and s[1] in (16, 32, 64, 128, 256)])
-def test_layernorm_prologue(M, K, N, dtype):
-    a, w, b, g = _mk(M, K, N, dtype, 2)
-    a = (a.float() * 1.7 + 0.3).to(dtype)
-    gamma = torch.rand(K, device='cuda', generator=g) + 0.5
-    beta = torch.randn(K, device='cuda', generator=g) * 0.2
-    mean = torch.empty(M, device='cuda')
-    rstd = torch.empty(M, device='cuda')
-    y = torch.empty(M, K, dtype=dtype, device='cuda')
-    out = ops.edge_linear_raw(a, w, b, ln=(gamma, beta, 1e-5), stats=(mean, rstd), y=y)
-    y64, mu64, rs64 = _ln64(a, gamma, beta, 1e-5)
-    assert rel(mean, mu64) < 1e-5 and rel(rstd, rs64) < 1e-5
-    assert rel(y, y64) < TOL[dtype]
-    # the GEMM consumes the normalised rows as stored (rounded): compare against exactly that
-    ref = y.double() @ w.double().t() + b.double()
-    assert rel(out, ref) < TOL[dtype]
-    # bit-identical to the standalone LayerNorm kernel's output and statistics
-    y2 = ops.layer_norm(a, gamma, beta, 1e-5, out_dtype=dtype)
-    assert rel(y, y2) < 2e-3 if dtype == torch.bfloat16 else 3e-4
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
@@ -102,7 +80,7 @@ def test_gelu_dropout_epilogue_equals_standalone_kernel(M, K, N, dtype, p):
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize('M,K,N', [(300, 16, 64), (700, 64, 256), (513, 256, 256), (384, 512, 256)])
+@pytest.mark.parametrize('M,K,N', [(300, 64, 64), (700, 64, 256), (513, 256, 256), (384, 128, 256)])
 def test_residual_epilogue(M, K, N, dtype):
     a, w, b, g = _mk(M, K, N, dtype, 4)
     res = torch.randn(M, N, device='cuda', generator=g).to(dtype)
@@ -157,7 +135,7 @@ def test_gelu_backward_epilogue_equals_standalone_kernel(dtype, p):
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize('M,K,N,with_ds,with_scale', [(300, 128, 256, True, True), (513, 1600, 256, True, False),
+@pytest.mark.parametrize('M,K,N,with_ds,with_scale', [(300, 128, 256, True, True), (513, 64, 256, True, False),
                                                       (260, 256, 128, False, True), (200, 64, 64, False, False),
                                                       (1024, 256, 256, True, True)])
 def test_layernorm_backward_epilogue(M, K, N, with_ds, with_scale, dtype):
@@ -198,9 +176,13 @@ def test_unsupported_shapes_raise_instead_of_falling_back():
     a, w, b, _ = _mk(64, 48, 64, torch.bfloat16, 7)
     with pytest.raises(RuntimeError, match='unsupported'):
         ops.edge_linear_raw(a, w, b)
-    a, w, b, _ = _mk(64, 512, 512, torch.bfloat16, 7)
-    with pytest.raises(RuntimeError, match='unsupported'):
-        ops.edge_linear_raw(a, w, b)
+    for K, N in ((512, 512), (16, 64), (272, 64), (1600, 256)):      # (the general tile kernel of round 2 is gone)
+        a, w, b, _ = _mk(64, K, N, torch.bfloat16, 7)
+        with pytest.raises(RuntimeError, match='unsupported'):
+            ops.edge_linear_raw(a, w, b)
+    a, w, b, g = _mk(64, 256, 256, torch.bfloat16, 7)
+    with pytest.raises(RuntimeError, match='unsupported'):            # no LayerNorm prologue any more
+        ops.edge_linear_raw(a, w, b, ln=(torch.ones(256, device='cuda'), torch.zeros(256, device='cuda'), 1e-5))
     with pytest.raises(RuntimeError):
         ops.edge_linear_raw(a.float(), w.float(), b.float())
 
@@ -400,3 +382,143 @@ def test_gelu_backward_with_bias_gradient_column_sums(dtype, rows, cols, p):
     assert torch.equal(dx0, dx1)
     want = dx0.double().sum(0)
     assert float((cs.double() - want).abs().max()) <= 1e-5 * float(want.abs().max()) + 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE size: M = B*N*N = 262144 rows -> 8192 row tiles on 256 persistent workgroups = 32 tiles per workgroup.
+# Everything above runs <= 1 tile per workgroup (unless capped); these cases walk the double-buffered stage hand-over
+# and the cross-tile accumulators of every DEFAULT-ON instantiation the way the benchmark does.
+#   (1) sampled row blocks (first / last tiles, a workgroup's 2nd..4th tile, odd tile indices) against float64;
+#   (2) slice equality: rows [s:e) of the full launch == a launch on that slice alone, bit for bit (a row's result
+#       does not depend on which workgroup / pipeline stage computed it).
+# ---------------------------------------------------------------------------------------------------------------
+SIZE_M = 262144
+SIZE_BLOCKS = [(0, 96), (32 * 255, 32 * 258), (32 * 256 * 3 - 32, 32 * 256 * 3 + 64), (32 * 4001, 32 * 4004),
+               (SIZE_M - 128, SIZE_M)]
+SIZE_SLICES = [(0, 4096), (32 * 1000 + 0, 32 * 1000 + 2048), (SIZE_M - 1024, SIZE_M)]
+SIZE_CASES = {
+    # name: (K, N, epilogue, prescaled bias, LayerNorm of the new row, row_scale)
+    'lin_W2+res+LN (K=256)': (256, 256, 'resid', False, True, True),
+    'lin_W2+res+LN prescaled (K=256)': (256, 256, 'resid', True, True, True),
+    'lin_O_e+res+LN prescaled (K=64)': (64, 256, 'resid', True, True, True),
+    'lin_O_e+res+LN (K=64)': (64, 256, 'resid', False, True, False),
+    'lin_W1+GELU+dropout (K=256)': (256, 256, 'gelu', False, False, True),
+    'lin_EG slice (N=128)': (256, 128, 'bias', False, False, False),
+    'third arm slice (N=64)': (256, 64, 'bias', False, False, False),
+    'ungated third arm slice (N=32)': (256, 32, 'bias', False, False, False),
+}
+
+
+def _size_case_run(case, a, w, b, res, sc, gamma, beta, rps, p=0.0, seed=0):
+    K, N, epi, pres, ln, with_sc = SIZE_CASES[case]
+    M = a.shape[0]
+    scale = sc if with_sc else None
+    if epi == 'bias':
+        return (ops.edge_linear_raw(a, w, b),)
+    if epi == 'gelu':
+        pre = torch.empty(M, N, dtype=a.dtype, device='cuda')
+        act = ops.edge_linear_raw(a, w, b, _lib.EPI_GELU, out2=pre, dropout=(p, seed), row_scale=scale, rows_per_sample=rps)
+        return act, pre
+    mean, rstd = torch.empty(M, device='cuda'), torch.empty(M, device='cuda')
+    y = torch.empty(M, N, dtype=a.dtype, device='cuda')
+    out = ops.edge_linear_raw(a, w, b, _lib.EPI_RESID, res=res, row_scale=scale, rows_per_sample=rps, ln=(gamma, beta, 1e-5),
+                              stats=(mean, rstd), y=y, flags=_lib.EDGE_BIAS_SCALED if pres else 0)
+    return out, y, mean, rstd
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('case', list(SIZE_CASES))
+def test_default_on_instantiations_at_baseline_size(case, dtype):
+    K, N, epi, pres, ln, with_sc = SIZE_CASES[case]
+    M, rps = SIZE_M, 1024
+    a, w, b, g = _mk(M, K, N, dtype, 31)
+    res = (torch.randn(M, N, device='cuda', generator=g) * 1.5).to(dtype)
+    sc = (torch.rand(M // rps, device='cuda', generator=g) > 0.2).float() / 0.8
+    gamma = torch.rand(N, device='cuda', generator=g) + 0.5
+    beta = torch.randn(N, device='cuda', generator=g) * 0.2
+    full = _size_case_run(case, a, w, b, res, sc, gamma, beta, rps)
+    torch.cuda.synchronize()
+    # (1) float64 on sampled row blocks
+    for s, e in SIZE_BLOCKS:
+        z = a[s:e].double() @ w.double().t()
+        f = sc.double().repeat_interleave(rps)[s:e, None] if with_sc else 1.0
+        if epi == 'bias':
+            assert rel(full[0][s:e], z + b.double()) < TOL[dtype], (case, s)
+        elif epi == 'gelu':
+            assert rel(full[1][s:e], z + b.double()) < TOL[dtype], (case, s)
+            pre = full[1][s:e].double()                              # the activation is a function of the STORED pre-activation
+            act = pre * 0.5 * (1 + torch.erf(pre / math.sqrt(2.0))) * f
+            assert rel(full[0][s:e], act) < TOL[dtype], (case, s)
+        else:
+            ref = res[s:e].double() + ((z + f * b.double()) if pres else (z + b.double()) * f)
+            assert rel(full[0][s:e], ref) < TOL[dtype], (case, s)
+            y64, mu64, rs64 = _ln64(full[0][s:e], gamma, beta, 1e-5)  # of the row AS STORED
+            assert rel(full[2][s:e], mu64) < 1e-5 and rel(full[3][s:e], rs64) < 1e-5, (case, s)
+            assert rel(full[1][s:e], y64) < TOL[dtype], (case, s)
+    # (2) slice equality, bit for bit (dropout off: its keep pattern is indexed by the absolute row)
+    for s, e in SIZE_SLICES:
+        part = _size_case_run(case, a[s:e], w, b, res[s:e], sc[s // rps:], gamma, beta, rps)
+        for t_full, t_part in zip(full, part):
+            assert torch.equal(t_full[s:e], t_part), (case, s)
+    # nothing non-finite anywhere, and the ragged end (M not a multiple of the 32-row tile) leaves the tail alone
+    for t in full:
+        assert bool(torch.isfinite(t.float()).all())
+    Mr = M - 17
+    sent = [torch.full_like(t, 7.0) for t in full]
+    if epi == 'bias':
+        ops.edge_linear_raw(a[:Mr], w, b, out=sent[0][:Mr])
+        assert torch.equal(sent[0][:Mr], full[0][:Mr]) and bool((sent[0][Mr:] == 7.0).all())
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_gelu_dropout_epilogue_at_baseline_size_equals_standalone_kernel(dtype):
+    """lin_W1 + GELU + dropout (p > 0, per-graph DropPath factor) at M = 262144: the stored activation equals the standalone
+    activation kernel's function of the stored pre-activation -- same keep pattern, every element."""
+    M, K, N, rps, p, seed = SIZE_M, 256, 256, 1024, 0.1, 0x5eed1234
+    a, w, b, g = _mk(M, K, N, dtype, 37)
+    sc = (torch.rand(M // rps, device='cuda', generator=g) > 0.2).float() / 0.8
+    pre = torch.empty(M, N, dtype=dtype, device='cuda')
+    act = ops.edge_linear_raw(a, w, b, _lib.EPI_GELU, out2=pre, dropout=(p, seed), row_scale=sc, rows_per_sample=rps)
+    y = torch.empty_like(pre)
+    _lib.check(_lib.lib().tgt_gelu_dropout_scaled_fwd(pre.data_ptr(), y.data_ptr(), pre.numel(), ops._DT[dtype], p, seed,
+                                                      sc.data_ptr(), rps * N, None), 'gd')
+    torch.cuda.synchronize()
+    # same arithmetic, compiled twice: hipcc contracts the erf polynomial into other fma forms in the two kernels, so one element
+    # in ~1e5 differs by one unit in the last place of the 16-bit result (the 1024-row test above never meets one).  The KEEP
+    # PATTERN must be identical.
+    assert torch.equal(act == 0, y == 0)
+    diff = (act.float() - y.float()).abs()
+    assert float((diff > 0).float().mean()) < 1e-4
+    assert float((diff / y.float().abs().clamp_min(1e-3)).max()) < (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -9)
+    kept = float((act.view(M // rps, -1)[sc > 0] != 0).float().mean())
+    assert abs(kept - (1 - p)) < 5e-3
+    for s, e in SIZE_BLOCKS:
+        assert rel(pre[s:e], a[s:e].double() @ w.double().t() + b.double()) < TOL[dtype]
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('case', ['lin_W2+res+LN prescaled (K=256)', 'lin_O_e+res+LN prescaled (K=64)', 'lin_W1+GELU+dropout (K=256)',
+                                  'lin_EG slice (N=128)'])
+@pytest.mark.parametrize('cap', [1, 3])
+def test_grid_cap_hook_walks_many_tiles_per_workgroup(case, dtype, cap):
+    """tgt_edge_linear_set_grid_cap: with `cap` persistent workgroups a 50-tile problem is 17..50 tiles per workgroup; the result
+    must equal the uncapped launch bit for bit (what the small-model tests rely on to exercise the tile walk)."""
+    K, N, epi, pres, ln, with_sc = SIZE_CASES[case]
+    M, rps = 1600 - 9, 100
+    a, w, b, g = _mk(M, K, N, dtype, 41)
+    res = torch.randn(M, N, device='cuda', generator=g).to(dtype)
+    sc = (torch.rand(-(-M // rps), device='cuda', generator=g) > 0.2).float() / 0.8
+    gamma = torch.rand(N, device='cuda', generator=g) + 0.5
+    beta = torch.randn(N, device='cuda', generator=g) * 0.2
+    ref = _size_case_run(case, a, w, b, res, sc, gamma, beta, rps)
+    try:
+        _lib.lib().tgt_edge_linear_set_grid_cap(cap)
+        got = _size_case_run(case, a, w, b, res, sc, gamma, beta, rps)
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib().tgt_edge_linear_set_grid_cap(0)
+    for r_, g_ in zip(ref, got):
+        assert torch.equal(r_, g_), case
+    z = a.double() @ w.double().t()
+    if epi == 'bias':
+        assert rel(got[0], z + b.double()) < TOL[dtype]

@@ -397,3 +397,101 @@ def test_drop_path_folded_into_producers_matches_the_plain_wiring(monkeypatch):
         assert (a[4][k] is None) == (b[4][k] is None), k
         if b[4][k] is not None and float(b[4][k].abs().max()) > 0:
             assert rel(a[4][k], b[4][k]) < 6e-2, (k, rel(a[4][k], b[4][k]))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The BASELINE-size code path at model level.  ops._EDGE_MIN_ROWS / _SPLIT_MIN_ROWS (65536 rows) keep every small model
+# test above on the UNFUSED edge path; the benchmark (262144 rows) runs the fused tgt_edge_linear launches, 32 row tiles per
+# persistent workgroup.  These tests (a) put the golden 24L cases on the fused path with the workgroup count capped, so
+# that each workgroup walks >= 3 tiles, and (b) hold a B = 256 run to the B = 8 slice the oracle pins.
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.fixture
+def fused_edge_path(monkeypatch):
+    from tgt_amd import ops, _lib
+    monkeypatch.setattr(ops, '_EDGE_MIN_ROWS', 1)
+    monkeypatch.setattr(ops, '_SPLIT_MIN_ROWS', 1)
+    _lib.lib().tgt_edge_linear_set_grid_cap(2)          # 288 rows = 9 row tiles on 2 workgroups: 5 and 4 tiles each
+    yield
+    _lib.lib().tgt_edge_linear_set_grid_cap(0)
+
+
+def test_full_width_24L_on_the_fused_edge_path_vs_reference_golden(fused_edge_path):
+    """TGT-At 24L at BASELINE widths, bf16 autocast, every edge Linear on the fused launches of the benchmark
+    (lin_O_e / lin_W2 + residual + LayerNorm, lin_W1 + GELU, slice kernels, split projection), >= 4 tiles per workgroup:
+    eval forward vs the reference's fp32 CPU forward, and loss + parameter gradients vs the oracle (dropouts off)."""
+    from tgt_amd import ops
+    from tgt_amd.pcqm import TGT_Multi
+    from tgt_amd.training.step import pretrain_loss, StepConfig
+    geom = dict(B=2, N=12, num_nodes=[12, 9])
+    # forward, against the golden file of test_full_width_24L_forward_vs_reference_golden
+    model = gu.fill_params(TGT_Multi(**gu.FULL_AT_CFG), seed=900).cuda().eval()
+    batch = {k: v.cuda() for k, v in gu.model_batch(geom, seed=901).items()}
+    z = np.load(os.path.join(gu.GOLDEN_DIR, 'model_full_at_24L_fp32.npz'))
+    prof = ops.profile_kernels(True)
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+        gap16, logits16 = model(batch)
+    torch.cuda.synchronize()
+    ops.profile_kernels(False)
+    assert len(prof.get('tgt_edge_linear', ())) >= 24 * 5, {k: len(v) for k, v in prof.items()}     # the fused path DID run
+    f16 = logits16.double().cpu().numpy().reshape(-1)
+    idx = gu.sample_index(f16.size)
+    ref_s = z['logits::samples']
+    assert np.linalg.norm(f16[idx] - ref_s) <= 3e-2 * np.linalg.norm(ref_s)
+    assert np.abs(gap16.double().cpu().numpy() - z['gap::full']).max() < 5e-2
+    del model
+    # training-step-equivalent, against the oracle (as test_full_width_24L_training_gradients_vs_oracle, bf16 leg)
+    cpu = gu.model_batch(geom, seed=911)
+    ref = gu.fill_params(om.TGT_Multi(**gu.FULL_AT_CFG), seed=910).train()
+    g_ref, l_ref = ref(cpu)
+    loss_ref = torch.nn.functional.l1_loss(g_ref, cpu['target']) + 0.1 * core.binned_distance_xent(
+        l_ref, core.pairwise_dist(cpu['dft_coords']), cpu['edge_mask'], 512, 8)
+    loss_ref.backward()
+    pr = dict(ref.named_parameters())
+    drift = gu.bf16_drift('full_at_24L')
+    batch = {k: v.cuda() for k, v in cpu.items()}
+    cfg = StepConfig(num_dist_bins=512, mixed_precision=None)
+    model = gu.fill_params(TGT_Multi(**gu.FULL_AT_CFG), seed=910).cuda().train()
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        loss = pretrain_loss(model(batch), batch, cfg)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-3 * abs(float(loss_ref.detach()))
+    pm = dict(model.named_parameters())
+    for k in gu.FULL_GRAD_KEYS:
+        tol = 2.0 * drift['pgrad.' + k]
+        assert rel(pm[k].grad, pr[k].grad) < tol, (k, rel(pm[k].grad, pr[k].grad), tol)
+
+
+def test_baseline_batch_256_equals_its_8_graph_slice():
+    """BASELINE config 2 geometry (TGT-At 24L, B = 256, N = 32, bf16 autocast, dropouts off): graphs are independent, so the
+    outputs of graphs [0:8] inside the 256-graph batch must equal a run on those 8 graphs alone -- the size the oracle pins --
+    and the parameter gradients of a loss that only sees those 8 graphs must equal the 8-graph run's.  Not bit for bit: the
+    library picks other GEMM tilings for 262144 rows than for 8192; the stated bound is the reference's own bf16 drift
+    (tests/golden/bf16_drift.npz, full_at_24L), i.e. the two runs may differ by no more than bf16 arithmetic itself does."""
+    from tgt_amd.pcqm import TGT_Multi
+    from tgt_amd.training.configs import tgt_at_24l
+    from tgt_amd.training.step import StepConfig, preprocess_batch
+    from tgt_amd.training.synthetic import make_batch
+    cfg = StepConfig(num_dist_bins=512, mixed_precision='bf16', coords_noise=0.0)
+    torch.manual_seed(0)
+    model = TGT_Multi(**tgt_at_24l(dropouts=False)).cuda().train()
+    host = make_batch(256, 32, seed=4242)
+    big = preprocess_batch(host, 'cuda', cfg, add_noise=False)
+    small = {k: v[:8].contiguous() for k, v in big.items()}
+    drift = gu.bf16_drift('full_at_24L')
+    keys = gu.FULL_GRAD_KEYS
+    runs = []
+    for b in (big, small):
+        model.zero_grad(set_to_none=True)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            gap, logits = model(b)
+        ((gap[:8].float() ** 2).sum() + (logits[:8].float() ** 2).mean()).backward()
+        torch.cuda.synchronize()
+        runs.append((gap[:8].detach().clone(), logits[:8].detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()
+                                                                             if k in keys}))
+    (g256, l256, p256), (g8, l8, p8) = runs
+    assert rel(l256, l8) < 2.0 * drift['logits'], rel(l256, l8)
+    assert float((g256 - g8).abs().max()) < 2e-2, float((g256 - g8).abs().max())
+    assert float((l256.argmax(-1) == l8.argmax(-1)).float().mean()) > 0.97
+    tol = 2.0 * max(v for k, v in drift.items() if k.startswith('pgrad.'))      # (another loss than the drift file's: one bound for all)
+    for k in keys:
+        assert rel(p256[k], p8[k]) < tol, (k, rel(p256[k], p8[k]), tol)

@@ -199,3 +199,14 @@ def test_hipgraph_replay_of_the_forward_is_bit_identical():
             assert torch.equal(gf(b), want)
     with pytest.raises(RuntimeError):
         gf({k: (v[:2] if k == 'node_mask' else v) for k, v in b0.items()})
+    # a missing / extra key must not silently replay the example batch's data
+    with pytest.raises(RuntimeError, match='keys'):
+        gf({k: v for k, v in b0.items() if k != 'node_mask'})
+    with pytest.raises(RuntimeError, match='keys'):
+        gf(dict(b0, extra=b0['node_mask']))
+    # a train-mode model with dropout would replay ONE captured drop pattern (S identical "Monte-Carlo samples"): refused
+    dk2 = dict(dk, source_dropout=0.3, drop_path=0.1, edge_act_dropout=0.1)
+    noisy = gu.fill_params(TGT_Distance(**dk2), seed=32).cuda().train()
+    with pytest.raises(RuntimeError, match='train mode'):
+        GraphedForward(noisy, b0)
+    GraphedForward(noisy.eval(), b0)

@@ -173,13 +173,18 @@ def _free_port():
     return p
 
 
-def _world2_worker(rank, world, port, out_dir, side_stream):
+def _world2_worker(rank, world, port, out_dir, side_stream, backend='gloo', exchange='all_reduce'):
     import os
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
-    torch.cuda.set_device(0)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # (dmabuf IPC: what the host driver supports)
+    if backend == 'nccl':                                           # RCCL: one device per rank, as bench.py / the reference run
+        torch.cuda.set_device(rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', rank))
+    else:
+        torch.cuda.set_device(0)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
     from tgt_amd import ops
     from tgt_amd.pcqm import TGT_Multi
     from tgt_amd.training.step import Trainer, StepConfig, preprocess_batch
@@ -188,7 +193,7 @@ def _world2_worker(rank, world, port, out_dir, side_stream):
     kwargs = dict(gu.MODEL_CASES['multi_at_tiny'][1])
     kwargs.update(model_height=4)
     cfg = StepConfig(num_dist_bins=24, mixed_precision='bf16', coords_noise=0.0, bucket_mbytes=0.05,
-                     lr_warmup_steps=10, lr_total_steps=100)
+                     lr_warmup_steps=10, lr_total_steps=100, grad_exchange=exchange)
     model = gu.fill_params(TGT_Multi(**kwargs), seed=5 + rank).cuda().eval()       # ranks start DIFFERENT: the broadcast fixes it
     tr = Trainer(model, cfg)
     assert tr.distributed and tr.world == 2 and tr.buckets is not None and len(tr.buckets) > 4
@@ -207,15 +212,10 @@ def _world2_worker(rank, world, port, out_dir, side_stream):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('side_stream', [True, False])
-def test_world2_on_one_gpu_matches_single_rank(tmp_path, side_stream):
-    """two ranks on disjoint half-batches == one rank on the whole batch (per-graph-mean losses; SURVEY 8e), and both ranks
-    hold the same parameters after three optimizer steps"""
-    import torch.multiprocessing as mp
+def _check_world2_against_single_rank(tmp_path):
     from tgt_amd.pcqm import TGT_Multi
     from tgt_amd.training.step import Trainer, StepConfig, preprocess_batch
     from tgt_amd.training.synthetic import make_batch
-    mp.spawn(_world2_worker, args=(2, _free_port(), str(tmp_path), side_stream), nprocs=2, join=True)
     r0 = torch.load(tmp_path / 'rank0.pt')
     r1 = torch.load(tmp_path / 'rank1.pt')
     assert torch.equal(r0['param'], r1['param'])                # replicas stay bit-identical
@@ -235,3 +235,25 @@ def test_world2_on_one_gpu_matches_single_rank(tmp_path, side_stream):
         assert rel(r0['grads'][step], tr.flat.grad) < 2e-2, (step, rel(r0['grads'][step], tr.flat.grad))
         tr.apply_gradients()
     assert rel(r0['param'], tr.flat.param) < 1e-3
+
+
+@pytest.mark.parametrize('side_stream', [True, False])
+def test_world2_on_one_gpu_matches_single_rank(tmp_path, side_stream):
+    """two ranks on disjoint half-batches == one rank on the whole batch (per-graph-mean losses; SURVEY 8e), and both ranks
+    hold the same parameters after three optimizer steps.  Two ranks SHARE cuda:0 and exchange device tensors over gloo (RCCL
+    refuses two ranks on one device); the RCCL form of the same test follows."""
+    import torch.multiprocessing as mp
+    mp.spawn(_world2_worker, args=(2, _free_port(), str(tmp_path), side_stream), nprocs=2, join=True)
+    _check_world2_against_single_rank(tmp_path)
+
+
+@pytest.mark.parametrize('exchange', ['all_reduce', 'reduce_scatter'])
+def test_world2_over_rccl_matches_single_rank(tmp_path, exchange):
+    """BASELINE config 3's exchange on real links: two ranks, one MI355X each, backend 'nccl' (= RCCL over xGMI) -- bucketed
+    all-reduce from the gradient hooks (and the reduce-scatter + all-gather option), rank-0 broadcast, packed loss all-reduce.
+    Skips on a box with one GPU (the 1-GPU test boxes); runs wherever torch sees two."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip(f'needs 2 GPUs for two RCCL ranks, this box has {torch.cuda.device_count()}')
+    import torch.multiprocessing as mp
+    mp.spawn(_world2_worker, args=(2, _free_port(), str(tmp_path), True, 'nccl', exchange), nprocs=2, join=True)
+    _check_world2_against_single_rank(tmp_path)

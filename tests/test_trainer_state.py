@@ -70,3 +70,32 @@ def test_new_flat_state_drops_stale_shadows():
         p._lp = p.detach().to(torch.bfloat16)          # what an earlier mixed-precision Trainer left behind
     FlatState(m)
     assert not any(hasattr(p, '_lp') for p in m.parameters())
+
+
+def test_trainer_close_releases_the_side_stream_and_the_hook():
+    """A dropped or closed Trainer must give the node side stream back (ops.side_stream is only safe while a Trainer orders the
+    gradient collection after both streams; torch DDP's reducer does not) and must not stay alive through its
+    load_state_dict hook."""
+    import gc
+    import weakref
+    from tgt_amd import ops
+    base = ops.side_stream._owners
+    m = _model()
+    hooks0 = len(m._load_state_dict_post_hooks)
+    tr = Trainer(m, StepConfig(mixed_precision=None), loss_fn=_loss)
+    assert ops.side_stream._owners == base + 1 and len(m._load_state_dict_post_hooks) == hooks0 + 1
+    tr.close()
+    tr.close()                                       # idempotent
+    assert ops.side_stream._owners == base and len(m._load_state_dict_post_hooks) == hooks0
+    m.load_state_dict(m.state_dict())                # no stale hook fires
+    # garbage collection alone does the same, and the hook does not keep the trainer (and its flat buffers) alive
+    tr2 = Trainer(m, StepConfig(mixed_precision=None), loss_fn=_loss)
+    ref = weakref.ref(tr2)
+    assert ops.side_stream._owners == base + 1
+    del tr2
+    gc.collect()
+    assert ref() is None
+    assert ops.side_stream._owners == base and len(m._load_state_dict_post_hooks) == hooks0
+    with Trainer(m, StepConfig(mixed_precision=None), loss_fn=_loss):
+        assert ops.side_stream._owners == base + 1
+    assert ops.side_stream._owners == base

@@ -5,6 +5,7 @@ RuntimeError is raised.  The library is built in-tree by `build_library()`
 (`__graft_entry__.build()` calls it) with hipcc for gfx950.
 """
 import ctypes as C
+import hashlib
 import importlib.util
 import os
 import shutil
@@ -17,7 +18,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 SOURCES = ['capi.hip', 'optimizer.hip', 'edge_gemm.hip', 'params.hip', 'loss.hip', 'predict.hip', 'gaussian.hip', 'triplet_attention_proj.hip',
            ('triplet_attention.hip', ['-DTGT_TRI_INST=9'], '.f32'), ('triplet_attention.hip', ['-DTGT_TRI_INST=2'], '.bf16'),
            ('triplet_attention.hip', ['-DTGT_TRI_INST=4'], '.f16'), 'triplet_attention16.hip', 'triplet_aggregate.hip', 'node_attention.hip', 'node_attention_mfma.hip', 'layernorm.hip', 'triangular_update.hip', 'elementwise.hip']
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 TGT_F32, TGT_BF16, TGT_F16 = 0, 1, 2
 TRI_BIASED, TRI_GATED, TRI_MASK_OUT = 1, 2, 4
@@ -128,6 +129,7 @@ SYMBOLS = {
     'tgt_edge_linear_supported': (C.c_int, [C.POINTER(EdgeLinearArgs)]),
     'tgt_edge_linear_parts': (C.c_int, [_i64, _i32]),
     'tgt_edge_linear': (C.c_int, [C.POINTER(EdgeLinearArgs), _vp]),
+    'tgt_edge_linear_set_grid_cap': (None, [_i32]),
     'tgt_adam_step': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _f32, _vp, _vp, _i32, _vp]),
     'tgt_grad_stats_parts': (C.c_int, []),
     'tgt_grad_scaler_step': (C.c_int, [_vp, _i64, _vp, _vp, _i32, _f32, _f32, _i32, _f32, _f32, _i32, _vp]),
@@ -166,11 +168,21 @@ def build_library(force=False, verbose=False):
     srcs = [os.path.join(CSRC, u[0]) for u in units]
     deps = srcs + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith('.hpp')] + \
         [os.path.join(os.path.dirname(_HERE), 'include', 'tgt_hip.h')]
-    if not force and os.path.exists(LIB_PATH) and \
-            os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
-        return LIB_PATH
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    # the compile commands (flags included) and the compiler's identity are part of the library's currency, not only mtimes:
+    # their hash is kept next to the library (libtgt_hip.stamp travels with the .so; the objects under build/ do not)
+    try:
+        hipcc_id = subprocess.run([hipcc, '--version'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode(errors='replace')
+    except OSError:
+        hipcc_id = 'unknown'
+    lib_stamp = hashlib.sha256(repr([(u[0], u[1], u[2]) for u in units]).encode() + hipcc_id.encode()).hexdigest()
+    stamp_path = LIB_PATH[:-3] + '.stamp'
+    if not force and os.path.exists(LIB_PATH) and \
+            os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps) and \
+            os.path.exists(stamp_path) and open(stamp_path).read() == lib_stamp:
+        return LIB_PATH
     objs = []
+    stamps = []
     procs = []
     build = os.path.join(_HERE, 'build')
     shared = max(os.path.getmtime(d) for d in deps[len(srcs):])        # headers: every unit depends on them
@@ -180,11 +192,15 @@ def build_library(force=False, verbose=False):
         d = os.path.join(build, os.path.basename(s) + suffix)
         o = os.path.join(d, 'unit.o')
         objs.append(o)
-        if not force and os.path.exists(o) and os.path.getmtime(o) >= max(shared, os.path.getmtime(s)):
+        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-save-temps=obj', *flags, '-c', s, '-o', o]
+        stamp = hashlib.sha256((' '.join(cmd) + '\n' + hipcc_id).encode()).hexdigest()
+        stamp_file = os.path.join(d, 'unit.cmd')
+        if not force and os.path.exists(o) and os.path.getmtime(o) >= max(shared, os.path.getmtime(s)) and \
+                os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
             continue                                                    # this unit's object is current
         shutil.rmtree(d, ignore_errors=True)
         os.makedirs(d)
-        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-save-temps=obj', *flags, '-c', s, '-o', o]
+        stamps.append((stamp_file, stamp))
         procs.append((cmd, d, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     undefined = {}
     failed = None
@@ -206,6 +222,10 @@ def build_library(force=False, verbose=False):
                         undefined[f'{os.path.basename(d)}:{k}'] = regs
             if f != 'unit.o' and not (f.endswith('-gfx950.s') and os.environ.get('TGT_KEEP_ISA')):
                 os.remove(path)
+    for stamp_file, stamp in stamps:
+        if os.path.isdir(os.path.dirname(stamp_file)):
+            with open(stamp_file, 'w') as fh:
+                fh.write(stamp)
     if failed:
         raise RuntimeError(failed)
     if undefined:
@@ -215,6 +235,8 @@ def build_library(force=False, verbose=False):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode:
         raise RuntimeError('link failed: ' + ' '.join(cmd) + '\n' + r.stdout.decode(errors='replace'))
+    with open(stamp_path, 'w') as fh:
+        fh.write(lib_stamp)
     return LIB_PATH
 
 

@@ -54,6 +54,7 @@ int xent_run(const void* x, int dtype, const int64_t* target, const float* lse_i
 int edge_linear_supported(const tgt_edge_linear_args* a);
 int edge_linear_parts(int64_t M, int N);
 int edge_linear_run(const tgt_edge_linear_args* a, hipStream_t st);
+void edge_linear_set_grid_cap(int cap);
 int layer_norm_fwd_run(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
                        float* mean, float* rstd, int64_t rows, int C, float eps, hipStream_t st);
 int layer_norm_bwd_run(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, const float* mean,
@@ -80,7 +81,7 @@ using namespace tgt;
 extern "C" {
 
 const char* tgt_last_error(void) { return g_err; }
-int tgt_abi_version(void) { return 24; }
+int tgt_abi_version(void) { return 25; }
 
 int tgt_triplet_attention_fwd(const tgt_triplet_attention_args* a, void* stream) {
     return triplet_attention_run(a, false, reinterpret_cast<hipStream_t>(stream));
@@ -228,5 +229,6 @@ int tgt_gaussian_basis_bwd(const float* x, const float* mul, const float* bias, 
 int tgt_edge_linear_supported(const tgt_edge_linear_args* a) { return edge_linear_supported(a); }
 int tgt_edge_linear_parts(int64_t M, int32_t N) { return edge_linear_parts(M, N); }
 int tgt_edge_linear(const tgt_edge_linear_args* a, void* stream) { return edge_linear_run(a, reinterpret_cast<hipStream_t>(stream)); }
+void tgt_edge_linear_set_grid_cap(int32_t cap) { edge_linear_set_grid_cap(cap); }
 
 }  // extern "C"

@@ -5,29 +5,22 @@
 // lib/tgt/layers/triplet.py:207-211,:229-230,:248-249).  With K = 256 every one of these Linears is
 // HBM-bound (arithmetic intensity K*N/(K+N) <= 128 FLOP/B against a ridge of ~310), so what matters is how
 // often the 134 MB edge tensor crosses HBM, not MFMA utilisation.  This kernel is one GEMM
-//     out[M, N] = epilogue( prologue(A[M, K]) . W[N, K]^T + bias )
-// whose prologue / epilogue absorb the passes around the library GEMM it replaces:
-//   prologue : LayerNorm over K in LDS (mean / rstd saved; the normalised rows optionally written out, the
-//              weight gradient still needs them)
-//   epilogue : EPI_BIAS  plain                                   (lin_EG, the fused triplet projection, dgrad)
-//              EPI_GELU  pre-activation + dropout(gelu(.))       (lin_W1 of the FFN)
-//              EPI_RESID res + DropPath-scale[graph] * (.)       (lin_O_e, lin_O, lin_W2: the result IS the new stream)
-//              EPI_GELU_BWD   (.) * gelu'(pre) * keep / (1-p)    (data gradient through lin_W2 and the activation)
-//              EPI_LN_BWD     LayerNorm backward of the result + the gradient arriving on the residual stream,
-//                             dgamma / dbeta / bias-gradient column sums as per-tile partials
+//     out[M, N] = epilogue( A[M, K] . W[N, K]^T + bias ),   K in {64, 128, 256}
+// whose epilogue absorbs the passes around the library GEMM it replaces:
+//   EPI_BIAS  plain                                   (lin_EG, the third-arm E/G projection)
+//   EPI_GELU  pre-activation + dropout(gelu(.))       (lin_W1 of the FFN)
+//   EPI_RESID res + DropPath-scale[graph] * (.)       (lin_O_e, lin_W2: the result IS the new stream), optionally followed
+//             by the LayerNorm of the NEW row = the entry of the next pre-norm sub-block
+//   EPI_GELU_BWD   (.) * gelu'(pre) * keep / (1-p)    (data gradient through lin_W2 and the activation)
+//   EPI_LN_BWD     LayerNorm backward of the result + the gradient arriving on the residual stream,
+//                  dgamma / dbeta / bias-gradient column sums as per-workgroup partials
 // so that the standalone LayerNorm / residual / GELU sweeps over the edge tensor disappear.
 //
-// Mapping.  Workgroup = 128 rows x up to 256 output columns, 4 waves; two workgroups per CU (64 KB of LDS,
-// <= 256 VGPRs) overlap each other's load / MFMA / store phases -- no software pipeline across tiles.
-// The A tile (128 rows x <= 256 k) sits in LDS, 16-byte slots XOR-swizzled by the row so that the 16 lanes
-// of a ds_read_b128 group hit 16 different bank groups; K > 256 is walked in 256-wide chunks with the
-// accumulators kept (only when the output has a single column tile).  Every wave owns ALL 128 rows x a
-// 64-column (NB = 2) or 32-column (NB = 1) slice: a weight element is fetched once per workgroup, straight
-// from L2 into registers (the weight is <= 0.8 MB and shared by all 2048 workgroups), never through LDS,
-// so the k-loop has no barrier.  v_mfma_f32_32x32x16 with the WEIGHT rows as the A operand and the
-// activation rows as the B operand: the result is transposed (lane = row, registers = columns), which makes
-// row reductions (LayerNorm backward) in-lane, and leaves 4 consecutive columns per register quad: a
-// v_permlane32_swap pairs two quads into one 16-byte store / load per lane.
+// Two kernels: the weight-resident SLICE kernel (narrow outputs, EPI_BIAS) and the ROW-PHASE kernel (N = 256, whole-row
+// epilogues, two wave roles).  v_mfma_f32_32x32x16 with the WEIGHT rows as the A operand and the activation rows as the B
+// operand: the result is transposed (lane = row, registers = columns), which leaves 4 consecutive columns per register quad:
+// a v_permlane32_swap pairs two quads into one 16-byte store / load per lane.  (A third, general tile kernel -- K > 256 in
+// chunks, LayerNorm prologue -- was parity-green but slower than the library everywhere and was removed in round 3.)
 #include <cstdlib>
 #include <type_traits>
 #include "common.hpp"
@@ -35,8 +28,6 @@
 namespace tgt {
 
 enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_GELU_BWD = 3, EPI_LN_BWD = 4 };
-
-constexpr int kKC = 256;          // k-chunk held in LDS
 
 struct EgGeo {                    // LDS geometry of the A tile for a given chunk width
     int rowbytes, rpw, mask;
@@ -138,507 +129,6 @@ __device__ __forceinline__ void decode_block(const uint4 (&L)[2], float* v) {
         swap_halves(a, b);
         unpack4<T>(a, v + 8 * p);
         unpack4<T>(b, v + 8 * p + 4);
-    }
-}
-
-// One workgroup per CU (4 waves, one per SIMD, the whole 512-register file each), persistent over row tiles of
-// 128 rows.  Work is a sequence of PHASES = (row tile, k-chunk, column tile); a phase multiplies the A block in LDS
-// by a weight panel (<= 256 k x 64*NB/2.. columns per wave) held in REGISTERS.  While phase p runs on the matrix
-// cores, the weight panel of phase p+1 streams from L2 into the other register set and the next A block streams
-// from HBM into the other LDS buffer (LDS-DMA): the k-loop itself issues no vector-memory instruction, so nothing
-// in it waits.  One `s_waitcnt vmcnt(0)` per phase sits AFTER the k-loop (everything prefetched has had the whole
-// loop to land) and BEFORE the epilogue's stores, which therefore stay in flight under the next phase.
-// MULTI = false: one phase per row tile (K <= 256, one column tile): the weight panel is loaded once.
-template <typename T, int NB, int EPI, bool LN, bool MULTI>
-__global__ void __launch_bounds__(256, 1) edge_linear_kernel(const tgt_edge_linear_args a) {
-    using F = frag_t<T>;
-    constexpr int MB = 4, kBM = 128, kBufBytes = kBM * kKC * 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hi = lane >> 5;
-    const int K = a.K, N = a.N;
-    float* st_mean = reinterpret_cast<float*>(smem + 2 * kBufBytes);
-    float* st_rstd = st_mean + kBM;
-    float* red = st_rstd + kBM;                         // EPI_LN_BWD: [4 waves][128 rows][2]
-    const T* A = reinterpret_cast<const T*>(a.a);
-    const T* W = reinterpret_cast<const T*>(a.w);
-    constexpr int NT = 4 * NB * 32;
-    const int n_tiles = (N + NT - 1) / NT, chunks = (K + kKC - 1) / kKC;
-    constexpr int KP = MULTI ? 8 : 16;                  // k-steps per weight panel (MULTI: two register sets of 8)
-    constexpr int PAN = 16 / KP;                        // panels per 256-wide chunk
-    const int PPT = MULTI ? n_tiles * chunks * PAN : 1; // phases per row tile (n_tiles or chunks is 1)
-    const int64_t row_tiles = (a.M + kBM - 1) / kBM;
-    const int ntl = (int)((row_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
-    const int nph = ntl * PPT;
-    const int ablate = a._pad0;
-
-    // a phase = one weight panel (KP k-steps of one column tile) against the A block (row tile, 256-wide k-chunk)
-    struct Ph { int64_t m0; int kc0, kcl, ks0, nks, nt, ab; bool newblock, first, last, endblock; };
-    auto decode = [&](int q) {
-        Ph p;
-        const int tl = q / PPT, w = q - tl * PPT;
-        p.m0 = (blockIdx.x + (int64_t)tl * gridDim.x) * kBM;
-        const int u = w / PAN, h = w - u * PAN;          // u: (chunk | column tile), h: panel inside the chunk
-        int c = 0;
-        if (chunks > 1) { c = u; p.nt = 0; p.ab = tl * chunks + c; p.newblock = h == 0; p.endblock = h == PAN - 1; }
-        else { p.nt = u; p.ab = tl; p.newblock = w == 0; p.endblock = w == PPT - 1; }
-        p.kc0 = c * kKC;
-        p.kcl = (K - p.kc0) < kKC ? (K - p.kc0) : kKC;
-        p.ks0 = h * KP;
-        const int left = (p.kcl >> 4) - p.ks0;
-        p.nks = left < 0 ? 0 : (left < KP ? left : KP);
-        p.first = c == 0 && h == 0;
-        p.last = c == chunks - 1 && h == PAN - 1;
-        return p;
-    };
-    // A block -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, asynchronous).  A wave instruction
-    // fills 1 KB of LDS linearly (lane l at +16 l), so the image is plain [row][physical slot] and the XOR swizzle is
-    // applied to the SOURCE column: physical slot ps of a row holds logical slot ps ^ key(row) (same cache lines).
-    // Rows past M re-read row M-1 (never stored; statistics of those rows are masked where they matter).
-    auto stage = [&](const Ph& p) {
-        const EgGeo g(p.kcl);
-        char* xs = smem + (p.ab & 1) * kBufBytes;
-        const int spr = p.kcl >> 3, total = kBM * spr;
-        for (int p0 = wave * 64; p0 < total; p0 += 256) {
-            const int pc = p0 + lane;
-            const int row = pc / spr, ps = pc - row * spr;
-            int64_t m = p.m0 + row;
-            m = m < a.M ? m : a.M - 1;
-            const T* src = A + m * a.lda + p.kc0 + ((ps ^ ((row / g.rpw) & g.mask)) << 3);
-            if (!(ablate & 4))
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(xs + p0 * 16), 16, 0, 0);
-        }
-    };
-    auto load_w = [&](F (&wp)[KP][NB], const Ph& p) {
-        const int n0 = p.nt * NT + wave * NB * 32;
-#pragma unroll
-        for (int ks = 0; ks < KP; ++ks)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const int n = n0 + nb * 32 + r;
-                if (ks < p.nks && !(ablate & 1))
-                    wp[ks][nb] = n < N ? load_frag<T>(W + (int64_t)n * a.ldw + p.kc0 + (p.ks0 + ks) * 16 + 8 * hi) : zero_frag<T>();
-            }
-    };
-
-    const uint32_t thresh = a.dropout_p <= 0.f ? 0u : (uint32_t)fminf(65535.f, fmaxf(1.f, rintf(a.dropout_p * 65536.f)));
-    const float inv_keep = a.dropout_p <= 0.f ? 1.f : 1.f / (1.f - a.dropout_p);
-    constexpr bool kOperand = EPI == EPI_RESID || EPI == EPI_GELU_BWD || EPI == EPI_LN_BWD;   // epilogue reads an (M, N) tensor
-    constexpr bool kEarly = kOperand && !(EPI == EPI_LN_BWD && MULTI);     // ... issued before the k-loop (registers permitting)
-
-    f32x16 acc[MB][NB];
-    F wp[MULTI ? 2 : 1][KP][NB];
-
-    auto phase = [&](auto S_, int q) {
-        constexpr int S = decltype(S_)::value;
-        const Ph p = decode(q);
-        const EgGeo g(p.kcl);
-        char* xs = smem + (p.ab & 1) * kBufBytes;
-        const int n0 = p.nt * NT + wave * NB * 32;
-        const bool active = n0 < N;                       // the wave's column slice exists (wave-uniform)
-
-        // ---- 1. everything this phase and the next will need from memory, oldest-needed first
-        uint2 braw[NB][4];
-        uint4 op1[MB][NB][2], op2[MB][NB][2];
-        float mu[MB], rs[MB];
-        if (p.last) {
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const int n = n0 + nb * 32 + 8 * gq + 4 * hi;
-                    braw[nb][gq] = make_uint2(0, 0);
-                    if (a.bias && n < N) braw[nb][gq] = *reinterpret_cast<const uint2*>(reinterpret_cast<const T*>(a.bias) + n);
-                }
-            if constexpr (kEarly) {
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) {
-                    const int64_t m = p.m0 + mb * 32 + r;
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        load_block_raw<T>(reinterpret_cast<const T*>(a.res), a.ldr, m, a.M, n0 + nb * 32, N, hi, op1[mb][nb]);
-                        if constexpr (EPI == EPI_LN_BWD) {
-                            if (a.ds_in) load_block_raw<T>(reinterpret_cast<const T*>(a.ds_in), a.ld_ds, m, a.M, n0 + nb * 32, N, hi, op2[mb][nb]);
-                        }
-                    }
-                    if constexpr (EPI == EPI_LN_BWD) {
-                        mu[mb] = m < a.M ? a.mean[m] : 0.f;
-                        rs[mb] = m < a.M ? a.rstd[m] : 0.f;
-                    }
-                }
-            }
-        }
-        if constexpr (MULTI) {
-            if (q + 1 < nph) load_w(wp[S ^ 1], decode(q + 1));
-        }
-        if (p.newblock) {                                 // the next A block goes to the other buffer (last read one block ago)
-            const int qn = chunks > 1 ? q + PAN : q + PPT;
-            if (qn < nph) stage(decode(qn));
-        }
-
-        // ---- 2. LayerNorm prologue, in place in LDS (first phase of a row tile)
-        if constexpr (LN) {
-            if (p.newblock) {
-                // statistics: 2 threads per row; thread `half` walks its 16-byte slots starting 8 later (other bank groups)
-                const int row = tid >> 1, half = tid & 1;
-                const int spr = K >> 3, per = spr >> 1;
-                float s = 0.f;
-                for (int j = 0; j < per; ++j) {
-                    const int slot = half * per + ((j + 8 * half) % per);
-                    F f = load_frag<T>(reinterpret_cast<const T*>(xs + g.off(row, slot)));
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) s += to_f32(f[t]);
-                }
-                s += __shfl_xor(s, 1, 64);
-                const float mean = s / (float)K;
-                float qv = 0.f;
-                for (int j = 0; j < per; ++j) {
-                    const int slot = half * per + ((j + 8 * half) % per);
-                    F f = load_frag<T>(reinterpret_cast<const T*>(xs + g.off(row, slot)));
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        const float d = to_f32(f[t]) - mean;
-                        qv += d * d;
-                    }
-                }
-                qv += __shfl_xor(qv, 1, 64);
-                const float rstd = rsqrtf(qv / (float)K + a.eps);
-                if (half == 0) {
-                    st_mean[row] = mean;
-                    st_rstd[row] = rstd;
-                    if (p.m0 + row < a.M) {
-                        if (a.mean) a.mean[p.m0 + row] = mean;
-                        if (a.rstd) a.rstd[p.m0 + row] = rstd;
-                    }
-                }
-                __syncthreads();
-                // normalise in place: thread -> fixed 16-byte column slot, rows tid/spr + (256/spr)*i
-                const int slot = tid % spr, rstep = 256 / spr;
-                float gam[8], bet[8];
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    gam[t] = a.gamma[slot * 8 + t];
-                    bet[t] = a.beta[slot * 8 + t];
-                }
-                T* Y = reinterpret_cast<T*>(a.y);
-                for (int row2 = tid / spr; row2 < kBM; row2 += rstep) {
-                    T* px = reinterpret_cast<T*>(xs + g.off(row2, slot));
-                    F f = load_frag<T>(px);
-                    const float m_ = st_mean[row2], r_ = st_rstd[row2];
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) f[t] = from_f32<T>((to_f32(f[t]) - m_) * r_ * gam[t] + bet[t]);
-                    uint4 raw;
-                    __builtin_memcpy(&raw, &f, 16);
-                    *reinterpret_cast<uint4*>(px) = raw;
-                    if (Y && p.m0 + row2 < a.M) *reinterpret_cast<uint4*>(Y + (p.m0 + row2) * a.ldy + slot * 8) = raw;
-                }
-                __syncthreads();
-            }
-        }
-
-        // ---- 3. the k-loop: LDS reads + MFMA only
-        if (p.first) {
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                    for (int q_ = 0; q_ < 16; ++q_) acc[mb][nb][q_] = 0.f;
-        }
-        if (active && !(ablate & 8)) {
-#pragma unroll
-            for (int ks = 0; ks < KP; ++ks) {
-                if (ks < p.nks) {
-                    F xf[MB];
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb)
-                        xf[mb] = load_frag<T>(reinterpret_cast<const T*>(xs + g.off(mb * 32 + r, 2 * (p.ks0 + ks) + hi)));
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = mma32(wp[MULTI ? S : 0][ks][nb], xf[mb], acc[mb][nb]);
-                }
-            }
-        }
-        // everything prefetched during the loop has landed; nothing younger is outstanding (the previous phase's
-        // stores are older): a full drain costs no more than the newest prefetch
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-        // ---- 4. epilogue
-        if (p.last && (active || EPI == EPI_LN_BWD)) {
-            if (ablate & 2) {                             // (ablation) keep the accumulators live, store nothing
-                float t = 0.f;
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) t += acc[mb][nb][0] + acc[mb][nb][15];
-                if (t == 123.456f) reinterpret_cast<float*>(a.out)[tid] = t;
-            } else {
-                float bv[NB][16];
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) unpack4<T>(braw[nb][gq], bv[nb] + 4 * gq);
-                T* out = reinterpret_cast<T*>(a.out);
-                if constexpr (EPI == EPI_BIAS) {
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) {
-                        const int64_t m = p.m0 + mb * 32 + r;
-                        const float al = a.out_scale ? a.out_scale[(m < a.M ? m : a.M - 1) / a.rows_per_sample] : 1.f;
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) {
-                            float v[16];
-#pragma unroll
-                            for (int q_ = 0; q_ < 16; ++q_) v[q_] = (acc[mb][nb][q_] + bv[nb][q_]) * al;
-                            store_block<T>(out, a.ldo, m, a.M, n0 + nb * 32, N, hi, v);
-                        }
-                    }
-                } else if constexpr (EPI == EPI_GELU) {
-                    T* pre = reinterpret_cast<T*>(a.out2);
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) {
-                        const int64_t m = p.m0 + mb * 32 + r;
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) {
-                            float v[16], gl[16];
-#pragma unroll
-                            for (int q_ = 0; q_ < 16; ++q_) v[q_] = acc[mb][nb][q_] + bv[nb][q_];
-                            store_block<T>(pre, a.ldo2, m, a.M, n0 + nb * 32, N, hi, v);
-#pragma unroll
-                            for (int gq = 0; gq < 4; ++gq) {
-                                bool keep[4] = {true, true, true, true};
-                                if (thresh) keep4(a.dropout_seed, m, N, n0 + nb * 32 + 8 * gq + 4 * hi, thresh, keep);
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) {
-                                    const float x = to_f32(from_f32<T>(v[4 * gq + j]));      // gelu of the value as stored
-                                    float e;
-                                    const float cdf = gelu_cdf(x, e);
-                                    gl[4 * gq + j] = keep[j] ? x * cdf * inv_keep : 0.f;
-                                }
-                            }
-                            store_block<T>(out, a.ldo, m, a.M, n0 + nb * 32, N, hi, gl);
-                        }
-                    }
-                } else if constexpr (EPI == EPI_RESID) {
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) {
-                        const int64_t m = p.m0 + mb * 32 + r;
-                        const float sc = a.row_scale ? a.row_scale[(m < a.M ? m : a.M - 1) / a.rows_per_sample] : 1.f;
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) {
-                            float rv[16], v[16];
-                            decode_block<T>(op1[mb][nb], rv);
-#pragma unroll
-                            for (int q_ = 0; q_ < 16; ++q_) v[q_] = rv[q_] + (acc[mb][nb][q_] + bv[nb][q_]) * sc;
-                            store_block<T>(out, a.ldo, m, a.M, n0 + nb * 32, N, hi, v);
-                        }
-                    }
-                } else if constexpr (EPI == EPI_GELU_BWD) {
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) {
-                        const int64_t m = p.m0 + mb * 32 + r;
-                        const float al = a.out_scale ? a.out_scale[(m < a.M ? m : a.M - 1) / a.rows_per_sample] : 1.f;
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) {
-                            float pv[16], v[16];
-                            decode_block<T>(op1[mb][nb], pv);             // the forward's pre-activation
-#pragma unroll
-                            for (int gq = 0; gq < 4; ++gq) {
-                                bool keep[4] = {true, true, true, true};
-                                if (thresh) keep4(a.dropout_seed, m, N, n0 + nb * 32 + 8 * gq + 4 * hi, thresh, keep);
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) {
-                                    const float x = pv[4 * gq + j];
-                                    float e;
-                                    const float cdf = gelu_cdf(x, e);
-                                    // the incoming gradient is rounded to the storage type first, as the unfused chain stores it
-                                    const float dy = to_f32(from_f32<T>(acc[mb][nb][4 * gq + j] * al));
-                                    v[4 * gq + j] = keep[j] ? dy * (cdf + x * 0.3989422804014327f * e) * inv_keep : 0.f;
-                                }
-                            }
-                            store_block<T>(out, a.ldo, m, a.M, n0 + nb * 32, N, hi, v);
-                        }
-                    }
-                } else {     // EPI_LN_BWD: acc = dy (gradient at the LayerNorm output); N = the normalised width, one column tile
-                    const T* Sg = reinterpret_cast<const T*>(a.res);          // the LayerNorm input (residual stream)
-                    const T* dsin = reinterpret_cast<const T*>(a.ds_in);      // gradient arriving on the residual stream (may be NULL)
-                    auto gamma4 = [&](int nb, int gq, float* g4) {            // gamma of the quad's 4 consecutive columns (L1-resident)
-                        const int n = n0 + nb * 32 + 8 * gq + 4 * hi;
-                        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (n < N) t = *reinterpret_cast<const float4*>(a.gamma + n);
-                        g4[0] = t.x; g4[1] = t.y; g4[2] = t.z; g4[3] = t.w;
-                    };
-                    if constexpr (!kEarly) {
-#pragma unroll
-                        for (int mb = 0; mb < MB; ++mb) {
-                            const int64_t m = p.m0 + mb * 32 + r;
-                            mu[mb] = m < a.M ? a.mean[m] : 0.f;
-                            rs[mb] = m < a.M ? a.rstd[m] : 0.f;
-#pragma unroll
-                            for (int nb = 0; nb < NB; ++nb) load_block_raw<T>(Sg, a.ldr, m, a.M, n0 + nb * 32, N, hi, op1[mb][nb]);
-                        }
-                    }
-                    float cs_a[NB][16], cs_b[NB][16];                         // per-lane column partials over the row blocks
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                        for (int q_ = 0; q_ < 16; ++q_) cs_a[nb][q_] = cs_b[nb][q_] = 0.f;
-                    float s1[MB], s2[MB];
-                    // pass 1: row sums of g = dy*gamma and g*xhat; column sums of dy*xhat (dgamma) and dy (dbeta);
-                    // acc <- dy as stored, op1 keeps the raw stream rows for pass 2
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) {
-                        const int64_t m = p.m0 + mb * 32 + r;
-                        const bool ok = m < a.M;
-                        float p1 = 0.f, p2 = 0.f;
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) {
-                            float sv[16];
-                            decode_block<T>(op1[mb][nb], sv);
-#pragma unroll
-                            for (int gq = 0; gq < 4; ++gq) {
-                                float g4[4];
-                                gamma4(nb, gq, g4);
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) {
-                                    const int q_ = 4 * gq + j;
-                                    const bool cok = ok && (n0 + nb * 32 + acc_row(q_, hi) < N);
-                                    const float dy = cok ? to_f32(from_f32<T>(acc[mb][nb][q_])) : 0.f;     // dy as the unfused chain stores it
-                                    acc[mb][nb][q_] = dy;
-                                    const float x = cok ? (sv[q_] - mu[mb]) * rs[mb] : 0.f;
-                                    const float gg = dy * g4[j];
-                                    p1 += gg;
-                                    p2 += gg * x;
-                                    cs_a[nb][q_] += dy * x;
-                                    cs_b[nb][q_] += dy;
-                                }
-                            }
-                        }
-                        s1[mb] = p1 + xhalf(p1);
-                        s2[mb] = p2 + xhalf(p2);
-                    }
-                    if (hi == 0) {
-#pragma unroll
-                        for (int mb = 0; mb < MB; ++mb) {
-                            red[(wave * kBM + mb * 32 + r) * 2] = s1[mb];
-                            red[(wave * kBM + mb * 32 + r) * 2 + 1] = s2[mb];
-                        }
-                    }
-                    // fold a per-lane 16-column partial over the 32 lanes of each half-wave: 16 + 8+4+2+1 exchanges;
-                    // lanes r < 16 end up with the total of register index q = r (column nbase + (q&3) + 8(q>>2) + 4hi)
-                    auto fold_store = [&](float (&v)[16], int nb, float* dst) {
-#pragma unroll
-                        for (int q_ = 0; q_ < 16; ++q_) v[q_] += __shfl_xor(v[q_], 16, 64);
-#pragma unroll
-                        for (int s_ = 0; s_ < 4; ++s_) {
-                            const int width = 8 >> s_;
-                            const bool upper = (r & width) != 0;
-#pragma unroll
-                            for (int c = 0; c < width; ++c) {
-                                const float mine = upper ? v[c + width] : v[c];
-                                const float send = upper ? v[c] : v[c + width];
-                                v[c] = mine + __shfl_xor(send, width, 64);
-                            }
-                        }
-                        const int q_ = r & 15;
-                        const int n = n0 + nb * 32 + (q_ & 3) + 8 * (q_ >> 2) + 4 * hi;
-                        if (r < 16 && n < N) dst[n] = v[0];
-                    };
-                    float* part = a.colsum_partial ? a.colsum_partial + (p.m0 / kBM) * 3 * N : nullptr;
-                    if (part) {
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) {
-                            fold_store(cs_a[nb], nb, part);
-                            fold_store(cs_b[nb], nb, part + N);
-                        }
-                    }
-                    __syncthreads();
-                    const float invC = 1.f / (float)N;
-                    T* dres = reinterpret_cast<T*>(a.out);
-                    T* dx = reinterpret_cast<T*>(a.out2);                     // d_res * row_scale (may be NULL)
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                        for (int q_ = 0; q_ < 16; ++q_) cs_a[nb][q_] = 0.f;   // now: column sums of the x-branch gradient
-                    // pass 2: dx = rstd * (g - mean(g) - xhat * mean(g*xhat)) + ds_in
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) {
-                        const int row = mb * 32 + r;
-                        float c1 = 0.f, c2 = 0.f;
-#pragma unroll
-                        for (int w_ = 0; w_ < 4; ++w_) {
-                            c1 += red[(w_ * kBM + row) * 2];
-                            c2 += red[(w_ * kBM + row) * 2 + 1];
-                        }
-                        c1 *= invC;
-                        c2 *= invC;
-                        const int64_t m = p.m0 + row;
-                        const float sc = a.row_scale ? a.row_scale[(m < a.M ? m : a.M - 1) / a.rows_per_sample] : 1.f;
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) {
-                            float sv[16], dv[16], ds[16];
-                            decode_block<T>(op1[mb][nb], sv);
-                            if (dsin) {
-                                if constexpr (!kEarly) load_block_raw<T>(dsin, a.ld_ds, m, a.M, n0 + nb * 32, N, hi, op2[mb][nb]);
-                                decode_block<T>(op2[mb][nb], ds);
-                            }
-#pragma unroll
-                            for (int gq = 0; gq < 4; ++gq) {
-                                float g4[4];
-                                gamma4(nb, gq, g4);
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) {
-                                    const int q_ = 4 * gq + j;
-                                    const float x = (sv[q_] - mu[mb]) * rs[mb];
-                                    float d = rs[mb] * (acc[mb][nb][q_] * g4[j] - c1 - x * c2);
-                                    if (dsin) d += ds[q_];
-                                    dv[q_] = d;
-                                }
-                            }
-                            store_block<T>(dres, a.ldo, m, a.M, n0 + nb * 32, N, hi, dv);
-                            if (dx || part) {
-#pragma unroll
-                                for (int q_ = 0; q_ < 16; ++q_) {
-                                    // the x-branch gradient as it is stored (rounded), so that its column sums equal a separate pass's
-                                    const float t = to_f32(from_f32<T>(to_f32(from_f32<T>(dv[q_])) * sc));
-                                    dv[q_] = t;
-                                    cs_a[nb][q_] += (m < a.M && n0 + nb * 32 + acc_row(q_, hi) < N) ? t : 0.f;
-                                }
-                                if (dx) store_block<T>(dx, a.ldo2, m, a.M, n0 + nb * 32, N, hi, dv);
-                            }
-                        }
-                    }
-                    if (part) {
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) fold_store(cs_a[nb], nb, part + 2 * N);
-                    }
-                }
-            }
-        }
-        // ---- 5. leaving an A block: every wave is done reading it (the first phase of the NEXT block issues the DMA that
-        //         overwrites it) and has waited for its own pieces of the next block, so after the barrier that block is
-        //         complete for everyone.  Raw barrier: __syncthreads() would also drain the stores just issued.
-        if (p.endblock) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-    };
-
-    if (nph <= 0) return;
-    {   // pipeline fill: first A block and first weight panel
-        const Ph p0 = decode(0);
-        stage(p0);
-        load_w(wp[0], p0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
-    for (int q = 0; q < nph; q += 2) {
-        phase(std::integral_constant<int, 0>{}, q);
-        if constexpr (MULTI) {
-            if (q + 1 < nph) phase(std::integral_constant<int, 1>{}, q + 1);
-        } else {
-            if (q + 1 < nph) phase(std::integral_constant<int, 0>{}, q + 1);
-        }
     }
 }
 
@@ -1354,9 +844,27 @@ __global__ void __launch_bounds__(1024, 4) edge_rows_kernel(const tgt_edge_linea
     }
 }
 
+// test hook (tgt_edge_linear_set_grid_cap): at most this many persistent workgroups / row groups per launch, so that a small
+// problem walks several tiles per workgroup -- the stage hand-over the BASELINE-size launches (32 tiles each) depend on
+static int g_grid_cap = 0;
+void edge_linear_set_grid_cap(int cap) { g_grid_cap = cap > 0 ? cap : 0; }
+
 static int er_grid(int64_t M) {
     const int64_t row_tiles = (M + 31) / 32;
-    return (int)(row_tiles < eg_num_cus() ? row_tiles : eg_num_cus());
+    int64_t g = row_tiles < eg_num_cus() ? row_tiles : eg_num_cus();
+    if (g_grid_cap && g > g_grid_cap) g = g_grid_cap;
+    return (int)g;
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember it per (kernel instantiation, device)
+static bool dyn_lds_once(bool (&done)[16], const void* fn, int lds) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    if (dev >= 16 || !done[dev]) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return false;
+        if (dev < 16) done[dev] = true;
+    }
+    return true;
 }
 
 template <typename T, int KS, int EPI>
@@ -1364,11 +872,9 @@ static int er_launch(const tgt_edge_linear_args& a, hipStream_t st) {
     constexpr int K = KS * 16;
     constexpr int lds0 = 2 * 32 * K * 2 + 2 * 32 * 256 * 2 + 2 * 256 * 4;
     constexpr int lds = lds0 < 49152 ? 49152 : lds0;                        // the final column-sum fold of LN_BWD needs 48 KB
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_rows_kernel<T, KS, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
+    static bool attr_set[16] = {};
+    if (!dyn_lds_once(attr_set, reinterpret_cast<const void*>(&edge_rows_kernel<T, KS, EPI>), lds))
+        return set_error(TGT_ERR_LAUNCH, "edge_rows_kernel: cannot reserve %d bytes of LDS", lds);
     hipLaunchKernelGGL((edge_rows_kernel<T, KS, EPI>), dim3((unsigned)er_grid(a.M)), dim3(1024), lds, st, a);
     return check_launch("edge_rows_kernel");
 }
@@ -1387,10 +893,9 @@ static int er_dispatch(const tgt_edge_linear_args& a, hipStream_t st) {
 // the row-phase kernel takes the 256-column Linears with a whole-row epilogue: K in {64, 128, 256}, contiguous-enough rows
 static bool er_eligible(const tgt_edge_linear_args& a) {
     if (a.N != 256 || (a.K != 64 && a.K != 128 && a.K != 256) || a.epilogue == EPI_BIAS) return false;
-    if (a.gamma && a.epilogue != EPI_RESID && a.epilogue != EPI_LN_BWD) return false;      // (LayerNorm PROLOGUE: the tile kernel)
+    if (a.gamma && a.epilogue != EPI_RESID && a.epilogue != EPI_LN_BWD) return false;
     if (a.gamma && a.epilogue == EPI_RESID && (!a.beta || !a.y)) return false;
-    static const bool off = getenv("TGT_EG_ROWS") && atoi(getenv("TGT_EG_ROWS")) == 0;
-    return !off;
+    return true;
 }
 
 template <typename T>
@@ -1406,12 +911,9 @@ template <typename T, int KS, int WN, int EPI, int RB>
 static int es_launch(const tgt_edge_linear_args& a, hipStream_t st) {
     constexpr int kBM = 32 * RB;
     constexpr int lds = 2 * kBM * KS * 32 + WN * kBM * 2 * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_slice_kernel<T, KS, WN, EPI, RB>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
+    static bool attr_set[16] = {};
+    if (!dyn_lds_once(attr_set, reinterpret_cast<const void*>(&edge_slice_kernel<T, KS, WN, EPI, RB>), lds))
+        return set_error(TGT_ERR_LAUNCH, "edge_slice_kernel: cannot reserve %d bytes of LDS", lds);
     const int n_slices = (a.N + 32 * WN - 1) / (32 * WN);
     const int64_t row_tiles = (a.M + kBM - 1) / kBM;
     // one workgroup per CU; per XCD (blocks b % 8) a whole number of row groups x all their slices
@@ -1419,6 +921,7 @@ static int es_launch(const tgt_edge_linear_args& a, hipStream_t st) {
     if (per_xcd < 1) per_xcd = 1;
     int64_t groups = (int64_t)per_xcd * 8;
     if (groups > row_tiles) groups = row_tiles;
+    if (g_grid_cap && groups > g_grid_cap) groups = g_grid_cap;
     const int64_t blocks = ((groups + 7) / 8) * n_slices * 8;
     hipLaunchKernelGGL((edge_slice_kernel<T, KS, WN, EPI, RB>), dim3((unsigned)blocks), dim3(512), lds, st, a, (int)groups);
     return check_launch("edge_slice_kernel");
@@ -1443,8 +946,7 @@ static bool es_eligible(const tgt_edge_linear_args& a) {
     if (a.epilogue == EPI_LN_BWD) return a.N <= 256;
     if (a.gamma && a.epilogue != EPI_RESID) return false;
     if (a.gamma && a.epilogue == EPI_RESID && (a.N > 256 || !a.beta || !a.y)) return false;
-    static const bool off = getenv("TGT_EG_SLICE") && atoi(getenv("TGT_EG_SLICE")) == 0;
-    return !off;
+    return true;
 }
 
 template <typename T>
@@ -1457,50 +959,21 @@ static int es_run(const tgt_edge_linear_args& a, hipStream_t st) {
     }
 }
 
-static int eg_num_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
+static int eg_num_cus() {                 // of the CURRENT device (a process may drive several)
+    static int n[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (!n[dev]) {
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n[dev] = prop.multiProcessorCount;
+        if (n[dev] <= 0) n[dev] = 256;
     }
-    return n;
+    return n[dev];
 }
 
-template <typename T, int NB, int EPI, bool LN, bool MULTI>
-static int eg_launch(const tgt_edge_linear_args& a, hipStream_t st) {
-    constexpr int lds = 2 * 128 * kKC * 2 + 2 * 128 * 4 + 4 * 128 * 2 * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_linear_kernel<T, NB, EPI, LN, MULTI>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
-    const int64_t tiles = (a.M + 127) / 128;
-    const int64_t grid = tiles < eg_num_cus() ? tiles : eg_num_cus();
-    hipLaunchKernelGGL((edge_linear_kernel<T, NB, EPI, LN, MULTI>), dim3((unsigned)grid), dim3(256), lds, st, a);
-    return check_launch("edge_linear_kernel");
-}
-
-template <typename T, int NB, bool MULTI>
-static int eg_dispatch(const tgt_edge_linear_args& a, hipStream_t st) {
-    const bool ln = a.gamma != nullptr && a.epilogue != EPI_LN_BWD;
-    switch (a.epilogue) {
-        case EPI_BIAS: return ln ? eg_launch<T, NB, EPI_BIAS, true, MULTI>(a, st) : eg_launch<T, NB, EPI_BIAS, false, MULTI>(a, st);
-        case EPI_GELU: return ln ? eg_launch<T, NB, EPI_GELU, true, MULTI>(a, st) : eg_launch<T, NB, EPI_GELU, false, MULTI>(a, st);
-        case EPI_RESID: if (a.gamma) return set_error(TGT_ERR_UNSUPPORTED, "edge linear: the LayerNorm epilogue needs K in {64,128,256}");
-            return eg_launch<T, NB, EPI_RESID, false, MULTI>(a, st);
-        case EPI_GELU_BWD: return eg_launch<T, NB, EPI_GELU_BWD, false, MULTI>(a, st);
-        case EPI_LN_BWD: return eg_launch<T, NB, EPI_LN_BWD, false, MULTI>(a, st);
-        default: return set_error(TGT_ERR_INVALID, "edge linear: bad epilogue %d", a.epilogue);
-    }
-}
-
-// rows of colsum_partial: one per (128-row tile, row group of waves WM = 8 / WN of the slice kernel)
-// rows of colsum_partial the caller provides (ZERO-FILLED: which kernel runs, and so which rows are written, also depends on K):
-// one per (128-row tile, row group of waves WM = 8 / WN) of the slice / tile kernels -- an upper bound for the row-phase
-// kernel, which writes one row per workgroup
+// rows of colsum_partial the caller provides (ZERO-FILLED: which kernel runs, and so which rows are written, also depends on N):
+// one per (128-row tile, row group of waves WM = 8 / WN) of the slice kernel -- an upper bound for the row-phase kernel,
+// which writes one row per workgroup
 int edge_linear_parts(int64_t M, int N) {
     const int wn = N <= 64 ? 2 : (N <= 128 ? 4 : 8);
     return wn == 8 ? (int)((M + 31) / 32) : (int)((M + 127) / 128) * (8 / wn);        // (row-phase LN_BWD: 32-row tiles)
@@ -1510,12 +983,9 @@ int edge_linear_supported(const tgt_edge_linear_args* a) {
     if (!a) return 0;
     if (a->dtype != TGT_BF16 && a->dtype != TGT_F16) return 0;
     const int K = a->K, N = a->N;
-    if (K < 16 || N < 8 || N % 8) return 0;
-    if (K >= kKC ? (K % 16 != 0) : (K != 16 && K != 32 && K != 64 && K != 128)) return 0;
-    const int nt = (N + 255) / 256, chunks = (K + kKC - 1) / kKC;
-    if (nt > 1 && chunks > 1) return 0;
-    if (a->gamma && a->epilogue == EPI_RESID && (N > 256 || (K != 64 && K != 128 && K != 256))) return 0;
-    if (a->gamma && a->epilogue != EPI_LN_BWD && chunks > 1) return 0;
+    if ((K != 64 && K != 128 && K != 256) || N < 8 || N % 8) return 0;
+    if (a->gamma && a->epilogue != EPI_RESID && a->epilogue != EPI_LN_BWD) return 0;          // (no LayerNorm prologue)
+    if (a->gamma && a->epilogue == EPI_RESID && N > 256) return 0;
     if (a->epilogue == EPI_LN_BWD && (N > 256 || !a->gamma || !a->mean || !a->rstd || !a->res)) return 0;
     // row_scale on the bias only (the input arrived pre-scaled): the row-phase kernel's residual epilogue
     if ((a->flags & TGT_EDGE_BIAS_SCALED) && (a->epilogue != EPI_RESID || !er_eligible(*a))) return 0;
@@ -1529,7 +999,7 @@ int edge_linear_run(const tgt_edge_linear_args* a, hipStream_t st) {
     if (a->M < 0 || a->K <= 0 || a->N <= 0) return set_error(TGT_ERR_INVALID, "edge linear: bad sizes");
     if (!edge_linear_supported(a))
         return set_error(TGT_ERR_UNSUPPORTED, "edge linear: unsupported shape/dtype (K=%d N=%d dtype=%d epilogue=%d): needs a 16-bit "
-                         "dtype, N %% 8 == 0, K in {16,32,64,128} or a multiple of 16 >= 256, and not both K > 256 and N > 256",
+                         "dtype, N %% 8 == 0, K in {64,128,256}; row-wise epilogues N <= 256",
                          a->K, a->N, a->dtype, a->epilogue);
     if (a->M == 0) return TGT_OK;
     static const int ablate = getenv("TGT_EG_ABLATE") ? atoi(getenv("TGT_EG_ABLATE")) : 0;   // kernel_bench probes: 1 no W stream, 2 no stores, 4 no A loads, 8 no MFMA
@@ -1549,15 +1019,7 @@ int edge_linear_run(const tgt_edge_linear_args* a, hipStream_t st) {
     if (a->dropout_p < 0.f || a->dropout_p >= 1.f) return set_error(TGT_ERR_INVALID, "edge linear: dropout_p outside [0,1)");
     if (er_eligible(*a)) return a->dtype == TGT_BF16 ? er_run<bf16_t>(*a, st) : er_run<f16_t>(*a, st);
     if (es_eligible(*a)) return a->dtype == TGT_BF16 ? es_run<bf16_t>(*a, st) : es_run<f16_t>(*a, st);
-    // narrow outputs: one 32-column block per wave keeps all four waves busy
-    const bool narrow = a->N <= 128;
-    const bool multi = a->K > kKC || a->N > (narrow ? 128 : 256);
-    if (a->dtype == TGT_BF16) {
-        if (narrow) return multi ? eg_dispatch<bf16_t, 1, true>(*a, st) : eg_dispatch<bf16_t, 1, false>(*a, st);
-        return multi ? eg_dispatch<bf16_t, 2, true>(*a, st) : eg_dispatch<bf16_t, 2, false>(*a, st);
-    }
-    if (narrow) return multi ? eg_dispatch<f16_t, 1, true>(*a, st) : eg_dispatch<f16_t, 1, false>(*a, st);
-    return multi ? eg_dispatch<f16_t, 2, true>(*a, st) : eg_dispatch<f16_t, 2, false>(*a, st);
+    return set_error(TGT_ERR_UNSUPPORTED, "edge linear: no kernel for K=%d N=%d epilogue=%d", a->K, a->N, a->epilogue);
 }
 
 }  // namespace tgt

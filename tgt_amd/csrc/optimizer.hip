@@ -13,7 +13,17 @@
 namespace tgt {
 
 enum { CTL_SCALE = 0, CTL_TRACKER = 1, CTL_FOUND_INF = 2, CTL_STEPS = 3, CTL_MULT = 4, CTL_COEF = 5, CTL_NORM = 6,
-       CTL_SKIPPED = 7, CTL_LOSS = 8, CTL_SAMPLES = 9, CTL_NAN = 10, CTL_PAIR = 12 };
+       CTL_SKIPPED = 7, CTL_LOSS = 8, CTL_SAMPLES = 9, CTL_NAN = 10, CTL_LOSS_LO = 11, CTL_PAIR = 12, CTL_SAMPLES_LO = 14 };
+
+// running sums of update_losses as float32 PAIRS (value, low-order part): an error-free two-sum per step, so that the sample
+// count stays exact far beyond 2^24 and the loss sum keeps ~48 bits (a plain float32 sum stops counting samples at 16.7 M)
+__device__ __forceinline__ void two_sum_into(float& hi, float& lo, float x) {
+    const float s = hi + x;
+    const float bb = s - hi;
+    const float err = (hi - (s - bb)) + (x - bb);
+    hi = s;
+    lo += err;
+}
 
 template <typename S>
 __device__ __forceinline__ void shadow_store4(void* shadow, int64_t i, const float* P) {
@@ -148,7 +158,9 @@ __global__ void __launch_bounds__(256) scaler_update_kernel(const float* __restr
     float S = ctl[CTL_SCALE];
     ctl[CTL_MULT] = 1.f / (S * world);
     ctl[CTL_NORM] = norm;
-    ctl[CTL_COEF] = clip_norm > 0.f ? fminf(1.f, clip_norm / (norm + 1e-6f)) : 1.f;
+    // torch's clip_grad_norm_ (reference training.py:461): clamp(max_norm / (norm + 1e-6), max = 1) -- a NaN norm gives a NaN
+    // coefficient that poisons every gradient, an infinite norm gives 0; fminf alone would DROP the NaN and apply the step
+    ctl[CTL_COEF] = clip_norm > 0.f ? (norm != norm ? norm : fminf(1.f, clip_norm / (norm + 1e-6f))) : 1.f;
     const bool skip = dynamic && nonfinite;
     ctl[CTL_FOUND_INF] = skip ? 1.f : 0.f;
     if (skip) {
@@ -184,14 +196,14 @@ __global__ void loss_accumulate_kernel(const void* loss, int loss_f64, float sam
         if (mixed) {                                   // a NaN loss (overflowed fp16 step) is skipped, unless 10 in a row
             if (sl == sl || ctl[CTL_NAN] >= 10.f) {
                 ctl[CTL_NAN] = 0.f;
-                ctl[CTL_LOSS] += sl;
-                ctl[CTL_SAMPLES] += ss;
+                two_sum_into(ctl[CTL_LOSS], ctl[CTL_LOSS_LO], sl);
+                two_sum_into(ctl[CTL_SAMPLES], ctl[CTL_SAMPLES_LO], ss);
             } else {
                 ctl[CTL_NAN] += 1.f;
             }
         } else {
-            ctl[CTL_LOSS] += sl;
-            ctl[CTL_SAMPLES] += ss;
+            two_sum_into(ctl[CTL_LOSS], ctl[CTL_LOSS_LO], sl);
+            two_sum_into(ctl[CTL_SAMPLES], ctl[CTL_SAMPLES_LO], ss);
         }
     }
 }

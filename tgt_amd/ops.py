@@ -654,7 +654,7 @@ def adam_step_(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), e
 
 # layout of the optimizer control block (include/tgt_hip.h TGT_CTL_*)
 CTL_SCALE, CTL_TRACKER, CTL_FOUND_INF, CTL_STEPS, CTL_MULT, CTL_COEF, CTL_NORM, CTL_SKIPPED = range(8)
-CTL_LOSS, CTL_SAMPLES, CTL_NAN, CTL_PAIR, CTL_SIZE = 8, 9, 10, 12, 16
+CTL_LOSS, CTL_SAMPLES, CTL_NAN, CTL_LOSS_LO, CTL_PAIR, CTL_SAMPLES_LO, CTL_SIZE = 8, 9, 10, 11, 12, 14, 16
 
 
 def grad_scaler_step_(grad, ctl, world=1, clip_value=0.0, clip_norm=0.0, dynamic=False, growth_factor=2.0,

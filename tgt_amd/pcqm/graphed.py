@@ -12,8 +12,23 @@ form of its `prediction_loop` inner call for small batches (lib/training/trainin
 import torch
 
 
+def _stochastic(model):
+    """does any sub-module carry a positive dropout / drop-path rate?"""
+    for m in model.modules():
+        for name in ('p', 'drop_prob', 'drop_path', 'source_dropout', 'act_dropout', 'attention_dropout', 'triplet_dropout'):
+            v = getattr(m, name, 0)
+            if isinstance(v, (int, float)) and not isinstance(v, bool) and v > 0:
+                return True
+    return False
+
+
 class GraphedForward:
-    def __init__(self, model, example_batch, autocast_dtype=None, warmup=3):
+    def __init__(self, model, example_batch, autocast_dtype=None, warmup=3, allow_frozen_dropout=False):
+        if model.training and not allow_frozen_dropout and _stochastic(model):
+            # the dropout kernels take host-drawn seeds: a captured train-mode forward replays ONE drop pattern, so S
+            # "Monte-Carlo samples" through it would be S copies of the same sample (prediction_loop(predict_in_train=True))
+            raise RuntimeError('GraphedForward: the model is in train mode with dropout / drop_path > 0 -- a replay would repeat '
+                               'the captured dropout pattern.  Capture in eval mode, or pass allow_frozen_dropout=True.')
         self.model, self.autocast_dtype = model, autocast_dtype
         self.static_in = {k: v.clone() for k, v in example_batch.items()}
         side = torch.cuda.Stream()
@@ -35,6 +50,8 @@ class GraphedForward:
     def __call__(self, batch):
         """the model's output for `batch` (same keys, shapes and dtypes as the example); the returned tensors are the graph's
         static outputs: clone them if they must survive the next call"""
+        if batch.keys() != self.static_in.keys():          # a missing key would silently replay the example's data
+            raise RuntimeError(f'GraphedForward: batch keys {sorted(batch)} differ from the captured {sorted(self.static_in)}')
         for k, v in batch.items():
             dst = self.static_in[k]
             if dst.shape != v.shape or dst.dtype != v.dtype:

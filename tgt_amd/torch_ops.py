@@ -13,6 +13,7 @@ through `tgt_amd.ops` (ctypes, with the fused-row layouts and the bias-gradient 
 library is the seam for callers that want plain torch custom ops, e.g. the reference's own
 `lib/tgt/layers/triplet.py:213-246` / `layers.py:62-77` einsum chains replaced in place.
 """
+import hashlib
 import os
 import subprocess
 
@@ -30,17 +31,28 @@ def build_op_library(force=False):
     from torch.utils import cpp_extension as ce
     _lib.build_library()
     deps = [_SRC, os.path.join(os.path.dirname(_HERE), 'include', 'tgt_hip.h'), _lib.LIB_PATH]
-    if not force and os.path.exists(OPS_LIB_PATH) and os.path.getmtime(OPS_LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
-        return OPS_LIB_PATH
     tlib = os.path.join(os.path.dirname(torch.__file__), 'lib')
-    cmd = [os.environ.get('CXX', 'g++'), '-O2', '-std=c++17', '-fPIC', '-shared', '-D__HIP_PLATFORM_AMD__=1', '-DUSE_ROCM=1',
+    cxx = os.environ.get('CXX', 'g++')
+    cmd = [cxx, '-O2', '-std=c++17', '-fPIC', '-shared', '-D__HIP_PLATFORM_AMD__=1', '-DUSE_ROCM=1',
            f'-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}']
     cmd += [f'-I{p}' for p in ce.include_paths()] + ['-I/opt/rocm/include', _SRC, '-o', OPS_LIB_PATH,
                                                     f'-L{tlib}', '-lc10', '-lc10_hip', '-ltorch_cpu', '-ltorch_hip', '-ltorch',
                                                     f'-L{_HERE}', '-l:libtgt_hip.so', '-Wl,-rpath,$ORIGIN', f'-Wl,-rpath,{tlib}']
+    # the command line, the compiler and the torch build are part of the library's currency (not only mtimes)
+    try:
+        cxx_id = subprocess.run([cxx, '--version'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode(errors='replace')
+    except OSError:
+        cxx_id = 'unknown'
+    stamp = hashlib.sha256((' '.join(cmd) + '\n' + cxx_id + torch.__version__).encode()).hexdigest()
+    stamp_path = OPS_LIB_PATH[:-3] + '.stamp'
+    if not force and os.path.exists(OPS_LIB_PATH) and os.path.getmtime(OPS_LIB_PATH) >= max(os.path.getmtime(d) for d in deps) and \
+            os.path.exists(stamp_path) and open(stamp_path).read() == stamp:
+        return OPS_LIB_PATH
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode:
         raise RuntimeError('building libtgt_torch_ops.so failed: ' + ' '.join(cmd) + '\n' + r.stdout.decode(errors='replace'))
+    with open(stamp_path, 'w') as fh:
+        fh.write(stamp)
     return OPS_LIB_PATH
 
 

@@ -16,6 +16,7 @@ training.py:152 DDP gradient averaging), re-designed for one process per GPU:
 """
 import math
 import os
+import weakref
 from dataclasses import dataclass, field
 
 import torch
@@ -48,6 +49,10 @@ class StepConfig:
     # gradient exchange dtype: None = the float32 flat buffer as it is (reference DDP semantics, bit-exact parity);
     # 'bf16' = each bucket crosses the links as bfloat16 (half the xGMI bytes, SURVEY 5.8 / 8(e): an option, off by default)
     grad_comm_dtype: str = None
+    # collective per bucket: 'all_reduce' (what torch DDP issues, reference training.py:152), or 'reduce_scatter': reduce-scatter +
+    # all-gather of the bucket -- on the fully connected 8-GPU xGMI mesh each rank then owns 1/world of the sum and the two halves
+    # use all seven links at once instead of a ring's one; same sums, another summation order
+    grad_exchange: str = 'all_reduce'
     # gradient clipping (reference training.py:446-462; None = off, as in the shipped YAMLs)
     clip_grad_value: float = None
     clip_grad_norm: float = None
@@ -222,10 +227,43 @@ class Trainer:
             self.flat.make_shadow(torch.bfloat16 if self.cfg.mixed_precision == 'bf16' else torch.float16)
         # parameters changed behind the trainer's back (the reference loads pretrained weights AFTER the
         # trainer exists, tgt_training.py:174-189): the 16-bit shadows must follow
-        self._hooks = [model.register_load_state_dict_post_hook(lambda m, keys: self.refresh_shadow())]
+        # (a weak reference: the hook must not keep a dropped trainer -- and its four flat buffers -- alive)
+        wself = weakref.ref(self)
+
+        def _post_load(m, keys):
+            t = wself()
+            if t is not None and not t._closed:
+                t.refresh_shadow()
+        self._hooks = [model.register_load_state_dict_post_hook(_post_load)]
         # this trainer orders its own gradient collection after both streams; the node side stream is
-        # only safe under it (torch DDP's reducer does not know about it): see ops.side_stream
+        # only safe under it (torch DDP's reducer does not know about it): see ops.side_stream.  close()
+        # (or garbage collection of the trainer) gives the ownership back.
         ops.side_stream.owner_present(True)
+        self._closed = False
+        self._finalizer = weakref.finalize(self, Trainer._release, self._hooks)
+
+    @staticmethod
+    def _release(hooks):
+        for h in hooks:
+            h.remove()
+        hooks.clear()
+        ops.side_stream.owner_present(False)
+
+    def close(self):
+        """Give up the step: the node side stream loses this owner (with none left, ops.side_stream runs its blocks on the
+        current stream again, which is what torch DDP's reducer needs), the load_state_dict hook is removed and the
+        parameters' 16-bit shadows are dropped.  The parameters keep living in the flat buffer.  Idempotent."""
+        if not self._closed:
+            self._closed = True
+            self._finalizer()               # runs _release once; a later garbage collection does nothing
+            self.flat.drop_shadow()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     @property
     def loss_scale(self):
@@ -264,17 +302,33 @@ class Trainer:
 
     def _all_reduce_async(self, g):
         """all-reduce (sum) of a slice of the flat gradient; returns something with .wait()"""
-        if self.cfg.grad_comm_dtype == 'bf16':
-            wire = g.to(torch.bfloat16)
-            h = dist.all_reduce(wire, group=self.pg, async_op=True)
+        assert self.cfg.grad_comm_dtype in (None, 'bf16'), self.cfg.grad_comm_dtype
+        assert self.cfg.grad_exchange in ('all_reduce', 'reduce_scatter'), self.cfg.grad_exchange
+        wire = g.to(torch.bfloat16) if self.cfg.grad_comm_dtype == 'bf16' else g
+        pg, world = self.pg, self.world
+        if self.cfg.grad_exchange == 'reduce_scatter' and world > 1 and wire.numel() % world == 0:
+            # the sum in two halves: every rank reduces its 1/world shard of the bucket (reduce-scatter), then the reduced
+            # shards are gathered back over the bucket
+            n = wire.numel() // world
+            shard = torch.empty(n, dtype=wire.dtype, device=wire.device)
+            h1 = dist.reduce_scatter_tensor(shard, wire, group=pg, async_op=True)
 
-            class _Done:
+            class _Two:
                 def wait(_self):
-                    h.wait()
-                    g.copy_(wire)
-            return _Done()
-        assert self.cfg.grad_comm_dtype is None, self.cfg.grad_comm_dtype
-        return dist.all_reduce(g, group=self.pg, async_op=True)
+                    h1.wait()
+                    dist.all_gather_into_tensor(wire, shard, group=pg)
+                    if wire is not g:
+                        g.copy_(wire)
+            return _Two()
+        h = dist.all_reduce(wire, group=pg, async_op=True)
+        if wire is g:
+            return h
+
+        class _Done:
+            def wait(_self):
+                h.wait()
+                g.copy_(wire)
+        return _Done()
 
     def _reduce_bucket(self, k):
         s, e, n, first = self.buckets[k]
@@ -354,7 +408,8 @@ class Trainer:
 
     # ---- running loss (reference tgt_training.py:137-171), sync-free -------
     def initialize_losses(self):
-        self.ctl[ops.CTL_LOSS:ops.CTL_NAN + 1] = 0
+        self.ctl[ops.CTL_LOSS:ops.CTL_LOSS_LO + 1] = 0          # loss, samples, NaN streak, low part of the loss sum
+        self.ctl[ops.CTL_SAMPLES_LO] = 0
 
     def update_losses(self, loss, batch):
         """total_loss += loss * samples, total_samples += samples (summed over ranks; a NaN step loss is
@@ -376,7 +431,7 @@ class Trainer:
     def mean_loss(self):
         """running mean loss per sample since initialize_losses (host read: synchronises)"""
         c = self.ctl.tolist()
-        return c[ops.CTL_LOSS] / (c[ops.CTL_SAMPLES] + 1e-12)
+        return (c[ops.CTL_LOSS] + c[ops.CTL_LOSS_LO]) / (c[ops.CTL_SAMPLES] + c[ops.CTL_SAMPLES_LO] + 1e-12)
 
     def step_stats(self):
         """host copy of the control block's counters (synchronises; for logging / tests)"""

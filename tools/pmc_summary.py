@@ -20,6 +20,20 @@ def short(name):
     return m.group(1) if m else name[:60]
 
 
+def kernel_source_sha(root=None):
+    """sha256 (16 hex) over every kernel source of tgt_amd/csrc: what a counter summary was measured ON (bench.py only quotes a
+    summary whose hash equals the tree's)"""
+    import hashlib
+    root = root or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, 'tgt_amd', 'csrc')
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.hpp', '.cpp')):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def main():
     out = sys.argv[1]
     acc = defaultdict(lambda: defaultdict(list))
@@ -53,6 +67,7 @@ def main():
         if 'SQ_INSTS_VALU' in a and 'SQ_INSTS_MFMA' in a and a['SQ_INSTS_MFMA']:
             d['valu_per_mfma'] = round(a['SQ_INSTS_VALU'] / a['SQ_INSTS_MFMA'], 1)
         res[k] = d
+    res['_kernel_src_sha'] = kernel_source_sha()
     json.dump(res, open(os.path.join(out, 'pmc_summary.json'), 'w'), indent=1)
     print(json.dumps(res, indent=1))
 
