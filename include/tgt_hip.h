@@ -282,9 +282,10 @@ int tgt_loss_accumulate(const void* loss, int32_t loss_is_f64, float samples, fl
  *   TGT_EPI_LN_BWD   z = dy, the gradient at the output of LayerNorm(res; gamma) with saved mean / rstd (N <= 256):
  *                    out  = ds_in + rstd * (dy*gamma - mean_n(dy*gamma) - xhat * mean_n(dy*gamma*xhat))   (ds_in may be NULL)
  *                    out2 = out * row_scale[..]  (when given: the gradient of the branch DropPath scaled)
- *                    colsum_partial (tgt_edge_linear_parts(M, N), 3N) float32, ZERO-FILLED by the caller, when given: per row tile
- *                    [sum dy*xhat | sum dy | sum out2-or-out]: dgamma, dbeta and the bias gradient of the Linear
- *                    that produced the branch, to be summed over the tiles (tgt_sum_planes)
+ *                    colsum_partial (tgt_edge_linear_parts(M, N), 3N) float32 when given (N = 256: one row per persistent workgroup,
+ *                    all written; N < 256: per row tile, ZERO-FILLED by the caller):
+ *                    [sum dy*xhat | sum dy | sum round(out * row_scale)]: dgamma, dbeta and the bias gradient of the Linear
+ *                    that produced the branch, to be summed over the rows (tgt_sum_planes).  No bias (a data-gradient GEMM).
  *   TGT_EPI_RESID with gamma / beta / y: additionally y = LayerNorm(out as stored; gamma, beta, eps), mean / rstd (M)
  *                    float32 written when given (N <= 256): the fused entry of the next pre-norm sub-block.
  * Element type 16-bit (TGT_BF16 / TGT_F16; bias in the same type); N % 8 == 0; K in {64, 128, 256}.

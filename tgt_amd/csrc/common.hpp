@@ -14,6 +14,7 @@ typedef __attribute__((ext_vector_type(8)))  _Float16 f16x8;
 typedef __attribute__((ext_vector_type(8)))  float    f32x8;
 typedef __attribute__((ext_vector_type(4)))  float    f32x4;
 typedef __attribute__((ext_vector_type(16))) float    f32x16;
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));      // raw buffer load / store data
 
 // ---------------------------------------------------------------------------
 // 32x32 matrix-core tile:  C[m][n] += sum_kk A[m][kk] * B[kk][n],  kk in [0,16)
@@ -100,6 +101,74 @@ __device__ __forceinline__ float xhalf(float v) {
     const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);     // r[0] = [lo, lo], r[1] = [hi, hi]
     return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
 }
+
+// ---------------------------------------------------------------------------
+// Cross-lane reductions without the LDS crossbar.  hipcc lowers __shfl_xor to ds_bpermute_b32 plus four index
+// instructions per step (v_xor / v_cmp / v_cndmask / v_lshl) and an lgkmcnt wait: ~7 instructions and one LDS round trip
+// (~100 cycles on the dependency chain) per step.  Here: DPP adds inside a 16-lane row (quad_perm, row_half_mirror,
+// row_mirror: one VALU instruction each), v_permlane16_swap / v_permlane32_swap (gfx950) across rows and halves.
+// ALL-REDUCE over aligned groups of W lanes: every lane of a group ends with the group's value.
+//
+// The swap builtins return {first operand after the swap, second operand after the swap}; called with ONE value for both
+// operands hipcc (ROCm 7.2) treats the two results as equal outside a select -- it stores r[0] where r[1] was asked for
+// (seen in the ISA of a probe: `v_permlane16_swap v2, v3` followed by `v_add_f32 v2, v2, v2`).  lane_swap_pair() therefore
+// hands it two values the compiler cannot relate (an empty asm on a copy) and fences the results the same way.
+// ---------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// (mine, partner's) in some order: the values of lanes l and l ^ 16 (ROWS16) or l ^ 32
+template <bool ROWS16>
+__device__ __forceinline__ void lane_swap_pair(float v, float& a, float& b) {
+    unsigned x = __builtin_bit_cast(unsigned, v), y = x;
+    asm volatile("" : "+v"(y));
+    unsigned r0, r1;
+    if constexpr (ROWS16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
+        r0 = r[0]; r1 = r[1];
+    } else {
+        const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+        r0 = r[0]; r1 = r[1];
+    }
+    asm volatile("" : "+v"(r0), "+v"(r1));
+    a = __builtin_bit_cast(float, r0);
+    b = __builtin_bit_cast(float, r1);
+}
+struct RedSum { static __device__ __forceinline__ float op(float a, float b) { return a + b; } };
+struct RedMax { static __device__ __forceinline__ float op(float a, float b) { return fmaxf(a, b); } };
+template <int W, typename OP>
+__device__ __forceinline__ float group_reduce(float v) {
+    static_assert(W == 1 || W == 2 || W == 4 || W == 8 || W == 16 || W == 32 || W == 64, "group width");
+    if constexpr (W >= 2) v = OP::op(v, dpp_mov<0xB1>(v));       // quad_perm [1,0,3,2]: l ^ 1
+    if constexpr (W >= 4) v = OP::op(v, dpp_mov<0x4E>(v));       // quad_perm [2,3,0,1]: l ^ 2
+    if constexpr (W >= 8) v = OP::op(v, dpp_mov<0x141>(v));      // row_half_mirror: the other quad of the 8
+    if constexpr (W >= 16) v = OP::op(v, dpp_mov<0x140>(v));     // row_mirror: the other half of the 16-lane row
+    if constexpr (W >= 32) { float a, b; lane_swap_pair<true>(v, a, b); v = OP::op(a, b); }
+    if constexpr (W >= 64) { float a, b; lane_swap_pair<false>(v, a, b); v = OP::op(a, b); }
+    return v;
+}
+template <int W> __device__ __forceinline__ float group_sum(float v) { return group_reduce<W, RedSum>(v); }
+template <int W> __device__ __forceinline__ float group_max(float v) { return group_reduce<W, RedMax>(v); }
+// the value of lane l ^ 16 / l ^ 32 alone (softmax statistics of the 16-wide tiles)
+__device__ __forceinline__ float xor16_max(float v) { float a, b; lane_swap_pair<true>(v, a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float xor16_sum(float v) { float a, b; lane_swap_pair<true>(v, a, b); return a + b; }
+
+// n / d for 32-bit unsigned n with a run-time divisor fixed for the kernel (rows_per_sample): one v_mul_hi + 4 cheap
+// instructions instead of the ~130-instruction 64-bit division sequence (Granlund & Montgomery, fig. 4.1)
+struct FastDiv {
+    uint32_t mul, sh1, sh2;
+    __device__ __forceinline__ explicit FastDiv(uint32_t d) {
+        const uint32_t l = d > 1 ? 32 - __builtin_clz(d - 1) : 0;               // ceil(log2 d)
+        mul = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << l) - d)) / (d ? d : 1) + 1);
+        sh1 = l < 1 ? l : 1;
+        sh2 = l > 1 ? l - 1 : 0;
+    }
+    __device__ __forceinline__ uint32_t div(uint32_t n) const {
+        const uint32_t t = __umulhi(mul, n);
+        return (t + ((n - t) >> sh1)) >> sh2;
+    }
+};
 
 // keep/drop of the V consecutive elements of vector `vec` (= first element index / V): one hash
 // of (seed, vec), then one 32-bit word per TWO elements, 16 bits each;

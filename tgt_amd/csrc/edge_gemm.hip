@@ -170,7 +170,6 @@ __global__ void __launch_bounds__(512, 2) edge_slice_kernel(const tgt_edge_linea
     const int n0 = slice * NT + wn * 32;
     const bool active = n0 < N;
     const int64_t row_tiles = (a.M + kBM - 1) / kBM;
-    const int ablate = a._pad0;
     const int rbase = wm * MB * 32;                        // first row (inside the tile) of this wave
 
     auto stage = [&](int64_t tile, int buf) {
@@ -183,7 +182,7 @@ __global__ void __launch_bounds__(512, 2) edge_slice_kernel(const tgt_edge_linea
             int64_t m = tile * kBM + row;
             m = m < a.M ? m : a.M - 1;
             const T* src = A + m * a.lda + ((ps ^ ((row / g.rpw) & g.mask)) << 3);
-            if ((total % 512 == 0 || p0 + wave * 64 < total) && !(ablate & 4))
+            if (total % 512 == 0 || p0 + wave * 64 < total)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(xs + (p0 + wave * 64) * 16), 16, 0, 0);
         }
@@ -231,7 +230,7 @@ __global__ void __launch_bounds__(512, 2) edge_slice_kernel(const tgt_edge_linea
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[mb][q] = 0.f;
-        if (active && !(ablate & 8)) {
+        if (active) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 F xf[MB];
@@ -250,12 +249,7 @@ __global__ void __launch_bounds__(512, 2) edge_slice_kernel(const tgt_edge_linea
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) unpack4<T>(braw[gq], bv + 4 * gq);
         T* out = reinterpret_cast<T*>(a.out);
-        if (ablate & 2) {
-            float t = 0.f;
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) t += acc[mb][0] + acc[mb][15];
-            if (t == 123.456f) reinterpret_cast<float*>(a.out)[tid] = t;
-        } else if constexpr (EPI == EPI_BIAS) {
+        if constexpr (EPI == EPI_BIAS) {
             if (active) {
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {
@@ -541,11 +535,59 @@ __device__ __forceinline__ uint4 rp_pack8(const float* v) {
     __builtin_memcpy(&raw, t, 16);
     return raw;
 }
-// sum over the 32 lanes of a half-wave (one row)
-__device__ __forceinline__ float rp_row_sum(float v) {
+// sum over the 32 lanes of a half-wave (one row): DPP adds + one v_permlane16_swap (common.hpp), no LDS crossbar
+__device__ __forceinline__ float rp_row_sum(float v) { return group_sum<32>(v); }
+
+// The row phase computes on PAIRS: the two 16-bit values of a dword become one f32x2, every arithmetic step is one packed
+// instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) and a pair goes back with ONE v_cvt_pk_bf16_f32 -- written on scalars,
+// hipcc pairs element 0 of one dword with element 0 of the next and then needs two fix-up instructions per dword to re-pair.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+template <typename T>
+__device__ __forceinline__ void rp_unpack(const uint4& raw, f32x2 (&v)[4]) {
+    const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    for (int k = 0; k < 4; ++k) {
+        if constexpr (std::is_same<T, bf16_t>::value) {
+            v[k].x = __builtin_bit_cast(float, w[k] << 16);
+            v[k].y = __builtin_bit_cast(float, w[k] & 0xffff0000u);
+        } else {
+            v[k] = __builtin_convertvector(__builtin_bit_cast(f16x2_t, w[k]), f32x2);
+        }
+    }
+}
+template <typename T>
+__device__ __forceinline__ unsigned rp_pack2(f32x2 v) {
+    if constexpr (std::is_same<T, bf16_t>::value) return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+    else return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
+}
+template <typename T>
+__device__ __forceinline__ uint4 rp_pack(const f32x2 (&v)[4]) {
+    return make_uint4(rp_pack2<T>(v[0]), rp_pack2<T>(v[1]), rp_pack2<T>(v[2]), rp_pack2<T>(v[3]));
+}
+// the value a pair has once stored in T (what a later pass over the stored tensor would read)
+template <typename T>
+__device__ __forceinline__ f32x2 rp_round(f32x2 v) {
+    const uint4 w = make_uint4(rp_pack2<T>(v), 0, 0, 0);
+    f32x2 o[4];
+    rp_unpack<T>(w, o);
+    return o[0];
+}
+__device__ __forceinline__ f32x2 rp_splat(float x) { f32x2 r = {x, x}; return r; }
+// gelu_cdf (common.hpp) on a pair: the polynomial in packed arithmetic, exp / rcp per element
+__device__ __forceinline__ f32x2 gelu_cdf2(f32x2 v, f32x2& e) {
+    f32x2 ax = {fabsf(v.x), fabsf(v.y)};
+    ax = ax * 0.70710678118654752f;
+    const f32x2 den = ax * 0.3275911f + 1.f;
+    const f32x2 t = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    const f32x2 q = -(ax * ax);
+    e.x = __expf(q.x);
+    e.y = __expf(q.y);
+    const f32x2 poly = t * (t * (t * (t * (t * 1.061405429f + -1.453152027f) + 1.421413741f) + -0.284496736f) + 0.254829592f);
+    const f32x2 h = 0.5f - 0.5f * poly * e;
+    f32x2 r = {0.5f + copysignf(h.x, v.x), 0.5f + copysignf(h.y, v.y)};
+    return r;
 }
 
 // Wave roles.  vmcnt is ONE in-order counter per wave, so a wave that both prefetches and stores can only wait for its
@@ -553,7 +595,7 @@ __device__ __forceinline__ float rp_row_sum(float v) {
 // row-phase time simply added up, 0.044 + 0.085 ms for W1+GELU; hipcc additionally answers an outstanding LDS-DMA with
 // `s_waitcnt vmcnt(0)` in front of the next LDS read it cannot prove disjoint).  So the two kinds of traffic live in
 // different waves of the workgroup:
-//   waves 0-7   GEMM role: fetch the next 32-row A tile into registers (plain 16-byte loads; these waves never store, so the
+//   waves 0-7   GEMM role: fetch the next 32-row A tile into registers (16-byte buffer loads; these waves never store, so the
 //               compiler's wait before the closing ds_writes counts exactly those loads), k-loop on the current tile, weight
 //               slice (32 columns x K per wave) resident in registers, accumulators out through the staging tile;
 //   waves 8-15  row role: one pipeline stage behind, the row phase of the previous tile -- operand rows prefetched from
@@ -563,6 +605,40 @@ __device__ __forceinline__ float rp_row_sum(float v) {
 // the row phase and both kinds of memory traffic overlap.  (With 4 + 4 waves the row role ran one wave per SIMD and was
 // latency-bound: 0.096 ms for the GELU row phase alone.)  One s_barrier per stage (32 rows) couples the roles; staging
 // tiles are double-buffered.
+//
+// Round 3: every global access goes through a raw BUFFER RESOURCE re-based on the tile (rows [32 t, 32 t + 32) of the tensor,
+// `tile_rsrc`): an absent tensor, a row at or past M, an inactive lane simply fall outside the resource -- loads return 0,
+// stores are dropped by the address unit.  So the loop bodies of both roles are STRAIGHT-LINE code: no validity predicate, no
+// 64-bit vector address arithmetic (one constant 32-bit offset per thread and tensor), and -- the point -- hipcc's wait-count
+// insertion can count the in-flight operations exactly.  Read off the ISA of the round-2 form: (1) the GEMM role spilled its
+// prefetched A tile to scratch at the 128-register cap, which needs the data and so made the "prefetch" a synchronous load:
+// every stage began with an HBM round trip; (2) the row role's conditional stores (`if (row < M)`, optional outputs) let the
+// compiler prove only `vmcnt(2..3)` where 4-8 stores were in flight, so every stage also waited for its own stores; (3) the
+// per-row `m / rows_per_sample` was a 64-bit software division (~130 instructions, twice a stage) and the row reductions went
+// through ds_bpermute.  (3) is FastDiv + DPP (common.hpp), (1) is the bias kept packed (16 registers less) + scalar addressing.
+// ---------------------------------------------------------------------------------------------------------------
+// rows [row0, row0 + 32) of an (M, ld) row-major tensor whose rows hold `row_used` bytes, as a raw buffer (see above)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const void* base, int64_t ld_bytes, int row_used, int64_t row0, int64_t M) {
+    int64_t n = base ? M - row0 : 0;
+    n = n < 0 ? 0 : (n > 32 ? 32 : n);
+    const int64_t bytes = n > 0 ? (n - 1) * ld_bytes + row_used : 0;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(base)) + row0 * ld_bytes, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 rp_ld16(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void rp_st16(__amdgpu_buffer_rsrc_t r, uint32_t off, const uint4& v) {
+    const u32x4_t d = {v.x, v.y, v.z, v.w};
+    __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)off, 0, 0);
+}
+__device__ __forceinline__ float rp_ld_f32(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ void rp_st_f32(__amdgpu_buffer_rsrc_t r, uint32_t off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)off, 0, 0);
+}
+
 template <typename T, int KS, int EPI>
 __global__ void __launch_bounds__(1024, 4) edge_rows_kernel(const tgt_edge_linear_args a) {
     using F = frag_t<T>;
@@ -570,51 +646,52 @@ __global__ void __launch_bounds__(1024, 4) edge_rows_kernel(const tgt_edge_linea
     constexpr bool kOperand = EPI == EPI_RESID || EPI == EPI_GELU_BWD || EPI == EPI_LN_BWD;
     constexpr bool kOp2 = EPI == EPI_LN_BWD;
     constexpr int kOffStage = 2 * kABytes, kOffGB = kOffStage + 2 * kSBytes;      // LDS: A tiles [2] | staging tiles [2] | gamma, beta
+    constexpr uint32_t kNone = 0xffffffffu;                                       // a byte offset outside every buffer
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hi = lane >> 5;
     const EgGeo g(K), gs(N);
     const int64_t row_tiles = (a.M + kBM - 1) / kBM;
-    const int ablate = a._pad0;
     float* gb = reinterpret_cast<float*>(smem + kOffGB);
     if (blockIdx.x >= row_tiles) return;
     const int n_tiles = (int)((row_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x);       // tiles of this workgroup
-    auto tile_of = [&](int s) { return (int64_t)blockIdx.x + (int64_t)s * gridDim.x; };
+    auto tile_of = [&](int s) { return (int64_t)blockIdx.x + (int64_t)s * gridDim.x; };    // (s >= n_tiles: past the last row -> empty buffers)
 
     if (wave < 8) {
         // ------------------------------------------------------------------------------------------------ GEMM role
-        const T* A = reinterpret_cast<const T*>(a.a);
         const T* W = reinterpret_cast<const T*>(a.w);
-        const int t4 = tid;                                // 0..511
         const int n0 = wave * 32;
         constexpr int spr = K >> 3, total = kBM * spr, kNA = (total + 511) / 512;
         F wr[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) wr[ks] = load_frag<T>(W + (int64_t)(n0 + r) * a.ldw + ks * 16 + 8 * hi);
-        uint2 braw[4];
+        uint2 braw[4];                                     // the bias of this lane's 16 columns, kept PACKED (unpacked per tile into the accumulator)
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             braw[gq] = make_uint2(0, 0);
             if (a.bias && !(EPI == EPI_RESID && (a.flags & TGT_EDGE_BIAS_SCALED)))      // (BIAS_SCALED: the row phase adds scale * bias)
                 braw[gq] = *reinterpret_cast<const uint2*>(reinterpret_cast<const T*>(a.bias) + n0 + 8 * gq + 4 * hi);
         }
-        uint4 pre[kNA];
-        auto fetch = [&](int64_t tile) {                   // 16-byte pieces (row, slot): consecutive threads = consecutive slots of a row
+        // this thread's 16-byte pieces (row, slot) of an A tile: byte offset inside the tile's buffer and LDS address
+        const int64_t lda_b = a.lda * 2;
+        uint32_t aoff[kNA];
+        int loff[kNA];
 #pragma unroll
-            for (int q = 0; q < kNA; ++q) {
-                const int pc = q * 512 + t4;
-                const int row = pc / spr, ps = pc % spr;
-                int64_t m = tile * kBM + row;
-                m = m < a.M ? m : a.M - 1;                 // rows past M re-read row M-1 (never stored)
-                if ((total % 512 == 0 || pc < total) && !(ablate & 4)) pre[q] = *reinterpret_cast<const uint4*>(A + m * a.lda + ps * 8);
-            }
+        for (int q = 0; q < kNA; ++q) {
+            const int pc = q * 512 + tid, row = pc / spr, ps = pc % spr;
+            const bool mine = total % 512 == 0 || pc < total;
+            aoff[q] = mine ? (uint32_t)row * (uint32_t)lda_b + (uint32_t)ps * 16u : kNone;
+            loff[q] = g.off(row % kBM, ps);
+        }
+        uint4 pre[kNA];
+        auto fetch = [&](int64_t tile) {
+            const __amdgpu_buffer_rsrc_t rs = tile_rsrc(a.a, lda_b, K * 2, tile * kBM, a.M);
+#pragma unroll
+            for (int q = 0; q < kNA; ++q) pre[q] = rp_ld16(rs, aoff[q]);
         };
         auto commit = [&](int buf) {
 #pragma unroll
-            for (int q = 0; q < kNA; ++q) {
-                const int pc = q * 512 + t4;
-                const int row = pc / spr, ps = pc % spr;
-                if (total % 512 == 0 || pc < total) *reinterpret_cast<uint4*>(smem + buf * kABytes + g.off(row, ps)) = pre[q];
-            }
+            for (int q = 0; q < kNA; ++q)
+                if (total % 512 == 0 || aoff[q] != kNone) *reinterpret_cast<uint4*>(smem + buf * kABytes + loff[q]) = pre[q];
         };
         fetch(tile_of(0));
         commit(0);
@@ -624,35 +701,37 @@ __global__ void __launch_bounds__(1024, 4) edge_rows_kernel(const tgt_edge_linea
             if (s < n_tiles) {
                 const char* xs = smem + (s & 1) * kABytes;
                 char* sg = smem + kOffStage + (s & 1) * kSBytes;
-                if (s + 1 < n_tiles) fetch(tile_of(s + 1));
+                fetch(tile_of(s + 1));
                 asm volatile("" ::: "memory");            // the prefetch is issued HERE, not sunk towards its use
                 f32x16 acc;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-                if (!(ablate & 8)) {
+                for (int gq = 0; gq < 4; ++gq) {           // accumulator <- bias
+                    float bv[4];
+                    unpack4<T>(braw[gq], bv);
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) {
-                        const F xf = load_frag<T>(reinterpret_cast<const T*>(xs + g.off(r, 2 * ks + hi)));
-                        acc = mma32(wr[ks], xf, acc);
-                    }
+                    for (int j = 0; j < 4; ++j) acc[4 * gq + j] = bv[j];
                 }
-                // accumulators -> staging tile: + bias, rounded to the storage type (what nn.Linear emits under autocast);
+                // (the 16-byte slot of k-step ks is XOR-swizzled by the row: left to itself hipcc hoists all KS slot addresses out of the
+                // tile loop -- 17 loop-invariant registers at K = 256, which at the 128-register cap it paid for by spilling two weight
+                // fragments and RELOADING them from scratch inside this loop, behind a vmcnt(0) that also waited for the prefetch just
+                // issued.  The empty asm pins the two-instruction address computation to its k-step.)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    int rr = r;
+                    asm volatile("" : "+v"(rr));
+                    const F xf = load_frag<T>(reinterpret_cast<const T*>(xs + g.off(rr, 2 * ks + hi)));
+                    acc = mma32(wr[ks], xf, acc);
+                }
+                // accumulators -> staging tile, rounded to the storage type (what nn.Linear emits under autocast);
                 // lanes (r, hi) of a row exchange halves so that each holds 8 consecutive columns = one 16-byte slot
-                {
-                    float bv[16];
 #pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) unpack4<T>(braw[gq], bv + 4 * gq);
-#pragma unroll
-                    for (int p = 0; p < 2; ++p) {
-                        uint2 lo = pack4<T>(acc[8 * p] + bv[8 * p], acc[8 * p + 1] + bv[8 * p + 1], acc[8 * p + 2] + bv[8 * p + 2],
-                                            acc[8 * p + 3] + bv[8 * p + 3]);
-                        uint2 up = pack4<T>(acc[8 * p + 4] + bv[8 * p + 4], acc[8 * p + 5] + bv[8 * p + 5], acc[8 * p + 6] + bv[8 * p + 6],
-                                            acc[8 * p + 7] + bv[8 * p + 7]);
-                        swap_halves(lo, up);
-                        *reinterpret_cast<uint4*>(sg + gs.off(r, (n0 >> 3) + 2 * p + hi)) = make_uint4(lo.x, lo.y, up.x, up.y);
-                    }
+                for (int p = 0; p < 2; ++p) {
+                    uint2 lo = pack4<T>(acc[8 * p], acc[8 * p + 1], acc[8 * p + 2], acc[8 * p + 3]);
+                    uint2 up = pack4<T>(acc[8 * p + 4], acc[8 * p + 5], acc[8 * p + 6], acc[8 * p + 7]);
+                    swap_halves(lo, up);
+                    *reinterpret_cast<uint4*>(sg + gs.off(r, (n0 >> 3) + 2 * p + hi)) = make_uint4(lo.x, lo.y, up.x, up.y);
                 }
-                if (s + 1 < n_tiles) commit((s + 1) & 1);  // (the A buffer of tile s-1: its k-loop ended before the last barrier)
+                commit((s + 1) & 1);                       // (the A buffer of tile s-1: its k-loop ended before the last barrier)
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -667,152 +746,171 @@ __global__ void __launch_bounds__(1024, 4) edge_rows_kernel(const tgt_edge_linea
         gb[t4] = a.gamma ? a.gamma[t4] : 1.f;
         gb[N + t4] = (a.gamma && a.beta) ? a.beta[t4] : 0.f;
     }
-    const bool ln_out = EPI == EPI_RESID && a.gamma != nullptr;
     const uint32_t thresh = a.dropout_p <= 0.f ? 0u : (uint32_t)fminf(65535.f, fmaxf(1.f, rintf(a.dropout_p * 65536.f)));
     const float inv_keep = a.dropout_p <= 0.f ? 1.f : 1.f / (1.f - a.dropout_p);
-    constexpr int kCs = EPI == EPI_LN_BWD ? 8 : 1;
-    float cs_g[kCs], cs_b[kCs], cs_x[kCs];               // EPI_LN_BWD: column sums over every row this workgroup processes
+    constexpr int kCs = EPI == EPI_LN_BWD ? 4 : 1;
+    f32x2 cs_g[kCs], cs_b[kCs], cs_x[kCs];               // EPI_LN_BWD: column sums over every row this workgroup processes
 #pragma unroll
-    for (int j = 0; j < kCs; ++j) cs_g[j] = cs_b[j] = cs_x[j] = 0.f;
+    for (int j = 0; j < kCs; ++j) cs_g[j] = cs_b[j] = cs_x[j] = rp_splat(0.f);
+
+    // per-graph factor (DropPath): one float per rows_per_sample rows, through a buffer of its own (absent: empty, and the 1.f below)
+    const float* scale_ptr = EPI == EPI_GELU_BWD ? a.out_scale : a.row_scale;
+    const bool has_scale = scale_ptr != nullptr;
+    const FastDiv per_sample((uint32_t)(has_scale ? a.rows_per_sample : 1));      // (host-checked: M < 2^31 when a scale is given)
+    const int64_t n_samples = has_scale ? (a.M + a.rows_per_sample - 1) / a.rows_per_sample : 0;
+    const __amdgpu_buffer_rsrc_t rs_scale = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(scale_ptr), 0, (int)(n_samples * 4), 0x00020000);
+    // this thread's constant byte offsets inside a tile (pass 0; pass 1 is 16 rows further)
+    const int64_t ldr_b = a.ldr * 2, ldd_b = a.ld_ds * 2, ldo_b = a.ldo * 2, ldo2_b = a.ldo2 * 2, ldy_b = a.ldy * 2;
+    const uint32_t c16 = (uint32_t)ch * 16u;
+    const uint32_t o_res = (uint32_t)rsub * (uint32_t)ldr_b + c16, o_ds = (uint32_t)rsub * (uint32_t)ldd_b + c16;
+    const uint32_t o_out = (uint32_t)rsub * (uint32_t)ldo_b + c16, o_out2 = (uint32_t)rsub * (uint32_t)ldo2_b + c16;
+    const uint32_t o_y = (uint32_t)rsub * (uint32_t)ldy_b + c16;
+    const uint32_t o_stat = (uint32_t)rsub * 4u;
 
     struct Ops { uint4 o1[kOperand ? kPass : 1]; uint4 o2[kOp2 ? kPass : 1]; float mu[kOp2 ? kPass : 1], rs[kOp2 ? kPass : 1], sc[kPass]; };
     auto fetch_ops = [&](int64_t tile, Ops& o) {          // the row phase's operands of `tile`: whole rows, straight from global memory
+        const int64_t r0 = tile * kBM;
+        const __amdgpu_buffer_rsrc_t rs1 = tile_rsrc(a.res, ldr_b, N * 2, r0, kOperand ? a.M : 0);
+        const __amdgpu_buffer_rsrc_t rs2 = tile_rsrc(a.ds_in, ldd_b, N * 2, r0, kOp2 ? a.M : 0);
+        const __amdgpu_buffer_rsrc_t rsm = tile_rsrc(a.mean, 4, 4, r0, kOp2 ? a.M : 0), rsr = tile_rsrc(a.rstd, 4, 4, r0, kOp2 ? a.M : 0);
 #pragma unroll
         for (int i = 0; i < kPass; ++i) {
-            int64_t m = tile * kBM + i * 16 + rsub;
-            m = m < a.M ? m : a.M - 1;
-            if (ablate & 4) continue;
-            if constexpr (kOperand) o.o1[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(a.res) + m * a.ldr + ch * 8);
+            if constexpr (kOperand) o.o1[i] = rp_ld16(rs1, o_res + (uint32_t)i * 16u * (uint32_t)ldr_b);
             if constexpr (kOp2) {
-                o.o2[i] = a.ds_in ? *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(a.ds_in) + m * a.ld_ds + ch * 8) : make_uint4(0, 0, 0, 0);
-                o.mu[i] = a.mean[m];
-                o.rs[i] = a.rstd[m];
+                o.o2[i] = rp_ld16(rs2, o_ds + (uint32_t)i * 16u * (uint32_t)ldd_b);
+                o.mu[i] = rp_ld_f32(rsm, o_stat + (uint32_t)i * 64u);
+                o.rs[i] = rp_ld_f32(rsr, o_stat + (uint32_t)i * 64u);
             }
-            o.sc[i] = 1.f;
-            if (EPI == EPI_GELU_BWD ? a.out_scale != nullptr : a.row_scale != nullptr)
-                o.sc[i] = (EPI == EPI_GELU_BWD ? a.out_scale : a.row_scale)[m / a.rows_per_sample];
+            const float f = rp_ld_f32(rs_scale, per_sample.div((uint32_t)(r0 + i * 16 + rsub)) * 4u);
+            o.sc[i] = has_scale ? f : 1.f;
         }
     };
     Ops nxt;
     fetch_ops(tile_of(0), nxt);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    float gam[8], bet[8];                                 // this thread's 8 columns, for the whole kernel
-    float bsc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};    // EPI_RESID + BIAS_SCALED: the bias, added as row_scale * bias
+    f32x2 gam[4], bet[4];                                 // this thread's 8 columns (4 pairs), for the whole kernel
+    f32x2 bsc[4];                                         // EPI_RESID + BIAS_SCALED: the bias, added as row_scale * bias (else 0)
+    const bool pres = EPI == EPI_RESID && (a.flags & TGT_EDGE_BIAS_SCALED) != 0;     // x arrived pre-scaled: res + x W^T + scale * bias
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bsc[k] = rp_splat(0.f);
     if constexpr (EPI == EPI_RESID) {
-        if ((a.flags & TGT_EDGE_BIAS_SCALED) && a.bias) rp_unpack8<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(a.bias) + ch * 8), bsc);
+        if (pres && a.bias) rp_unpack<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(a.bias) + ch * 8), bsc);
     }
-    {
-        const float4 g0 = *reinterpret_cast<const float4*>(gb + ch * 8), g1 = *reinterpret_cast<const float4*>(gb + ch * 8 + 4);
-        gam[0] = g0.x; gam[1] = g0.y; gam[2] = g0.z; gam[3] = g0.w; gam[4] = g1.x; gam[5] = g1.y; gam[6] = g1.z; gam[7] = g1.w;
-        const float4 b0 = *reinterpret_cast<const float4*>(gb + N + ch * 8), b1 = *reinterpret_cast<const float4*>(gb + N + ch * 8 + 4);
-        bet[0] = b0.x; bet[1] = b0.y; bet[2] = b0.z; bet[3] = b0.w; bet[4] = b1.x; bet[5] = b1.y; bet[6] = b1.z; bet[7] = b1.w;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        gam[k] = *reinterpret_cast<const f32x2*>(gb + ch * 8 + 2 * k);
+        bet[k] = *reinterpret_cast<const f32x2*>(gb + N + ch * 8 + 2 * k);
     }
-    for (int s = 0; s <= n_tiles; ++s) {
-        if (s >= 1 && !(ablate & 2)) {
-            const Ops cur = nxt;                           // operands of tile s-1 (fetched a stage ago)
-            if (s < n_tiles) fetch_ops(tile_of(s), nxt);
-            asm volatile("" ::: "memory");
-            const char* sg = smem + kOffStage + ((s - 1) & 1) * kSBytes;
-            const int64_t m0 = tile_of(s - 1) * kBM;
+    // vmcnt is in order: the operands of stage s are fetched at the TOP of stage s-1, i.e. they are OLDER than that stage's stores,
+    // and the wait in front of their first use leaves exactly those stores in flight -- a full stage to drain under the next one.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                          // stage 0: the GEMM role fills the first staging tile
+    for (int s = 1; s <= n_tiles; ++s) {
+        const Ops cur = nxt;                               // operands of tile s-1 (fetched a stage ago)
+        fetch_ops(tile_of(s), nxt);
+        asm volatile("" ::: "memory");
+        const char* sg = smem + kOffStage + ((s - 1) & 1) * kSBytes;
+        const int64_t m0 = tile_of(s - 1) * kBM;
+        const __amdgpu_buffer_rsrc_t rs_out = tile_rsrc(a.out, ldo_b, N * 2, m0, a.M);
+        const __amdgpu_buffer_rsrc_t rs_out2 = tile_rsrc(a.out2, ldo2_b, N * 2, m0, (EPI == EPI_GELU || EPI == EPI_LN_BWD) ? a.M : 0);
+        const __amdgpu_buffer_rsrc_t rs_y = tile_rsrc(a.y, ldy_b, N * 2, m0, (EPI == EPI_RESID && a.gamma) ? a.M : 0);
+        const __amdgpu_buffer_rsrc_t rs_mean = tile_rsrc(a.mean, 4, 4, m0, (EPI == EPI_RESID && a.gamma) ? a.M : 0);
+        const __amdgpu_buffer_rsrc_t rs_rstd = tile_rsrc(a.rstd, 4, 4, m0, (EPI == EPI_RESID && a.gamma) ? a.M : 0);
 #pragma unroll
-            for (int i = 0; i < kPass; ++i) {
-                const int row = i * 16 + rsub;
-                const int64_t m = m0 + row;
-                const bool ok = m < a.M;
-                const int64_t mc = ok ? m : a.M - 1;
-                float v[8];
-                rp_unpack8<T>(*reinterpret_cast<const uint4*>(sg + gs.off(row, ch)), v);
-                if constexpr (EPI == EPI_GELU) {
-                    T* pre = reinterpret_cast<T*>(a.out2);
-                    T* out = reinterpret_cast<T*>(a.out);
-                    if (ok) *reinterpret_cast<uint4*>(pre + m * a.ldo2 + ch * 8) = rp_pack8<T>(v);
-                    bool keep[8] = {true, true, true, true, true, true, true, true};
-                    if (thresh) keep_vector<8>(a.dropout_seed, (mc * N + ch * 8) >> 3, thresh, keep);
-                    float gl[8];
-                    const float ik = inv_keep * cur.sc[i];       // (row_scale: the DropPath factor of the branch, folded into the activation)
+        for (int i = 0; i < kPass; ++i) {
+            const int row = i * 16 + rsub;
+            const int64_t m = m0 + row;
+            const uint32_t po = (uint32_t)i * 16u;          // rows of this pass below the thread's pass-0 row
+            f32x2 v[4];
+            rp_unpack<T>(*reinterpret_cast<const uint4*>(sg + gs.off(row, ch)), v);
+            if constexpr (EPI == EPI_GELU) {
+                rp_st16(rs_out2, o_out2 + po * (uint32_t)ldo2_b, rp_pack<T>(v));                  // the pre-activation
+                bool keep[8] = {true, true, true, true, true, true, true, true};
+                if (thresh) keep_vector<8>(a.dropout_seed, (m * N + ch * 8) >> 3, thresh, keep);
+                f32x2 gl[4];
+                const float ik = inv_keep * cur.sc[i];       // (row_scale: the DropPath factor of the branch, folded into the activation)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        float e;
-                        const float cdf = gelu_cdf(v[j], e);
-                        gl[j] = keep[j] ? v[j] * cdf * ik : 0.f;
-                    }
-                    if (ok) *reinterpret_cast<uint4*>(out + m * a.ldo + ch * 8) = rp_pack8<T>(gl);
-                } else if constexpr (EPI == EPI_GELU_BWD) {
-                    const float al = cur.sc[i];
-                    float pv[8], o[8];
-                    rp_unpack8<T>(cur.o1[i], pv);
-                    bool keep[8] = {true, true, true, true, true, true, true, true};
-                    if (thresh) keep_vector<8>(a.dropout_seed, (mc * N + ch * 8) >> 3, thresh, keep);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        float e;
-                        const float cdf = gelu_cdf(pv[j], e);
-                        const float dy = a.out_scale ? to_f32(from_f32<T>(v[j] * al)) : v[j];
-                        o[j] = keep[j] ? dy * (cdf + pv[j] * 0.3989422804014327f * e) * inv_keep : 0.f;
-                    }
-                    if (ok) *reinterpret_cast<uint4*>(reinterpret_cast<T*>(a.out) + m * a.ldo + ch * 8) = rp_pack8<T>(o);
-                } else if constexpr (EPI == EPI_RESID) {
-                    const float sc = cur.sc[i];
-                    float rv[8], t[8];
-                    rp_unpack8<T>(cur.o1[i], rv);
-                    float p1 = 0.f;
-                    const bool pres = (a.flags & TGT_EDGE_BIAS_SCALED) != 0;     // x arrived pre-scaled: res + x W^T + scale * bias
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        t[j] = to_f32(from_f32<T>(pres ? rv[j] + v[j] + sc * bsc[j] : rv[j] + v[j] * sc));      // the stream value as stored: LayerNorm sees that
-                        p1 += t[j];
-                    }
-                    if (ok) *reinterpret_cast<uint4*>(reinterpret_cast<T*>(a.out) + m * a.ldo + ch * 8) = rp_pack8<T>(t);
-                    if (ln_out) {
-                        const float mean = rp_row_sum(p1) * (1.f / N);
-                        float p2 = 0.f;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            t[j] -= mean;
-                            p2 += t[j] * t[j];
-                        }
-                        const float rstd = rsqrtf(rp_row_sum(p2) * (1.f / N) + a.eps);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) t[j] = t[j] * rstd * gam[j] + bet[j];
-                        if (ok) *reinterpret_cast<uint4*>(reinterpret_cast<T*>(a.y) + m * a.ldy + ch * 8) = rp_pack8<T>(t);
-                        if (ch == 0 && ok) {
-                            if (a.mean) a.mean[m] = mean;
-                            if (a.rstd) a.rstd[m] = rstd;
-                        }
-                    }
-                } else if constexpr (EPI == EPI_LN_BWD) {
-                    // v = dy at the output of LayerNorm(res; gamma); d_res = rstd (g - mean(g) - xhat mean(g xhat)) + ds_in, g = dy gamma
-                    const float mu = cur.mu[i], rs = cur.rs[i], sc = cur.sc[i];
-                    float sv[8], ds[8], xh[8], gg[8];
-                    rp_unpack8<T>(cur.o1[i], sv);
-                    rp_unpack8<T>(cur.o2[i], ds);
-                    float p1 = 0.f, p2 = 0.f;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        xh[j] = ok ? (sv[j] - mu) * rs : 0.f;
-                        const float dy = ok ? v[j] : 0.f;
-                        gg[j] = dy * gam[j];
-                        p1 += gg[j];
-                        p2 += gg[j] * xh[j];
-                        cs_g[j] += dy * xh[j];
-                        cs_b[j] += dy;
-                    }
-                    const float c1 = rp_row_sum(p1) * (1.f / N), c2 = rp_row_sum(p2) * (1.f / N);
-                    float d[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) d[j] = rs * (gg[j] - c1 - xh[j] * c2) + ds[j];
-                    if (ok) *reinterpret_cast<uint4*>(reinterpret_cast<T*>(a.out) + m * a.ldo + ch * 8) = rp_pack8<T>(d);
-                    if (a.out2 || a.colsum_partial) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            // the x-branch gradient as it is stored (rounded), so that its column sums equal a separate pass's
-                            d[j] = to_f32(from_f32<T>(to_f32(from_f32<T>(d[j])) * sc));
-                            cs_x[j] += ok ? d[j] : 0.f;
-                        }
-                        if (a.out2 && ok) *reinterpret_cast<uint4*>(reinterpret_cast<T*>(a.out2) + m * a.ldo2 + ch * 8) = rp_pack8<T>(d);
-                    }
+                for (int k = 0; k < 4; ++k) {
+                    f32x2 e;
+                    const f32x2 cdf = gelu_cdf2(v[k], e);
+                    const f32x2 y = v[k] * cdf * ik;
+                    gl[k].x = keep[2 * k] ? y.x : 0.f;
+                    gl[k].y = keep[2 * k + 1] ? y.y : 0.f;
                 }
+                rp_st16(rs_out, o_out + po * (uint32_t)ldo_b, rp_pack<T>(gl));
+            } else if constexpr (EPI == EPI_GELU_BWD) {
+                const float al = cur.sc[i];
+                f32x2 pv[4], o[4];
+                rp_unpack<T>(cur.o1[i], pv);
+                bool keep[8] = {true, true, true, true, true, true, true, true};
+                if (thresh) keep_vector<8>(a.dropout_seed, (m * N + ch * 8) >> 3, thresh, keep);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    f32x2 e;
+                    const f32x2 cdf = gelu_cdf2(pv[k], e);
+                    const f32x2 dy = has_scale ? rp_round<T>(v[k] * al) : v[k];
+                    const f32x2 y = dy * (cdf + pv[k] * 0.3989422804014327f * e) * inv_keep;
+                    o[k].x = keep[2 * k] ? y.x : 0.f;
+                    o[k].y = keep[2 * k + 1] ? y.y : 0.f;
+                }
+                rp_st16(rs_out, o_out + po * (uint32_t)ldo_b, rp_pack<T>(o));
+            } else if constexpr (EPI == EPI_RESID) {
+                // t = res + s1 * z + s2 * bias:  (s1, s2) = (scale, 0) plain [z carries the bias], (1, scale) when z arrived pre-scaled
+                const float s1 = pres ? 1.f : cur.sc[i], s2 = pres ? cur.sc[i] : 0.f;
+                f32x2 rv[4], t[4];
+                rp_unpack<T>(cur.o1[i], rv);
+                f32x2 p1 = rp_splat(0.f);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    t[k] = rp_round<T>(bsc[k] * s2 + (v[k] * s1 + rv[k]));      // the stream value as stored: LayerNorm sees that
+                    p1 += t[k];
+                }
+                rp_st16(rs_out, o_out + po * (uint32_t)ldo_b, rp_pack<T>(t));
+                // LayerNorm of the new row (y, mean, rstd: empty buffers when not asked for -- the arithmetic is the same few instructions)
+                const float mean = rp_row_sum(p1.x + p1.y) * (1.f / N);
+                f32x2 p2 = rp_splat(0.f);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    t[k] -= mean;
+                    p2 += t[k] * t[k];
+                }
+                const float rstd = rsqrtf(rp_row_sum(p2.x + p2.y) * (1.f / N) + a.eps);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) t[k] = t[k] * rstd * gam[k] + bet[k];
+                rp_st16(rs_y, o_y + po * (uint32_t)ldy_b, rp_pack<T>(t));
+                const uint32_t so = ch == 0 ? o_stat + po * 4u : kNone;      // (one lane of the row stores its statistics)
+                rp_st_f32(rs_mean, so, mean);
+                rp_st_f32(rs_rstd, so, rstd);
+            } else if constexpr (EPI == EPI_LN_BWD) {
+                // v = dy at the output of LayerNorm(res; gamma); d_res = rstd (g - mean(g) - xhat mean(g xhat)) + ds_in, g = dy gamma
+                // (rows at or past M: A, res, mean, rstd, ds all read as 0 and there is no bias, so they add nothing to the column sums)
+                const float mu = cur.mu[i], rs = cur.rs[i], sc = cur.sc[i];
+                f32x2 sv[4], ds[4], xh[4], gg[4];
+                rp_unpack<T>(cur.o1[i], sv);
+                rp_unpack<T>(cur.o2[i], ds);
+                f32x2 p1 = rp_splat(0.f), p2 = rp_splat(0.f);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    xh[k] = (sv[k] - mu) * rs;
+                    gg[k] = v[k] * gam[k];
+                    p1 += gg[k];
+                    p2 += gg[k] * xh[k];
+                    cs_g[k] += v[k] * xh[k];
+                    cs_b[k] += v[k];
+                }
+                const float c1 = rp_row_sum(p1.x + p1.y) * (1.f / N), c2 = rp_row_sum(p2.x + p2.y) * (1.f / N);
+                f32x2 d[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) d[k] = (gg[k] - c1 - xh[k] * c2) * rs + ds[k];
+                rp_st16(rs_out, o_out + po * (uint32_t)ldo_b, rp_pack<T>(d));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    // the x-branch gradient as it is stored (rounded), so that its column sums equal a separate pass's
+                    d[k] = rp_round<T>(rp_round<T>(d[k]) * sc);
+                    cs_x[k] += d[k];
+                }
+                rp_st16(rs_out2, o_out2 + po * (uint32_t)ldo2_b, rp_pack<T>(d));
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -826,10 +924,10 @@ __global__ void __launch_bounds__(1024, 4) edge_rows_kernel(const tgt_edge_linea
             // counts as arrived at a barrier)
             float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                red[(rsub * 3 + 0) * N + ch * 8 + j] = cs_g[j];
-                red[(rsub * 3 + 1) * N + ch * 8 + j] = cs_b[j];
-                red[(rsub * 3 + 2) * N + ch * 8 + j] = cs_x[j];
+            for (int k = 0; k < 4; ++k) {
+                *reinterpret_cast<f32x2*>(red + (rsub * 3 + 0) * N + ch * 8 + 2 * k) = cs_g[k];
+                *reinterpret_cast<f32x2*>(red + (rsub * 3 + 1) * N + ch * 8 + 2 * k) = cs_b[k];
+                *reinterpret_cast<f32x2*>(red + (rsub * 3 + 2) * N + ch * 8 + 2 * k) = cs_x[k];
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -971,12 +1069,13 @@ static int eg_num_cus() {                 // of the CURRENT device (a process ma
     return n[dev];
 }
 
-// rows of colsum_partial the caller provides (ZERO-FILLED: which kernel runs, and so which rows are written, also depends on N):
-// one per (128-row tile, row group of waves WM = 8 / WN) of the slice kernel -- an upper bound for the row-phase kernel,
-// which writes one row per workgroup
+// rows of colsum_partial the caller provides: N = 256 runs on the row-phase kernel, which writes ONE row per persistent workgroup
+// (every workgroup of the launch writes its row: no zero fill needed); narrower outputs run on the slice kernel: one row per
+// (128-row tile, row group of waves WM = 8 / WN), ZERO-FILLED by the caller
 int edge_linear_parts(int64_t M, int N) {
+    if (N == 256) return er_grid(M);
     const int wn = N <= 64 ? 2 : (N <= 128 ? 4 : 8);
-    return wn == 8 ? (int)((M + 31) / 32) : (int)((M + 127) / 128) * (8 / wn);        // (row-phase LN_BWD: 32-row tiles)
+    return (int)((M + 127) / 128) * (8 / wn);
 }
 
 int edge_linear_supported(const tgt_edge_linear_args* a) {
@@ -1002,10 +1101,6 @@ int edge_linear_run(const tgt_edge_linear_args* a, hipStream_t st) {
                          "dtype, N %% 8 == 0, K in {64,128,256}; row-wise epilogues N <= 256",
                          a->K, a->N, a->dtype, a->epilogue);
     if (a->M == 0) return TGT_OK;
-    static const int ablate = getenv("TGT_EG_ABLATE") ? atoi(getenv("TGT_EG_ABLATE")) : 0;   // kernel_bench probes: 1 no W stream, 2 no stores, 4 no A loads, 8 no MFMA
-    tgt_edge_linear_args aa = *a;
-    aa._pad0 = ablate;
-    a = &aa;
     const uintptr_t al = (uintptr_t)a->a | (uintptr_t)a->w | (uintptr_t)a->out | (uintptr_t)a->out2 | (uintptr_t)a->res |
                          (uintptr_t)a->y | (uintptr_t)a->ds_in;
     if (al % 16 || (a->lda * 2) % 16 || (a->ldw * 2) % 16 || (a->ldo * 2) % 16 || (a->ldo2 * 2) % 16 || (a->ldr * 2) % 16 ||
@@ -1013,8 +1108,10 @@ int edge_linear_run(const tgt_edge_linear_args* a, hipStream_t st) {
         return set_error(TGT_ERR_INVALID, "edge linear: tensors and row strides must be 16-byte aligned");
     if ((a->epilogue == EPI_GELU && !a->out2) || ((a->epilogue == EPI_RESID || a->epilogue == EPI_GELU_BWD) && !a->res))
         return set_error(TGT_ERR_INVALID, "edge linear: epilogue operand missing");
-    if ((a->row_scale || a->out_scale) && a->rows_per_sample <= 0)
-        return set_error(TGT_ERR_INVALID, "edge linear: rows_per_sample missing");
+    if ((a->epilogue == EPI_GELU_BWD || a->epilogue == EPI_LN_BWD) && a->bias)
+        return set_error(TGT_ERR_INVALID, "edge linear: the backward epilogues are data-gradient GEMMs, they take no bias");
+    if ((a->row_scale || a->out_scale) && (a->rows_per_sample <= 0 || a->rows_per_sample > 0x7fffffffLL || a->M > 0x7fffffffLL))
+        return set_error(TGT_ERR_INVALID, "edge linear: rows_per_sample missing (or more than 2^31 rows with a per-sample scale)");
     if (a->gamma && a->epilogue != EPI_LN_BWD && !a->beta) return set_error(TGT_ERR_INVALID, "edge linear: beta missing");
     if (a->dropout_p < 0.f || a->dropout_p >= 1.f) return set_error(TGT_ERR_INVALID, "edge linear: dropout_p outside [0,1)");
     if (er_eligible(*a)) return a->dtype == TGT_BF16 ? er_run<bf16_t>(*a, st) : er_run<f16_t>(*a, st);

@@ -104,8 +104,7 @@ __global__ void __launch_bounds__(256) gaussian_bwd_kernel(const float* x, const
                 }
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        acc = group_sum<64>(acc);
         if (lane == 0) dt[p] = acc;
     }
     float* row = partial + wave * 2 * K;

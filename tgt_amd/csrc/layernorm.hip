@@ -65,12 +65,7 @@ __device__ __forceinline__ void ln_store8(void* p, int dtype, int64_t idx, const
     }
 }
 
-template <int LPR>
-__device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+// (group_sum<LPR>: common.hpp -- DPP adds inside a 16-lane row, v_permlane16_swap / v_permlane32_swap across; no ds_bpermute)
 
 struct LnArgs {
     const void* x; const void* dy; void* y; void* dx;

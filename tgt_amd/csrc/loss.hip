@@ -42,14 +42,10 @@ __device__ __forceinline__ void xe_store8(T* p, const float (&v)[8]) {
     }
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    return group_max<64>(v);
 }
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    return group_sum<64>(v);
 }
 
 // forward: lse[row] = log sum_c exp(x[row][c]);  xent[row] = lse[row] - x[row][target[row]]

@@ -431,9 +431,7 @@ __device__ __forceinline__ void tile_bwd(char* lds, const tgt_node_attention_arg
                 float amax = 0.f;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) amax = fmaxf(amax, fabsf(s[q]));
-                amax = fmaxf(amax, xhalf(amax));
-#pragma unroll
-                for (int o = 16; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+                amax = group_max<64>(amax);
                 const int ex = (int)((__builtin_bit_cast(uint32_t, amax) >> 23) & 0xffu);
                 float c = 1.f;
                 if (ex >= 14 && ex <= 253) {

@@ -116,11 +116,8 @@ __global__ void __launch_bounds__(256) grad_stats_kernel(const float* __restrict
             ss += c * c;
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        ss += __shfl_xor(ss, o);
-        bad += __shfl_xor(bad, o);
-    }
+    ss = group_sum<64>(ss);
+    bad = group_sum<64>(bad);
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { red[0][wave] = ss; red[1][wave] = bad; }
     __syncthreads();

@@ -36,14 +36,10 @@ __device__ __forceinline__ void pr_load8(const T* p, float (&v)[8]) {
     }
 }
 __device__ __forceinline__ float pr_wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    return group_max<64>(v);
 }
 __device__ __forceinline__ float pr_wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    return group_sum<64>(v);
 }
 __device__ __forceinline__ bool pr_finite(float x) { return fabsf(x) <= 3.402823466e+38f; }       // false for NaN and +-Inf
 

@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(HG * NQ * 64) tri_att16_fwd_kernel(const tgt_t
                 mx = fmaxf(mx, s[kb][q]);
             }
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = xor16_max(mx);
         mx = fmaxf(mx, xhalf(mx));
         float sum = 0.f;
 #pragma unroll
@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(HG * NQ * 64) tri_att16_fwd_kernel(const tgt_t
                 s[kb][q] = fast_exp(s[kb][q] - mx);
                 sum += s[kb][q];
             }
-        sum += __shfl_xor(sum, 16);
+        sum = xor16_sum(sum);
         sum += xhalf(sum);
         const float inv = fast_rcp(sum);
         f32x4 o = z;
@@ -411,7 +411,7 @@ __global__ void __launch_bounds__(HG * NQ * 64) tri_att16_bwd_kernel(const tgt_t
                     mx = fmaxf(mx, s[kb][q]);
                 }
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = xor16_max(mx);
             mx = fmaxf(mx, xhalf(mx));
             if (mx == -INFINITY) mx = 0.f;                // padding query: every weight is exactly 0
             float sum = 0.f;
@@ -422,7 +422,7 @@ __global__ void __launch_bounds__(HG * NQ * 64) tri_att16_bwd_kernel(const tgt_t
                     s[kb][q] = fast_exp(s[kb][q] - mx);
                     sum += s[kb][q];
                 }
-            sum += __shfl_xor(sum, 16);
+            sum = xor16_sum(sum);
             sum += xhalf(sum);
             const float inv = sum > 0.f ? fast_rcp(sum) : 0.f;
             float delta = 0.f;
@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(HG * NQ * 64) tri_att16_bwd_kernel(const tgt_t
                     s[kb][q] = p;
                     da[kb][q] = dp;
                 }
-            delta += __shfl_xor(delta, 16);
+            delta = xor16_sum(delta);
             delta += xhalf(delta);
             // Q^T, dO^T in operand layout (lane d, queries 4g..4g+3) for phase 2
             {

@@ -969,6 +969,94 @@ def _take_colsum(grad, C_):
     return tag[0]
 
 
+# LayerNorm backward as the epilogue of the data-gradient GEMM that produces its dy (tgt_edge_linear, TGT_EPI_LN_BWD): the Linear
+# that consumes a LayerNorm output does NOT compute dx = dz W in its backward when the LayerNorm entry that produced its input
+# has said it will (`_tgt_lazy_ok` on the forward tensor): it returns a TOKEN -- a NaN scalar expanded to the gradient's shape (no
+# memory; anything that consumed it as a real gradient would turn into NaNs, loudly) carrying (dz, W) -- and the entry's backward
+# runs GEMM + LayerNorm backward + stream-gradient add + dgamma / dbeta / bias-gradient sums as ONE launch: the 134 MB dy is neither
+# written nor read back (0.126 ms against 0.060 + 0.135 at the BASELINE shape).  Same object-identity hand-over as _hand_colsum.
+_EPI_LN_BWD = os.environ.get('TGT_EPI_LN_BWD', '1') != '0'           # A/B knob
+_nan_scalars = {}
+_lazy_dgrads = [0, 0]              # [offered, fused]  (tests / diagnostics)
+
+
+def _lazy_ok(x, weight, cd):
+    """forward-time decision of a Linear: may its backward leave dx to the LayerNorm entry that produced x?"""
+    return (_EPI_LN_BWD and getattr(x, '_tgt_lazy_ok', False) and x.is_cuda and cd in (torch.bfloat16, torch.float16) and
+            x.dtype == cd and weight.shape[1] == 256 and weight.shape[0] in (64, 128, 256) and
+            x.numel() // 256 >= _EDGE_MIN_ROWS)
+
+
+def _lazy_dgrad(dz2, w, shape):
+    """the un-computed gradient dz2 @ w of `shape` (see above)"""
+    key = (dz2.device, dz2.dtype)
+    nan = _nan_scalars.get(key)
+    if nan is None:
+        nan = _nan_scalars[key] = torch.full((), float('nan'), dtype=dz2.dtype, device=dz2.device)
+    token = nan.expand(shape)
+    token._tgt_lazy = (dz2, w, token._version)
+    _lazy_dgrads[0] += 1
+    return token
+
+
+def _offer_lazy(s, y):
+    """(s, y) of a residual + LayerNorm entry, y marked: this entry's backward accepts a lazy data gradient for y (_ln_backward)"""
+    if _EPI_LN_BWD and y.is_cuda and y.shape[-1] == 256 and y.dtype == s.dtype and y.dtype in (torch.bfloat16, torch.float16):
+        y._tgt_lazy_ok = True
+    return s, y
+
+
+def _take_lazy_dgrad(dy):
+    """(dz2, w) when dy is a token of _lazy_dgrad, else None"""
+    tag = getattr(dy, '_tgt_lazy', None)
+    if tag is None:
+        return None
+    if tag[2] != dy._version:
+        raise RuntimeError('a lazy data-gradient token was written to in place')
+    return tag[0], tag[1]
+
+
+def _materialize_dgrad(dy):
+    """dy itself, or the product a token stands for"""
+    lazy = _take_lazy_dgrad(dy)
+    return dy if lazy is None else (lazy[0] @ lazy[1]).view(dy.shape)
+
+
+def _ln_backward(dy, s, g, mean, rstd, ds, scale, rps, want_dz):
+    """(d_res, d_z, dgamma, dbeta, colsum of d_z) of the residual entry  s = res + scale z, y = LayerNorm(s; g):
+    d_res = ds + LN_bwd(dy), d_z = scale * d_res (a separate tensor only when want_dz; else d_res stands for it and only the
+    column sums carry the factor).  dy a lazy token of a K <= 256 data gradient: one fused launch; else tgt_add_layer_norm_bwd."""
+    N = s.shape[-1]
+    rows = s.numel() // N
+    L = _lib.lib()
+    ds = None if ds is None else ds.contiguous()
+    d_res = torch.empty_like(s)
+    d_z = torch.empty_like(s) if want_dz else None
+    lazy = _take_lazy_dgrad(dy)
+    if lazy is not None and N == 256 and lazy[0].dtype == s.dtype and (ds is None or ds.dtype == s.dtype) and lazy[0].is_contiguous():
+        dz2, w = lazy
+        partial = torch.empty(L.tgt_edge_linear_parts(rows, N), 3 * N, dtype=torch.float32, device=s.device)
+        edge_linear_raw(dz2, w.t().contiguous(), None, _lib.EPI_LN_BWD, ln=(g, None, 1e-5), stats=(mean, rstd), res=s.view(rows, N),
+                        ds_in=None if ds is None else ds.view(rows, N), out=d_res.view(rows, N),
+                        out2=None if d_z is None else d_z.view(rows, N), row_scale=scale, rows_per_sample=rps if scale is not None else 0,
+                        colsum_partial=partial)
+        tot = sum_planes(partial, torch.empty(3 * N, dtype=torch.float32, device=s.device))
+        _lazy_dgrads[1] += 1
+        return d_res, d_z, tot[:N], tot[N:2 * N], tot[2 * N:]
+    dy = _materialize_dgrad(dy).contiguous()
+    dg = torch.empty(N, dtype=torch.float32, device=s.device)
+    db_cs = torch.empty(2 * N, dtype=torch.float32, device=s.device)
+    partial = torch.empty(L.tgt_layer_norm_parts() * 3 * N, dtype=torch.float32, device=s.device)
+    p0, p1 = _prof_begin()
+    _lib.check(L.tgt_add_layer_norm_bwd(_ptr(dy), _DT[dy.dtype], _ptr(s), _DT[s.dtype], _ptr(ds),
+                                        0 if ds is None else _DT[ds.dtype], _ptr(scale), rps, _ptr(g), _ptr(mean),
+                                        _ptr(rstd), _ptr(d_res), _ptr(d_z), _DT[s.dtype], _ptr(dg), _ptr(db_cs),
+                                        db_cs.data_ptr() + 4 * N, _ptr(partial), rows, N, _stream()),
+               'tgt_add_layer_norm_bwd')
+    _prof_end('tgt_add_layer_norm_bwd', p0, p1)
+    return d_res, d_z, dg, db_cs[:N], db_cs[N:]
+
+
 _WGRAD_MAXP = int(os.environ.get('TGT_WGRAD_MAXP', '128'))      # A/B knob: cap on the row chunks of a weight gradient
 
 
@@ -1048,7 +1136,7 @@ def _linear_forward(x, weight, bias, cd):
     return x2, w, y
 
 
-def _linear_backward(x2, w, dy2, xs, xdt, wdt, bdt, need_dx, need_dw, need_db):
+def _linear_backward(x2, w, dy2, xs, xdt, wdt, bdt, need_dx, need_dw, need_db, lazy_dx=False):
     """(dx, dW, db) of y = x W^T + b.  dW = dY^T X contracts over M = B*N*N = 262144 rows into a
     tiny (out,in) result; as one GEMM the library runs it on a handful of workgroups
     (0.4-0.8 ms), as 64-128 independent chunk products + an fp32 sum it is HBM-bound (57 us for
@@ -1057,7 +1145,8 @@ def _linear_backward(x2, w, dy2, xs, xdt, wdt, bdt, need_dx, need_dw, need_db):
         dy2 = dy2.to(w.dtype)
     dx = dw = db = None
     if need_dx:
-        dx = (dy2 @ w).view(xs).to(xdt)
+        # lazy_dx: the LayerNorm entry that produced x runs this GEMM itself, fused with its own backward (_lazy_dgrad)
+        dx = _lazy_dgrad(dy2.contiguous(), w, xs) if (lazy_dx and xdt == dy2.dtype) else (dy2 @ w).view(xs).to(xdt)
     if need_dw:
         M = x2.shape[0]
         P = _wgrad_chunks(M, dy2.shape[1] * x2.shape[1])
@@ -1078,10 +1167,11 @@ class _Linear(torch.autograd.Function):
     over row chunks (see _linear_backward)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, cd):
+    def forward(ctx, x, weight, bias, cd, lazy=False):
         x2, w, y = _linear_forward(x, weight, bias, cd)
         ctx.save_for_backward(x2, w)
         ctx.meta = (x.shape, x.dtype, weight.dtype, None if bias is None else bias.dtype)
+        ctx.lazy = lazy
         return y
 
     @staticmethod
@@ -1091,10 +1181,10 @@ class _Linear(torch.autograd.Function):
         need_db = bdt is not None and ctx.needs_input_grad[2]
         cs = _take_colsum(dy, dy.shape[-1]) if need_db else None
         dx, dw, db = _linear_backward(x2, w, dy.reshape(-1, dy.shape[-1]), xs, xdt, wdt, bdt,
-                                      ctx.needs_input_grad[0], ctx.needs_input_grad[1], need_db and cs is None)
+                                      ctx.needs_input_grad[0], ctx.needs_input_grad[1], need_db and cs is None, ctx.lazy)
         if cs is not None:
             db = cs.to(bdt)
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 def _permute_cols(src, idx, dtype):
@@ -1173,7 +1263,7 @@ def linear(x, weight, bias=None):
     """F.linear replacement for the TGT modules (autocast-aware: computes in the autocast
     dtype when autocast is on, else in x.dtype)."""
     cd = torch.get_autocast_dtype('cuda') if (x.is_cuda and torch.is_autocast_enabled('cuda')) else x.dtype
-    return _Linear.apply(x, weight, bias, cd)
+    return _Linear.apply(x, weight, bias, cd, _lazy_ok(x, weight, cd))
 
 
 # ---------------------------------------------------------------------------
@@ -1256,9 +1346,10 @@ def edge_linear_supported(K, N, dtype, epilogue=_lib.EPI_BIAS, ln=False, row_sca
 _GELU_BWD_COLSUM = os.environ.get('TGT_GELU_BWD_COLSUM', '0') == '1'
 _FFN_GELU_EPI = os.environ.get('TGT_FFN_GELU_EPI', '1') != '0'     # A/B knob: lin_W1 + GELU + dropout as one launch on the edge rows
 # A/B knob: GELU backward as the epilogue of lin_W2's data-gradient GEMM (the closing node takes the activation detached and returns the
-# gradient of the pre-activation).  Parity-green, measured NEUTRAL in the step (2506.0 vs 2506.8 graphs/s over three same-box pairs: the
-# row phase of that epilogue is instruction-bound, 0.122 ms against 0.068 + 0.072 for GEMM + activation pass): off by default
-_FFN_GELU_BWD_EPI = os.environ.get('TGT_FFN_GELU_BWD_EPI', '0') == '1'
+# gradient of the pre-activation).  Round 2: neutral (the row phase of that epilogue was instruction-bound, 0.122 ms against 0.068 + 0.072
+# for GEMM + activation pass).  Round 3, after the row-phase rewrite (0.101 ms): +1.5 % graphs/s same-box (2749.7 / 2750.0 against
+# 2709.9 / 2708.8, profiles/r03e_ab.txt): on by default
+_FFN_GELU_BWD_EPI = os.environ.get('TGT_FFN_GELU_BWD_EPI', '1') != '0'
 
 
 class _LinearGeluDropout(torch.autograd.Function):
@@ -1268,8 +1359,9 @@ class _LinearGeluDropout(torch.autograd.Function):
     the stored pre-activation; the backward is that kernel's backward followed by the Linear's."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, cd, p, seed, sample_scale):
+    def forward(ctx, x, weight, bias, cd, p, seed, sample_scale, lazy=False):
         _dev(x, weight, sample_scale)
+        ctx.lazy = lazy
         xs = x.shape
         x2 = x.reshape(-1, xs[-1])
         if x2.dtype != cd:
@@ -1319,12 +1411,12 @@ class _LinearGeluDropout(torch.autograd.Function):
         if d_pre_in is not None:
             d_pre = d_pre_in.contiguous() if d_pre is None else d_pre + d_pre_in
         if d_pre is None:
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         dx, dw, db = _linear_backward(x2, w, d_pre.view(-1, d_pre.shape[-1]), xs, xdt, wdt, bdt, ctx.needs_input_grad[0],
-                                      ctx.needs_input_grad[1], need_db and cs is None)
+                                      ctx.needs_input_grad[1], need_db and cs is None, ctx.lazy)
         if need_db and cs is not None:
             db = cs.to(bdt)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 def linear_gelu_dropout_ok(x, weight, sample_scale=None):
@@ -1344,7 +1436,7 @@ def linear_gelu_dropout(x, weight, bias, p, training, sample_scale=None):
     cd = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled('cuda') else x.dtype
     p = float(p) if training else 0.0
     seed = int(torch.empty((), dtype=torch.int64).random_().item()) if p > 0 else 0
-    act, pre = _LinearGeluDropout.apply(x, weight, bias, cd, p, seed, sample_scale)
+    act, pre = _LinearGeluDropout.apply(x, weight, bias, cd, p, seed, sample_scale, _lazy_ok(x, weight, cd))
     # rides on the tensor object (as _tgt_colsum does): what a consumer needs to take over the activation's backward
     act._tgt_gelu = (pre, p, seed, sample_scale)
     return act
@@ -1387,26 +1479,13 @@ class _AddLayerNorm(torch.autograd.Function):
             d_res = ds
             d_x = ds if scale is None else ds * scale.view(-1, *([1] * (ds.ndim - 1))).to(ds.dtype)
             return d_x, d_res.to(rdt), None, None, None, None, None
-        dy = dy.contiguous()
-        ds = None if ds is None else ds.contiguous()
-        d_res = torch.empty_like(s)
-        d_x = torch.empty_like(s) if scale is not None else None
-        # [dbeta | column sums of d_x]: the second half is the bias gradient of the Linear that
-        # produced x (lin_O / lin_W2 / lin_O_e), handed over on the gradient tensor (see _hand_colsum)
-        dg = torch.empty(C_, dtype=torch.float32, device=s.device)
-        db_cs = torch.empty(2 * C_, dtype=torch.float32, device=s.device)
-        partial = torch.empty(L.tgt_layer_norm_parts() * 3 * C_, dtype=torch.float32, device=s.device)
-        p0, p1 = _prof_begin()
-        _lib.check(L.tgt_add_layer_norm_bwd(_ptr(dy), _DT[dy.dtype], _ptr(s), _DT[s.dtype], _ptr(ds),
-                                            0 if ds is None else _DT[ds.dtype], _ptr(scale), rps, _ptr(w), _ptr(mean),
-                                            _ptr(rstd), _ptr(d_res), _ptr(d_x), _DT[s.dtype], _ptr(dg), _ptr(db_cs),
-                                            db_cs.data_ptr() + 4 * C_, _ptr(partial), rows, C_, _stream()),
-                   'tgt_add_layer_norm_bwd')
-        _prof_end('tgt_add_layer_norm_bwd', p0, p1)
+        # (column sums of d_x: the bias gradient of the Linear that produced x (lin_O / lin_W2 / lin_O_e), handed over on the
+        # gradient tensor, see _hand_colsum)
+        d_res, d_x, dg, dbeta, cs = _ln_backward(dy, s, w, mean, rstd, ds, scale, rps, scale is not None)
         if d_x is None:
             d_x = d_res
-        _hand_colsum(d_x, db_cs[C_:])
-        return d_x, (d_res if rdt == d_res.dtype else d_res.to(rdt)), None, dg.to(wdt), db_cs[:C_].to(wdt), None, None
+        _hand_colsum(d_x, cs)
+        return d_x, (d_res if rdt == d_res.dtype else d_res.to(rdt)), None, dg.to(wdt), dbeta.to(wdt), None, None
 
 
 class _LinearResidualLN(torch.autograd.Function):
@@ -1465,23 +1544,10 @@ class _LinearResidualLN(torch.autograd.Function):
             if pres and bdt is not None and ctx.needs_input_grad[2]:
                 cs = (ds.reshape(scale.numel(), -1, N).float().sum(1) * scale.view(-1, 1)).sum(0)
         else:
-            dy = dy.contiguous()
-            ds = None if ds is None else ds.contiguous()
-            d_res = torch.empty_like(s)
-            d_z = torch.empty_like(s) if (scale is not None and not pres) else None
-            dg = torch.empty(N, dtype=torch.float32, device=s.device)
-            db_cs = torch.empty(2 * N, dtype=torch.float32, device=s.device)
-            partial = torch.empty(L.tgt_layer_norm_parts() * 3 * N, dtype=torch.float32, device=s.device)
-            p0, p1 = _prof_begin()
-            _lib.check(L.tgt_add_layer_norm_bwd(_ptr(dy), _DT[dy.dtype], _ptr(s), _DT[s.dtype], _ptr(ds),
-                                                0 if ds is None else _DT[ds.dtype], _ptr(scale), rps, _ptr(g), _ptr(mean),
-                                                _ptr(rstd), _ptr(d_res), _ptr(d_z), _DT[s.dtype], _ptr(dg), _ptr(db_cs),
-                                                db_cs.data_ptr() + 4 * N, _ptr(partial), rows, N, _stream()),
-                       'tgt_add_layer_norm_bwd')
-            _prof_end('tgt_add_layer_norm_bwd', p0, p1)
+            d_res, d_z, dg, dbeta, cs = _ln_backward(dy, s, g, mean, rstd, ds, scale, rps, scale is not None and not pres)
             if d_z is None:
                 d_z = d_res
-            dbeta, cs = db_cs[:N], db_cs[N:]
+
         need_db = bdt is not None and ctx.needs_input_grad[2]
         d_pre = None
         need_dx = ctx.needs_input_grad[0]
@@ -1537,14 +1603,14 @@ def linear_residual_layer_norm(x, weight, bias, res, scale, ln_weight, ln_bias, 
         x = x.detach()
     if prescaled and scale is not None:
         if _residual_fusable(x, weight, res, cd) and weight.shape[0] == 256:
-            return _LinearResidualLN.apply(x, weight, bias, res, scale, ln_weight, ln_bias, eps, cd, cd, True, *extra)
+            return _offer_lazy(*_LinearResidualLN.apply(x, weight, bias, res, scale, ln_weight, ln_bias, eps, cd, cd, True, *extra))
         # composition with the same arithmetic (shapes the fused launch does not take)
         z = linear(x, weight, None)
         if bias is not None:
             z = z + scale.view([-1] + [1] * (z.ndim - 1)).to(z.dtype) * bias.to(z.dtype)
         return add_layer_norm(z, res, None, ln_weight, ln_bias, eps)
     if _residual_fusable(x, weight, res, cd):
-        return _LinearResidualLN.apply(x, weight, bias, res, scale, ln_weight, ln_bias, eps, cd, cd, False, *extra)
+        return _offer_lazy(*_LinearResidualLN.apply(x, weight, bias, res, scale, ln_weight, ln_bias, eps, cd, cd, False, *extra))
     return add_layer_norm(linear(x, weight, bias), res, scale, ln_weight, ln_bias, eps)
 
 
@@ -1634,7 +1700,7 @@ def add_layer_norm(x, res, scale, weight, bias, eps=1e-5, out_dtype=None):
     """(s, y) with s = res + x*scale (per-sample scale or None), y = LayerNorm(s)."""
     if out_dtype is None:
         out_dtype = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled('cuda') else x.dtype
-    return _AddLayerNorm.apply(x, res, scale, weight, bias, eps, out_dtype)
+    return _offer_lazy(*_AddLayerNorm.apply(x, res, scale, weight, bias, eps, out_dtype))
 
 
 # ---------------------------------------------------------------------------

@@ -1,15 +1,4 @@
-run() { env "$@" python bench.py --no-cpu-baseline --steps 25 --warmup 6 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$*', d['value'], d['ms_per_step'])"; }
-run A=0
-run TGT_TRI_FWD_PF=2
-run TGT_LN_GRID_CAP=2048
-run TGT_LN_GRID_CAP=8192
-run A=0
-run TGT_LN_BWD_GRID=1024
-run TGT_LN_BWD_GRID=1536
-run TGT_NODE_MFMA_HG=8
-run TGT_TRI_SPLIT=0
-run A=0
-run TGT_EW_GRID_CAP=4096
-run TGT_NODE_CHAIN=0
-run TGT_DEFER_EDGE=0
-run A=0
+# same-box A/B of environment knobs inside the training step (boxes of the pool differ by +-2.5 %, one box repeats to +-0.1 %):
+#   bash tools/ab_knobs.sh "A=0" "TGT_EPI_LN_BWD=0" "TGT_FFN_GELU_BWD_EPI=1" "A=0"
+run() { env "$@" python bench.py --no-cpu-baseline --steps 25 --warmup 6 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$*', d['value'], d['ms_per_step'])"; }
+for k in "$@"; do run $k; done
