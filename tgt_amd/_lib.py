@@ -13,6 +13,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtgt_hip.so')
+# same-box A/B of KERNEL changes: a second build of the library (e.g. of another commit, built in a git worktree) loaded instead
+LIB_OVERRIDE = os.environ.get('TGT_HIP_LIB')
 CSRC = os.path.join(_HERE, 'csrc')
 # (source, extra flags, object suffix): the triplet attention kernels compile one dtype per translation unit
 SOURCES = ['capi.hip', 'optimizer.hip', 'edge_gemm.hip', 'params.hip', 'loss.hip', 'predict.hip', 'gaussian.hip', 'triplet_attention_proj.hip',
@@ -203,6 +205,7 @@ def build_library(force=False, verbose=False):
         stamps.append((stamp_file, stamp))
         procs.append((cmd, d, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     undefined = {}
+    bad_units = set()
     failed = None
     for cmd, d, p in procs:
         out, _ = p.communicate()
@@ -220,14 +223,17 @@ def build_library(force=False, verbose=False):
                 with open(path) as fh:
                     for k, regs in isa_lint().lint_all(fh.read()).items():
                         undefined[f'{os.path.basename(d)}:{k}'] = regs
+                        bad_units.add(d)
             if f != 'unit.o' and not (f.endswith('-gfx950.s') and os.environ.get('TGT_KEEP_ISA')):
                 os.remove(path)
     for stamp_file, stamp in stamps:
-        if os.path.isdir(os.path.dirname(stamp_file)):
+        if os.path.isdir(os.path.dirname(stamp_file)) and os.path.dirname(stamp_file) not in bad_units:
             with open(stamp_file, 'w') as fh:
                 fh.write(stamp)
     if failed:
         raise RuntimeError(failed)
+    for d in bad_units:                 # a unit that fails the lint must not be taken for current by the next build
+        shutil.rmtree(d, ignore_errors=True)
     if undefined:
         raise RuntimeError('hipcc produced kernels that read vector registers no instruction writes (miscompiled spill?):\n' +
                            '\n'.join(f'  {k}: {v}' for k, v in undefined.items()))
@@ -252,7 +258,7 @@ def lib():
         # torch bundles its own libamdhip64.so.7; it must be the process's HIP runtime BEFORE
         # this library is mapped, or two runtimes (two HSA instances) end up in one process.
         import torch  # noqa: F401
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(LIB_OVERRIDE or LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)          # AttributeError if the symbol is not exported
             fn.restype, fn.argtypes = res, args
