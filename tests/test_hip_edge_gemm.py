@@ -85,7 +85,7 @@ def test_gelu_dropout_epilogue_equals_standalone_kernel(M, K, N, dtype, p):
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize('M,K,N', [(300, 64, 64), (700, 64, 256), (513, 256, 256), (384, 128, 256)])
+@pytest.mark.parametrize('M,K,N', [(300, 64, 64), (700, 64, 256), (513, 256, 256), (384, 128, 256), (391, 512, 256)])
 def test_residual_epilogue(M, K, N, dtype):
     a, w, b, g = _mk(M, K, N, dtype, 4)
     res = torch.randn(M, N, device='cuda', generator=g).to(dtype)
@@ -98,7 +98,7 @@ def test_residual_epilogue(M, K, N, dtype):
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize('M,K,N', [(300, 64, 256), (1000, 256, 256), (257, 128, 128), (640, 256, 64), (129, 64, 200)])
+@pytest.mark.parametrize('M,K,N', [(300, 64, 256), (1000, 256, 256), (257, 128, 128), (640, 256, 64), (129, 64, 200), (1003, 512, 256)])
 def test_residual_epilogue_with_layernorm_of_the_new_row(M, K, N, dtype):
     """out = res + scale*(a W^T + b) and y = LayerNorm(out as stored): the fused `residual add + LayerNorm` entry of
     the next sub-block (reference layers.py:270-290 followed by the next block's nn.LayerNorm)"""
@@ -181,7 +181,7 @@ def test_unsupported_shapes_raise_instead_of_falling_back():
     a, w, b, _ = _mk(64, 48, 64, torch.bfloat16, 7)
     with pytest.raises(RuntimeError, match='unsupported'):
         ops.edge_linear_raw(a, w, b)
-    for K, N in ((512, 512), (16, 64), (272, 64), (1600, 256)):      # (the general tile kernel of round 2 is gone)
+    for K, N in ((512, 512), (512, 128), (16, 64), (272, 64), (1600, 256)):      # (the general tile kernel of round 2 is gone)
         a, w, b, _ = _mk(64, K, N, torch.bfloat16, 7)
         with pytest.raises(RuntimeError, match='unsupported'):
             ops.edge_linear_raw(a, w, b)
@@ -400,7 +400,7 @@ def test_gelu_backward_with_bias_gradient_column_sums(dtype, rows, cols, p):
 SIZE_M = 262144
 SIZE_BLOCKS = [(0, 96), (32 * 255, 32 * 258), (32 * 256 * 3 - 32, 32 * 256 * 3 + 64), (32 * 4001, 32 * 4004),
                (SIZE_M - 128, SIZE_M)]
-SIZE_SLICES = [(0, 4096), (32 * 1000 + 0, 32 * 1000 + 2048), (SIZE_M - 1024, SIZE_M)]
+SIZE_SLICES = [(0, 4096), (1024 * 31, 1024 * 33), (SIZE_M - 1024, SIZE_M)]      # (whole graphs: the per-graph factor is indexed from the slice's first row)
 SIZE_CASES = {
     # name: (K, N, epilogue, prescaled bias, LayerNorm of the new row, row_scale)
     'lin_W2+res+LN (K=256)': (256, 256, 'resid', False, True, True),
@@ -408,6 +408,8 @@ SIZE_CASES = {
     'lin_O_e+res+LN prescaled (K=64)': (64, 256, 'resid', True, True, True),
     'lin_O_e+res+LN (K=64)': (64, 256, 'resid', False, True, False),
     'lin_W1+GELU+dropout (K=256)': (256, 256, 'gelu', False, False, True),
+    'lin_O+res+LN (K=512)': (512, 256, 'resid', False, True, True),
+    'lin_O+res+LN no DropPath (K=512)': (512, 256, 'resid', False, True, False),
     'lin_EG slice (N=128)': (256, 128, 'bias', False, False, False),
     'third arm slice (N=64)': (256, 64, 'bias', False, False, False),
     'ungated third arm slice (N=32)': (256, 32, 'bias', False, False, False),
@@ -503,7 +505,7 @@ def test_gelu_dropout_epilogue_at_baseline_size_equals_standalone_kernel(dtype):
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('case', ['lin_W2+res+LN prescaled (K=256)', 'lin_O_e+res+LN prescaled (K=64)', 'lin_W1+GELU+dropout (K=256)',
-                                  'lin_EG slice (N=128)'])
+                                  'lin_EG slice (N=128)', 'lin_O+res+LN (K=512)'])
 @pytest.mark.parametrize('cap', [1, 3])
 def test_grid_cap_hook_walks_many_tiles_per_workgroup(case, dtype, cap):
     """tgt_edge_linear_set_grid_cap: with `cap` persistent workgroups a 50-tile problem is 17..50 tiles per workgroup; the result
@@ -595,3 +597,41 @@ def test_lazy_dgrad_token_is_loud_when_misused():
     assert rel(got.view(64, 256), dz.double() @ w.double()) < TOL[torch.bfloat16]
     plain = torch.randn(4, 16, 256, device='cuda')
     assert ops._materialize_dgrad(plain) is plain and ops._take_lazy_dgrad(plain) is None
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('with_scale', [True, False])
+def test_lin_O_residual_layer_norm_with_permuted_columns(dtype, with_scale, monkeypatch):
+    """ops.linear_residual_layer_norm(col_perm=...): lin_O of the triplet modules (in_features 512, its input columns in the
+    kernels' channel order) + DropPath + residual + the edge FFN's LayerNorm as ONE launch (K = 512 row kernel), against the
+    composition linear_permuted_cols -> add_layer_norm: outputs and every gradient (reference triplet.py:248-249, layers.py:284-290)"""
+    monkeypatch.setattr(ops, '_EDGE_MIN_ROWS', 1)
+    B, N, C = 4, 11, 256
+    g = torch.Generator(device='cuda').manual_seed(19)
+    mk = lambda *shape, scale=1.0: torch.randn(*shape, device='cuda', generator=g) * scale
+    va0, res0 = mk(B, N, N, 2 * C).to(dtype), mk(B, N, N, C).to(dtype)
+    w0, b0 = mk(C, 2 * C, scale=(2 * C) ** -0.5), mk(C, scale=0.3)
+    lw0, lb0 = torch.rand(C, device='cuda', generator=g) + 0.5, mk(C, scale=0.2)
+    perm = torch.randperm(2 * C, device='cuda', generator=g).int()
+    inv = torch.empty_like(perm)
+    inv[perm.long()] = torch.arange(2 * C, device='cuda', dtype=torch.int32)
+    sc = ((torch.rand(B, device='cuda', generator=g) > 0.3).float() / 0.7) if with_scale else None
+    gs, gy = mk(B, N, N, C).to(dtype), mk(B, N, N, C).to(dtype)
+    outs = []
+    for fused in (True, False):
+        monkeypatch.setattr(ops, '_EDGE_K512', fused)
+        leaves = [t.clone().requires_grad_(True) for t in (va0, res0, w0, b0, lw0, lb0)]
+        va, res, w, b, lw, lb = leaves
+        with torch.autocast('cuda', dtype=dtype):
+            s, y = ops.linear_residual_layer_norm(va, w, b, res, sc, lw, lb, 1e-5, col_perm=(perm, inv))
+        assert (type(s.grad_fn).__name__ == '_LinearResidualLNBackward') == fused
+        ((s.float() * gs.float()).sum() + (y.float() * gy.float()).sum()).backward()
+        outs.append([s, y] + [t.grad for t in leaves])
+    # float64 of the forward, independent of both paths
+    z = va0.double() @ w0.to(dtype).double()[:, perm.long()].t() + b0.to(dtype).double()
+    ref = res0.double() + (z if sc is None else z * sc.double().view(-1, 1, 1, 1))
+    assert rel(outs[0][0], ref) < TOL[dtype]
+    names = ['s', 'y', 'dva', 'dres', 'dW', 'db', 'dln_w', 'dln_b']
+    for name, a, b_ in zip(names, *outs):
+        tol = 3 * TOL[dtype] if name.startswith('d') else TOL[dtype]
+        assert rel(a, b_) < tol, (name, rel(a, b_))

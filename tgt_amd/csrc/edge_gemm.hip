@@ -781,8 +781,7 @@ __global__ void __launch_bounds__(1024, 4) edge_rows_kernel(const tgt_edge_linea
                 o.mu[i] = rp_ld_f32(rsm, o_stat + (uint32_t)i * 64u);
                 o.rs[i] = rp_ld_f32(rsr, o_stat + (uint32_t)i * 64u);
             }
-            const float f = rp_ld_f32(rs_scale, per_sample.div((uint32_t)(r0 + i * 16 + rsub)) * 4u);
-            o.sc[i] = has_scale ? f : 1.f;
+            o.sc[i] = rp_ld_f32(rs_scale, per_sample.div((uint32_t)(r0 + i * 16 + rsub)) * 4u);      // (raw: 0 without a scale)
         }
     };
     Ops nxt;
@@ -824,12 +823,13 @@ __global__ void __launch_bounds__(1024, 4) edge_rows_kernel(const tgt_edge_linea
             const uint32_t po = (uint32_t)i * 16u;          // rows of this pass below the thread's pass-0 row
             f32x2 v[4];
             rp_unpack<T>(*reinterpret_cast<const uint4*>(sg + gs.off(row, ch)), v);
+            const float sc_i = has_scale ? cur.sc[i] : 1.f;
             if constexpr (EPI == EPI_GELU) {
                 rp_st16(rs_out2, o_out2 + po * (uint32_t)ldo2_b, rp_pack<T>(v));                  // the pre-activation
                 bool keep[8] = {true, true, true, true, true, true, true, true};
                 if (thresh) keep_vector<8>(a.dropout_seed, (m * N + ch * 8) >> 3, thresh, keep);
                 f32x2 gl[4];
-                const float ik = inv_keep * cur.sc[i];       // (row_scale: the DropPath factor of the branch, folded into the activation)
+                const float ik = inv_keep * sc_i;       // (row_scale: the DropPath factor of the branch, folded into the activation)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     f32x2 e;
@@ -840,7 +840,7 @@ __global__ void __launch_bounds__(1024, 4) edge_rows_kernel(const tgt_edge_linea
                 }
                 rp_st16(rs_out, o_out + po * (uint32_t)ldo_b, rp_pack<T>(gl));
             } else if constexpr (EPI == EPI_GELU_BWD) {
-                const float al = cur.sc[i];
+                const float al = sc_i;
                 f32x2 pv[4], o[4];
                 rp_unpack<T>(cur.o1[i], pv);
                 bool keep[8] = {true, true, true, true, true, true, true, true};
@@ -857,7 +857,7 @@ __global__ void __launch_bounds__(1024, 4) edge_rows_kernel(const tgt_edge_linea
                 rp_st16(rs_out, o_out + po * (uint32_t)ldo_b, rp_pack<T>(o));
             } else if constexpr (EPI == EPI_RESID) {
                 // t = res + s1 * z + s2 * bias:  (s1, s2) = (scale, 0) plain [z carries the bias], (1, scale) when z arrived pre-scaled
-                const float s1 = pres ? 1.f : cur.sc[i], s2 = pres ? cur.sc[i] : 0.f;
+                const float s1 = pres ? 1.f : sc_i, s2 = pres ? sc_i : 0.f;
                 f32x2 rv[4], t[4];
                 rp_unpack<T>(cur.o1[i], rv);
                 f32x2 p1 = rp_splat(0.f);
@@ -885,7 +885,7 @@ __global__ void __launch_bounds__(1024, 4) edge_rows_kernel(const tgt_edge_linea
             } else if constexpr (EPI == EPI_LN_BWD) {
                 // v = dy at the output of LayerNorm(res; gamma); d_res = rstd (g - mean(g) - xhat mean(g xhat)) + ds_in, g = dy gamma
                 // (rows at or past M: A, res, mean, rstd, ds all read as 0 and there is no bias, so they add nothing to the column sums)
-                const float mu = cur.mu[i], rs = cur.rs[i], sc = cur.sc[i];
+                const float mu = cur.mu[i], rs = cur.rs[i], sc = sc_i;
                 f32x2 sv[4], ds[4], xh[4], gg[4];
                 rp_unpack<T>(cur.o1[i], sv);
                 rp_unpack<T>(cur.o2[i], ds);
@@ -942,6 +942,177 @@ __global__ void __launch_bounds__(1024, 4) edge_rows_kernel(const tgt_edge_linea
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// K = 512, N = 256: lin_O of the triplet modules (reference triplet.py:248-249) + DropPath + residual add + the LayerNorm that
+// opens the edge FFN (layers.py:284-290), ONE launch instead of library GEMM -> z -> add + LayerNorm pass (the 134 MB z is
+// neither written nor read back).
+//
+// The 256 x 512 weight is 256 KB: resident in registers only when ALL 16 waves of the workgroup hold a piece (32 columns x 256 k
+// = 64 registers each) -- there is no room for a separate row role.  So the roles of the K <= 256 kernel become PHASES of every
+// wave: k-loop on its (column block, K half), fp32 partial tile to LDS, barrier, row phase (thread = row x 16-byte chunk: the two
+// K halves are added, rounded to the storage type, residual + LayerNorm as in the K <= 256 kernel), barrier.  The matrix pipe and
+// the row arithmetic no longer overlap, but with straight-line phases and exact wait counts (buffer-resource addressing, see
+// above) the memory traffic does: the next tile's A rows and residual rows are in flight from the top of the stage, this tile's
+// stores drain under the next stage -- and the two phases together (~5500 cycles per 32-row tile) stay under the tile's HBM time
+// (80 KB per tile and CU: ~9800 cycles at 5 TB/s).
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(1024, 4) edge_rows512_kernel(const tgt_edge_linear_args a) {
+    using F = frag_t<T>;
+    constexpr int K = 512, KS = 16, N = 256, kBM = 32;
+    constexpr int kABytes = kBM * K * 2, kPBytes = kBM * N * 4;
+    constexpr int kOffP = 2 * kABytes, kOffGB = kOffP + 2 * kPBytes;         // LDS: A tiles [2] | fp32 partial tiles [2 K halves] | gamma, beta, bias
+    constexpr uint32_t kNone = 0xffffffffu;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hi = lane >> 5;
+    const int kh = wave >> 3, n0 = (wave & 7) * 32;       // K half and column block of this wave's GEMM phase
+    const int row = tid >> 5, ch = tid & 31;              // row and 16-byte chunk (8 columns) of this thread's row phase
+    const EgGeo g(K);
+    const int64_t row_tiles = (a.M + kBM - 1) / kBM;
+    float* gb = reinterpret_cast<float*>(smem + kOffGB);
+    if (blockIdx.x >= row_tiles) return;
+    const int n_tiles = (int)((row_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
+    auto tile_of = [&](int s) { return (int64_t)blockIdx.x + (int64_t)s * gridDim.x; };
+    const bool pres = (a.flags & TGT_EDGE_BIAS_SCALED) != 0;                  // a arrived pre-scaled: res + a W^T + scale * bias
+    if (tid < N) {
+        gb[tid] = a.gamma ? a.gamma[tid] : 1.f;
+        gb[N + tid] = (a.gamma && a.beta) ? a.beta[tid] : 0.f;
+        gb[2 * N + tid] = a.bias ? to_f32(reinterpret_cast<const T*>(a.bias)[tid]) : 0.f;
+    }
+    const T* W = reinterpret_cast<const T*>(a.w);
+    F wr[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) wr[ks] = load_frag<T>(W + (int64_t)(n0 + r) * a.ldw + kh * 256 + ks * 16 + 8 * hi);
+    // this thread's two 16-byte pieces of an A tile (32 rows x 64 slots)
+    const int64_t lda_b = a.lda * 2;
+    uint32_t aoff[2];
+    int loff[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int pc = q * 1024 + tid, prow = pc >> 6, ps = pc & 63;
+        aoff[q] = (uint32_t)prow * (uint32_t)lda_b + (uint32_t)ps * 16u;
+        loff[q] = g.off(prow, ps);
+    }
+    const float* scale_ptr = a.row_scale;
+    const bool has_scale = scale_ptr != nullptr;
+    const FastDiv per_sample((uint32_t)(has_scale ? a.rows_per_sample : 1));
+    const int64_t n_samples = has_scale ? (a.M + a.rows_per_sample - 1) / a.rows_per_sample : 0;
+    const __amdgpu_buffer_rsrc_t rs_scale = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(scale_ptr), 0, (int)(n_samples * 4), 0x00020000);
+    const int64_t ldr_b = a.ldr * 2, ldo_b = a.ldo * 2, ldy_b = a.ldy * 2;
+    const uint32_t c16 = (uint32_t)ch * 16u;
+    const uint32_t o_res = (uint32_t)row * (uint32_t)ldr_b + c16, o_out = (uint32_t)row * (uint32_t)ldo_b + c16;
+    const uint32_t o_y = (uint32_t)row * (uint32_t)ldy_b + c16, o_stat = ch == 0 ? (uint32_t)row * 4u : kNone;
+    // the partial tile as 16-byte slots (4 floats), XOR-swizzled by the row: conflict-free for the accumulator writes
+    auto poff = [&](int prow, int slot) { return prow * 1024 + ((slot ^ (prow & 15)) << 4); };
+
+    // Register budget: 64 (weights) + 16 (accumulator) + 8 (A prefetch) at the 128-register cap leaves room for ONE set of row
+    // operands: the A rows of tile s+1 are requested at the top of stage s (a whole stage ahead), the residual rows of tile s+1
+    // right after stage s's stores (one GEMM phase ahead).
+    uint4 pre[2];
+    uint4 op_res;
+    float op_sc;
+    auto fetch_a = [&](int64_t tile) {
+        const __amdgpu_buffer_rsrc_t rsa = tile_rsrc(a.a, lda_b, K * 2, tile * kBM, a.M);
+        pre[0] = rp_ld16(rsa, aoff[0]);
+        pre[1] = rp_ld16(rsa, aoff[1]);
+    };
+    auto fetch_ops = [&](int64_t tile) {
+        const int64_t r0 = tile * kBM;
+        const __amdgpu_buffer_rsrc_t rs1 = tile_rsrc(a.res, ldr_b, N * 2, r0, a.M);
+        op_res = rp_ld16(rs1, o_res);
+        op_sc = rp_ld_f32(rs_scale, per_sample.div((uint32_t)(r0 + row)) * 4u);      // (raw: 0 without a scale; selected where it is used)
+    };
+    auto commit = [&](int buf) {
+        *reinterpret_cast<uint4*>(smem + buf * kABytes + loff[0]) = pre[0];
+        *reinterpret_cast<uint4*>(smem + buf * kABytes + loff[1]) = pre[1];
+    };
+    fetch_a(tile_of(0));
+    fetch_ops(tile_of(0));
+    commit(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    for (int s = 0; s < n_tiles; ++s) {
+        fetch_a(tile_of(s + 1));                           // (past the last tile: empty buffers)
+        asm volatile("" ::: "memory");
+        // ------------------------------------------------------------------------------------------- GEMM phase
+        const char* xs = smem + (s & 1) * kABytes;
+        f32x16 acc;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {                   // K half 0 starts from the bias (unless the row phase adds scale * bias)
+            const float4 bv = *reinterpret_cast<const float4*>(gb + 2 * N + n0 + 8 * gq + 4 * hi);
+            const bool use = kh == 0 && !pres;
+            acc[4 * gq] = use ? bv.x : 0.f; acc[4 * gq + 1] = use ? bv.y : 0.f; acc[4 * gq + 2] = use ? bv.z : 0.f; acc[4 * gq + 3] = use ? bv.w : 0.f;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            int rr = r;
+            asm volatile("" : "+v"(rr));                   // (keeps the swizzled address arithmetic at its k-step: see edge_rows_kernel)
+            const F xf = load_frag<T>(reinterpret_cast<const T*>(xs + g.off(rr, kh * 32 + 2 * ks + hi)));
+            acc = mma32(wr[ks], xf, acc);
+        }
+        {
+            char* pt = smem + kOffP + kh * kPBytes;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+                *reinterpret_cast<float4*>(pt + poff(r, (n0 >> 2) + 2 * gq + hi)) = make_float4(acc[4 * gq], acc[4 * gq + 1], acc[4 * gq + 2], acc[4 * gq + 3]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // -------------------------------------------------------------------------------------------- row phase
+        {
+            const int64_t m0 = tile_of(s) * kBM;
+            const __amdgpu_buffer_rsrc_t rs_out = tile_rsrc(a.out, ldo_b, N * 2, m0, a.M);
+            const __amdgpu_buffer_rsrc_t rs_y = tile_rsrc(a.y, ldy_b, N * 2, m0, a.gamma ? a.M : 0);
+            const __amdgpu_buffer_rsrc_t rs_mean = tile_rsrc(a.mean, 4, 4, m0, a.gamma ? a.M : 0);
+            const __amdgpu_buffer_rsrc_t rs_rstd = tile_rsrc(a.rstd, 4, 4, m0, a.gamma ? a.M : 0);
+            const char* p0 = smem + kOffP;
+            f32x2 v[4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {                  // columns 8 ch + 4 h .. + 3: slot 2 ch + h of both K halves
+                const float4 x0 = *reinterpret_cast<const float4*>(p0 + poff(row, 2 * ch + h));
+                const float4 x1 = *reinterpret_cast<const float4*>(p0 + kPBytes + poff(row, 2 * ch + h));
+                v[2 * h].x = x0.x + x1.x; v[2 * h].y = x0.y + x1.y;
+                v[2 * h + 1].x = x0.z + x1.z; v[2 * h + 1].y = x0.w + x1.w;
+            }
+            const float sc = has_scale ? op_sc : 1.f;
+            const float s1 = pres ? 1.f : sc, s2 = pres ? sc : 0.f;
+            f32x2 rv[4], t[4];
+            rp_unpack<T>(op_res, rv);
+            f32x2 p1 = rp_splat(0.f);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x2 z = rp_round<T>(v[k]);          // the Linear's output as stored (what nn.Linear emits under autocast)
+                const f32x2 bk = *reinterpret_cast<const f32x2*>(gb + 2 * N + ch * 8 + 2 * k);
+                t[k] = rp_round<T>(bk * s2 + (z * s1 + rv[k]));
+                p1 += t[k];
+            }
+            rp_st16(rs_out, o_out, rp_pack<T>(t));
+            const float mean = rp_row_sum(p1.x + p1.y) * (1.f / N);
+            f32x2 p2 = rp_splat(0.f);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                t[k] -= mean;
+                p2 += t[k] * t[k];
+            }
+            const float rstd = rsqrtf(rp_row_sum(p2.x + p2.y) * (1.f / N) + a.eps);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x2 gk = *reinterpret_cast<const f32x2*>(gb + ch * 8 + 2 * k), be = *reinterpret_cast<const f32x2*>(gb + N + ch * 8 + 2 * k);
+                t[k] = t[k] * rstd * gk + be;
+            }
+            rp_st16(rs_y, o_y, rp_pack<T>(t));
+            rp_st_f32(rs_mean, o_stat, mean);
+            rp_st_f32(rs_rstd, o_stat, rstd);
+        }
+        fetch_ops(tile_of(s + 1));
+        asm volatile("" ::: "memory");
+        commit((s + 1) & 1);                               // (the A buffer of tile s-1; its k-loop ended two barriers ago)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
 // test hook (tgt_edge_linear_set_grid_cap): at most this many persistent workgroups / row groups per launch, so that a small
 // problem walks several tiles per workgroup -- the stage hand-over the BASELINE-size launches (32 tiles each) depend on
 static int g_grid_cap = 0;
@@ -975,6 +1146,16 @@ static int er_launch(const tgt_edge_linear_args& a, hipStream_t st) {
         return set_error(TGT_ERR_LAUNCH, "edge_rows_kernel: cannot reserve %d bytes of LDS", lds);
     hipLaunchKernelGGL((edge_rows_kernel<T, KS, EPI>), dim3((unsigned)er_grid(a.M)), dim3(1024), lds, st, a);
     return check_launch("edge_rows_kernel");
+}
+
+template <typename T>
+static int er512_launch(const tgt_edge_linear_args& a, hipStream_t st) {
+    constexpr int lds = 2 * 32 * 512 * 2 + 2 * 32 * 256 * 4 + 3 * 256 * 4;
+    static bool attr_set[16] = {};
+    if (!dyn_lds_once(attr_set, reinterpret_cast<const void*>(&edge_rows512_kernel<T>), lds))
+        return set_error(TGT_ERR_LAUNCH, "edge_rows512_kernel: cannot reserve %d bytes of LDS", lds);
+    hipLaunchKernelGGL((edge_rows512_kernel<T>), dim3((unsigned)er_grid(a.M)), dim3(1024), lds, st, a);
+    return check_launch("edge_rows512_kernel");
 }
 
 template <typename T, int KS>
@@ -1082,6 +1263,7 @@ int edge_linear_supported(const tgt_edge_linear_args* a) {
     if (!a) return 0;
     if (a->dtype != TGT_BF16 && a->dtype != TGT_F16) return 0;
     const int K = a->K, N = a->N;
+    if (K == 512) return (N == 256 && a->epilogue == EPI_RESID && (!a->gamma || (a->beta && a->y))) ? 1 : 0;      // lin_O + residual [+ LayerNorm]
     if ((K != 64 && K != 128 && K != 256) || N < 8 || N % 8) return 0;
     if (a->gamma && a->epilogue != EPI_RESID && a->epilogue != EPI_LN_BWD) return 0;          // (no LayerNorm prologue)
     if (a->gamma && a->epilogue == EPI_RESID && N > 256) return 0;
@@ -1098,7 +1280,7 @@ int edge_linear_run(const tgt_edge_linear_args* a, hipStream_t st) {
     if (a->M < 0 || a->K <= 0 || a->N <= 0) return set_error(TGT_ERR_INVALID, "edge linear: bad sizes");
     if (!edge_linear_supported(a))
         return set_error(TGT_ERR_UNSUPPORTED, "edge linear: unsupported shape/dtype (K=%d N=%d dtype=%d epilogue=%d): needs a 16-bit "
-                         "dtype, N %% 8 == 0, K in {64,128,256}; row-wise epilogues N <= 256",
+                         "dtype, N %% 8 == 0, K in {64,128,256} (K = 512: residual epilogue, N = 256); row-wise epilogues N <= 256",
                          a->K, a->N, a->dtype, a->epilogue);
     if (a->M == 0) return TGT_OK;
     const uintptr_t al = (uintptr_t)a->a | (uintptr_t)a->w | (uintptr_t)a->out | (uintptr_t)a->out2 | (uintptr_t)a->res |
@@ -1114,6 +1296,7 @@ int edge_linear_run(const tgt_edge_linear_args* a, hipStream_t st) {
         return set_error(TGT_ERR_INVALID, "edge linear: rows_per_sample missing (or more than 2^31 rows with a per-sample scale)");
     if (a->gamma && a->epilogue != EPI_LN_BWD && !a->beta) return set_error(TGT_ERR_INVALID, "edge linear: beta missing");
     if (a->dropout_p < 0.f || a->dropout_p >= 1.f) return set_error(TGT_ERR_INVALID, "edge linear: dropout_p outside [0,1)");
+    if (a->K == 512) return a->dtype == TGT_BF16 ? er512_launch<bf16_t>(*a, st) : er512_launch<f16_t>(*a, st);
     if (er_eligible(*a)) return a->dtype == TGT_BF16 ? er_run<bf16_t>(*a, st) : er_run<f16_t>(*a, st);
     if (es_eligible(*a)) return a->dtype == TGT_BF16 ? es_run<bf16_t>(*a, st) : es_run<f16_t>(*a, st);
     return set_error(TGT_ERR_UNSUPPORTED, "edge linear: no kernel for K=%d N=%d epilogue=%d", a->K, a->N, a->epilogue);

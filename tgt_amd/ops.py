@@ -1108,9 +1108,9 @@ _EDGE_GEMM = os.environ.get('TGT_EDGE_GEMM', '1') != '0'          # A/B knob: th
 _EDGE_MIN_ROWS = 65536                                            # (tests lower it)
 
 
-def _edge_kernel_ok(x2, N, cd):
-    """edge-row GEMMs the slice kernel of csrc/edge_gemm.hip takes: device, 16-bit, K in {64,128,256}, many rows"""
-    return (_EDGE_GEMM and x2.is_cuda and cd in (torch.bfloat16, torch.float16) and x2.shape[1] in (64, 128, 256) and
+def _edge_kernel_ok(x2, N, cd, ks=(64, 128, 256)):
+    """edge-row GEMMs the kernels of csrc/edge_gemm.hip take: device, 16-bit, K in {64,128,256} (512: the residual entry of lin_O), many rows"""
+    return (_EDGE_GEMM and x2.is_cuda and cd in (torch.bfloat16, torch.float16) and x2.shape[1] in ks and
             N % 8 == 0 and x2.shape[0] >= _EDGE_MIN_ROWS and x2.stride(-1) == 1 and (x2.stride(0) * 2) % 16 == 0)
 
 
@@ -1495,7 +1495,7 @@ class _LinearResidualLN(torch.autograd.Function):
     Backward: the add+LN backward kernel (it also yields the bias gradient), then the Linear's gradients."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, res, scale, ln_w, ln_b, eps, cd, out_dtype, prescaled=False, pre=None, gelu=None):
+    def forward(ctx, x, weight, bias, res, scale, ln_w, ln_b, eps, cd, out_dtype, prescaled=False, pre=None, gelu=None, col_perm=None):
         # pre / gelu = (p, seed, sample_scale): x is dropout(gelu(pre)) * sample_scale, handed in DETACHED; this node then owns the
         # activation's derivative and returns the gradient of `pre` (GELU backward as the epilogue of the data-gradient GEMM)
         _dev(x, weight, res, ln_w, ln_b)
@@ -1503,7 +1503,13 @@ class _LinearResidualLN(torch.autograd.Function):
         x2 = x.reshape(-1, xs[-1])
         if x2.dtype != cd:
             x2 = x2.to(cd)
-        w = _as_dtype(weight, cd).contiguous()
+        if col_perm is not None:
+            # the weight's input columns in the order the producing kernel emits its channels (lin_O of the triplet modules:
+            # one launch, cast included); the weight gradient goes back through the inverse permutation
+            w = _permute_cols(_as_dtype_view(weight, cd).contiguous(), col_perm[0], cd)
+        else:
+            w = _as_dtype(weight, cd).contiguous()
+        ctx.col_inv = None if col_perm is None else col_perm[1]
         b = None if bias is None else _as_dtype(bias, cd).contiguous()
         N, rows = weight.shape[0], x2.shape[0]
         res2 = res.reshape(rows, N)
@@ -1560,18 +1566,24 @@ class _LinearResidualLN(torch.autograd.Function):
                 d_pre = torch.empty_like(pre)
                 edge_linear_raw(d_z.reshape(rows, N), w.t().contiguous(), None, _lib.EPI_GELU_BWD, out=d_pre.view(rows, -1),
                                 res=pre.view(rows, -1), out_scale=g_scale, rows_per_sample=rps, dropout=(ctx.gelu[0], ctx.gelu[1]))
-        dx, dw, db = _linear_backward(x2, w, d_z.reshape(rows, N), xs, xdt, wdt, bdt, need_dx,
-                                      ctx.needs_input_grad[1], need_db and cs is None)
+        dx, dw, db = _linear_backward(x2, w, d_z.reshape(rows, N), xs, xdt, torch.float32 if ctx.col_inv is not None else wdt, bdt,
+                                      need_dx, ctx.needs_input_grad[1], need_db and cs is None)
+        if dw is not None and ctx.col_inv is not None:
+            dw = _permute_cols(dw.contiguous(), ctx.col_inv, wdt)
         if need_db and cs is not None:
             db = cs.to(bdt)
         return (dx, dw, db, d_res if rdt == d_res.dtype else d_res.to(rdt), None,
-                None if dg is None else dg.to(lndt), None if dbeta is None else dbeta.to(lndt), None, None, None, None, d_pre, None)
+                None if dg is None else dg.to(lndt), None if dbeta is None else dbeta.to(lndt), None, None, None, None, d_pre, None, None)
+
+
+_EDGE_K512 = os.environ.get('TGT_EDGE_K512', '1') != '0'        # A/B knob: lin_O (K = 512) + residual + LayerNorm as one launch
 
 
 def _residual_fusable(x, weight, res, cd):
     N = weight.shape[0]
     x2 = x.reshape(-1, x.shape[-1])
-    return N <= 256 and res.is_cuda and _edge_kernel_ok(x2, N, cd) and res.dtype in (cd,) and res.is_contiguous()
+    ks = (64, 128, 256, 512) if (N == 256 and _EDGE_K512) else (64, 128, 256)
+    return N <= 256 and res.is_cuda and _edge_kernel_ok(x2, N, cd, ks) and res.dtype in (cd,) and res.is_contiguous()
 
 
 _PRESCALE = os.environ.get('TGT_PRESCALE', '1') != '0'       # A/B knob: DropPath factor folded into the branch's producer
@@ -1584,11 +1596,13 @@ def can_prescale(rows, in_features, out_features, dtype):
             in_features in (64, 128, 256) and rows >= _EDGE_MIN_ROWS)
 
 
-def linear_residual_layer_norm(x, weight, bias, res, scale, ln_weight, ln_bias, eps=1e-5, prescaled=False):
+def linear_residual_layer_norm(x, weight, bias, res, scale, ln_weight, ln_bias, eps=1e-5, prescaled=False, col_perm=None):
     """(s, y): s = res + scale[graph] * linear(x, weight, bias) (scale: per-sample DropPath factors or None),
     y = LayerNorm(s).  One fused launch on the MI355X slice kernel when the shape qualifies (16-bit compute dtype,
     in_features in {64,128,256}, out_features <= 256 and a multiple of 8, >= 65536 rows); otherwise the composition of
     ops.linear and ops.add_layer_norm (same arithmetic, two launches + one more pass over the rows).
+    col_perm = (idx, inv) int32 device tensors: the Linear is linear(x, weight[:, idx], bias) (lin_O of the triplet modules, whose
+    input arrives in the kernels' channel order; in_features 512 runs on the K = 512 form of the fused launch).
     prescaled: x already carries the factor (its producer folded it in: gelu_dropout(sample_scale=), node_attention(
     hhat_scale=)), so s = res + x W^T + scale[graph] * bias -- the same value, and the backward hands the stream gradient
     itself to the Linear's gradient GEMMs instead of writing a scaled copy of it (one pass over the rows less)."""
@@ -1601,8 +1615,12 @@ def linear_residual_layer_norm(x, weight, bias, res, scale, ln_weight, ln_bias, 
     extra = () if gelu is None else (gelu[0], gelu[1:])
     if gelu is not None:
         x = x.detach()
+    if col_perm is not None:
+        if _residual_fusable(x, weight, res, cd) and weight.shape[0] == 256 and not prescaled:
+            return _offer_lazy(*_LinearResidualLN.apply(x, weight, bias, res, scale, ln_weight, ln_bias, eps, cd, cd, False, None, None, col_perm))
+        return add_layer_norm(linear_permuted_cols(x, weight, bias, *col_perm), res, scale, ln_weight, ln_bias, eps)
     if prescaled and scale is not None:
-        if _residual_fusable(x, weight, res, cd) and weight.shape[0] == 256:
+        if _residual_fusable(x, weight, res, cd) and weight.shape[0] == 256 and weight.shape[1] <= 256:
             return _offer_lazy(*_LinearResidualLN.apply(x, weight, bias, res, scale, ln_weight, ln_bias, eps, cd, cd, True, *extra))
         # composition with the same arithmetic (shapes the fused launch does not take)
         z = linear(x, weight, None)

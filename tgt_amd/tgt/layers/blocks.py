@@ -317,7 +317,13 @@ class TGT_Layer(nn.Module):
                 # the triplet branch's DropPath factor is drawn BEFORE the branch runs: the attention kernels skip the
                 # graphs it drops (zeros out, zero gradients -- what the multiplication at the residual add gives anyway)
                 sc_tri = ops.drop_path_scale(x, dp, tr) if (_TRI_SKIP and getattr(self.tria, 'takes_graph_scale', False)) else None
-                if sc_tri is not None:
+                if hasattr(self.tria, 'out_proj_residual_ln'):
+                    # lin_O + DropPath + residual + the edge FFN's LayerNorm as one launch (K = 512 row kernel; the same two-step
+                    # composition where the shape does not qualify)
+                    va = self.tria.attend(x, mask, graph_scale=sc_tri) if sc_tri is not None else self.tria.attend(x, mask)
+                    e, x = self.tria.out_proj_residual_ln(va, e, sc_tri if sc_tri is not None else ops.drop_path_scale(va, dp, tr),
+                                                          self.edge_ffn.ffn_ln)
+                elif sc_tri is not None:
                     e, x = enter(self.tria.forward_normed(x, mask, graph_scale=sc_tri), e, self.edge_ffn.ffn_ln, scale=sc_tri)
                 else:
                     e, x = enter(self.tria.forward_normed(x, mask), e, self.edge_ffn.ffn_ln)

@@ -52,14 +52,24 @@ class _TripletBase(nn.Module):
             self._idx[key] = (perm.to(device), inv.to(device))
         return self._idx[key]
 
+    def _va_perm(self, device):
+        key = ('va32', device)
+        if key not in self._idx:
+            perm, inv = self._index('va', lambda: layout.va_cols_head_major(self.edge_width, self.num_heads), device)
+            self._idx[key] = (perm.int(), inv.int())
+        return self._idx[key]
+
     def _out_proj(self, va):
         """lin_O on the kernel's [dir][h][d] channel order (reference order is
         d*2H + dir*H + h, triplet.py:248): the weight's input columns are re-ordered, one launch"""
-        key = ('va32', va.device)
-        if key not in self._idx:
-            perm, inv = self._index('va', lambda: layout.va_cols_head_major(self.edge_width, self.num_heads), va.device)
-            self._idx[key] = (perm.int(), inv.int())
-        return ops.linear_permuted_cols(va, self.lin_O.weight, self.lin_O.bias, *self._idx[key])
+        return ops.linear_permuted_cols(va, self.lin_O.weight, self.lin_O.bias, *self._va_perm(va.device))
+
+    def out_proj_residual_ln(self, va, res, scale, ln):
+        """(s, LayerNorm(s)), s = res + scale * lin_O(va): the module's output projection, the DropPath + residual add that follows
+        it in TGT_Layer (reference layers.py:284-287) and the LayerNorm that opens the edge FFN, ONE launch where the shape
+        qualifies (ops.linear_residual_layer_norm, K = 512)"""
+        return ops.linear_residual_layer_norm(va, self.lin_O.weight, self.lin_O.bias, res, scale, ln.weight, ln.bias, ln.eps,
+                                              col_perm=self._va_perm(va.device))
 
     def _param_table(self, blocks, width):
         """ops.ParamTable of a fused projection: blocks = [(source id, row index tensor)], in
@@ -116,12 +126,16 @@ class TripletAttention(_TripletBase):
         """the block after tri_ln_e (TGT_Layer fuses that LayerNorm with the residual add before it).
         graph_scale (B,) float32: the DropPath factor the CALLER multiplies this block's result with at the residual add
         (reference layers.py:286-287); graphs whose factor is 0 are skipped by the attention kernels"""
+        return self._out_proj(self.attend(x, mask, graph_scale))
+
+    def attend(self, x, mask, graph_scale=None):
+        """forward_normed without lin_O: Va in the kernels' channel order (TGT_Layer fuses lin_O with what follows it:
+        out_proj_residual_ln)"""
         B, N = x.shape[0], x.shape[1]
-        va = ops.projected_triplet_attention(x, self._projection_params(), None, ops.as_mask3(mask, B, N),
-                                             self._layout, table=self._table,
-                                             dropout=ops.draw_dropout(self.attention_dropout, self.training),
-                                             graph_scale=graph_scale)
-        return self._out_proj(va)
+        return ops.projected_triplet_attention(x, self._projection_params(), None, ops.as_mask3(mask, B, N),
+                                               self._layout, table=self._table,
+                                               dropout=ops.draw_dropout(self.attention_dropout, self.training),
+                                               graph_scale=graph_scale)
 
 
 class TripletAttentionUngated(TripletAttention):
@@ -159,12 +173,15 @@ class TripletAggregate(_TripletBase):
         return self.forward_normed(self.tri_ln_e(e), mask)
 
     def forward_normed(self, x, mask):
+        return self._out_proj(self.attend(x, mask))
+
+    def attend(self, x, mask, graph_scale=None):
+        """forward_normed without lin_O (see TripletAttention.attend; the aggregate kernels compute every graph)"""
         B, N = x.shape[0], x.shape[1]
         lin_b = self.lin_EG if self.gated else self.lin_E
         fused = ops.fused_linear(x, self._table, (self.lin_V.weight, self.lin_V.bias, lin_b.weight, lin_b.bias))
-        va = ops.triplet_aggregate(fused, ops.as_mask3(mask, B, N), self._layout,
-                                   ops.draw_dropout(self.attention_dropout, self.training))
-        return self._out_proj(va)
+        return ops.triplet_aggregate(fused, ops.as_mask3(mask, B, N), self._layout,
+                                     ops.draw_dropout(self.attention_dropout, self.training))
 
 
 class TripletAggregateUngated(TripletAggregate):
