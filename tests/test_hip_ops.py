@@ -113,6 +113,8 @@ def test_triplet_attention_skips_droppath_dropped_graphs(case, dtype, variant, p
     computation's."""
     from tgt_amd import ops
     monkeypatch.setattr(ops, '_TRI_SKIP_BWD', skip_backward)      # (TGT_TRI_SKIP=2; the default hands the factors to the forward only)
+    if projected:
+        monkeypatch.setattr(ops, '_SPLIT_MIN_ROWS', 1)            # (C = 256, H = 16, N <= 32: the projection-fused forward kernel, which never writes a dropped graph's Q/K/V)
     B, N, nn_, C, H = case
     gated, biased = variant == 'gated', variant != 'axial'
     L = ops.TripletLayout(C, H, gated=gated, biased=biased)
@@ -162,7 +164,8 @@ def test_projected_triplet_attention_bias_gradient(case, dtype, variant, proj_ke
     L = ops.TripletLayout(C, H, gated=gated, biased=biased)
     # proj_kernel: the Q/K/V projection runs INSIDE the attention forward kernel (opt-in path)
     monkeypatch.setattr(ops, '_TRI_PROJ', bool(proj_kernel))
-    if proj_kernel and not ops._proj_fused_ok(torch.empty(0), N, L, dtype):
+    monkeypatch.setattr(ops, '_SPLIT_MIN_ROWS', 1)
+    if proj_kernel and not ops._proj_fused_ok(torch.empty(B, N, N, C), N, L, dtype):
         pytest.skip('shape not covered by the projection-fused kernel')
     rng = np.random.default_rng(7 + hash((B, N, C, H)) % 1000)
     x = rnd(rng, B, N, N, C).to(dtype).cuda()
@@ -197,8 +200,8 @@ def test_projected_triplet_attention_bias_gradient(case, dtype, variant, proj_ke
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize('case', [(2, 20, [20, 13], 256, 16), (3, 32, [32, 17, 32], 256, 16), (2, 17, [17, 9], 128, 8),
-                                  (2, 32, [32, 30], 128, 8)])
+@pytest.mark.parametrize('case', [(2, 20, [20, 13], 256, 16), (3, 32, [32, 17, 32], 256, 16), (2, 17, [17, 9], 256, 16),
+                                  (5, 32, [32, 30, 32, 1, 32], 256, 16)])
 @pytest.mark.parametrize('variant', ['gated', 'ungated', 'axial'])
 def test_projection_fused_triplet_attention_vs_oracle(case, dtype, variant, monkeypatch):
     """tgt_triplet_attention_proj_fwd (the Q/K/V projection computed INSIDE the attention kernel) and its backward,
@@ -209,7 +212,8 @@ def test_projection_fused_triplet_attention_vs_oracle(case, dtype, variant, monk
     gated, biased = variant == 'gated', variant != 'axial'
     L = ops.TripletLayout(C, H, gated=gated, biased=biased)
     monkeypatch.setattr(ops, '_TRI_PROJ', True)
-    assert ops._proj_fused_ok(torch.empty(0), N, L, dtype), 'shape must be one the projection-fused kernel takes'
+    monkeypatch.setattr(ops, '_SPLIT_MIN_ROWS', 1)
+    assert ops._proj_fused_ok(torch.empty(B, N, N, C), N, L, dtype), 'shape must be one the projection-fused kernel takes'
     rng = np.random.default_rng(11 + hash((B, N, C, H)) % 1000)
     x = rnd(rng, B, N, N, C).to(dtype)
     w = (rnd(rng, L.width, C) * C ** -0.5).to(dtype)

@@ -20,7 +20,7 @@ _PROFILE = None
 
 
 _TRI_SPLIT = os.environ.get('TGT_TRI_SPLIT', '1') != '0'        # A/B knobs, read once
-_TRI_PROJ = os.environ.get('TGT_TRI_PROJ', '0') == '1'
+_TRI_PROJ = os.environ.get('TGT_TRI_PROJ', '1') != '0'
 _TRI_COLSUM = os.environ.get('TGT_TRI_COLSUM', '1') != '0'
 # graph_scale (DropPath-dropped graphs skipped by the triplet kernels) reaches the BACKWARD kernel only with TGT_TRI_SKIP=2: at the
 # BASELINE shapes the backward is 1024 workgroups in exactly four rounds on 256 CUs (one workgroup per CU), and with ~10 % of them
@@ -300,11 +300,10 @@ def _split_projection_ok(x, L):
 
 
 def _proj_fused_ok(x, N, L, cd):
-    """the projection-fused forward kernel (tgt_triplet_attention_proj_fwd): opt-in with
-    TGT_TRI_PROJ=1 -- correct, but in round 1 still slower than the library GEMM + attention
-    kernel pair it replaces (0.77 vs 0.63 ms at the BASELINE shape)"""
-    return (_TRI_PROJ and N <= 32 and L.D == 16 and L.H % 8 == 0 and
-            cd in (torch.bfloat16, torch.float16) and L.C in (64, 128, 256))
+    """the projection-fused forward kernel (tgt_triplet_attention_proj_fwd, wave roles: DESIGN.md section 4.1a): Q/K/V are
+    projected inside the attention kernel (still written once, for the backward); TGT_TRI_PROJ=0 is the A/B knob"""
+    return (_TRI_PROJ and N <= 32 and L.D == 16 and L.H % 8 == 0 and L.width == L.used and
+            cd in (torch.bfloat16, torch.float16) and L.C == 256 and x.numel() // L.C >= _SPLIT_MIN_ROWS)
 
 
 class _ProjectedTripletAttention(torch.autograd.Function):
@@ -321,6 +320,7 @@ class _ProjectedTripletAttention(torch.autograd.Function):
         weight, bias = wb if table is None else _fuse_params(table, wb, cd)
         out = torch.empty(B, N, N, 2 * L.C, dtype=cd, device=x.device)
         eg = None
+        proj_skip = None
         if dropout[0] == 0 and _proj_fused_ok(x, N, L, cd):
             # Q/K/V projected inside the attention kernel (it still writes them once, for the
             # backward); only the narrow E/G third-arm projection stays a library GEMM, written
@@ -328,14 +328,22 @@ class _ProjectedTripletAttention(torch.autograd.Function):
             x2 = x.reshape(-1, L.C)
             x2 = (x2 if x2.dtype == cd else x2.to(cd)).contiguous()
             w, b = _as_dtype(weight, cd).contiguous(), _as_dtype(bias, cd).contiguous()
-            fused = torch.empty(B, N, N, L.width, dtype=cd, device=x.device)
-            if L.biased:       # (a GEMM straight into the column slice fails under TunableOp: GEMM, then a strided copy)
-                fused.view(-1, L.width)[:, 6 * L.C:L.used].copy_(torch.addmm(b[6 * L.C:L.used], x2, w[6 * L.C:L.used].t()))
-            a = _tri_args(fused, mask3, out, L)
+            # the Q/K/V rows (written by the kernel, for the backward) and the narrow third-arm E/G projection as two tensors,
+            # as in the split-GEMM path below
+            fused = torch.empty(B, N, N, 6 * L.C, dtype=cd, device=x.device)
+            we, be = w[6 * L.C:L.used], b[6 * L.C:L.used]
+            if not L.biased:
+                eg = None                      # (axial: no third arm)
+            elif we.shape[0] <= 128 and _edge_kernel_ok(x2, we.shape[0], cd):
+                eg = edge_linear_raw(x2, we, be.contiguous()).view(B, N, N, L.used - 6 * L.C)
+            else:
+                eg = torch.addmm(be, x2, we.t()).view(B, N, N, L.used - 6 * L.C)
+            a = _tri_args(fused, mask3, out, L, eg=eg, graph_scale=graph_scale)
             s0, s1 = _prof_begin()
             _lib.check(_lib.lib().tgt_triplet_attention_proj_fwd(C.byref(a), _ptr(x2), L.C, _ptr(w), _ptr(b), _stream()),
                        'tgt_triplet_attention_proj_fwd')
             _prof_end('tgt_triplet_attention_fwd', s0, s1)
+            proj_skip = graph_scale        # (dropped graphs have NO Q/K/V rows: the backward must skip them too)
         elif _split_projection_ok(x, L):
             # two GEMMs: Q/K/V (6C = 1536 channels: six full 256-wide tile columns, 294 us) and the
             # narrow E/G (39 us) instead of one ragged 1600-wide GEMM (376 us; tools/gemm_probe.py);
@@ -358,7 +366,8 @@ class _ProjectedTripletAttention(torch.autograd.Function):
             _call('tgt_triplet_attention_fwd', _lib.lib().tgt_triplet_attention_fwd, a)
         ctx.save_for_backward(x2, w, fused, mask3, out, eg if eg is not None else fused.new_empty(0),
                               *(wb if table is not None else ()))
-        ctx.L, ctx.table, ctx.dropout, ctx.graph_scale = L, table, dropout, (graph_scale if _TRI_SKIP_BWD else None)
+        ctx.L, ctx.table, ctx.dropout = L, table, dropout
+        ctx.graph_scale = proj_skip if proj_skip is not None else (graph_scale if _TRI_SKIP_BWD else None)
         ctx.meta = (x.shape, x.dtype, weight.dtype, bias.dtype)
         return out
 

@@ -73,23 +73,14 @@ def main():
         del x, w, bias, g
 
     if 'proj' in a.only:
-        import ctypes
-        from tgt_amd import _lib
+        # projection + attention forward as the training step runs it: fused kernel (TGT_TRI_PROJ=1, default) or GEMM + GEMM + attention
         L = ops.TripletLayout(C, Ht)
         x = torch.randn(B, N, N, C, device=dev, dtype=dt)
         w = (torch.randn(L.width, C, device=dev) * C ** -0.5).to(dt)
         bias = torch.randn(L.width, device=dev).to(dt)
-        fused = torch.randn(B, N, N, L.width, device=dev, dtype=dt)
-        o = torch.empty(B, N, N, 2 * C, device=dev, dtype=dt)
-        args = ops._tri_args(fused, mask, o, L)
-        lib = _lib.lib()
-        st = torch.cuda.current_stream().cuda_stream
-
-        def run():
-            _lib.check(lib.tgt_triplet_attention_proj_fwd(ctypes.byref(args), x.data_ptr(), C, w.data_ptr(), bias.data_ptr(), st), 'proj')
-        t = timeit(run, a.iters)
-        wb = B * (2 * (4 * n2 * C) * esz + n2 * C * esz)
-        out['tri_att_proj_fwd'] = dict(ms=round(t, 4), write_GBs=round(wb / t / 1e6, 1), mode=os.environ.get('TGT_PROJ_MODE', '0'))
+        with torch.no_grad():
+            t = timeit(lambda: ops.projected_triplet_attention(x, w, bias, mask, L), a.iters)
+        out['proj+tri_att_fwd'] = dict(ms=round(t, 4), fused=bool(ops._TRI_PROJ))
 
     if not a.only or 'agg' in a.only:
         L = ops.AggregateLayout(C, Ht)
