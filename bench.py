@@ -43,28 +43,28 @@ def node_algorithmic_bytes(kind, B, N, W, Hn, esz=2):
     return B * per_graph
 
 
+def _per_graph_bytes(kind, N, C, Ht, esz):
+    """(all bytes, bytes still moved for a DropPath-dropped graph) of one graph in one launch, both directions"""
+    n2 = N * N
+    if kind == 'fwd':            # Q,K,V in + O out = 4 N^2 C, E,G = 2 N^2 Ht per direction, + mask; dropped: zero O rows
+        return 2 * (4 * n2 * C + 2 * n2 * Ht) * esz + n2 * 4, 2 * (n2 * C) * esz
+    if kind == 'fwd_proj':       # projection-fused forward (DESIGN 4.1a): X in ONCE (the kernel reads it 4 times: Q rows and K/V rows of
+        #                          both directions), Q,K,V out (kept for the backward) + O out per direction, E,G in, + mask
+        return (n2 * C + 2 * (4 * n2 * C + 2 * n2 * Ht)) * esz + n2 * 4, 2 * (n2 * C) * esz
+    # bwd: Q,K,V,dO in + dQ,dK,dV out = 7 N^2 C, E,G in + dE,dG out = 4 N^2 Ht per direction, + mask; dropped: zero gradient rows
+    return 2 * (7 * n2 * C + 4 * n2 * Ht) * esz + n2 * 4, 2 * (3 * n2 * C + 2 * n2 * Ht) * esz
+
+
 def dropped_graph_discount(kind, N, C, Ht, drop_frac, esz=2):
     """factor on algorithmic_bytes for launches in which a fraction `drop_frac` of the graphs is DropPath-dropped and
-    skipped by the kernel (tgt_triplet_attention_args.graph_scale): such a graph only has its zeros written
-    (fwd: O = N^2 C of the 4 N^2 C + 2 N^2 Ht elements; bwd: dQ,dK,dV,dE,dG = 3 N^2 C + 2 N^2 Ht of 7 N^2 C + 4 N^2 Ht)"""
-    n2 = N * N
-    if kind == 'fwd':
-        full, moved = 2 * (4 * n2 * C + 2 * n2 * Ht) * esz + n2 * 4, 2 * (n2 * C) * esz
-    else:
-        full, moved = 2 * (7 * n2 * C + 4 * n2 * Ht) * esz + n2 * 4, 2 * (3 * n2 * C + 2 * n2 * Ht) * esz
+    skipped by the kernel (tgt_triplet_attention_args.graph_scale): such a graph only has its zeros written"""
+    full, moved = _per_graph_bytes(kind, N, C, Ht, esz)
     return 1.0 - drop_frac * (1.0 - moved / full)
 
 
 def algorithmic_bytes(kind, B, N, C, Ht, esz=2):
-    """HBM bytes one launch must move (both directions), SURVEY §8(d):
-    fwd: 2 dirs x (Q,K,V in + O out = 4 N^2 C, E,G = 2 N^2 Ht) elements + mask
-    bwd: 2 dirs x (Q,K,V,dO in + dQ,dK,dV out = 7 N^2 C, E,G in + dE,dG out = 4 N^2 Ht) + mask"""
-    n2 = N * N
-    if kind == 'fwd':
-        per_graph = 2 * (4 * n2 * C + 2 * n2 * Ht) * esz + n2 * 4
-    else:
-        per_graph = 2 * (7 * n2 * C + 4 * n2 * Ht) * esz + n2 * 4
-    return B * per_graph
+    """HBM bytes one launch must move (both directions), SURVEY §8(d): see _per_graph_bytes"""
+    return B * _per_graph_bytes(kind, N, C, Ht, esz)[0]
 
 
 def cpu_baseline_worker(threads, micro=8, nodes=32, budget_s=40.0, full=False):
@@ -211,6 +211,8 @@ def main():
     ap.add_argument('--ragged', action='store_true',
                     help='SURVEY 8(d) secondary: num_nodes ~ U{nodes/2..nodes} with the first graph at `nodes` (padded batch)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--roofline-steps', type=int, default=3,
+                    help='untimed single-stream steps after the timed region that measure the roofline kernels alone (0: use the timed region)')
     ap.add_argument('--cpu-baseline-worker', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--cpu-baseline-full', action='store_true',
                     help='CPU baseline over all 256 graphs of one step (16 accumulated micro-batches; minutes)')
@@ -296,6 +298,20 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     ops.profile_kernels(False)
+    # Kernel durations for `roofline`: inside the timed region the node channel runs on a second HIP stream and its kernels share
+    # the CUs with the edge kernels, so an event pair around an edge launch also sees the other stream's work (and the wait for
+    # CUs it holds).  A few more steps of the same loop, NOT timed, with everything on one stream give the kernel's own duration
+    # -- the number `TGT_NODE_STREAM=0 rocprofv3 --kernel-trace --stats` of this command shows (profiles/).  Both are reported.
+    prof_iso = None
+    if ops.side_stream.enabled and args.roofline_steps > 0:
+        ops.side_stream.enabled = False
+        step(args.warmup + args.steps)                    # (one step for the allocator to settle on the new stream pattern)
+        prof_iso = ops.profile_kernels(True)
+        for i in range(args.roofline_steps):
+            step(args.warmup + args.steps + 1 + i)
+        fence()
+        ops.profile_kernels(False)
+        ops.side_stream.enabled = True
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -303,7 +319,8 @@ def main():
     loss_val = float(loss.detach())
 
     if rank == 0:
-        times = ops.kernel_times_ms(prof)
+        times_region = ops.kernel_times_ms(prof)
+        times = ops.kernel_times_ms(prof_iso) if prof_iso is not None else times_region
         C, Ht = mcfg['edge_width'], mcfg['triplet_heads']
         esz = 4 if args.precision == 'fp32' else 2
         # DropPath ramps linearly 0 .. drop_path over the layers (tgt_amd/tgt/stack.py): the mean fraction of graphs a triplet launch
@@ -312,11 +329,13 @@ def main():
         skip_mode = skip_mode if skip_mode in ('1', '2') else ''
         drop_frac = 0.5 * float(mcfg.get('drop_path', 0.0))
         cand = {}
-        for name, kind in (('tgt_triplet_attention_bwd', 'bwd'), ('tgt_triplet_attention_fwd', 'fwd')):
+        proj_on = bool(times.get('tgt_triplet_attention_proj_fwd'))     # (then the backward skips dropped graphs too: no Q/K/V rows)
+        for name, kind in (('tgt_triplet_attention_bwd', 'bwd'), ('tgt_triplet_attention_fwd', 'fwd'),
+                           ('tgt_triplet_attention_proj_fwd', 'fwd_proj')):
             if name in times and times[name]:
                 avg_ms = sum(times[name]) / len(times[name])
                 nbytes_k = algorithmic_bytes(kind, args.batch, args.nodes, C, Ht, esz)
-                if skip_mode and (kind == 'fwd' or skip_mode == '2'):
+                if skip_mode and (kind != 'bwd' or skip_mode == '2' or proj_on):
                     # the kernel does not move the bytes of the graphs DropPath drops: count what it moves (expected fraction)
                     nbytes_k = int(nbytes_k * dropped_graph_discount(kind, args.nodes, C, Ht, drop_frac, esz))
                 cand[name] = (sum(times[name]), avg_ms, nbytes_k)
@@ -339,7 +358,8 @@ def main():
             if not pmc and summaries:
                 pmc_note = dict(file='profiles/' + summaries[-1], kernel_src_sha=sha, match=False,
                                 note='kernel sources changed since the last counter pass: traffic / mfma_util not quoted')
-            for short, name in (('tri_att_fwd_kernel', 'tgt_triplet_attention_fwd'), ('tri_att_bwd_kernel', 'tgt_triplet_attention_bwd')):
+            for short, name in (('tri_att_fwd_kernel', 'tgt_triplet_attention_fwd'), ('tri_att_bwd_kernel', 'tgt_triplet_attention_bwd'),
+                                ('tri_att_proj_fwd_kernel', 'tgt_triplet_attention_proj_fwd')):
                 if short in pmc and 'hbm_bytes_per_launch' in pmc[short]:
                     traffic[name] = dict(traffic_bytes=pmc[short]['hbm_bytes_per_launch'])
         roofline = None
@@ -354,11 +374,21 @@ def main():
                             share_of_step=round(tot / (dt * 1e3), 4),
                             # matrix-core utilisation of this kernel from the SQ counter pass (offline, same shape):
                             # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs); an HBM-bound core at 15.5 FLOP/B
-                            mfma_util=pmc.get('tri_att_bwd_kernel' if name.endswith('bwd') else 'tri_att_fwd_kernel', {}).get('mfma_util'),
+                            mfma_util=pmc.get({'tgt_triplet_attention_bwd': 'tri_att_bwd_kernel', 'tgt_triplet_attention_fwd': 'tri_att_fwd_kernel',
+                                               'tgt_triplet_attention_proj_fwd': 'tri_att_proj_fwd_kernel'}[name], {}).get('mfma_util'),
                             other_kernels={k: dict(avg_launch_ms=round(v[1], 4),
                                                    achieved=round(v[2] / (v[1] * 1e-3) / 1e9, 1))
                                            for k, v in cand.items() if k != name})
             roofline['offline_pmc'] = pmc_note
+            if prof_iso is not None and times_region.get(name):
+                reg = sum(times_region[name]) / len(times_region[name])
+                roofline['timing'] = dict(
+                    how=f'HIP events on the launch stream over {args.roofline_steps} extra steps after the timed region with the node '
+                        'channel on the same stream (kernel alone; = TGT_NODE_STREAM=0 rocprofv3 --stats of this command)',
+                    in_timed_region=dict(avg_launch_ms=round(reg, 4), achieved=round(nbytes / (reg * 1e-3) / 1e9, 1),
+                                         frac=round(nbytes / (reg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                         note='event pairs inside the timed region: the second stream\'s node kernels share the CUs'))
+                roofline['share_of_step'] = round(sum(times_region[name]) / (dt * 1e3), 4)
             if skip_mode and drop_frac > 0:
                 roofline['droppath_skip'] = dict(kernels='forward' if skip_mode == '1' else 'forward+backward',
                                                  expected_dropped_fraction=drop_frac,

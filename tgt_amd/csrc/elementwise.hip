@@ -90,8 +90,6 @@ static int gd_launch(const void* x, const void* dy, void* out, int64_t n, float 
     int64_t blocks = (n / V + 255) / 256;
     // one 16-byte vector per thread, no revisits: +5 % over a 4096-workgroup grid-stride grid (a plain
     // copy shows the same: tools/probes/hbm_probe.hip)
-    static const int64_t cap = getenv("TGT_EW_GRID_CAP") ? atoll(getenv("TGT_EW_GRID_CAP")) : (int64_t)1 << 30;
-    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     if (!bwd)
         hipLaunchKernelGGL((gelu_dropout_kernel<T, false>), dim3((unsigned)blocks), dim3(256), 0, st,

@@ -357,16 +357,14 @@ static int ln_launch(const LnArgs& a, bool bwd, float* dgamma, float* dbeta, hip
     if (!bwd) {
         // grid-stride over at most 4096 workgroups: swept 1024..32768 on MI355X (tools/kernel_bench.py --only ln);
         // smaller grids lose parallelism, larger ones pay the per-workgroup gamma/beta loads (uncapped: 4x slower)
-        static const int64_t cap = getenv("TGT_LN_GRID_CAP") ? atoll(getenv("TGT_LN_GRID_CAP")) : 4096;
+        constexpr int64_t cap = 4096;
         if (blocks > cap) blocks = cap;
         hipLaunchKernelGGL((ln_fwd_kernel<LPR, VPL>), dim3((unsigned)blocks), dim3(256), 0, st, a);
         return check_launch("ln_fwd_kernel");
     }
-    static const int grid_env = getenv("TGT_LN_BWD_GRID") ? atoi(getenv("TGT_LN_BWD_GRID")) : 0;
     // grid = rows of the partial buffer that get written.  One vector per lane: 96 registers = 5 waves per SIMD, 1280 workgroups of
     // 4 waves are exactly one round on 256 CUs (measured: 1024 and 1536 are both slower)
-    const int dflt = VPL == 1 ? 1280 : 1024;
-    const int parts = grid_env > 0 && grid_env <= kLnParts ? grid_env : dflt;
+    const int parts = VPL == 1 ? 1280 : 1024;
     const bool cs = a.x_colsum != nullptr;     // then dbeta and x_colsum are ONE buffer [dbeta | x_colsum] (checked by the caller)
     const int np = cs ? 3 : 2;
     size_t lds = (size_t)4 * RPW * np * VPL * LPR * 8 * sizeof(float);

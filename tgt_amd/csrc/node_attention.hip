@@ -633,8 +633,6 @@ static int node_vec(const tgt_node_attention_args& a, int esz, int want) {
     return 1;
 }
 
-static int env_int(const char* name, int dflt) { return getenv(name) ? atoi(getenv(name)) : dflt; }
-
 #define TGT_NODE_LAUNCH_HM(KERNEL, NAME, WANT, HM)                                                                 \
     do {                                                                                                          \
         const int hv = node_vec(a, (int)sizeof(T), (D <= 16) ? (WANT) : ((WANT) > 2 ? 2 : (WANT)));               \
@@ -652,12 +650,12 @@ static int env_int(const char* name, int dflt) { return getenv(name) ? atoi(gete
 template <typename T, int D>
 static int launch_node(const tgt_node_attention_args& a, bool bwd, hipStream_t st) {
     // measured on MI355X (B=256 N=32 H=64 D=12 bf16): forward best with 4 heads per lane, both
-    // backward passes with 2 (4 pushes them to one wave per SIMD); env knobs for experiments
-    static const int hv_f = env_int("TGT_NODE_HV_F", 4), hv_r = env_int("TGT_NODE_HV_R", 2), hv_c = env_int("TGT_NODE_HV_C", 2);
+    // backward passes with 2 (4 pushes them to one wave per SIMD)
+    constexpr int hv_f = 4, hv_r = 2, hv_c = 2;
     if (!bwd) {
         // LDS variant: 16-bit types, 4 heads per lane, K/V rows 16-byte aligned, one key tile of <= 32 keys
         // fits the 160 KB LDS (2 * 32 * W * 2 bytes = 96 KB at W = 768)
-        static const int use_lds = env_int("TGT_NODE_LDS", 1);
+        constexpr bool use_lds = true;
         if constexpr (sizeof(T) == 2 && D <= 16) {
             constexpr int MT = 32;
             const int W = D * a.H;

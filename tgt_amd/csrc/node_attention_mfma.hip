@@ -621,11 +621,10 @@ static int dispatch_d(const tgt_node_attention_args& a, bool bwd, hipStream_t st
     }
 }
 
-// heads per workgroup: 16 (32-byte row segments) unless the shape or TGT_NODE_MFMA_HG says 8 (16-byte segments; the
+// heads per workgroup: 16 (32-byte row segments) unless the shape says 8 (16-byte segments; the
 // 16-head backward image of D = 16 does not fit the LDS, that shape takes the 8-head form)
 static int heads_per_group(const tgt_node_attention_args& a, bool bwd) {
-    static const int want = getenv("TGT_NODE_MFMA_HG") ? atoi(getenv("TGT_NODE_MFMA_HG")) : 16;
-    if (want == 16 && a.H % 16 == 0 && !(bwd && a.D == 16)) return 16;
+    if (a.H % 16 == 0 && !(bwd && a.D == 16)) return 16;
     return 8;
 }
 

@@ -565,18 +565,14 @@ static int launch_tri_nt(const tgt_triplet_attention_args& a, bool bwd, hipStrea
     constexpr int kBwdLds = 2 * (2 + 2 * NT) * G::kSlabBytes > kArm ? 2 * (2 + 2 * NT) * G::kSlabBytes : kArm;
     const bool drop = a.dropout_p > 0.f;
     if (!bwd) {
-        static const int pf = getenv("TGT_TRI_FWD_PF") ? atoi(getenv("TGT_TRI_FWD_PF")) : 1;
+        // (a prefetch depth of 2 was measured neutral in round 1 and is gone)
         if (drop)
             hipLaunchKernelGGL((tri_att_fwd_kernel<T, D, HG, NT, 1, true>), dim3(grid), dim3(G::kThreads), kFwdLds, st, a);
-        else if (NT == 1 && pf == 2)
-            hipLaunchKernelGGL((tri_att_fwd_kernel<T, D, HG, NT, (NT == 1 ? 2 : 1), false>), dim3(grid), dim3(G::kThreads),
-                               kFwdLds, st, a);
         else
             hipLaunchKernelGGL((tri_att_fwd_kernel<T, D, HG, NT, 1, false>), dim3(grid), dim3(G::kThreads),
                                kFwdLds, st, a);
     } else {
-        // experiment knob: TGT_TRI_BWD_OCC=2 caps registers for 2 waves/SIMD (NT == 1 only)
-        static const int occ = getenv("TGT_TRI_BWD_OCC") ? atoi(getenv("TGT_TRI_BWD_OCC")) : 2;
+        // one node tile: registers capped for 2 waves per SIMD (kOcc)
         const bool cs = a.d_qkv_colsum[0] != nullptr;
         constexpr int kCs = (3 * slab_colsum_plane_floats<G, T>() + G::kThreads) * 4;
         constexpr int kOcc = NT == 1 ? 2 : 1;
@@ -588,7 +584,7 @@ static int launch_tri_nt(const tgt_triplet_attention_args& a, bool bwd, hipStrea
             else
                 hipLaunchKernelGGL((tri_att_bwd_kernel<T, D, HG, NT, kOcc, false, -1, true>), dim3(grid), dim3(G::kThreads),
                                    kBwdLds, st, a);
-        } else if (NT == 1 && occ == 2) {
+        } else if (NT == 1) {
             if (cs && HG == 8 && (a.flags & kBG) == kBG)         // the training hot path: flags compiled in
                 hipLaunchKernelGGL((tri_att_bwd_kernel<T, D, HG, NT, kOcc, true, (HG == 8 ? kBG : -1), false>), dim3(grid),
                                    dim3(G::kThreads), kBwdLds + kCs, st, a);
@@ -619,9 +615,8 @@ static int launch_tri(const tgt_triplet_attention_args& a, bool bwd, hipStream_t
 
 template <typename T, int D>
 static int dispatch_hg(const tgt_triplet_attention_args& a, bool bwd, hipStream_t st) {
-    static const int hg = getenv("TGT_TRI_HG") ? atoi(getenv("TGT_TRI_HG")) : 8;     // 8 heads/workgroup: 256-byte row pieces
-    if constexpr (D == 16 && sizeof(T) == 2) {
-        if (hg == 8 && a.H % 8 == 0 && a.N <= 32) return launch_tri_nt<T, D, 8, 1>(a, bwd, st);
+    if constexpr (D == 16 && sizeof(T) == 2) {         // 8 heads per workgroup: 256-byte row pieces
+        if (a.H % 8 == 0 && a.N <= 32) return launch_tri_nt<T, D, 8, 1>(a, bwd, st);
     }
     if (a.H % 4 == 0) return launch_tri<T, D, 4>(a, bwd, st);
     if constexpr (D * sizeof(T) >= 16) return launch_tri<T, D, 1>(a, bwd, st);

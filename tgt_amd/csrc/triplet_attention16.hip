@@ -633,21 +633,13 @@ static int run(const tgt_triplet_attention_args& a, hipStream_t st) {
 }  // namespace t16
 
 // backward on 16-wide tiles: as the forward (N <= 48: 4 heads x 3 blocks; 49..64: 2 heads x 4 blocks)
-// TGT_TRI16_N32: the same kernels for 17 <= N <= 32 (two blocks, 8 heads x 2 waves) instead of the 32-wide ones: bit 0 forward,
-// bit 1 backward.  Measured (B = 256, N = 32, bf16, rocprofv3): forward 254.8 -> 242.5 us, backward 484 -> 617 us (534 -> 799 us
-// with the column sums: 128 registers at 16 waves spill, two barriers per j); inside the training step the forward is neutral
-// (2535 vs 2533 graphs/s same-box), so N <= 32 stays on the 32-wide kernels (default 0).
-static bool n32_on(const tgt_triplet_attention_args& a, int bit) {
-    static const int on = getenv("TGT_TRI16_N32") ? atoi(getenv("TGT_TRI16_N32")) : 0;
-    return (on & bit) && a.N > 16 && a.N <= 32 && a.H % 8 == 0;
-}
+// The same kernels for 17 <= N <= 32 (two blocks, 8 heads x 2 waves) were measured in round 2 and are gone: forward 254.8 -> 242.5 us
+// but backward 484 -> 617 us (128 registers at 16 waves spill, two barriers per j); N <= 32 stays on the 32-wide kernels.
 bool tri_att16_bwd_eligible(const tgt_triplet_attention_args& a) {
-    static const int on = getenv("TGT_TRI16_BWD") ? atoi(getenv("TGT_TRI16_BWD")) : 1;
-    return on && (a.dtype == TGT_BF16 || a.dtype == TGT_F16) && a.D == 16 && ((a.N > 32 && a.N <= 48 && a.H % 4 == 0) || (a.N > 48 && a.N <= 64 && a.H % 2 == 0) || n32_on(a, 2)) &&
+    return (a.dtype == TGT_BF16 || a.dtype == TGT_F16) && a.D == 16 && ((a.N > 32 && a.N <= 48 && a.H % 4 == 0) || (a.N > 48 && a.N <= 64 && a.H % 2 == 0)) &&
            !(a.dropout_p > 0.f);
 }
 int tri_att16_bwd_run(const tgt_triplet_attention_args& a, hipStream_t st) {
-    if (a.N <= 32) return a.dtype == TGT_BF16 ? t16::launch_bwd<bf16_t, 8, 2>(a, st) : t16::launch_bwd<f16_t, 8, 2>(a, st);
     // four blocks: 2 heads x 4 waves (8 waves, up to 256 registers; 64-byte row pieces) -- 16 waves would leave 128 registers
     if (a.N > 48) return a.dtype == TGT_BF16 ? t16::launch_bwd<bf16_t, 2, 4>(a, st) : t16::launch_bwd<f16_t, 2, 4>(a, st);
     return a.dtype == TGT_BF16 ? t16::launch_bwd<bf16_t, 4, 3>(a, st) : t16::launch_bwd<f16_t, 4, 3>(a, st);
@@ -655,11 +647,9 @@ int tri_att16_bwd_run(const tgt_triplet_attention_args& a, hipStream_t st) {
 
 // forward on 16-wide tiles: 16-bit, D = 16, 33 <= N <= 64, H a multiple of 4, no attention dropout
 bool tri_att16_fwd_eligible(const tgt_triplet_attention_args& a) {
-    static const int on = getenv("TGT_TRI16") ? atoi(getenv("TGT_TRI16")) : 1;
-    return on && (a.dtype == TGT_BF16 || a.dtype == TGT_F16) && a.D == 16 && ((a.N > 32 && a.N <= 64 && a.H % 4 == 0) || n32_on(a, 1)) && !(a.dropout_p > 0.f);
+    return (a.dtype == TGT_BF16 || a.dtype == TGT_F16) && a.D == 16 && a.N > 32 && a.N <= 64 && a.H % 4 == 0 && !(a.dropout_p > 0.f);
 }
 int tri_att16_fwd_run(const tgt_triplet_attention_args& a, hipStream_t st) {
-    if (a.N <= 32) return a.dtype == TGT_BF16 ? t16::launch<bf16_t, 8, 2>(a, st) : t16::launch<f16_t, 8, 2>(a, st);
     return a.dtype == TGT_BF16 ? t16::run<bf16_t>(a, st) : t16::run<f16_t>(a, st);
 }
 

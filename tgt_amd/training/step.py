@@ -15,7 +15,6 @@ training.py:152 DDP gradient averaging), re-designed for one process per GPU:
    the caller logs.
 """
 import math
-import os
 import weakref
 from dataclasses import dataclass, field
 
@@ -97,7 +96,7 @@ def preprocess_batch(batch, device, cfg, training=True, generator=None, add_nois
     return b
 
 
-_HIP_XENT = os.environ.get('TGT_HIP_XENT', '1') != '0'       # A/B knob: ATen's cross entropy on an fp32 image of the logits
+_HIP_XENT = True       # settled on (tests patch this); False: ATen's cross entropy on an fp32 image of the logits
 
 
 def binned_distance_loss(logits, dist_target, edge_mask, num_bins, range_bins):

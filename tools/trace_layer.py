@@ -6,7 +6,7 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'] for r in rows]
-fw = [i for i, n in enumerate(names) if 'tri_att_fwd' in n]
+fw = [i for i, n in enumerate(names) if 'tri_att_fwd' in n or 'tri_att_proj_fwd' in n]
 bw = [i for i, n in enumerate(names) if 'tri_att_bwd' in n]
 
 
