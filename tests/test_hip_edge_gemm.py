@@ -38,7 +38,7 @@ def _ln64(x, gamma, beta, eps):
 
 
 SHAPES = [(300, 64, 8), (300, 64, 24), (257, 64, 256), (1000, 128, 128), (1024, 256, 128), (513, 256, 256),
-          (640, 256, 1600), (384, 128, 256), (130, 256, 32), (128, 256, 64)]
+          (640, 256, 1600), (384, 128, 256), (130, 256, 32), (128, 256, 64), (777, 256, 512), (64, 256, 512)]
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
@@ -413,6 +413,7 @@ SIZE_CASES = {
     'lin_EG slice (N=128)': (256, 128, 'bias', False, False, False),
     'third arm slice (N=64)': (256, 64, 'bias', False, False, False),
     'ungated third arm slice (N=32)': (256, 32, 'bias', False, False, False),
+    'lin_O data gradient (K=256 -> N=512)': (256, 512, 'bias', False, False, False),
 }
 
 
@@ -505,7 +506,7 @@ def test_gelu_dropout_epilogue_at_baseline_size_equals_standalone_kernel(dtype):
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('case', ['lin_W2+res+LN prescaled (K=256)', 'lin_O_e+res+LN prescaled (K=64)', 'lin_W1+GELU+dropout (K=256)',
-                                  'lin_EG slice (N=128)', 'lin_O+res+LN (K=512)'])
+                                  'lin_EG slice (N=128)', 'lin_O+res+LN (K=512)', 'lin_O data gradient (K=256 -> N=512)'])
 @pytest.mark.parametrize('cap', [1, 3])
 def test_grid_cap_hook_walks_many_tiles_per_workgroup(case, dtype, cap):
     """tgt_edge_linear_set_grid_cap: with `cap` persistent workgroups a 50-tile problem is 17..50 tiles per workgroup; the result
@@ -635,3 +636,27 @@ def test_lin_O_residual_layer_norm_with_permuted_columns(dtype, with_scale, monk
     for name, a, b_ in zip(names, *outs):
         tol = 3 * TOL[dtype] if name.startswith('d') else TOL[dtype]
         assert rel(a, b_) < tol, (name, rel(a, b_))
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('rows', [1000, 4096 + 5])
+def test_lin_O_data_gradient_on_the_wide_kernel_vs_library_and_float64(rows, dtype, monkeypatch):
+    """the data gradient of a 512 -> 256 Linear on the edge rows (lin_O, reference triplet.py:248-249 under autograd) runs on
+    edge_wide512_kernel (K = 256 -> N = 512, weights resident): against the library GEMM it replaces and against float64"""
+    monkeypatch.setattr(ops, '_EDGE_MIN_ROWS', 1)
+    g = torch.Generator(device='cuda').manual_seed(23)
+    x0 = torch.randn(rows, 512, device='cuda', generator=g).to(dtype)
+    w0 = torch.randn(256, 512, device='cuda', generator=g) * 512 ** -0.5
+    dy = torch.randn(rows, 256, device='cuda', generator=g).to(dtype)
+    grads = []
+    for own in (True, False):
+        monkeypatch.setattr(ops, '_EDGE_N512', own)
+        x, w = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+        with torch.autocast('cuda', dtype=dtype):
+            y = ops.linear(x, w)
+        y.backward(dy)
+        grads.append((x.grad, w.grad))
+    ref = dy.double() @ w0.to(dtype).double()
+    assert rel(grads[0][0], ref) < TOL[dtype] and rel(grads[1][0], ref) < TOL[dtype]
+    assert rel(grads[0][0], grads[1][0]) < TOL[dtype]
+    assert torch.equal(grads[0][1], grads[1][1])            # (the weight gradient does not depend on the route)

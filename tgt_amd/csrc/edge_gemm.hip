@@ -1113,6 +1113,87 @@ __global__ void __launch_bounds__(1024, 4) edge_rows512_kernel(const tgt_edge_li
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// K = 256, N = 512, plain (bias) epilogue: the DATA GRADIENT of lin_O (d_z (M,256) x W_O (256,512) -> dVa (M,512), reference
+// triplet.py:248-249 under autograd) -- and any 256 -> 512 Linear on the edge rows.  The library runs it at 3.5 TB/s on its
+// 3 E of traffic (0.115 ms); this is the mirror image of the K = 512 kernel above: all 16 waves hold 32 output columns x 256 k
+// (64 registers of weights), one k-loop per 32-row tile, the accumulators go through ONE storage-type tile in LDS
+// (32 rows x 1 KB, 16-byte slots XOR-swizzled by the row) and leave as whole 1 KB rows, 16 bytes per thread and store.
+// Straight-line stages on tile-based buffer resources, exact wait counts (see edge_rows_kernel).
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(1024, 4) edge_wide512_kernel(const tgt_edge_linear_args a) {
+    using F = frag_t<T>;
+    constexpr int K = 256, KS = 16, N = 512, kBM = 32;
+    constexpr int kABytes = kBM * K * 2, kOBytes = kBM * N * 2;
+    constexpr int kOffO = 2 * kABytes, kOffB = kOffO + kOBytes;               // LDS: A tiles [2] | output tile | bias (fp32)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hi = lane >> 5;
+    const int n0 = wave * 32;                             // column block of this wave's k-loop
+    const int row = tid >> 5, ch = tid & 31;              // row and 16-byte chunk of this thread's loads / stores
+    const EgGeo g(K);
+    const int64_t row_tiles = (a.M + kBM - 1) / kBM;
+    float* bs = reinterpret_cast<float*>(smem + kOffB);
+    if (blockIdx.x >= row_tiles) return;
+    const int n_tiles = (int)((row_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
+    auto tile_of = [&](int s) { return (int64_t)blockIdx.x + (int64_t)s * gridDim.x; };
+    if (tid < N) bs[tid] = a.bias ? to_f32(reinterpret_cast<const T*>(a.bias)[tid]) : 0.f;
+    const T* W = reinterpret_cast<const T*>(a.w);
+    F wr[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) wr[ks] = load_frag<T>(W + (int64_t)(n0 + r) * a.ldw + ks * 16 + 8 * hi);
+    const int64_t lda_b = a.lda * 2, ldo_b = a.ldo * 2;
+    const uint32_t aoff = (uint32_t)row * (uint32_t)lda_b + (uint32_t)ch * 16u;
+    const int loff = g.off(row, ch);
+    const uint32_t o_out = (uint32_t)row * (uint32_t)ldo_b + (uint32_t)ch * 16u;
+    auto ooff = [&](int prow, int slot) { return prow * 1024 + ((slot ^ (prow & 31)) << 4); };
+    uint4 pre;
+    auto fetch_a = [&](int64_t tile) { pre = rp_ld16(tile_rsrc(a.a, lda_b, K * 2, tile * kBM, a.M), aoff); };
+    auto commit = [&](int buf) { *reinterpret_cast<uint4*>(smem + buf * kABytes + loff) = pre; };
+    fetch_a(tile_of(0));
+    commit(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    char* ot = smem + kOffO;
+    for (int s = 0; s < n_tiles; ++s) {
+        fetch_a(tile_of(s + 1));                           // (past the last tile: an empty buffer)
+        asm volatile("" ::: "memory");
+        const char* xs = smem + (s & 1) * kABytes;
+        f32x16 acc;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const float4 bv = *reinterpret_cast<const float4*>(bs + n0 + 8 * gq + 4 * hi);
+            acc[4 * gq] = bv.x; acc[4 * gq + 1] = bv.y; acc[4 * gq + 2] = bv.z; acc[4 * gq + 3] = bv.w;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            int rr = r;
+            asm volatile("" : "+v"(rr));                   // (keeps the swizzled address arithmetic at its k-step: see edge_rows_kernel)
+            const F xf = load_frag<T>(reinterpret_cast<const T*>(xs + g.off(rr, 2 * ks + hi)));
+            acc = mma32(wr[ks], xf, acc);
+        }
+        // accumulator element 4 gq + e = (tile row r, column n0 + 8 gq + 4 hi + e): 8 bytes of slot n0/8 + gq
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            f32x2 lo = {acc[4 * gq], acc[4 * gq + 1]}, hi2 = {acc[4 * gq + 2], acc[4 * gq + 3]};
+            *reinterpret_cast<uint2*>(ot + ooff(r, (n0 >> 3) + gq) + 8 * hi) = make_uint2(rp_pack2<T>(lo), rp_pack2<T>(hi2));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        {
+            const __amdgpu_buffer_rsrc_t rs_out = tile_rsrc(a.out, ldo_b, N * 2, tile_of(s) * kBM, a.M);
+            const uint4 v0 = *reinterpret_cast<const uint4*>(ot + ooff(row, ch));
+            const uint4 v1 = *reinterpret_cast<const uint4*>(ot + ooff(row, ch + 32));
+            rp_st16(rs_out, o_out, v0);
+            rp_st16(rs_out, o_out + 512u, v1);
+        }
+        commit((s + 1) & 1);                               // (the A buffer of tile s-1; its k-loop ended two barriers ago)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
 // test hook (tgt_edge_linear_set_grid_cap): at most this many persistent workgroups / row groups per launch, so that a small
 // problem walks several tiles per workgroup -- the stage hand-over the BASELINE-size launches (32 tiles each) depend on
 static int g_grid_cap = 0;
@@ -1156,6 +1237,20 @@ static int er512_launch(const tgt_edge_linear_args& a, hipStream_t st) {
         return set_error(TGT_ERR_LAUNCH, "edge_rows512_kernel: cannot reserve %d bytes of LDS", lds);
     hipLaunchKernelGGL((edge_rows512_kernel<T>), dim3((unsigned)er_grid(a.M)), dim3(1024), lds, st, a);
     return check_launch("edge_rows512_kernel");
+}
+
+template <typename T>
+static int ew512_launch(const tgt_edge_linear_args& a, hipStream_t st) {
+    constexpr int lds = 2 * 32 * 256 * 2 + 32 * 512 * 2 + 512 * 4;
+    static bool attr_set[16] = {};
+    if (!dyn_lds_once(attr_set, reinterpret_cast<const void*>(&edge_wide512_kernel<T>), lds))
+        return set_error(TGT_ERR_LAUNCH, "edge_wide512_kernel: cannot reserve %d bytes of LDS", lds);
+    hipLaunchKernelGGL((edge_wide512_kernel<T>), dim3((unsigned)er_grid(a.M)), dim3(1024), lds, st, a);
+    return check_launch("edge_wide512_kernel");
+}
+// K = 256 -> N = 512 with the plain epilogue and nothing else attached
+static bool ew512_eligible(const tgt_edge_linear_args& a) {
+    return a.K == 256 && a.N == 512 && a.epilogue == EPI_BIAS && !a.gamma && !a.row_scale && !a.out_scale;
 }
 
 template <typename T, int KS>
@@ -1297,6 +1392,7 @@ int edge_linear_run(const tgt_edge_linear_args* a, hipStream_t st) {
     if (a->gamma && a->epilogue != EPI_LN_BWD && !a->beta) return set_error(TGT_ERR_INVALID, "edge linear: beta missing");
     if (a->dropout_p < 0.f || a->dropout_p >= 1.f) return set_error(TGT_ERR_INVALID, "edge linear: dropout_p outside [0,1)");
     if (a->K == 512) return a->dtype == TGT_BF16 ? er512_launch<bf16_t>(*a, st) : er512_launch<f16_t>(*a, st);
+    if (ew512_eligible(*a)) return a->dtype == TGT_BF16 ? ew512_launch<bf16_t>(*a, st) : ew512_launch<f16_t>(*a, st);
     if (er_eligible(*a)) return a->dtype == TGT_BF16 ? er_run<bf16_t>(*a, st) : er_run<f16_t>(*a, st);
     if (es_eligible(*a)) return a->dtype == TGT_BF16 ? es_run<bf16_t>(*a, st) : es_run<f16_t>(*a, st);
     return set_error(TGT_ERR_UNSUPPORTED, "edge linear: no kernel for K=%d N=%d epilogue=%d", a->K, a->N, a->epilogue);
