@@ -1114,7 +1114,7 @@ def _as_dtype_view(p, cd):
 
 
 _EDGE_GEMM = os.environ.get('TGT_EDGE_GEMM', '1') != '0'          # A/B knob: the weight-resident slice kernel where it wins
-_EDGE_N512 = os.environ.get('TGT_EDGE_N512', '1') != '0'          # A/B knob: lin_O's data gradient (K = 256 -> N = 512) on edge_wide512_kernel
+_EDGE_N512 = os.environ.get('TGT_EDGE_N512', '1') != '0'          # A/B knob: lin_O's (256 -> 512) and the narrow (-> <= 128) data gradients on the weight-resident kernels
 _EDGE_MIN_ROWS = 65536                                            # (tests lower it)
 
 
@@ -1158,9 +1158,11 @@ def _linear_backward(x2, w, dy2, xs, xdt, wdt, bdt, need_dx, need_dw, need_db, l
         # lazy_dx: the LayerNorm entry that produced x runs this GEMM itself, fused with its own backward (_lazy_dgrad)
         if lazy_dx and xdt == dy2.dtype:
             dx = _lazy_dgrad(dy2.contiguous(), w, xs)
-        elif _EDGE_N512 and tuple(w.shape) == (256, 512) and _edge_kernel_ok(dy2, 512, dy2.dtype, (256,)):
-            # lin_O's data gradient (256 -> 512 channels): the weight-resident kernel moves its 3 E at ~5 TB/s (library: 3.5)
-            dx = edge_linear_raw(dy2, w.t().contiguous()).view(xs).to(xdt)
+        elif _EDGE_N512 and _edge_kernel_ok(dy2, w.shape[1], dy2.dtype) and \
+                ((w.shape[0] == 256 and w.shape[1] == 512) or w.shape[1] <= 128):
+            # data gradients the weight-resident kernels win: lin_O's (256 -> 512 channels: 3 E at ~5 TB/s, library 3.5) on
+            # edge_wide512_kernel, narrow ones (lin_O_e: 256 -> 64) on the slice kernel
+            dx = edge_linear_raw(dy2.contiguous(), w.t().contiguous()).view(xs).to(xdt)
         else:
             dx = (dy2 @ w).view(xs).to(xdt)
     if need_dw:

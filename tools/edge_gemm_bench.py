@@ -33,7 +33,7 @@ def main():
                                 ('lin_O_e (+res+LN)', 64, 256, 'resid_ln', False),
                                 ('dgrad lin_EG + LN_BWD', 128, 256, _lib.EPI_LN_BWD, False),
                                 ('W2 (+res)', 256, 256, _lib.EPI_RESID, False), ('lin_O (+res+LN)', 512, 256, 'resid_ln', False), ('lin_O_e (+res)', 64, 256, _lib.EPI_RESID, False),
-                                ('plain 256x256', 256, 256, _lib.EPI_BIAS, False),
+                                ('plain 256x256', 256, 256, _lib.EPI_BIAS, False), ('dgrad lin_O (256->512)', 256, 512, _lib.EPI_BIAS, False),
                                 ('dgrad W1 + LN_BWD', 256, 256, _lib.EPI_LN_BWD, False),
                                 ('dgrad W2 + GELU_BWD', 256, 256, _lib.EPI_GELU_BWD, False)]:
         a = torch.randn(M, K, device=dev, generator=g).to(dt)
