@@ -13,9 +13,13 @@ python tools/edge_gemm_bench.py > $O/edge_gemm_bench.txt 2>&1
 bash tools/probes/prof_steady.sh $tag
 rm -rf /tmp/pstats
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pstats -o bench -- python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline ) > /tmp/pstats.log 2>&1
-tail -1 /tmp/pstats.log > $O/bench_under_rocprof.json
+grep "^{" /tmp/pstats.log | tail -1 > $O/bench_under_rocprof.json
 cp $(find /tmp/pstats -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
 cd $R
 python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --steps 50 --warmup 10 --no-cpu-baseline > $O/bench_50steps.json 2>> $O/bench.err
+python bench.py --no-cpu-baseline --batch 128 --nodes 48 > $O/bench_n48_b128.json 2>> $O/bench.err
+python bench.py --no-cpu-baseline --ragged > $O/bench_ragged.json 2>> $O/bench.err
+python tools/infer_bench.py > $O/infer_bench.jsonl 2>> $O/bench.err
+bash tools/pmc_edge.sh $O > $O/pmc_edge_summary.txt 2>&1
 tail -c 600 $O/bench.json
