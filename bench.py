@@ -390,7 +390,7 @@ def main():
                                          note='event pairs inside the timed region: the second stream\'s node kernels share the CUs'))
                 roofline['share_of_step'] = round(sum(times_region[name]) / (dt * 1e3), 4)
             if skip_mode and drop_frac > 0:
-                roofline['droppath_skip'] = dict(kernels='forward' if skip_mode == '1' else 'forward+backward',
+                roofline['droppath_skip'] = dict(kernels='forward+backward' if (skip_mode == '2' or proj_on) else 'forward',
                                                  expected_dropped_fraction=drop_frac,
                                                  note='algorithmic bytes of the skipping kernels count only what they move for a dropped graph')
             # the bias/softmax path (node attention with edge bias and gate), same accounting

@@ -177,9 +177,7 @@ int tgt_triangular_update_bwd(const void* e4, const void* v4, const float* mask,
 typedef struct tgt_node_attention_args {
     int32_t B, N, H, D;
     int32_t dtype, scale_degree, logits_only;
-    int32_t head_major;               /* 0: channel = d*H + h (the reference's order); 1: channel = h*D + d inside each of
-                                       * Q, K, V (and V_att): the caller permuted the projection's weight rows.  Same
-                                       * arithmetic; a lane's D values are then one contiguous block (16-byte fetches). */
+    int32_t _pad0;                    /* (ABI <= 25: head_major, a head-major channel order measured slower and removed) */
     float   scale;                    /* D^-0.5 */
     int32_t _pad1;
     const void* qkv;   int64_t ld_qkv;  int32_t q_off, k_off, v_off, _pad2;
@@ -194,9 +192,7 @@ typedef struct tgt_node_attention_args {
     const void* d_hhat;
     void*  d_qkv;
     void*  d_eg;
-    void*  w_ws;                      /* backward scratch (may be NULL): (B,N,N,H) of `dtype`.  When given, the row pass leaves the
-                                       * attention weights A[l,m,h] * log(1+sum gates) there and the column pass (dK, dV) reads them
-                                       * and the stored dE instead of re-reading E, G and recomputing softmax and gate per pair */
+    void*  _reserved0;                /* (ABI <= 25: w_ws, a pair-weight scratch between the two backward passes: neutral, removed) */
     const float* hhat_scale;          /* optional (B) float32: H_hat is WRITTEN as hhat_scale[b] * H_hat (the softmax still sees the
                                        * unscaled logits) and the backward reads d_hhat as the gradient of that scaled tensor.  The
                                        * DropPath factors of the edge branch lin_O_e(H_hat) feeds (reference layers.py:270-272),

@@ -435,18 +435,9 @@ NODE_CASES = [  # B, N, num_nodes, W, H
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('case', NODE_CASES)
 @pytest.mark.parametrize('scale_degree,want_edges', [(True, True), (False, False)])
-@pytest.mark.parametrize('head_major', [False, True])
-def test_node_attention(case, dtype, scale_degree, want_edges, head_major):
-    """head_major: the kernels' alternative Q/K/V (and V_att) channel order h*D + d; the test permutes
-    the reference-layout tensors into it and back"""
+def test_node_attention(case, dtype, scale_degree, want_edges):
     from tgt_amd import ops
     B, N, nn_, W, H = case
-    D = W // H
-    if head_major and (H % 2 or (2 * D * (4 if dtype == torch.float32 else 2)) % 16):
-        pytest.skip('shape not eligible for the head-major layout')
-    c = torch.arange(W)
-    hm_src = (c % D) * H + c // D                      # head-major channel c = h*D + d  <-  reference channel d*H + h
-    hm3 = torch.cat([p_ * W + hm_src for p_ in range(3)])
     rng = np.random.default_rng(hash((B, N, W, H)) % 1000)
     qkv = rnd(rng, B, N, 3 * W).to(dtype)
     eg = rnd(rng, B, N, N, 2 * H).to(dtype)
@@ -461,16 +452,15 @@ def test_node_attention(case, dtype, scale_degree, want_edges, head_major):
         loss = loss + (h_ref * d_h.double()).sum()
     loss.backward()
 
-    q_in, dv_in = (qkv[..., hm3], d_v[..., hm_src]) if head_major else (qkv, d_v)
-    qx, ex = q_in.contiguous().cuda().requires_grad_(True), eg.cuda().requires_grad_(True)
-    v, hh = ops.node_attention(qx, ex, mask.reshape(B, N, N).cuda(), H, scale_degree, want_edges, head_major=head_major)
-    loss = (v.float() * dv_in.cuda().float()).sum()
+    qx, ex = qkv.cuda().requires_grad_(True), eg.cuda().requires_grad_(True)
+    v, hh = ops.node_attention(qx, ex, mask.reshape(B, N, N).cuda(), H, scale_degree, want_edges)
+    loss = (v.float() * d_v.cuda().float()).sum()
     if want_edges:
         loss = loss + (hh.float() * d_h.cuda().float()).sum()
     loss.backward()
     torch.cuda.synchronize()
     tol = TOL[dtype]
-    v_want, dq_want = (v_ref[..., hm_src], q64.grad[..., hm3]) if head_major else (v_ref, q64.grad)
+    v_want, dq_want = v_ref, q64.grad
     assert rel(v, v_want) < tol, ('vatt', rel(v, v_want))
     if want_edges:
         assert rel(hh, h_ref) < tol, ('hhat', rel(hh, h_ref))

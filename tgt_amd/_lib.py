@@ -20,7 +20,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 SOURCES = ['capi.hip', 'optimizer.hip', 'edge_gemm.hip', 'params.hip', 'loss.hip', 'predict.hip', 'gaussian.hip', 'triplet_attention_proj.hip',
            ('triplet_attention.hip', ['-DTGT_TRI_INST=9'], '.f32'), ('triplet_attention.hip', ['-DTGT_TRI_INST=2'], '.bf16'),
            ('triplet_attention.hip', ['-DTGT_TRI_INST=4'], '.f16'), 'triplet_attention16.hip', 'triplet_aggregate.hip', 'node_attention.hip', 'node_attention_mfma.hip', 'layernorm.hip', 'triangular_update.hip', 'elementwise.hip']
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 TGT_F32, TGT_BF16, TGT_F16 = 0, 1, 2
 TRI_BIASED, TRI_GATED, TRI_MASK_OUT = 1, 2, 4
@@ -60,13 +60,13 @@ class TripletAggregateArgs(C.Structure):
 class NodeAttentionArgs(C.Structure):
     _fields_ = [
         ('B', _i32), ('N', _i32), ('H', _i32), ('D', _i32),
-        ('dtype', _i32), ('scale_degree', _i32), ('logits_only', _i32), ('head_major', _i32),
+        ('dtype', _i32), ('scale_degree', _i32), ('logits_only', _i32), ('_pad0', _i32),
         ('scale', _f32), ('_pad1', _i32),
         ('qkv', _vp), ('ld_qkv', _i64), ('q_off', _i32), ('k_off', _i32), ('v_off', _i32), ('_pad2', _i32),
         ('eg', _vp), ('ld_eg', _i64), ('e_off', _i32), ('g_off', _i32),
         ('mask', _vp),
         ('vatt', _vp), ('hhat', _vp), ('lse', _vp), ('gsum', _vp),
-        ('d_vatt', _vp), ('d_hhat', _vp), ('d_qkv', _vp), ('d_eg', _vp), ('w_ws', _vp), ('hhat_scale', _vp),
+        ('d_vatt', _vp), ('d_hhat', _vp), ('d_qkv', _vp), ('d_eg', _vp), ('_reserved0', _vp), ('hhat_scale', _vp),
     ]
 
 

@@ -82,72 +82,34 @@ __device__ __forceinline__ void ldf(const float* p, int64_t i, float (&o)[HV]) {
     for (int k = 0; k < HV; ++k) o[k] = p[i + k];
 }
 
-// All D values of HV adjacent heads of one Q/K/V (or V_att) row, kept packed in T.
-//   HM = false: the reference's head-MINOR channel order c = d*H + h  -> D accesses of HV elements
-//   HM = true : head-MAJOR c = h*D + d (tgt_node_attention_args.head_major: the projection's weight
-//               rows are permuted instead) -> ONE contiguous block of HV*D elements, fetched with
-//               16-byte accesses.  These kernels are bound by the NUMBER of vector-memory
-//               instructions (2*D four-byte K/V fetches per key and lane otherwise).
-template <typename T, int D, int HV, bool HM>
+// All D values of HV adjacent heads of one Q/K/V (or V_att) row, kept packed in T: the reference's head-MINOR channel
+// order c = d*H + h -> D accesses of HV elements.  (A head-major ABI option, c = h*D + d with one contiguous block per lane,
+// was measured slower end to end in round 1 and removed in round 3.)
+template <typename T, int D, int HV>
 struct DH {
     T v[D * HV];
-    __device__ __forceinline__ float at(int d, int k) const { return to_f32(HM ? v[k * D + d] : v[d * HV + k]); }
+    __device__ __forceinline__ float at(int d, int k) const { return to_f32(v[d * HV + k]); }
     __device__ __forceinline__ void load(const T* p, int64_t base, int H, int h) {
-        if constexpr (HM) {
-            constexpr int NB = HV * D * (int)sizeof(T);
-            const char* src = reinterpret_cast<const char*>(p + base + (int64_t)h * D);
-            if constexpr (NB % 16 == 0) {
 #pragma unroll
-                for (int x = 0; x < NB / 16; ++x) { uint4 w = reinterpret_cast<const uint4*>(src)[x]; __builtin_memcpy(reinterpret_cast<char*>(v) + 16 * x, &w, 16); }
-            } else if constexpr (NB % 8 == 0) {
-#pragma unroll
-                for (int x = 0; x < NB / 8; ++x) { uint2 w = reinterpret_cast<const uint2*>(src)[x]; __builtin_memcpy(reinterpret_cast<char*>(v) + 8 * x, &w, 8); }
-            } else {
-#pragma unroll
-                for (int x = 0; x < HV * D; ++x) v[x] = p[base + (int64_t)h * D + x];
-            }
-        } else {
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                constexpr int NB = HV * (int)sizeof(T);
-                const T* src = p + base + (int64_t)d * H + h;
-                if constexpr (NB == 16) { uint4 w = *reinterpret_cast<const uint4*>(src); __builtin_memcpy(v + d * HV, &w, 16); }
-                else if constexpr (NB == 8) { uint2 w = *reinterpret_cast<const uint2*>(src); __builtin_memcpy(v + d * HV, &w, 8); }
-                else if constexpr (NB == 4) { uint32_t w = *reinterpret_cast<const uint32_t*>(src); __builtin_memcpy(v + d * HV, &w, 4); }
-                else { v[d * HV] = src[0]; }
-            }
+        for (int d = 0; d < D; ++d) {
+            constexpr int NB = HV * (int)sizeof(T);
+            const T* src = p + base + (int64_t)d * H + h;
+            if constexpr (NB == 16) { uint4 w = *reinterpret_cast<const uint4*>(src); __builtin_memcpy(v + d * HV, &w, 16); }
+            else if constexpr (NB == 8) { uint2 w = *reinterpret_cast<const uint2*>(src); __builtin_memcpy(v + d * HV, &w, 8); }
+            else if constexpr (NB == 4) { uint32_t w = *reinterpret_cast<const uint32_t*>(src); __builtin_memcpy(v + d * HV, &w, 4); }
+            else { v[d * HV] = src[0]; }
         }
     }
     __device__ static __forceinline__ void store(T* p, int64_t base, int H, int h, const float (&x)[D][HV]) {
-        if constexpr (HM) {
-            T t[D * HV];
 #pragma unroll
-            for (int d = 0; d < D; ++d)
-#pragma unroll
-                for (int k = 0; k < HV; ++k) t[k * D + d] = from_f32<T>(x[d][k]);
-            constexpr int NB = HV * D * (int)sizeof(T);
-            char* dst = reinterpret_cast<char*>(p + base + (int64_t)h * D);
-            if constexpr (NB % 16 == 0) {
-#pragma unroll
-                for (int y = 0; y < NB / 16; ++y) { uint4 w; __builtin_memcpy(&w, reinterpret_cast<const char*>(t) + 16 * y, 16); reinterpret_cast<uint4*>(dst)[y] = w; }
-            } else if constexpr (NB % 8 == 0) {
-#pragma unroll
-                for (int y = 0; y < NB / 8; ++y) { uint2 w; __builtin_memcpy(&w, reinterpret_cast<const char*>(t) + 8 * y, 8); reinterpret_cast<uint2*>(dst)[y] = w; }
-            } else {
-#pragma unroll
-                for (int y = 0; y < HV * D; ++y) p[base + (int64_t)h * D + y] = t[y];
-            }
-        } else {
-#pragma unroll
-            for (int d = 0; d < D; ++d) stv<T, HV>(p, base + (int64_t)d * H + h, x[d]);
-        }
+        for (int d = 0; d < D; ++d) stv<T, HV>(p, base + (int64_t)d * H + h, x[d]);
     }
 };
 
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
-template <typename T, int D, int HV, bool HM>
+template <typename T, int D, int HV>
 __global__ void __launch_bounds__(256) node_att_fwd_kernel(const tgt_node_attention_args a) {
     const NodeLane n = node_lane<HV>(a);
     if (!n.active) return;
@@ -160,7 +122,7 @@ __global__ void __launch_bounds__(256) node_att_fwd_kernel(const tgt_node_attent
 
     float q[D][HV], acc[D][HV], mx[HV], sum[HV], gsum[HV];
     {
-        DH<T, D, HV, HM> qb;
+        DH<T, D, HV> qb;
         qb.load(qkv, row_l * a.ld_qkv + a.q_off, H, h);
 #pragma unroll
         for (int d = 0; d < D; ++d)
@@ -183,7 +145,7 @@ __global__ void __launch_bounds__(256) node_att_fwd_kernel(const tgt_node_attent
 #pragma unroll
         for (int k = 0; k < HV; ++k) s[k] = e[k];
         {
-            DH<T, D, HV, HM> kb;
+            DH<T, D, HV> kb;
             kb.load(qkv, row_m * a.ld_qkv + a.k_off, H, h);
 #pragma unroll
             for (int d = 0; d < D; ++d)
@@ -214,7 +176,7 @@ __global__ void __launch_bounds__(256) node_att_fwd_kernel(const tgt_node_attent
             mx[k] = mnew;
         }
         {
-            DH<T, D, HV, HM> vb;
+            DH<T, D, HV> vb;
             vb.load(qkv, row_m * a.ld_qkv + a.v_off, H, h);
 #pragma unroll
             for (int d = 0; d < D; ++d)
@@ -234,7 +196,7 @@ __global__ void __launch_bounds__(256) node_att_fwd_kernel(const tgt_node_attent
     for (int d = 0; d < D; ++d)
 #pragma unroll
         for (int k = 0; k < HV; ++k) acc[d][k] *= f[k];
-    DH<T, D, HV, HM>::store(vatt, row_l * (int64_t)(D * H), H, h, acc);
+    DH<T, D, HV>::store(vatt, row_l * (int64_t)(D * H), H, h, acc);
 #pragma unroll
     for (int k = 0; k < HV; ++k) {
         a.lse[row_l * H + h + k] = lse[k];
@@ -249,7 +211,7 @@ __global__ void __launch_bounds__(256) node_att_fwd_kernel(const tgt_node_attent
 // (written), 8 bytes per lane -- and those run PD keys ahead in a register ring.
 //   lane = (query l, HV heads), lanes of the same wave that share heads read the same LDS words.
 // ---------------------------------------------------------------------------
-template <typename T, int D, int HV, int MT, bool HM>
+template <typename T, int D, int HV, int MT>
 __global__ void __launch_bounds__(512) node_att_fwd_lds_kernel(const tgt_node_attention_args a, int lpr, int qb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int N = a.N, H = a.H, W = D * H;
@@ -267,7 +229,7 @@ __global__ void __launch_bounds__(512) node_att_fwd_lds_kernel(const tgt_node_at
 
     float q[D][HV], acc[D][HV], mx[HV], sum[HV], gsum[HV];
     {
-        DH<T, D, HV, HM> qb;
+        DH<T, D, HV> qb;
         if (active) qb.load(qkv, row_l * a.ld_qkv + a.q_off, H, h);
 #pragma unroll
         for (int d = 0; d < D; ++d)
@@ -320,7 +282,7 @@ __global__ void __launch_bounds__(512) node_att_fwd_lds_kernel(const tgt_node_at
 #pragma unroll
                     for (int k = 0; k < HV; ++k) s[k] = er[kk][k];
                     {
-                        DH<T, D, HV, HM> kb;
+                        DH<T, D, HV> kb;
                         kb.load(sK, (int64_t)m * W, H, h);
 #pragma unroll
                         for (int d = 0; d < D; ++d)
@@ -350,7 +312,7 @@ __global__ void __launch_bounds__(512) node_att_fwd_lds_kernel(const tgt_node_at
                             mx[k] = mnew;
                         }
                         {
-                            DH<T, D, HV, HM> vb;
+                            DH<T, D, HV> vb;
                             vb.load(sV, (int64_t)m * W, H, h);
 #pragma unroll
                             for (int d = 0; d < D; ++d)
@@ -376,13 +338,13 @@ __global__ void __launch_bounds__(512) node_att_fwd_lds_kernel(const tgt_node_at
     for (int d = 0; d < D; ++d)
 #pragma unroll
         for (int k = 0; k < HV; ++k) acc[d][k] *= f[k];
-    DH<T, D, HV, HM>::store(vatt, row_l * (int64_t)(D * H), H, h, acc);
+    DH<T, D, HV>::store(vatt, row_l * (int64_t)(D * H), H, h, acc);
 }
 
 // ---------------------------------------------------------------------------
 // backward, row pass: lane = (query l, HV heads).  Writes dE, dG and dQ.
 // ---------------------------------------------------------------------------
-template <typename T, int D, int HV, bool HM>
+template <typename T, int D, int HV>
 __global__ void __launch_bounds__(256) node_att_bwd_row_kernel(const tgt_node_attention_args a) {
     const NodeLane n = node_lane<HV>(a);
     if (!n.active) return;
@@ -397,7 +359,7 @@ __global__ void __launch_bounds__(256) node_att_bwd_row_kernel(const tgt_node_at
 
     float q[D][HV], dq[D][HV];
     {
-        DH<T, D, HV, HM> qb;
+        DH<T, D, HV> qb;
         qb.load(qkv, row_l * a.ld_qkv + a.q_off, H, h);
 #pragma unroll
         for (int d = 0; d < D; ++d)
@@ -420,7 +382,7 @@ __global__ void __launch_bounds__(256) node_att_bwd_row_kernel(const tgt_node_at
                 for (int k = 0; k < HV; ++k) dH[k] *= hs;
             }
             stv<T, HV>(deg, lm * a.ld_eg + a.e_off + h, dH);
-            DH<T, D, HV, HM> kb;
+            DH<T, D, HV> kb;
             kb.load(qkv, (row0 + m) * a.ld_qkv + a.k_off, H, h);
 #pragma unroll
             for (int d = 0; d < D; ++d)
@@ -441,7 +403,7 @@ __global__ void __launch_bounds__(256) node_att_bwd_row_kernel(const tgt_node_at
         }
         // unscaled V_att from the saved forward output: V_att = vu * log(1+gsum)
         {
-            DH<T, D, HV, HM> db, ob;
+            DH<T, D, HV> db, ob;
             db.load(dva, row_l * (int64_t)(D * H), H, h);
             ob.load(va, row_l * (int64_t)(D * H), H, h);
 #pragma unroll
@@ -471,7 +433,7 @@ __global__ void __launch_bounds__(256) node_att_bwd_row_kernel(const tgt_node_at
             }
 #pragma unroll
             for (int k = 0; k < HV; ++k) dot[k] = dA[k] = 0.f;
-            DH<T, D, HV, HM> kb, vb;
+            DH<T, D, HV> kb, vb;
             kb.load(qkv, row_m * a.ld_qkv + a.k_off, H, h);
             vb.load(qkv, row_m * a.ld_qkv + a.v_off, H, h);
 #pragma unroll
@@ -482,7 +444,6 @@ __global__ void __launch_bounds__(256) node_att_bwd_row_kernel(const tgt_node_at
                     dA[k] += dvu[d][k] * vb.at(d, k);
                 }
             const float mk = a.mask[lm];
-            float wv[HV];
 #pragma unroll
             for (int k = 0; k < HV; ++k) {
                 const float p = fast_exp(dot[k] + e[k] + mk - lse[k]);
@@ -490,11 +451,9 @@ __global__ void __launch_bounds__(256) node_att_bwd_row_kernel(const tgt_node_at
                 const float dS = p * (dA[k] * gt - delta[k]);
                 dGl[k] = (dA[k] * p + dgsum[k]) * gt * (1.f - gt);
                 dH[k] += dS;
-                wv[k] = p * gt * dsc[k];                       // what the column pass needs of this pair for dV
             }
             stv<T, HV>(deg, lm * a.ld_eg + a.e_off + h, dH);
             stv<T, HV>(deg, lm * a.ld_eg + a.g_off + h, dGl);
-            if (a.w_ws) stv<T, HV>(reinterpret_cast<T*>(a.w_ws), lm * H + h, wv);
 #pragma unroll
             for (int d = 0; d < D; ++d)
 #pragma unroll
@@ -505,14 +464,14 @@ __global__ void __launch_bounds__(256) node_att_bwd_row_kernel(const tgt_node_at
     for (int d = 0; d < D; ++d)
 #pragma unroll
         for (int k = 0; k < HV; ++k) dq[d][k] *= a.scale;
-    DH<T, D, HV, HM>::store(dqkv, row_l * a.ld_qkv + a.q_off, H, h, dq);
+    DH<T, D, HV>::store(dqkv, row_l * a.ld_qkv + a.q_off, H, h, dq);
 }
 
 // ---------------------------------------------------------------------------
 // backward, column pass: lane = (key m, HV heads).  dK and dV, reading the
 // dH = dE the row pass stored (same stream, so ordered).
 // ---------------------------------------------------------------------------
-template <typename T, int D, int HV, bool HM>
+template <typename T, int D, int HV>
 __global__ void __launch_bounds__(256) node_att_bwd_col_kernel(const tgt_node_attention_args a) {
     const NodeLane n = node_lane<HV>(a);
     if (!n.active) return;
@@ -526,7 +485,7 @@ __global__ void __launch_bounds__(256) node_att_bwd_col_kernel(const tgt_node_at
 
     float kv[D][HV], dk[D][HV], dv[D][HV];
     {
-        DH<T, D, HV, HM> kb;
+        DH<T, D, HV> kb;
         kb.load(qkv, row_m * a.ld_qkv + a.k_off, H, h);
 #pragma unroll
         for (int d = 0; d < D; ++d)
@@ -536,34 +495,6 @@ __global__ void __launch_bounds__(256) node_att_bwd_col_kernel(const tgt_node_at
                 dk[d][k] = dv[d][k] = 0.f;
             }
     }
-    if (a.w_ws && !a.logits_only) {
-        // the row pass left dE = dH_hat and the weights A*log(1+sum g) of every pair: two streamed values per query instead of
-        // E, G, the mask, the row statistics and a softmax / gate recomputation
-        const T* wws = reinterpret_cast<const T*>(a.w_ws);
-        for (int l = 0; l < N; ++l) {
-            const int64_t row_l = row0 + l, lm = row_l * N + m;
-            float dH[HV], w[HV];
-            ldv<T, HV>(deg, lm * a.ld_eg + a.e_off + h, dH);
-            ldv<T, HV>(wws, lm * H + h, w);
-            DH<T, D, HV, HM> qb, db;
-            qb.load(qkv, row_l * a.ld_qkv + a.q_off, H, h);
-            db.load(dva, row_l * (int64_t)(D * H), H, h);
-#pragma unroll
-            for (int d = 0; d < D; ++d)
-#pragma unroll
-                for (int k = 0; k < HV; ++k) {
-                    dk[d][k] += dH[k] * qb.at(d, k);
-                    dv[d][k] += w[k] * db.at(d, k);
-                }
-        }
-#pragma unroll
-        for (int d = 0; d < D; ++d)
-#pragma unroll
-            for (int k = 0; k < HV; ++k) dk[d][k] *= a.scale;
-        DH<T, D, HV, HM>::store(dqkv, row_m * a.ld_qkv + a.k_off, H, h, dk);
-        DH<T, D, HV, HM>::store(dqkv, row_m * a.ld_qkv + a.v_off, H, h, dv);
-        return;
-    }
     for (int l = 0; l < N; ++l) {
         const int64_t row_l = row0 + l, lm = row_l * N + m;
         float dH[HV], dot[HV];
@@ -571,7 +502,7 @@ __global__ void __launch_bounds__(256) node_att_bwd_col_kernel(const tgt_node_at
 #pragma unroll
         for (int k = 0; k < HV; ++k) dot[k] = 0.f;
         {
-            DH<T, D, HV, HM> qb;
+            DH<T, D, HV> qb;
             qb.load(qkv, row_l * a.ld_qkv + a.q_off, H, h);
 #pragma unroll
             for (int d = 0; d < D; ++d)
@@ -596,7 +527,7 @@ __global__ void __launch_bounds__(256) node_att_bwd_col_kernel(const tgt_node_at
             w[k] = p * gt * (a.scale_degree ? __logf(1.f + gsum[k]) : 1.f);
         }
         {
-            DH<T, D, HV, HM> db;
+            DH<T, D, HV> db;
             db.load(dva, row_l * (int64_t)(D * H), H, h);
 #pragma unroll
             for (int d = 0; d < D; ++d)
@@ -608,8 +539,8 @@ __global__ void __launch_bounds__(256) node_att_bwd_col_kernel(const tgt_node_at
     for (int d = 0; d < D; ++d)
 #pragma unroll
         for (int k = 0; k < HV; ++k) dk[d][k] *= a.scale;
-    DH<T, D, HV, HM>::store(dqkv, row_m * a.ld_qkv + a.k_off, H, h, dk);
-    if (!a.logits_only) DH<T, D, HV, HM>::store(dqkv, row_m * a.ld_qkv + a.v_off, H, h, dv);
+    DH<T, D, HV>::store(dqkv, row_m * a.ld_qkv + a.k_off, H, h, dk);
+    if (!a.logits_only) DH<T, D, HV>::store(dqkv, row_m * a.ld_qkv + a.v_off, H, h, dv);
 }
 
 // ---------------------------------------------------------------------------
@@ -633,18 +564,13 @@ static int node_vec(const tgt_node_attention_args& a, int esz, int want) {
     return 1;
 }
 
-#define TGT_NODE_LAUNCH_HM(KERNEL, NAME, WANT, HM)                                                                 \
+#define TGT_NODE_LAUNCH(KERNEL, NAME, WANT)                                                                        \
     do {                                                                                                          \
         const int hv = node_vec(a, (int)sizeof(T), (D <= 16) ? (WANT) : ((WANT) > 2 ? 2 : (WANT)));               \
-        if (hv == 4) { if constexpr (D <= 16) hipLaunchKernelGGL((KERNEL<T, D, 4, HM>), dim3(node_grid(a, 4)), dim3(256), 0, st, a); } \
-        else if (hv == 2) hipLaunchKernelGGL((KERNEL<T, D, 2, HM>), dim3(node_grid(a, 2)), dim3(256), 0, st, a);   \
-        else hipLaunchKernelGGL((KERNEL<T, D, 1, HM>), dim3(node_grid(a, 1)), dim3(256), 0, st, a);                \
+        if (hv == 4) { if constexpr (D <= 16) hipLaunchKernelGGL((KERNEL<T, D, 4>), dim3(node_grid(a, 4)), dim3(256), 0, st, a); } \
+        else if (hv == 2) hipLaunchKernelGGL((KERNEL<T, D, 2>), dim3(node_grid(a, 2)), dim3(256), 0, st, a);       \
+        else hipLaunchKernelGGL((KERNEL<T, D, 1>), dim3(node_grid(a, 1)), dim3(256), 0, st, a);                    \
         if (int e = check_launch(NAME)) return e;                                                                 \
-    } while (0)
-#define TGT_NODE_LAUNCH(KERNEL, NAME, WANT)                                    \
-    do {                                                                       \
-        if (a.head_major) TGT_NODE_LAUNCH_HM(KERNEL, NAME, WANT, true);        \
-        else TGT_NODE_LAUNCH_HM(KERNEL, NAME, WANT, false);                    \
     } while (0)
 
 template <typename T, int D>
@@ -668,10 +594,7 @@ static int launch_node(const tgt_node_attention_args& a, bool bwd, hipStream_t s
                 if (qb > 32) qb = 32;
                 const int threads = ((qb * lpr + 63) / 64) * 64;
                 const int grid = a.B * ((a.N + qb - 1) / qb);
-                if (a.head_major)
-                    hipLaunchKernelGGL((node_att_fwd_lds_kernel<T, D, 4, MT, true>), dim3(grid), dim3(threads), lds, st, a, lpr, qb);
-                else
-                    hipLaunchKernelGGL((node_att_fwd_lds_kernel<T, D, 4, MT, false>), dim3(grid), dim3(threads), lds, st, a, lpr, qb);
+                hipLaunchKernelGGL((node_att_fwd_lds_kernel<T, D, 4, MT>), dim3(grid), dim3(threads), lds, st, a, lpr, qb);
                 return check_launch("node_att_fwd_lds_kernel");
             }
         }
@@ -709,13 +632,6 @@ int node_attention_run(const tgt_node_attention_args* a, bool bwd, hipStream_t s
         if (!bwd && !a->hhat) return set_error(TGT_ERR_INVALID, "node attention: logits_only needs hhat");
     } else if (!a->mask || !a->lse || !a->gsum || !a->vatt) {
         return set_error(TGT_ERR_INVALID, "node attention: null mask/vatt/lse/gsum");
-    }
-    if (a->head_major) {       // Q/K/V and V_att rows as [h][d]: blocks are fetched with 16-byte accesses
-        const int64_t esz = a->dtype == TGT_F32 ? 4 : 2;
-        if ((a->ld_qkv * esz) % 16 || (a->q_off * esz) % 16 || (a->k_off * esz) % 16 || (a->v_off * esz) % 16 ||
-            ((int64_t)a->D * esz * 2) % 16 || a->H % 2 || (uintptr_t)a->qkv % 16 || (uintptr_t)a->vatt % 16 ||
-            (uintptr_t)a->d_qkv % 16 || (uintptr_t)a->d_vatt % 16)
-            return set_error(TGT_ERR_INVALID, "node attention: head_major needs 16-byte aligned rows/offsets/tensors, an even H and 2*D*sizeof(T) %% 16 == 0");
     }
     if (bwd) {
         if (!a->d_qkv || !a->d_eg) return set_error(TGT_ERR_INVALID, "node attention bwd: null d_qkv/d_eg");

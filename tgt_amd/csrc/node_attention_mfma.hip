@@ -638,7 +638,7 @@ static int dispatch(const tgt_node_attention_args& a, bool bwd, hipStream_t st) 
 // Is this call one of the shapes the matrix-core kernels take?  (the rest stays on node_attention.hip)
 bool node_attention_mfma_eligible(const tgt_node_attention_args& a, bool bwd) {
     static const int on = getenv("TGT_NODE_MFMA") ? atoi(getenv("TGT_NODE_MFMA")) : 1;
-    if (!on || a.logits_only || a.head_major || a.dtype == TGT_F32) return false;
+    if (!on || a.logits_only || a.dtype == TGT_F32) return false;
     if (a.N < 1 || a.N > 32 || a.H % 8 || !(a.D == 8 || a.D == 12 || a.D == 16)) return false;
     if (!a.mask || !a.vatt || !a.lse || !a.gsum) return false;
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };

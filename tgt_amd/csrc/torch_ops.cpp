@@ -50,7 +50,7 @@ tgt_node_attention_args node_args(const Tensor& qkv, const Tensor& eg, const Ten
     tgt_node_attention_args a{};
     const int64_t W = qkv.size(2) / 3;
     a.B = (int32_t)qkv.size(0); a.N = (int32_t)qkv.size(1); a.H = (int32_t)H; a.D = (int32_t)(W / H);
-    a.dtype = dtype_code(qkv); a.scale_degree = scale_degree; a.logits_only = 0; a.head_major = 0;
+    a.dtype = dtype_code(qkv); a.scale_degree = scale_degree; a.logits_only = 0;
     a.scale = 1.f / std::sqrt((float)a.D);
     a.qkv = qkv.data_ptr(); a.ld_qkv = qkv.size(2); a.q_off = 0; a.k_off = (int32_t)W; a.v_off = (int32_t)(2 * W);
     a.eg = eg.data_ptr(); a.ld_eg = eg.size(3); a.e_off = 0; a.g_off = (int32_t)H;

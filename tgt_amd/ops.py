@@ -548,19 +548,15 @@ def _node_args(qkv, eg, mask3, H, scale_degree, logits_only):
     return a, W
 
 
-_NODE_W_WS = False        # settled off (tests patch this): row pass hands A*log(1+sum g) to the column pass (0.189 -> 0.168 ms alone, neutral inside the step: the row pass pays in stores what the column pass saves)
-
-
 class _NodeAttention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, eg, mask3, H, scale_degree, want_edges, head_major=False, hhat_scale=None):
+    def forward(ctx, qkv, eg, mask3, H, scale_degree, want_edges, hhat_scale=None):
         _dev(qkv, eg, mask3, hhat_scale)
         qkv, eg = qkv.contiguous(), eg.contiguous()
         if eg.dtype != qkv.dtype:
             eg = eg.to(qkv.dtype)
         B, N = qkv.shape[0], qkv.shape[1]
         a, W = _node_args(qkv, eg, mask3, H, scale_degree, False)
-        a.head_major = int(bool(head_major))
         vatt = torch.empty(B, N, W, dtype=qkv.dtype, device=qkv.device)
         hhat = torch.empty(B, N, N, H, dtype=qkv.dtype, device=qkv.device) if want_edges else None
         lse = torch.empty(B, N, H, dtype=torch.float32, device=qkv.device)
@@ -569,7 +565,7 @@ class _NodeAttention(torch.autograd.Function):
         a.hhat_scale = _ptr(hhat_scale)
         _call('tgt_node_attention_fwd', _lib.lib().tgt_node_attention_fwd, a)
         ctx.save_for_backward(qkv, eg, mask3, lse, gsum, vatt, hhat_scale)
-        ctx.cfg = (H, scale_degree, want_edges, bool(head_major))
+        ctx.cfg = (H, scale_degree, want_edges)
         if want_edges:
             return vatt, hhat
         return vatt, None
@@ -577,9 +573,8 @@ class _NodeAttention(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_vatt, d_hhat):
         qkv, eg, mask3, lse, gsum, vatt, hhat_scale = ctx.saved_tensors
-        H, scale_degree, want_edges, head_major = ctx.cfg
+        H, scale_degree, want_edges = ctx.cfg
         a, W = _node_args(qkv, eg, mask3, H, scale_degree, False)
-        a.head_major = int(head_major)
         d_vatt = torch.zeros_like(qkv[..., :W]).contiguous() if d_vatt is None else d_vatt.contiguous()
         if d_hhat is not None:
             d_hhat = d_hhat.contiguous()
@@ -587,24 +582,17 @@ class _NodeAttention(torch.autograd.Function):
         a.lse, a.gsum, a.vatt = lse.data_ptr(), gsum.data_ptr(), vatt.data_ptr()
         a.d_vatt, a.d_hhat, a.d_qkv, a.d_eg = d_vatt.data_ptr(), _ptr(d_hhat), d_qkv.data_ptr(), d_eg.data_ptr()
         a.hhat_scale = _ptr(hhat_scale)
-        if _NODE_W_WS:      # the pairs' attention weights, handed from the row pass to the column pass (freed on return)
-            w_ws = torch.empty(qkv.shape[0], qkv.shape[1], qkv.shape[1], H, dtype=qkv.dtype, device=qkv.device)
-            a.w_ws = w_ws.data_ptr()
         _call('tgt_node_attention_bwd', _lib.lib().tgt_node_attention_bwd, a)
-        return d_qkv, d_eg, None, None, None, None, None, None
+        return d_qkv, d_eg, None, None, None, None, None
 
 
-def node_attention(qkv, eg, mask3, num_heads, scale_degree=True, want_edges=True, head_major=False, hhat_scale=None):
+def node_attention(qkv, eg, mask3, num_heads, scale_degree=True, want_edges=True, hhat_scale=None):
     """qkv (B,N,3W) and eg (B,N,N,2H) in the reference's head-minor layout (channel = d*H + h);
     returns V_att (B,N,W) and H_hat (B,N,N,H) (or None).
-    head_major: Q, K, V and V_att use channel = h*D + d instead (a caller would permute the rows
-    of lin_QKV and the columns of lin_O_h) -- same arithmetic, a lane's D values in one block.
-    Measured SLOWER at the BASELINE shape (0.112 / 0.210 ms against 0.074 / 0.179 ms forward /
-    backward), so the modules do not use it.
     hhat_scale (B,) float32: H_hat is returned multiplied by hhat_scale[b] (the DropPath factor of the edge branch it
     feeds, folded in: linear_residual_layer_norm(prescaled=True)).
     Reference arithmetic: lib/tgt/layers/layers.py:62-77."""
-    return _NodeAttention.apply(qkv, eg, mask3, num_heads, scale_degree, want_edges, head_major, hhat_scale)
+    return _NodeAttention.apply(qkv, eg, mask3, num_heads, scale_degree, want_edges, hhat_scale)
 
 
 class _EdgeLogits(torch.autograd.Function):
