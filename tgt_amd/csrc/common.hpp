@@ -14,6 +14,7 @@ typedef __attribute__((ext_vector_type(8)))  _Float16 f16x8;
 typedef __attribute__((ext_vector_type(8)))  float    f32x8;
 typedef __attribute__((ext_vector_type(4)))  float    f32x4;
 typedef __attribute__((ext_vector_type(16))) float    f32x16;
+typedef __attribute__((ext_vector_type(2)))  float    f32x2;     // packed fp32 pairs: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));      // raw buffer load / store data
 
 // ---------------------------------------------------------------------------

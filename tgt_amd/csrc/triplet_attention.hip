@@ -289,20 +289,29 @@ __global__ void __launch_bounds__(HG * 64, OCC) __attribute__((amdgpu_waves_per_
     for (int it = 0; it < NT; ++it) {
         const int i0 = 32 * it;
         if (i0 >= N) break;
-        float biasM[NT][16], gate[NT][16], dE[NT][16], dG[NT][16];
+        // The 32 x 32 tile of a wave is 16 values per lane; all element-wise arithmetic below runs on PAIRS (f32x2: v_pk_fma_f32 /
+        // v_pk_mul_f32 / v_pk_add_f32 -- two results per VALU issue).  Written on scalars hipcc packed 28 of ~190 operations of
+        // the j-loop; the loop is 2 waves per SIMD in lockstep behind one barrier per j, so its VALU phase is issue-bound.
+        f32x2 biasM[NT][8], gate[NT][8], dE[NT][8], dG[NT][8];
         arm_stage_load<T, HG, NT>(ta, c.b, c.dir, c.g, N, i0, smem, tid);
         __syncthreads();
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
-            arm_stage_read<T, HG, NT, true>(ta, smem, c.dir, wave, N, r, hi, i0, kt, biasM[kt], gate[kt]);
+            float b16[16], g16[16];
+            arm_stage_read<T, HG, NT, true>(ta, smem, c.dir, wave, N, r, hi, i0, kt, b16, g16);
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 // log2 domain.  A masked entry is finfo.min (-3.4e38): times log2(e) it would overflow to
                 // -inf and a fully masked row would lose its (reference) uniform softmax -- clamp it
                 // back to finfo.min; real -inf (padding past N) stays -inf.
-                const float bl = biasM[kt][q] * kLog2e;
-                biasM[kt][q] = (bl == -INFINITY && biasM[kt][q] != -INFINITY) ? -3.402823466e38f : bl;
-                dE[kt][q] = dG[kt][q] = 0.f;          // dG accumulates sum_j dA*P; the gate factor is applied once, after the walk
+                const float bl = b16[q] * kLog2e;
+                b16[q] = (bl == -INFINITY && b16[q] != -INFINITY) ? -3.402823466e38f : bl;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                biasM[kt][k] = f32x2{b16[2 * k], b16[2 * k + 1]};
+                gate[kt][k] = f32x2{g16[2 * k], g16[2 * k + 1]};
+                dE[kt][k] = dG[kt][k] = f32x2{0.f, 0.f};     // dG accumulates sum_j dA*P; the gate factor is applied once, after the walk
             }
         }
         __syncthreads();
@@ -365,7 +374,7 @@ __global__ void __launch_bounds__(HG * 64, OCC) __attribute__((amdgpu_waves_per_
             read_frags<T, D, HG>(fq, sQ, wave, r, hi);
             read_frags<T, D, HG>(fo, sO, wave, r, hi);
 
-            f32x16 s[NT], da[NT];
+            f32x2 s[NT][8], da[NT][8];
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt) {
                 F fk[G::kDC], fv[G::kDC];
@@ -376,8 +385,11 @@ __global__ void __launch_bounds__(HG * 64, OCC) __attribute__((amdgpu_waves_per_
                 for (int dc = 0; dc < G::kDC; ++dc) z0 = mma32(fk[dc], fq[dc], z0);         // S^T[k][i]
 #pragma unroll
                 for (int dc = 0; dc < G::kDC; ++dc) z1 = mma32(fv[dc], fo[dc], z1);         // dA^T[k][i]
-                s[kt] = z0;
-                da[kt] = z1;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    s[kt][k] = f32x2{z0[2 * k], z0[2 * k + 1]};
+                    da[kt][k] = f32x2{z1[2 * k], z1[2 * k + 1]};
+                }
             }
 
             // softmax statistics are recomputed (in-lane values + the partner lane); saving a
@@ -386,20 +398,22 @@ __global__ void __launch_bounds__(HG * 64, OCC) __attribute__((amdgpu_waves_per_
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    s[kt][q] = s[kt][q] * scale2 + biasM[kt][q];
-                    mx = fmaxf(mx, s[kt][q]);
+                for (int k = 0; k < 8; ++k) {
+                    s[kt][k] = s[kt][k] * scale2 + biasM[kt][k];
+                    mx = fmaxf(mx, fmaxf(s[kt][k].x, s[kt][k].y));
                 }
             mx = fmaxf(mx, xhalf(mx));
             if (mx == -INFINITY) mx = 0.f;           // padding column: every weight is exactly 0
-            float sum = 0.f;
+            f32x2 sum2 = {0.f, 0.f};
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    s[kt][q] = fast_exp2(s[kt][q] - mx);
-                    sum += s[kt][q];
+                for (int k = 0; k < 8; ++k) {
+                    const f32x2 t = s[kt][k] - mx;
+                    s[kt][k] = f32x2{fast_exp2(t.x), fast_exp2(t.y)};
+                    sum2 += s[kt][k];
                 }
+            float sum = sum2.x + sum2.y;
             sum += xhalf(sum);
             const float inv = sum > 0.f ? fast_rcp(sum) : 0.f;
             // attention dropout: the kept weights were scaled by 1/(1-p), so dA (and A below) carry the mask
@@ -409,22 +423,26 @@ __global__ void __launch_bounds__(HG * 64, OCC) __attribute__((amdgpu_waves_per_
                 for (int kt = 0; kt < NT; ++kt) {
                     keep[kt] = tri_drop_bits(drop, drop_unit0 + j, i0 + r, kt, hi);
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) da[kt][q] = (keep[kt] >> q) & 1u ? da[kt][q] * drop.scale : 0.f;
+                    for (int k = 0; k < 8; ++k) {
+                        da[kt][k].x = (keep[kt] >> (2 * k)) & 1u ? da[kt][k].x * drop.scale : 0.f;
+                        da[kt][k].y = (keep[kt] >> (2 * k + 1)) & 1u ? da[kt][k].y * drop.scale : 0.f;
+                    }
                 }
             }
             // s -> P;  da -> dP = dA * g;  delta_i = sum_k P dP
-            float delta = 0.f;
+            f32x2 delta2 = {0.f, 0.f};
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const float p = s[kt][q] * inv;
-                    const float dp = da[kt][q] * gate[kt][q];
-                    delta += p * dp;
-                    if (gated) dG[kt][q] += da[kt][q] * p;
-                    s[kt][q] = p;
-                    da[kt][q] = dp;
+                for (int k = 0; k < 8; ++k) {
+                    const f32x2 p = s[kt][k] * inv;
+                    const f32x2 dp = da[kt][k] * gate[kt][k];
+                    delta2 += p * dp;
+                    if (gated) dG[kt][k] += da[kt][k] * p;
+                    s[kt][k] = p;
+                    da[kt][k] = dp;
                 }
+            float delta = delta2.x + delta2.y;
             delta += xhalf(delta);
 
             f32x16 qT = {0}, oT = {0};
@@ -441,18 +459,23 @@ __global__ void __launch_bounds__(HG * 64, OCC) __attribute__((amdgpu_waves_per_
             for (int kt = 0; kt < NT; ++kt) {
                 F dsf[2], af[2];
                 {
-                    f32x16 att;
+                    f32x16 att, dsv;
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const float ds = s[kt][q] * (da[kt][q] - delta);
-                        if (biased) dE[kt][q] += ds;
-                        att[q] = s[kt][q] * gate[kt][q];
-                        if constexpr (DROP) att[q] = (keep[kt] >> q) & 1u ? att[q] * drop.scale : 0.f;
-                        s[kt][q] = ds * a.scale;
+                    for (int k = 0; k < 8; ++k) {
+                        const f32x2 ds = s[kt][k] * (da[kt][k] - delta);
+                        if (biased) dE[kt][k] += ds;
+                        f32x2 at = s[kt][k] * gate[kt][k];
+                        if constexpr (DROP) {
+                            at.x = (keep[kt] >> (2 * k)) & 1u ? at.x * drop.scale : 0.f;
+                            at.y = (keep[kt] >> (2 * k + 1)) & 1u ? at.y * drop.scale : 0.f;
+                        }
+                        const f32x2 dss = ds * a.scale;
+                        att[2 * k] = at.x; att[2 * k + 1] = at.y;
+                        dsv[2 * k] = dss.x; dsv[2 * k + 1] = dss.y;
                     }
 #pragma unroll
                     for (int cc = 0; cc < 2; ++cc) {
-                        dsf[cc] = pack_chunk<T>(s[kt], cc);
+                        dsf[cc] = pack_chunk<T>(dsv, cc);
                         af[cc] = pack_chunk<T>(att, cc);
                     }
                 }
@@ -517,11 +540,15 @@ __global__ void __launch_bounds__(HG * 64, OCC) __attribute__((amdgpu_waves_per_
         // third-arm gradients of this query tile (summed over j in registers) leave through LDS
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
-            if (gated) {
+            float e16[16], g16[16];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) dG[kt][q] *= gate[kt][q] * (1.f - gate[kt][q]);      // d sigmoid, once per tile
+            for (int k = 0; k < 8; ++k) {
+                f32x2 gg = dG[kt][k];
+                if (gated) gg *= gate[kt][k] * (1.f - gate[kt][k]);      // d sigmoid, once per tile
+                e16[2 * k] = dE[kt][k].x; e16[2 * k + 1] = dE[kt][k].y;
+                g16[2 * k] = gg.x; g16[2 * k + 1] = gg.y;
             }
-            arm_stage_put_grad<T, HG, NT>(smem, c.dir, wave, r, hi, kt, dE[kt], dG[kt]);
+            arm_stage_put_grad<T, HG, NT>(smem, c.dir, wave, r, hi, kt, e16, g16);
         }
         __syncthreads();
         {
