@@ -275,6 +275,8 @@ int tgt_loss_accumulate(const void* loss, int32_t loss_is_f64, float samples, fl
  *                    (generator of tgt_gelu_dropout_fwd on the (M, N) index space)
  *   TGT_EPI_RESID    out = res + row_scale[row / rows_per_sample] * z   (row_scale may be NULL)
  *   TGT_EPI_GELU_BWD out = z' * gelu'(res) * keep / (1-p), z' = z * out_scale[..]; res = the forward's pre-activation
+ *                    N = 256: colsum_partial (tgt_edge_linear_parts(M, N), N) float32 when given = per-workgroup column sums of
+ *                    `out` as stored: the bias gradient of the Linear in front of the activation (sum the rows: tgt_sum_rows)
  *   TGT_EPI_LN_BWD   z = dy, the gradient at the output of LayerNorm(res; gamma) with saved mean / rstd (N <= 256):
  *                    out  = ds_in + rstd * (dy*gamma - mean_n(dy*gamma) - xhat * mean_n(dy*gamma*xhat))   (ds_in may be NULL)
  *                    out2 = out * row_scale[..]  (when given: the gradient of the branch DropPath scaled)

@@ -748,10 +748,13 @@ __global__ void __launch_bounds__(1024, 4) edge_rows_kernel(const tgt_edge_linea
     }
     const uint32_t thresh = a.dropout_p <= 0.f ? 0u : (uint32_t)fminf(65535.f, fmaxf(1.f, rintf(a.dropout_p * 65536.f)));
     const float inv_keep = a.dropout_p <= 0.f ? 1.f : 1.f / (1.f - a.dropout_p);
-    constexpr int kCs = EPI == EPI_LN_BWD ? 4 : 1;
-    f32x2 cs_g[kCs], cs_b[kCs], cs_x[kCs];               // EPI_LN_BWD: column sums over every row this workgroup processes
+    constexpr int kCs = EPI == EPI_LN_BWD ? 4 : 1, kCsX = (EPI == EPI_LN_BWD || EPI == EPI_GELU_BWD) ? 4 : 1;
+    f32x2 cs_g[kCs], cs_b[kCs], cs_x[kCsX];              // column sums over every row this workgroup processes (LN_BWD: three
+                                                          // planes; GELU_BWD: of the result = the bias gradient of the Linear in front)
 #pragma unroll
-    for (int j = 0; j < kCs; ++j) cs_g[j] = cs_b[j] = cs_x[j] = rp_splat(0.f);
+    for (int j = 0; j < kCs; ++j) cs_g[j] = cs_b[j] = rp_splat(0.f);
+#pragma unroll
+    for (int j = 0; j < kCsX; ++j) cs_x[j] = rp_splat(0.f);
 
     // per-graph factor (DropPath): one float per rows_per_sample rows, through a buffer of its own (absent: empty, and the 1.f below)
     const float* scale_ptr = EPI == EPI_GELU_BWD ? a.out_scale : a.row_scale;
@@ -853,6 +856,7 @@ __global__ void __launch_bounds__(1024, 4) edge_rows_kernel(const tgt_edge_linea
                     const f32x2 y = dy * (cdf + pv[k] * 0.3989422804014327f * e) * inv_keep;
                     o[k].x = keep[2 * k] ? y.x : 0.f;
                     o[k].y = keep[2 * k + 1] ? y.y : 0.f;
+                    cs_x[k] += rp_round<T>(o[k]);          // (of the values AS STORED: equal to a separate pass over the result)
                 }
                 rp_st16(rs_out, o_out + po * (uint32_t)ldo_b, rp_pack<T>(o));
             } else if constexpr (EPI == EPI_RESID) {
@@ -917,25 +921,28 @@ __global__ void __launch_bounds__(1024, 4) edge_rows_kernel(const tgt_edge_linea
         __builtin_amdgcn_s_barrier();
     }
 
-    if constexpr (EPI == EPI_LN_BWD) {
+    if constexpr (EPI == EPI_LN_BWD || EPI == EPI_GELU_BWD) {
         if (a.colsum_partial) {
-            // fold the 16 row groups, fixed order: [16][3][256] floats in LDS (the A / staging tiles are dead: every wave is past
+            // fold the 16 row groups, fixed order: [16][planes][256] floats in LDS (the A / staging tiles are dead: every wave is past
             // the last barrier; only the row role takes part from here on -- the GEMM waves have exited, and an exited wave
-            // counts as arrived at a barrier)
+            // counts as arrived at a barrier).  Planes: LN_BWD dgamma | dbeta | sum of the scaled x-gradient; GELU_BWD the result.
+            constexpr int kPl = EPI == EPI_LN_BWD ? 3 : 1;
             float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                *reinterpret_cast<f32x2*>(red + (rsub * 3 + 0) * N + ch * 8 + 2 * k) = cs_g[k];
-                *reinterpret_cast<f32x2*>(red + (rsub * 3 + 1) * N + ch * 8 + 2 * k) = cs_b[k];
-                *reinterpret_cast<f32x2*>(red + (rsub * 3 + 2) * N + ch * 8 + 2 * k) = cs_x[k];
+                if constexpr (EPI == EPI_LN_BWD) {
+                    *reinterpret_cast<f32x2*>(red + (rsub * 3 + 0) * N + ch * 8 + 2 * k) = cs_g[k];
+                    *reinterpret_cast<f32x2*>(red + (rsub * 3 + 1) * N + ch * 8 + 2 * k) = cs_b[k];
+                }
+                *reinterpret_cast<f32x2*>(red + (rsub * kPl + kPl - 1) * N + ch * 8 + 2 * k) = cs_x[k];
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            float* part = a.colsum_partial + (int64_t)blockIdx.x * 3 * N;
-            for (int c = t4; c < 3 * N; c += 512) {
+            float* part = a.colsum_partial + (int64_t)blockIdx.x * kPl * N;
+            for (int c = t4; c < kPl * N; c += 512) {
                 float t = 0.f;
 #pragma unroll
-                for (int s_ = 0; s_ < 16; ++s_) t += red[s_ * 3 * N + c];
+                for (int s_ = 0; s_ < 16; ++s_) t += red[s_ * kPl * N + c];
                 part[c] = t;
             }
         }

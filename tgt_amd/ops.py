@@ -1416,6 +1416,8 @@ class _LinearGeluDropout(torch.autograd.Function):
                                                          _ptr(sample_scale), eps_, _stream()), 'tgt_gelu_dropout_bwd')
             _prof_end('tgt_gelu_dropout_bwd', s, e)
         if d_pre_in is not None:
+            if d_pre is None and need_db:
+                cs = _take_colsum(d_pre_in, d_pre_in.shape[-1])        # (the GELU_BWD epilogue that wrote it summed its columns)
             d_pre = d_pre_in.contiguous() if d_pre is None else d_pre + d_pre_in
         if d_pre is None:
             return None, None, None, None, None, None, None, None
@@ -1571,8 +1573,14 @@ class _LinearResidualLN(torch.autograd.Function):
             need_dx = False
             if ctx.needs_input_grad[11]:
                 d_pre = torch.empty_like(pre)
+                # (256 outputs = the row-phase kernel: it also returns the column sums of d_pre, lin_W1's bias gradient)
+                part = torch.empty(_lib.lib().tgt_edge_linear_parts(rows, 256), 256, dtype=torch.float32, device=pre.device) \
+                    if (pre.shape[-1] == 256 and _GELU_BWD_EPI_COLSUM) else None
                 edge_linear_raw(d_z.reshape(rows, N), w.t().contiguous(), None, _lib.EPI_GELU_BWD, out=d_pre.view(rows, -1),
-                                res=pre.view(rows, -1), out_scale=g_scale, rows_per_sample=rps, dropout=(ctx.gelu[0], ctx.gelu[1]))
+                                res=pre.view(rows, -1), out_scale=g_scale, rows_per_sample=rps, dropout=(ctx.gelu[0], ctx.gelu[1]),
+                                colsum_partial=part)
+                if part is not None:
+                    _hand_colsum(d_pre, sum_rows(part))
         dx, dw, db = _linear_backward(x2, w, d_z.reshape(rows, N), xs, xdt, torch.float32 if ctx.col_inv is not None else wdt, bdt,
                                       need_dx, ctx.needs_input_grad[1], need_db and cs is None)
         if dw is not None and ctx.col_inv is not None:
@@ -1583,6 +1591,7 @@ class _LinearResidualLN(torch.autograd.Function):
                 None if dg is None else dg.to(lndt), None if dbeta is None else dbeta.to(lndt), None, None, None, None, d_pre, None, None)
 
 
+_GELU_BWD_EPI_COLSUM = os.environ.get('TGT_GELU_BWD_EPI_COLSUM', '1') != '0'      # A/B knob: lin_W1's bias gradient from the GELU_BWD epilogue
 _EDGE_K512 = os.environ.get('TGT_EDGE_K512', '1') != '0'        # A/B knob: lin_O (K = 512) + residual + LayerNorm as one launch
 
 
