@@ -437,6 +437,14 @@ int tgt_sum_rows(const float* x, int32_t rows, int32_t C, float* out, void* stre
  * over B*N*N = 262144 rows). */
 int tgt_sum_planes(const float* x, int32_t planes, int64_t n, float* out, void* stream);
 
+/* dst_i (cols_i, rows_i) = transpose of src_i (rows_i, cols_i), i < n, 16-bit elements, row-major contiguous, ONE launch.
+ * `items` is a DEVICE array.  No reference counterpart: the data-gradient launches of tgt_edge_linear take W^T of the
+ * nn.Linear they differentiate (autograd of lib/tgt/layers/layers.py:155-160, triplet.py:248-249); weights change once per
+ * optimizer step, so the trainer refreshes every W^T of the model with this call instead of one copy kernel per Linear and
+ * backward launch.  blocks_per_item: workgroups per matrix (each walks 32 x 32 tiles). */
+typedef struct tgt_transpose_item { const void* src; void* dst; int32_t rows, cols; } tgt_transpose_item;
+int tgt_transpose_many(const tgt_transpose_item* items, int32_t n, int32_t blocks_per_item, void* stream);
+
 /* Row-wise cross entropy of the binned-distance head: replaces
  * `F.cross_entropy(dist_logits.view(-1, num_bins), dist_targ.view(-1), reduction='none')`
  * (reference lib/training_schemes/pcqm/commons.py:36-38) and its autograd chain, on the logits in

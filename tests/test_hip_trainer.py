@@ -160,6 +160,40 @@ def test_shadow_follows_load_state_dict():
         assert torch.equal(p._lp, p.detach().to(torch.bfloat16))
 
 
+@pytest.mark.parametrize('precision', ['bf16', 'fp16'])
+def test_cached_weight_transposes_follow_every_optimizer_step(precision, monkeypatch):
+    """ops.WeightTransposes: W^T of the shadowed weights for the data-gradient kernels is refreshed in one launch after each
+    optimizer step (and after load_state_dict); five steps with the cache equal five steps with a fresh transpose per launch,
+    bit for bit, and every cached W^T equals the transpose of its shadow at the end."""
+    from tgt_amd import ops
+    monkeypatch.setattr(ops, '_EDGE_MIN_ROWS', 1)             # the tiny model's edge Linears on the kernels that ask for W^T
+    from tgt_amd.pcqm import TGT_Multi
+    from tgt_amd.training.step import Trainer, StepConfig
+    kwargs = dict(gu.FULL_AT_CFG, model_height=2)             # BASELINE widths (the kernels take K in {64,128,256}), two layers
+    cfg = StepConfig(num_dist_bins=512, mixed_precision=precision, coords_noise=0.0, lr_warmup_steps=10, lr_total_steps=100)
+    runs = []
+    for cached in (True, False):
+        monkeypatch.setattr(ops, '_WT_CACHE', cached)
+        m1 = gu.fill_params(TGT_Multi(**kwargs), seed=3).cuda().eval()
+        tr = Trainer(m1, cfg)
+        for step in range(1, 4):
+            tr.training_step(_batch(cfg, step))
+        m1.load_state_dict({k: v * 1.01 for k, v in m1.state_dict().items()})      # out-of-band change: the hook refreshes
+        for step in range(4, 6):
+            tr.training_step(_batch(cfg, step))
+        runs.append(_params(m1).clone())
+        if cached:
+            assert len(tr._wt.entries) > 0
+            lo = tr.flat.shadow.data_ptr()
+            for ptr, (t, shape) in tr._wt.entries.items():
+                off = (ptr - lo) // 2
+                w = tr.flat.shadow[off:off + shape[0] * shape[1]].view(shape)
+                assert torch.equal(t, w.t())
+        tr.close()
+        assert tr._wt not in ops.WeightTransposes.live
+    assert torch.equal(runs[0], runs[1])
+
+
 # ---- world-size 2 on the GPU: two ranks share cuda:0 and exchange over gloo (device tensors staged through the host by
 # the backend).  RCCL refuses two ranks on one device and the test boxes have one GPU, so this is the closest a 1-GPU box gets
 # to the N > 1 path: autograd hooks -> bucket gather behind BOTH streams -> asynchronous all-reduce -> one-launch Adam, on

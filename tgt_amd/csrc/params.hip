@@ -154,4 +154,42 @@ int sum_planes_run(const float* x, int planes, int64_t n, float* out, hipStream_
     return check_launch("sum_planes_kernel");
 }
 
+// ---------------------------------------------------------------------------
+// Transposes of many small 16-bit matrices in ONE launch: the data-gradient kernels of csrc/edge_gemm.hip take the weight as
+// (N, K) = W^T of the nn.Linear they differentiate.  Per step that was one 4 us copy kernel per Linear (plus its dispatch gap)
+// in front of 96 backward launches; the weights only change in the optimizer step, so the trainer refreshes all of them at once.
+// items: device array of {src, dst, rows, cols}; src (rows, cols) row-major contiguous, dst (cols, rows).
+// ---------------------------------------------------------------------------
+struct TransposeItem { const uint16_t* src; uint16_t* dst; int32_t rows, cols; };
+__global__ void __launch_bounds__(256) transpose_many_kernel(const TransposeItem* items) {
+    __shared__ uint16_t tile[32][33];
+    const TransposeItem it = items[blockIdx.y];
+    const int tc = (it.cols + 31) / 32, tr = (it.rows + 31) / 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int t = blockIdx.x; t < tc * tr; t += gridDim.x) {
+        const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = r0 + ty + 8 * k, c = c0 + tx;
+            if (r < it.rows && c < it.cols) tile[ty + 8 * k][tx] = it.src[(int64_t)r * it.cols + c];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + ty + 8 * k, r = r0 + tx;
+            if (r < it.rows && c < it.cols) it.dst[(int64_t)c * it.rows + r] = tile[tx][ty + 8 * k];
+        }
+        __syncthreads();
+    }
+}
+int transpose_many_run(const void* items, int n, int blocks_per_item, hipStream_t st) {
+    if (n < 0 || (n > 0 && !items) || blocks_per_item <= 0) return set_error(TGT_ERR_INVALID, "transpose_many: bad arguments");
+    if (n == 0) return TGT_OK;
+    if (n > 65535) return set_error(TGT_ERR_UNSUPPORTED, "transpose_many: more than 65535 matrices");
+    static_assert(sizeof(TransposeItem) == 24, "tgt_transpose_item layout");
+    hipLaunchKernelGGL(transpose_many_kernel, dim3((unsigned)blocks_per_item, (unsigned)n), dim3(256), 0, st,
+                       reinterpret_cast<const TransposeItem*>(items));
+    return check_launch("transpose_many_kernel");
+}
+
 }  // namespace tgt

@@ -787,11 +787,12 @@ class _ScalePool:
 
     @classmethod
     def take(cls, B, keep, device):
-        """one pool per stream: a refill and the reads of its rows stay on one stream"""
+        """one pool per stream (a refill and the reads of its rows stay on one stream) AND per keep probability: the DropPath
+        rate ramps over the layers, and a pool keyed by the stream alone was refilled by every layer (two launches each)"""
         sid = torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0
-        pool = cls._pools.get(sid)
+        pool = cls._pools.get((sid, B, keep))
         if pool is None:
-            pool = cls._pools[sid] = cls()
+            pool = cls._pools[(sid, B, keep)] = cls()
         return pool._take(B, keep, device)
 
 
@@ -1033,7 +1034,7 @@ def _ln_backward(dy, s, g, mean, rstd, ds, scale, rps, want_dz):
     if lazy is not None and N == 256 and lazy[0].dtype == s.dtype and (ds is None or ds.dtype == s.dtype) and lazy[0].is_contiguous():
         dz2, w = lazy
         partial = torch.empty(L.tgt_edge_linear_parts(rows, N), 3 * N, dtype=torch.float32, device=s.device)
-        edge_linear_raw(dz2, w.t().contiguous(), None, _lib.EPI_LN_BWD, ln=(g, None, 1e-5), stats=(mean, rstd), res=s.view(rows, N),
+        edge_linear_raw(dz2, weight_t(w), None, _lib.EPI_LN_BWD, ln=(g, None, 1e-5), stats=(mean, rstd), res=s.view(rows, N),
                         ds_in=None if ds is None else ds.view(rows, N), out=d_res.view(rows, N),
                         out2=None if d_z is None else d_z.view(rows, N), row_scale=scale, rows_per_sample=rps if scale is not None else 0,
                         colsum_partial=partial)
@@ -1102,6 +1103,61 @@ def _as_dtype_view(p, cd):
     return lp if (lp is not None and lp.dtype == cd and p.dtype != cd) else p.detach()
 
 
+class WeightTransposes:
+    """W^T (contiguous) of the 16-bit weight shadows a Trainer maintains, for the data-gradient launches of tgt_edge_linear.
+    The first request for a weight computes and registers its transpose; `refresh()` -- called by the Trainer right after every
+    optimizer step / shadow refresh, the only places the shadow changes -- rewrites all registered ones in ONE launch
+    (tgt_transpose_many) instead of one copy kernel per Linear and backward launch (96 a step, each with its dispatch gap).
+    Only tensors INSIDE the registered shadow buffer are cached (looked up by address: saved tensors come back from autograd as
+    new Python objects); everything else gets a fresh transpose."""
+    live = []
+
+    def __init__(self, shadow):
+        self.shadow = shadow
+        self.lo, self.hi = shadow.data_ptr(), shadow.data_ptr() + shadow.numel() * shadow.element_size()
+        self.entries = {}               # address -> (W^T, shape of W)
+        self.table = None
+        WeightTransposes.live.append(self)
+
+    def close(self):
+        if self in WeightTransposes.live:
+            WeightTransposes.live.remove(self)
+        self.entries.clear()
+        self.table = None
+
+    def get(self, w):
+        e = self.entries.get(w.data_ptr())
+        if e is not None and e[1] == tuple(w.shape):
+            return e[0]
+        t = w.t().contiguous()
+        self.entries[w.data_ptr()] = (t, tuple(w.shape))
+        self.table = None               # (rebuilt at the next refresh)
+        return t
+
+    def refresh(self):
+        if not self.entries:
+            return
+        if self.table is None:
+            rows = []
+            for ptr, (t, shape) in self.entries.items():
+                rows += [ptr, t.data_ptr(), shape[0] | (shape[1] << 32)]        # {src, dst, int32 rows, int32 cols}
+            self.table = torch.tensor(rows, dtype=torch.int64).to(self.shadow.device)
+        _lib.check(_lib.lib().tgt_transpose_many(_ptr(self.table), len(self.entries), 16, _stream()), 'tgt_transpose_many')
+
+
+_WT_CACHE = os.environ.get('TGT_WT_CACHE', '1') != '0'          # A/B knob
+
+
+def weight_t(w):
+    """w.t().contiguous() for a 2-D 16-bit weight; served from a Trainer's WeightTransposes when w lives in its shadow"""
+    if _WT_CACHE and w.dim() == 2 and w.is_contiguous() and w.element_size() == 2:
+        ptr = w.data_ptr()
+        for c in WeightTransposes.live:
+            if c.lo <= ptr < c.hi and w.dtype == c.shadow.dtype:
+                return c.get(w)
+    return w.t().contiguous()
+
+
 _EDGE_GEMM = os.environ.get('TGT_EDGE_GEMM', '1') != '0'          # A/B knob: the weight-resident slice kernel where it wins
 _EDGE_N512 = os.environ.get('TGT_EDGE_N512', '1') != '0'          # A/B knob: lin_O's (256 -> 512) and the narrow (-> <= 128) data gradients on the weight-resident kernels
 _EDGE_MIN_ROWS = 65536                                            # (tests lower it)
@@ -1151,7 +1207,7 @@ def _linear_backward(x2, w, dy2, xs, xdt, wdt, bdt, need_dx, need_dw, need_db, l
                 ((w.shape[0] == 256 and w.shape[1] == 512) or w.shape[1] <= 128):
             # data gradients the weight-resident kernels win: lin_O's (256 -> 512 channels: 3 E at ~5 TB/s, library 3.5) on
             # edge_wide512_kernel, narrow ones (lin_O_e: 256 -> 64) on the slice kernel
-            dx = edge_linear_raw(dy2.contiguous(), w.t().contiguous()).view(xs).to(xdt)
+            dx = edge_linear_raw(dy2.contiguous(), weight_t(w)).view(xs).to(xdt)
         else:
             dx = (dy2 @ w).view(xs).to(xdt)
     if need_dw:
@@ -1576,7 +1632,7 @@ class _LinearResidualLN(torch.autograd.Function):
                 # (256 outputs = the row-phase kernel: it also returns the column sums of d_pre, lin_W1's bias gradient)
                 part = torch.empty(_lib.lib().tgt_edge_linear_parts(rows, 256), 256, dtype=torch.float32, device=pre.device) \
                     if (pre.shape[-1] == 256 and _GELU_BWD_EPI_COLSUM) else None
-                edge_linear_raw(d_z.reshape(rows, N), w.t().contiguous(), None, _lib.EPI_GELU_BWD, out=d_pre.view(rows, -1),
+                edge_linear_raw(d_z.reshape(rows, N), weight_t(w), None, _lib.EPI_GELU_BWD, out=d_pre.view(rows, -1),
                                 res=pre.view(rows, -1), out_scale=g_scale, rows_per_sample=rps, dropout=(ctx.gelu[0], ctx.gelu[1]),
                                 colsum_partial=part)
                 if part is not None:

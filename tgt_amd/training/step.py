@@ -222,8 +222,11 @@ class Trainer:
             # replicas start from rank 0's parameters (DDP's broadcast at wrap, training.py:152)
             dist.broadcast(self.flat.param, src=0, group=self.pg)
             self._setup_buckets()
+        self._wt = None
         if self.cfg.mixed_precision in ('bf16', 'fp16') and self.flat.param.is_cuda:
             self.flat.make_shadow(torch.bfloat16 if self.cfg.mixed_precision == 'bf16' else torch.float16)
+            # W^T of the shadowed weights for the data-gradient kernels, refreshed in one launch after every optimizer step
+            self._wt = ops.WeightTransposes(self.flat.shadow)
         # parameters changed behind the trainer's back (the reference loads pretrained weights AFTER the
         # trainer exists, tgt_training.py:174-189): the 16-bit shadows must follow
         # (a weak reference: the hook must not keep a dropped trainer -- and its four flat buffers -- alive)
@@ -239,13 +242,15 @@ class Trainer:
         # (or garbage collection of the trainer) gives the ownership back.
         ops.side_stream.owner_present(True)
         self._closed = False
-        self._finalizer = weakref.finalize(self, Trainer._release, self._hooks)
+        self._finalizer = weakref.finalize(self, Trainer._release, self._hooks, self._wt)
 
     @staticmethod
-    def _release(hooks):
+    def _release(hooks, wt=None):
         for h in hooks:
             h.remove()
         hooks.clear()
+        if wt is not None:
+            wt.close()
         ops.side_stream.owner_present(False)
 
     def close(self):
@@ -356,6 +361,8 @@ class Trainer:
         model.load_state_dict (hook); call it after any other out-of-band parameter change."""
         if self.flat.shadow is not None:
             self.flat.shadow.copy_(self.flat.param)
+            if self._wt is not None:
+                self._wt.refresh()
 
     # ---- one step ----------------------------------------------------------
     def autocast(self):
@@ -396,6 +403,8 @@ class Trainer:
             ops.adam_step_(f.param, f.grad, f.exp_avg, f.exp_avg_sq, self._applied_steps, lr,
                            betas=cfg.betas, eps=cfg.eps, weight_decay=cfg.weight_decay, grad_scale=1.0 / self.world,
                            shadow=f.shadow, clip_value=cfg.clip_grad_value)
+        if self._wt is not None:
+            self._wt.refresh()              # (the shadow just changed: every registered W^T follows, one launch)
 
     def training_step(self, batch):
         """batch: device tensors incl. edge_mask / dist_input (see preprocess_batch).
