@@ -392,18 +392,23 @@ class _ProjectedTripletAttention(torch.autograd.Function):
             # weight gradient as two batched GEMMs as well: the 1536-row block has no ragged tile row
             # (213 us with 32 chunks) and the 64-row E/G block is cheap (35 us), against 303 us for the
             # 1600-row product (tools/wgrad_chunk_probe.py); dx stays one GEMM over the fused row
+            ws = _wgrad_fork(d2, x2, db)
             dx, _, _ = _linear_backward(x2, w, d2, xs, xdt, torch.float32, None, ctx.needs_input_grad[0], False, False)
-            dw = torch.empty(L.width, L.C, dtype=torch.float32, device=d2.device)
-            _wgrad_into(dw[:6 * L.C], d2[:, :6 * L.C], x2, 32)
-            _wgrad_into(dw[6 * L.C:], d2[:, 6 * L.C:], x2, 128)
+            with _on_stream(ws):
+                dw = torch.empty(L.width, L.C, dtype=torch.float32, device=d2.device)
+                _wgrad_into(dw[:6 * L.C], d2[:, :6 * L.C], x2, 32)
+                _wgrad_into(dw[6 * L.C:], d2[:, 6 * L.C:], x2, 128)
         else:
+            ws = None
             dx, dw, _ = _linear_backward(x2, w, d2, xs, xdt, torch.float32, None,
                                          ctx.needs_input_grad[0], need_p, False)
         if not need_p:
             return (dx, None, None, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 7)
         if table is None:
             return dx, None, None, None, None, None, None, dw.to(wdt), db.to(bdt)
-        return (dx, None, None, None, None, None, None, *_unfuse_grads(table, params, dw, db))
+        with _on_stream(ws):           # (the parameter gradients leave on the stream their weight gradient was computed on)
+            grads = _unfuse_grads(table, params, dw, db)
+        return (dx, None, None, None, None, None, None, *grads)
 
 
 def projected_triplet_attention(x, weight, bias, mask3, layout, table=None, dropout=(0.0, 0), graph_scale=None):
@@ -1103,6 +1108,35 @@ def _as_dtype_view(p, cd):
     return lp if (lp is not None and lp.dtype == cd and p.dtype != cd) else p.detach()
 
 
+_WGRAD_STREAM = os.environ.get('TGT_WGRAD_STREAM', '1') != '0'      # A/B knob: weight gradients of the edge Linears on a third stream
+_wgrad_streams = {}
+
+
+def _wgrad_fork(*tensors):
+    """The stream a weight gradient may run on -- nothing consumes it before the step ends (the Trainer's gradient collection waits
+    for every stream, wait_side_streams) -- ordered after the work queued so far on the current stream; None = stay.  Only under a
+    Trainer (ops.side_stream's ownership rule), only for the edge rows, never from the node side stream."""
+    t0 = tensors[0]
+    if not (_WGRAD_STREAM and side_stream._owners > 0 and t0.is_cuda and t0.shape[0] >= _EDGE_MIN_ROWS):
+        return None
+    dev = t0.device
+    cur = torch.cuda.current_stream(dev)
+    if _side_streams.get(dev) == cur:
+        return None
+    ws = _wgrad_streams.get(dev)
+    if ws is None:
+        ws = _wgrad_streams[dev] = torch.cuda.Stream(dev, priority=0)
+    ws.wait_stream(cur)
+    for t in tensors:
+        t.record_stream(ws)
+    _main_streams.setdefault(dev, cur)
+    return ws
+
+
+def _on_stream(ws):
+    return torch.cuda.stream(ws) if ws is not None else contextlib.nullcontext()
+
+
 _SIDE_PRIO = int(os.environ.get('TGT_SIDE_PRIO', '-1'))           # A/B knob: HIP priority of the node side stream (-1 = high: its short kernels are
 #                                                                    dispatched ahead of the edge kernels' next workgroups; +0.5 % over 5 same-box pairs)
 
@@ -1195,7 +1229,7 @@ def _linear_forward(x, weight, bias, cd):
     return x2, w, y
 
 
-def _linear_backward(x2, w, dy2, xs, xdt, wdt, bdt, need_dx, need_dw, need_db, lazy_dx=False):
+def _linear_backward(x2, w, dy2, xs, xdt, wdt, bdt, need_dx, need_dw, need_db, lazy_dx=False, dw_post=None, fork=True):
     """(dx, dW, db) of y = x W^T + b.  dW = dY^T X contracts over M = B*N*N = 262144 rows into a
     tiny (out,in) result; as one GEMM the library runs it on a handful of workgroups
     (0.4-0.8 ms), as 64-128 independent chunk products + an fp32 sum it is HBM-bound (57 us for
@@ -1203,6 +1237,8 @@ def _linear_backward(x2, w, dy2, xs, xdt, wdt, bdt, need_dx, need_dw, need_db, l
     if dy2.dtype != w.dtype:
         dy2 = dy2.to(w.dtype)
     dx = dw = db = None
+    # dw_post: what the caller still does to dW (it must run where dW was computed); fork=False: the caller reads dW itself
+    ws = _wgrad_fork(dy2, x2) if (need_dw and fork) else None  # (forked BEFORE the data gradient is queued: it waits for dy only)
     if need_dx:
         # lazy_dx: the LayerNorm entry that produced x runs this GEMM itself, fused with its own backward (_lazy_dgrad)
         if lazy_dx and xdt == dy2.dtype:
@@ -1217,15 +1253,19 @@ def _linear_backward(x2, w, dy2, xs, xdt, wdt, bdt, need_dx, need_dw, need_db, l
     if need_dw:
         M = x2.shape[0]
         P = _wgrad_chunks(M, dy2.shape[1] * x2.shape[1])
-        if P > 1:
-            part = torch.bmm(dy2.view(P, M // P, -1).transpose(1, 2), x2.view(P, M // P, -1),
-                             out_dtype=torch.float32) if dy2.dtype != torch.float32 else \
-                torch.bmm(dy2.view(P, M // P, -1).transpose(1, 2), x2.view(P, M // P, -1))
-            dw = sum_planes(part, torch.empty(part.shape[1:], dtype=torch.float32, device=part.device)).to(wdt)
-        else:
-            dw = (dy2.t() @ x2).to(wdt)
+        with _on_stream(ws):
+            if P > 1:
+                part = torch.bmm(dy2.view(P, M // P, -1).transpose(1, 2), x2.view(P, M // P, -1),
+                                 out_dtype=torch.float32) if dy2.dtype != torch.float32 else \
+                    torch.bmm(dy2.view(P, M // P, -1).transpose(1, 2), x2.view(P, M // P, -1))
+                dw = sum_planes(part, torch.empty(part.shape[1:], dtype=torch.float32, device=part.device)).to(wdt)
+            else:
+                dw = (dy2.t() @ x2).to(wdt)
+            if dw_post is not None:
+                dw = dw_post(dw)
     if need_db:
-        db = column_sum(dy2).to(bdt)
+        with _on_stream(ws):             # (a parameter gradient as well: nothing reads it before the step ends)
+            db = column_sum(dy2).to(bdt)
     return dx, dw, db
 
 
@@ -1281,11 +1321,10 @@ class _LinearPermutedCols(torch.autograd.Function):
         need_db = bdt is not None and ctx.needs_input_grad[2]
         cs = _take_colsum(dy, dy.shape[-1]) if need_db else None
         dx, dw, db = _linear_backward(x2, w, dy.reshape(-1, dy.shape[-1]), xs, xdt, torch.float32, bdt,
-                                      ctx.needs_input_grad[0], ctx.needs_input_grad[1], need_db and cs is None)
+                                      ctx.needs_input_grad[0], ctx.needs_input_grad[1], need_db and cs is None,
+                                      dw_post=lambda t: _permute_cols(t.contiguous(), inv, wdt))
         if cs is not None:
             db = cs.to(bdt)
-        if dw is not None:
-            dw = _permute_cols(dw.contiguous(), inv, wdt)
         return dx, dw, db, None, None, None
 
 
@@ -1315,7 +1354,7 @@ class _FusedLinear(torch.autograd.Function):
         xs, xdt = ctx.meta
         need_p = any(ctx.needs_input_grad[3:])
         dx, dw, db = _linear_backward(x2, w, dy.reshape(-1, dy.shape[-1]), xs, xdt, torch.float32, torch.float32,
-                                      ctx.needs_input_grad[0], need_p, need_p)
+                                      ctx.needs_input_grad[0], need_p, need_p, fork=False)
         grads = _unfuse_grads(ctx.table, params, dw, db) if need_p else (None,) * len(params)
         return (dx, None, None, *grads)
 
@@ -1642,9 +1681,8 @@ class _LinearResidualLN(torch.autograd.Function):
                 if part is not None:
                     _hand_colsum(d_pre, sum_rows(part))
         dx, dw, db = _linear_backward(x2, w, d_z.reshape(rows, N), xs, xdt, torch.float32 if ctx.col_inv is not None else wdt, bdt,
-                                      need_dx, ctx.needs_input_grad[1], need_db and cs is None)
-        if dw is not None and ctx.col_inv is not None:
-            dw = _permute_cols(dw.contiguous(), ctx.col_inv, wdt)
+                                      need_dx, ctx.needs_input_grad[1], need_db and cs is None,
+                                      dw_post=None if ctx.col_inv is None else (lambda t: _permute_cols(t.contiguous(), ctx.col_inv, wdt)))
         if need_db and cs is not None:
             db = cs.to(bdt)
         return (dx, dw, db, d_res if rdt == d_res.dtype else d_res.to(rdt), None,
@@ -1774,10 +1812,10 @@ def wait_side_streams(device=None):
     """make the current stream wait for everything queued on the side stream AND on the stream it
     was forked from -- before reading tensors (e.g. gradients inside an autograd hook, which may
     itself be running on either of the two) that blocks on both streams have produced"""
-    for dev, st in _side_streams.items():
+    for dev in set(_side_streams) | set(_wgrad_streams):
         if device is None or dev == device:
             cur = torch.cuda.current_stream(dev)
-            for other in (st, _main_streams.get(dev)):
+            for other in (_side_streams.get(dev), _wgrad_streams.get(dev), _main_streams.get(dev)):
                 if other is not None and other != cur:
                     cur.wait_stream(other)
 
