@@ -194,6 +194,38 @@ def test_cached_weight_transposes_follow_every_optimizer_step(precision, monkeyp
     assert torch.equal(runs[0], runs[1])
 
 
+def test_forked_parameter_gradient_stream_changes_nothing(monkeypatch):
+    """ops._wgrad_fork: inside the Trainer's backward the weight gradients of the edge Linears, their bias column sums and the
+    closing sums of the LayerNorm / bias partials run on a third stream that only the gradient collection joins.  Same kernels,
+    same order of summation: three steps with the fork equal three steps without it, bit for bit -- and outside a Trainer's
+    backward (torch.autograd.grad here) nothing is forked."""
+    from tgt_amd import ops
+    from tgt_amd.pcqm import TGT_Multi
+    from tgt_amd.training.step import Trainer, StepConfig
+    monkeypatch.setattr(ops, '_EDGE_MIN_ROWS', 1)
+    monkeypatch.setattr(ops, '_SPLIT_MIN_ROWS', 1)
+    kwargs = dict(gu.FULL_AT_CFG, model_height=2)
+    cfg = StepConfig(num_dist_bins=512, mixed_precision='bf16', coords_noise=0.0, lr_warmup_steps=10, lr_total_steps=100)
+    runs = []
+    for forked in (True, False):
+        monkeypatch.setattr(ops, '_WGRAD_STREAM', forked)
+        m1 = gu.fill_params(TGT_Multi(**kwargs), seed=3).cuda().eval()
+        with Trainer(m1, cfg) as tr:
+            for step in range(1, 4):
+                tr.training_step(_batch(cfg, step))
+            runs.append(_params(m1).clone())
+            if forked:
+                assert len(ops._wgrad_streams) > 0
+                x = torch.randn(300, 256, device='cuda', dtype=torch.bfloat16, requires_grad=True)
+                w = torch.randn(256, 256, device='cuda', requires_grad=True)
+                before = ops._trainer_backward[0]
+                with torch.autocast('cuda', dtype=torch.bfloat16):
+                    y = ops.linear(x, w)
+                dw, = torch.autograd.grad(y.float().sum(), w)             # not the Trainer's backward: computed on this stream
+                assert before == 0 and torch.isfinite(dw).all()
+    assert torch.equal(runs[0], runs[1])
+
+
 # ---- world-size 2 on the GPU: two ranks share cuda:0 and exchange over gloo (device tensors staged through the host by
 # the backend).  RCCL refuses two ranks on one device and the test boxes have one GPU, so this is the closest a 1-GPU box gets
 # to the N > 1 path: autograd hooks -> bucket gather behind BOTH streams -> asynchronous all-reduce -> one-launch Adam, on

@@ -386,8 +386,13 @@ class _ProjectedTripletAttention(torch.autograd.Function):
         a = _tri_args(fused, mask3, out, L, d_out, d_fused, colsum, dropout=ctx.dropout, eg=eg, graph_scale=ctx.graph_scale)
         _call('tgt_triplet_attention_bwd', _lib.lib().tgt_triplet_attention_bwd, a)
         need_p = any(ctx.needs_input_grad[7:])
-        db = sum_rows(colsum) if need_p else None
         d2 = d_fused.view(-1, L.width)
+        if eg is not None and need_p:
+            ws0 = _terminal_fork(d2.shape[0], colsum)
+            with _on_stream(ws0):
+                db = sum_rows(colsum)
+        else:
+            db = sum_rows(colsum) if need_p else None
         if eg is not None and need_p:
             # weight gradient as two batched GEMMs as well: the 1536-row block has no ragged tile row
             # (213 us with 32 chunks) and the 64-row E/G block is cheap (35 us), against 303 us for the
@@ -405,7 +410,7 @@ class _ProjectedTripletAttention(torch.autograd.Function):
         if not need_p:
             return (dx, None, None, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 7)
         if table is None:
-            return dx, None, None, None, None, None, None, dw.to(wdt), db.to(bdt)
+            return dx, None, None, None, None, None, None, _param_grad(dw, wdt), _param_grad(db, bdt)
         with _on_stream(ws):           # (the parameter gradients leave on the stream their weight gradient was computed on)
             grads = _unfuse_grads(table, params, dw, db)
         return (dx, None, None, None, None, None, None, *grads)
@@ -1043,7 +1048,8 @@ def _ln_backward(dy, s, g, mean, rstd, ds, scale, rps, want_dz):
                         ds_in=None if ds is None else ds.view(rows, N), out=d_res.view(rows, N),
                         out2=None if d_z is None else d_z.view(rows, N), row_scale=scale, rows_per_sample=rps if scale is not None else 0,
                         colsum_partial=partial)
-        tot = sum_planes(partial, torch.empty(3 * N, dtype=torch.float32, device=s.device))
+        with _on_stream(_terminal_fork(rows, partial)):
+            tot = sum_planes(partial, torch.empty(3 * N, dtype=torch.float32, device=s.device))
         _lazy_dgrads[1] += 1
         return d_res, d_z, tot[:N], tot[N:2 * N], tot[2 * N:]
     dy = _materialize_dgrad(dy).contiguous()
@@ -1110,14 +1116,29 @@ def _as_dtype_view(p, cd):
 
 _WGRAD_STREAM = os.environ.get('TGT_WGRAD_STREAM', '1') != '0'      # A/B knob: weight gradients of the edge Linears on a third stream
 _wgrad_streams = {}
+_trainer_backward = [0]           # > 0 while a Trainer runs its backward: the only caller that joins the forked stream afterwards
 
 
-def _wgrad_fork(*tensors):
+class trainer_backward:
+    """`with ops.trainer_backward():` around loss.backward() -- inside, parameter gradients may be produced on a forked stream
+    (autograd does not know about it: the stream switch happens inside a node).  The caller MUST order its reads of the
+    gradients after ops.wait_side_streams(); the Trainer's gradient collection does.  Anyone else (torch.autograd.grad in a
+    test, another optimizer) gets every gradient on the current stream."""
+
+    def __enter__(self):
+        _trainer_backward[0] += 1
+
+    def __exit__(self, *exc):
+        _trainer_backward[0] -= 1
+        return False
+
+
+def _wgrad_fork(*tensors, rows=None):
     """The stream a weight gradient may run on -- nothing consumes it before the step ends (the Trainer's gradient collection waits
-    for every stream, wait_side_streams) -- ordered after the work queued so far on the current stream; None = stay.  Only under a
-    Trainer (ops.side_stream's ownership rule), only for the edge rows, never from the node side stream."""
+    for every stream, wait_side_streams) -- ordered after the work queued so far on the current stream; None = stay.  Only inside a
+    Trainer's backward (ops.trainer_backward), only for the edge rows, never from the node side stream."""
     t0 = tensors[0]
-    if not (_WGRAD_STREAM and side_stream._owners > 0 and t0.is_cuda and t0.shape[0] >= _EDGE_MIN_ROWS):
+    if not (_WGRAD_STREAM and _trainer_backward[0] > 0 and t0.is_cuda and (rows if rows is not None else t0.shape[0]) >= _EDGE_MIN_ROWS):
         return None
     dev = t0.device
     cur = torch.cuda.current_stream(dev)
@@ -1135,6 +1156,24 @@ def _wgrad_fork(*tensors):
 
 def _on_stream(ws):
     return torch.cuda.stream(ws) if ws is not None else contextlib.nullcontext()
+
+
+_TERMINAL_SUMS = os.environ.get('TGT_TERMINAL_SUMS', '1') != '0'     # A/B knob: the closing sums of parameter gradients on the forked stream too
+
+
+def _terminal_fork(rows, *tensors):
+    """as _wgrad_fork, for the small closing sums (column-sum partials -> a bias / LayerNorm parameter gradient) behind a kernel
+    that is already queued: nothing on the step's own chain reads their result"""
+    return _wgrad_fork(*tensors, rows=rows) if _TERMINAL_SUMS else None
+
+
+def _param_grad(t, dtype):
+    """t in the parameter's dtype.  A gradient computed on the forked stream is only ever RETURNED to autograd; if it needs a
+    cast kernel first (parameters that are not float32), that kernel runs on the current stream and has to wait."""
+    if t is None or t.dtype == dtype:
+        return t
+    wait_side_streams(t.device)
+    return t.to(dtype)
 
 
 _SIDE_PRIO = int(os.environ.get('TGT_SIDE_PRIO', '-1'))           # A/B knob: HIP priority of the node side stream (-1 = high: its short kernels are
@@ -1290,7 +1329,7 @@ class _Linear(torch.autograd.Function):
         dx, dw, db = _linear_backward(x2, w, dy.reshape(-1, dy.shape[-1]), xs, xdt, wdt, bdt,
                                       ctx.needs_input_grad[0], ctx.needs_input_grad[1], need_db and cs is None, ctx.lazy)
         if cs is not None:
-            db = cs.to(bdt)
+            db = _param_grad(cs, bdt)
         return dx, dw, db, None, None
 
 
@@ -1324,7 +1363,7 @@ class _LinearPermutedCols(torch.autograd.Function):
                                       ctx.needs_input_grad[0], ctx.needs_input_grad[1], need_db and cs is None,
                                       dw_post=lambda t: _permute_cols(t.contiguous(), inv, wdt))
         if cs is not None:
-            db = cs.to(bdt)
+            db = _param_grad(cs, bdt)
         return dx, dw, db, None, None, None
 
 
@@ -1523,7 +1562,7 @@ class _LinearGeluDropout(torch.autograd.Function):
         dx, dw, db = _linear_backward(x2, w, d_pre.view(-1, d_pre.shape[-1]), xs, xdt, wdt, bdt, ctx.needs_input_grad[0],
                                       ctx.needs_input_grad[1], need_db and cs is None, ctx.lazy)
         if need_db and cs is not None:
-            db = cs.to(bdt)
+            db = _param_grad(cs, bdt)
         return dx, dw, db, None, None, None, None, None
 
 
@@ -1593,7 +1632,7 @@ class _AddLayerNorm(torch.autograd.Function):
         if d_x is None:
             d_x = d_res
         _hand_colsum(d_x, cs)
-        return d_x, (d_res if rdt == d_res.dtype else d_res.to(rdt)), None, dg.to(wdt), dbeta.to(wdt), None, None
+        return d_x, (d_res if rdt == d_res.dtype else d_res.to(rdt)), None, _param_grad(dg, wdt), _param_grad(dbeta, wdt), None, None
 
 
 class _LinearResidualLN(torch.autograd.Function):
@@ -1679,14 +1718,15 @@ class _LinearResidualLN(torch.autograd.Function):
                                 res=pre.view(rows, -1), out_scale=g_scale, rows_per_sample=rps, dropout=(ctx.gelu[0], ctx.gelu[1]),
                                 colsum_partial=part)
                 if part is not None:
-                    _hand_colsum(d_pre, sum_rows(part))
+                    with _on_stream(_terminal_fork(rows, part)):
+                        _hand_colsum(d_pre, sum_rows(part))
         dx, dw, db = _linear_backward(x2, w, d_z.reshape(rows, N), xs, xdt, torch.float32 if ctx.col_inv is not None else wdt, bdt,
                                       need_dx, ctx.needs_input_grad[1], need_db and cs is None,
                                       dw_post=None if ctx.col_inv is None else (lambda t: _permute_cols(t.contiguous(), ctx.col_inv, wdt)))
         if need_db and cs is not None:
-            db = cs.to(bdt)
+            db = _param_grad(cs, bdt)
         return (dx, dw, db, d_res if rdt == d_res.dtype else d_res.to(rdt), None,
-                None if dg is None else dg.to(lndt), None if dbeta is None else dbeta.to(lndt), None, None, None, None, d_pre, None, None)
+                _param_grad(dg, lndt), _param_grad(dbeta, lndt), None, None, None, None, d_pre, None, None)
 
 
 _GELU_BWD_EPI_COLSUM = os.environ.get('TGT_GELU_BWD_EPI_COLSUM', '1') != '0'      # A/B knob: lin_W1's bias gradient from the GELU_BWD epilogue

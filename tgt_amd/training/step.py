@@ -14,6 +14,7 @@ training.py:152 DDP gradient averaging), re-designed for one process per GPU:
  * no per-step host sync: the loss stays on the device; `.item()` only when
    the caller logs.
 """
+import contextlib
 import math
 import weakref
 from dataclasses import dataclass, field
@@ -223,6 +224,7 @@ class Trainer:
             dist.broadcast(self.flat.param, src=0, group=self.pg)
             self._setup_buckets()
         self._wt = None
+        self._shared = getattr(model, 'layer_multiplier', 1) > 1 or getattr(getattr(model, 'encoder', None), 'layer_multiplier', 1) > 1
         if self.cfg.mixed_precision in ('bf16', 'fp16') and self.flat.param.is_cuda:
             self.flat.make_shadow(torch.bfloat16 if self.cfg.mixed_precision == 'bf16' else torch.float16)
             # W^T of the shadowed weights for the data-gradient kernels, refreshed in one launch after every optimizer step
@@ -382,7 +384,10 @@ class Trainer:
             outputs = self.model(batch)
             loss = self.loss_fn(outputs, batch, cfg)
         # GradScaler.scale(loss): the scale is a device scalar, so a changed scale costs no sync
-        (loss * self.ctl[ops.CTL_SCALE].to(loss.dtype) if self.dynamic_scale else loss).backward()
+        # parameter gradients may come from a forked stream (collect_grads joins it) -- unless a parameter takes part in the graph
+        # more than once (weight-shared stacks): autograd then ADDS into .grad on the current stream, unordered with the fork
+        with (ops.trainer_backward() if not self._shared else contextlib.nullcontext()):
+            (loss * self.ctl[ops.CTL_SCALE].to(loss.dtype) if self.dynamic_scale else loss).backward()
         self._armed = False
         self._finish_reduce()
         return outputs, loss
