@@ -305,6 +305,7 @@ def main():
     prof_iso = None
     if ops.side_stream.enabled and args.roofline_steps > 0:
         ops.side_stream.enabled = False
+        forked, ops._WGRAD_STREAM = ops._WGRAD_STREAM, False      # (the forked parameter-gradient stream as well: one stream, kernels alone)
         step(args.warmup + args.steps)                    # (one step for the allocator to settle on the new stream pattern)
         prof_iso = ops.profile_kernels(True)
         for i in range(args.roofline_steps):
@@ -312,6 +313,7 @@ def main():
         fence()
         ops.profile_kernels(False)
         ops.side_stream.enabled = True
+        ops._WGRAD_STREAM = forked
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -384,7 +386,7 @@ def main():
                 reg = sum(times_region[name]) / len(times_region[name])
                 roofline['timing'] = dict(
                     how=f'HIP events on the launch stream over {args.roofline_steps} extra steps after the timed region with the node '
-                        'channel on the same stream (kernel alone; = TGT_NODE_STREAM=0 rocprofv3 --stats of this command)',
+                        'channel and the parameter-gradient fork on the same stream (kernel alone; = TGT_NODE_STREAM=0 TGT_WGRAD_STREAM=0 rocprofv3 --stats of this command)',
                     in_timed_region=dict(avg_launch_ms=round(reg, 4), achieved=round(nbytes / (reg * 1e-3) / 1e9, 1),
                                          frac=round(nbytes / (reg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                          note='event pairs inside the timed region: the second stream\'s node kernels share the CUs'))
