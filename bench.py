@@ -290,6 +290,7 @@ def main():
         step(i)
     prof = ops.profile_kernels(True)
     fence()
+    ms0 = torch.cuda.memory_stats(dev)
     t0 = time.perf_counter()
     for i in range(args.steps):
         _, loss = step(args.warmup + i)
@@ -297,6 +298,7 @@ def main():
             trainer.mean_loss()                      # host read of the control block: synchronises this rank
     fence()
     dt = time.perf_counter() - t0
+    ms1 = torch.cuda.memory_stats(dev)
     ops.profile_kernels(False)
     # Kernel durations for `roofline`: inside the timed region the node channel runs on a second HIP stream and its kernels share
     # the CUs with the edge kernels, so an event pair around an edge launch also sees the other stream's work (and the wait for
@@ -425,6 +427,12 @@ def main():
                         **({'host_loss_read_every': args.sync_every} if args.sync_every else {})),
             final_loss=round(loss_val, 5),
             roofline=roofline,
+            # the caching allocator inside the timed region: device allocations / frees there are synchronous driver calls
+            memory=dict(reserved_GB=round(ms1.get('reserved_bytes.all.current', 0) / 1e9, 2),
+                        peak_allocated_GB=round(ms1.get('allocated_bytes.all.peak', 0) / 1e9, 2),
+                        device_allocs_in_timed_region=ms1.get('num_device_alloc', 0) - ms0.get('num_device_alloc', 0),
+                        device_frees_in_timed_region=ms1.get('num_device_free', 0) - ms0.get('num_device_free', 0),
+                        alloc_retries=ms1.get('num_alloc_retries', 0)),
         )
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(full=args.cpu_baseline_full)

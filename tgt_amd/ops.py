@@ -1114,7 +1114,9 @@ def _as_dtype_view(p, cd):
     return lp if (lp is not None and lp.dtype == cd and p.dtype != cd) else p.detach()
 
 
-_WGRAD_STREAM = os.environ.get('TGT_WGRAD_STREAM', '1') != '0'      # A/B knob: weight gradients of the edge Linears on a third stream
+# opt-in (TGT_WGRAD_STREAM=1): weight gradients of the edge Linears on a third stream.  Measured over 20 same-box pairs on five boxes:
+# +1.7 % on one, -1.9 % on another, occasional runs 5-10 % low -- two equal-priority queues of HBM-bound kernels; the mean is ~0
+_WGRAD_STREAM = os.environ.get('TGT_WGRAD_STREAM', '0') == '1'
 _wgrad_streams = {}
 _trainer_backward = [0]           # > 0 while a Trainer runs its backward: the only caller that joins the forked stream afterwards
 
