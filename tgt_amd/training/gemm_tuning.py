@@ -12,7 +12,8 @@ import os
 
 import torch
 
-TUNING_FILE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tuning', 'tunableop_gfx950.csv')
+TUNING_FILE = os.environ.get('TGT_TUNING_FILE') or \
+    os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tuning', 'tunableop_gfx950.csv')      # (the variable: A/B of a re-tuned table)
 
 
 def enable_gemm_tuning(online=True, filename=None, max_ms=50, max_iters=20):
