@@ -660,3 +660,28 @@ def test_lin_O_data_gradient_on_the_wide_kernel_vs_library_and_float64(rows, dty
     assert rel(grads[0][0], ref) < TOL[dtype] and rel(grads[1][0], ref) < TOL[dtype]
     assert rel(grads[0][0], grads[1][0]) < TOL[dtype]
     assert torch.equal(grads[0][1], grads[1][1])            # (the weight gradient does not depend on the route)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_transpose_many_one_launch(dtype):
+    """tgt_transpose_many (ABI 27): W^T of many 16-bit matrices in one launch, ragged shapes included -- what the Trainer refreshes
+    after every optimizer step for the data-gradient launches (ops.WeightTransposes)"""
+    import ctypes as C
+    g = torch.Generator(device='cuda').manual_seed(5)
+    shapes = [(256, 256), (128, 256), (256, 64), (256, 512), (33, 70), (1, 17), (100, 1), (64, 64)]
+    src = [torch.randn(r, c, device='cuda', generator=g).to(dtype) for r, c in shapes]
+    dst = [torch.full((c, r), 7.0, dtype=dtype, device='cuda') for r, c in shapes]
+    rows = []
+    for s_, d_, (r, c) in zip(src, dst, shapes):
+        rows += [s_.data_ptr(), d_.data_ptr(), r | (c << 32)]
+    table = torch.tensor(rows, dtype=torch.int64).cuda()
+    L = _lib.lib()
+    for blocks in (1, 16):
+        for d_ in dst:
+            d_.fill_(7.0)
+        _lib.check(L.tgt_transpose_many(C.c_void_p(table.data_ptr()), len(shapes), blocks,
+                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'tgt_transpose_many')
+        torch.cuda.synchronize()
+        for s_, d_ in zip(src, dst):
+            assert torch.equal(d_, s_.t())
+    _lib.check(L.tgt_transpose_many(None, 0, 16, C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'empty')
