@@ -14,8 +14,52 @@ typedef __attribute__((ext_vector_type(8)))  _Float16 f16x8;
 typedef __attribute__((ext_vector_type(8)))  float    f32x8;
 typedef __attribute__((ext_vector_type(4)))  float    f32x4;
 typedef __attribute__((ext_vector_type(16))) float    f32x16;
+// Cache policy of the big streaming RESULT stores (buffer_store aux field / __builtin_nontemporal_store): 2 = nt.  Every kernel here
+// writes each output byte once and nobody re-reads it before the kernel ends; as ordinary write-back stores they leave the
+// XCDs' L2s full of dirty lines that are written back at the dependent-kernel boundary and evict what the NEXT kernel wants to
+// keep (weights, third-arm tiles).  Same-box A/B inside the training step: nt +2.6 %, sc0 sc1 (write-through) +0.1 %
+// (profiles/r04m_ab_nt_stores.txt).  Extending it to the
+// plain-pointer stores of the slice / LayerNorm / activation / node kernels (consumers that DO hit in L2 / MALL) lost 2.4 %.
+#ifndef TGT_ST_AUX
+#define TGT_ST_AUX 2
+#endif
+#ifndef TGT_LD_AUX
+#define TGT_LD_AUX 2            // the same for the streaming operand loads (rows each workgroup reads once): +0.5 ... +1.2 % on top
+#endif
 typedef __attribute__((ext_vector_type(2)))  float    f32x2;     // packed fp32 pairs: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));      // raw buffer load / store data
+// 16 bytes to / from global memory through a plain pointer, optionally with the streaming (nt) policy above
+template <bool NT>
+__device__ __forceinline__ void st16_stream(void* p, const uint4& v) {
+    if constexpr (NT) {
+        const u32x4_t d = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(d, reinterpret_cast<u32x4_t*>(p));
+    } else {
+        *reinterpret_cast<uint4*>(p) = v;
+    }
+}
+template <bool NT>
+__device__ __forceinline__ uint4 ld16_stream(const void* p) {
+    if constexpr (NT) {
+        const u32x4_t d = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+        return make_uint4(d.x, d.y, d.z, d.w);
+    } else {
+        return *reinterpret_cast<const uint4*>(p);
+    }
+}
+// per-site switches of the experiments behind the defaults (profiles/r04o_ab_nt_sites.txt, r04q_*)
+#ifndef TGT_NT_NODE
+#define TGT_NT_NODE 0
+#endif
+#ifndef TGT_NT_SLICE
+#define TGT_NT_SLICE 0
+#endif
+#ifndef TGT_NT_LN
+#define TGT_NT_LN 0
+#endif
+#ifndef TGT_NT_LNLOAD
+#define TGT_NT_LNLOAD 0
+#endif
 
 // ---------------------------------------------------------------------------
 // 32x32 matrix-core tile:  C[m][n] += sum_kk A[m][kk] * B[kk][n],  kk in [0,16)

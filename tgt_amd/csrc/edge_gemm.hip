@@ -76,7 +76,7 @@ __device__ __forceinline__ void store_block(T* base, int64_t ld, int64_t m, int6
         uint2 b = pack4<T>(v[8 * p + 4], v[8 * p + 5], v[8 * p + 6], v[8 * p + 7]);
         swap_halves(a, b);
         const int col = nbase + 16 * p + 8 * hi;
-        if (m < M && col < N) *reinterpret_cast<uint4*>(base + m * ld + col) = make_uint4(a.x, a.y, b.x, b.y);
+        if (m < M && col < N) st16_stream<TGT_NT_SLICE != 0>(base + m * ld + col, make_uint4(a.x, a.y, b.x, b.y));
     }
 }
 template <typename T>
@@ -625,12 +625,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const void* base, in
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(base)) + row0 * ld_bytes, 0, (int)bytes, 0x00020000);
 }
 __device__ __forceinline__ uint4 rp_ld16(__amdgpu_buffer_rsrc_t r, uint32_t off) {
-    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, TGT_LD_AUX);
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ void rp_st16(__amdgpu_buffer_rsrc_t r, uint32_t off, const uint4& v) {
     const u32x4_t d = {v.x, v.y, v.z, v.w};
-    __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)off, 0, TGT_ST_AUX);
 }
 __device__ __forceinline__ float rp_ld_f32(__amdgpu_buffer_rsrc_t r, uint32_t off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));

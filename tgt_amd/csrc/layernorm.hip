@@ -28,7 +28,7 @@ __device__ __forceinline__ void ln_load8(const void* p, int dtype, int64_t idx, 
         float4 a = q[0], b = q[1];
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
     } else {
-        uint4 raw = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p) + idx);
+        uint4 raw = ld16_stream<TGT_NT_LNLOAD != 0>(reinterpret_cast<const uint16_t*>(p) + idx);
         if (dtype == TGT_BF16) {
             bf16_t t[8];
             __builtin_memcpy(t, &raw, 16);
@@ -61,7 +61,7 @@ __device__ __forceinline__ void ln_store8(void* p, int dtype, int64_t idx, const
             for (int i = 0; i < 8; ++i) t[i] = from_f32<f16_t>(v[i]);
             __builtin_memcpy(&raw, t, 16);
         }
-        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p) + idx) = raw;
+        st16_stream<TGT_NT_LN != 0>(reinterpret_cast<uint16_t*>(p) + idx, raw);
     }
 }
 

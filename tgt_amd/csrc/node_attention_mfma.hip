@@ -89,7 +89,7 @@ __device__ __forceinline__ uint4 buf_ld16(__amdgpu_buffer_rsrc_t r, uint32_t off
 }
 __device__ __forceinline__ void buf_st16(__amdgpu_buffer_rsrc_t r, uint32_t off, const uint4& v) {
     const u32x4_t d = {v.x, v.y, v.z, v.w};
-    __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)off, 0, TGT_NT_NODE ? TGT_ST_AUX : 0);
 }
 
 struct Unit { int b, hg; };

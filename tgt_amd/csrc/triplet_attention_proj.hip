@@ -98,9 +98,9 @@ __device__ __forceinline__ void proj2_walk(const tgt_triplet_attention_args& a, 
         u32x4_t da = {va.x, va.y, va.z, va.w}, db = {vb.x, vb.y, vb.z, vb.w};
         if (ablate & 2) return;
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_raw_buffer_store_b128(da, r_dst, (int)((row_ok && qkv_live) ? vo_a : kNone), 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(db, r_dst, (int)((row_ok && qkv_live && shalf == 0) ? vo_v : kNone), 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(db, r_out, (int)((row_ok && o_live && shalf == 1) ? vo_o : kNone), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(da, r_dst, (int)((row_ok && qkv_live) ? vo_a : kNone), 0, TGT_ST_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(db, r_dst, (int)((row_ok && qkv_live && shalf == 0) ? vo_v : kNone), 0, TGT_ST_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(db, r_out, (int)((row_ok && o_live && shalf == 1) ? vo_o : kNone), 0, TGT_ST_AUX);
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -111,7 +111,7 @@ __device__ __forceinline__ void proj2_walk(const tgt_triplet_attention_args& a, 
         const uint32_t vo = (srow < N && tid >= 512) ? (uint32_t)srow * o_row + (uint32_t)(a.o_off[DIR] * sz) + hch + (uint32_t)sslot * 16u : kNone;
         for (int j = 0; j < N; ++j) {
             u32x4_t z = {0, 0, 0, 0};
-            __builtin_amdgcn_raw_buffer_store_b128(z, r_out, (int)vo, (int)((uint32_t)j * o_j), 0);
+            __builtin_amdgcn_raw_buffer_store_b128(z, r_out, (int)vo, (int)((uint32_t)j * o_j), TGT_ST_AUX);
         }
         return;
     }

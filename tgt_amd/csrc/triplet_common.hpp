@@ -97,13 +97,13 @@ __device__ __forceinline__ void slab_issue(uint4 (&pre)[IT], const SlabBuf& s, i
         const int row = c / G::kSlots, slot = c % G::kSlots;
         u32x4_t v = {0, 0, 0, 0};
         if (c < SlabIO<G, ROWS>::kChunks && row0 + row < N)
-            v = __builtin_amdgcn_raw_buffer_load_b128(s.rsrc, (int)((uint32_t)row * s.row_stride + (uint32_t)slot * 16u), (int)so, 0);
+            v = __builtin_amdgcn_raw_buffer_load_b128(s.rsrc, (int)((uint32_t)row * s.row_stride + (uint32_t)slot * 16u), (int)so, TGT_LD_AUX);
         pre[it] = make_uint4(v.x, v.y, v.z, v.w);
     }
 }
 __device__ __forceinline__ void buf_store16(const SlabBuf& s, uint4 v, uint32_t voff, uint32_t so) {
     u32x4_t d = {v.x, v.y, v.z, v.w};
-    __builtin_amdgcn_raw_buffer_store_b128(d, s.rsrc, (int)voff, (int)so, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(d, s.rsrc, (int)voff, (int)so, TGT_ST_AUX);
 }
 template <typename G, int ROWS>
 __device__ __forceinline__ void slab_store(const char* slab, const SlabBuf& s, int j, int row0, int N, int tid) {
