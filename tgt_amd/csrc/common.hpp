@@ -248,4 +248,16 @@ template <> struct DType<f16_t>  { static constexpr int id = TGT_F16; };
 int set_error(int code, const char* fmt, ...);
 int check_launch(const char* what);
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember it per (kernel instantiation, device).
+// `done` is a function-local `static bool attr_set[16] = {}` of the launcher of ONE kernel instantiation.
+static inline bool dyn_lds_once(bool (&done)[16], const void* fn, int lds) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    if (dev >= 16 || !done[dev]) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return false;
+        if (dev < 16) done[dev] = true;
+    }
+    return true;
+}
+
 }  // namespace tgt

@@ -1213,16 +1213,6 @@ static int er_grid(int64_t M) {
     return (int)g;
 }
 
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember it per (kernel instantiation, device)
-static bool dyn_lds_once(bool (&done)[16], const void* fn, int lds) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
-    if (dev >= 16 || !done[dev]) {
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return false;
-        if (dev < 16) done[dev] = true;
-    }
-    return true;
-}
 
 template <typename T, int KS, int EPI>
 static int er_launch(const tgt_edge_linear_args& a, hipStream_t st) {

@@ -206,6 +206,22 @@ __global__ void __launch_bounds__(HG * 64, (NT == 1 && sizeof(T) == 2) ? 4 : (si
 // NT > 1: one pass per query tile; dK/dV sum over query tiles, so pass `it > 0`
 // adds its partial to what pass it-1 stored (same thread wrote that address).
 // ---------------------------------------------------------------------------
+#ifdef TGT_PROBES
+// Probe build only (tools/probes/tri_bwd_probe.py; never in the shipped library): per-segment cycle totals of wave 0 of every
+// workgroup, and ablation bits (TGT_TRI_BWD_ABLATE -> _pad0: 1 no loads, 2 no stores, 4 no tile math).
+static __device__ unsigned long long g_tri_probe[4096 * 8];
+__device__ __forceinline__ unsigned long long probe_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define TGT_PROBE_T(i) do { const unsigned long long t_ = probe_now(); pt[i] += t_ - t_last; t_last = t_; } while (0)
+#else
+#define TGT_PROBE_T(i) do { } while (0)
+#endif
+
 // FL >= 0: the BIASED/GATED flags are compile-time (the hot gated+biased instantiation: no
 // per-element selects); FL < 0: read from the arguments.
 template <typename T, int D, int HG, int NT, int OCC, bool CS, int FL, bool DROP>
@@ -219,6 +235,13 @@ __global__ void __launch_bounds__(HG * 64, OCC) __attribute__((amdgpu_waves_per_
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hi = lane >> 5;
+#ifdef TGT_PROBES
+    unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = probe_now();
+    const unsigned long long t_begin = t_last;
+    const int ablate = a._pad0;
+#else
+    constexpr int ablate = 0;
+#endif
     const TriCtx c = tri_ctx<T, D, HG>(a, wave);
     const int N = c.N;
     const ThirdArm ta = tri_third_arm(a, c.dir);
@@ -349,6 +372,7 @@ __global__ void __launch_bounds__(HG * 64, OCC) __attribute__((amdgpu_waves_per_
             char* sO = sQ + G::kSlabBytes;
             char* sK = sQ + 2 * G::kSlabBytes;
             char* sV = sK + NT * G::kSlabBytes;
+            TGT_PROBE_T(0);                // (loop overhead + whatever the previous iteration left)
             if (j + 1 < N) {
                 char* nQ = smem + ((j + 1) & 1) * kSet;
                 slab_commit<G, 32>(pq, nQ, tid);
@@ -356,7 +380,8 @@ __global__ void __launch_bounds__(HG * 64, OCC) __attribute__((amdgpu_waves_per_
                 slab_commit<G, KR>(pk, nQ + 2 * G::kSlabBytes, tid);
                 slab_commit<G, KR>(pv, nQ + (2 + NT) * G::kSlabBytes, tid);
             }
-            if (j + 2 < N) {
+            TGT_PROBE_T(1);                // commit: the wait for the prefetched slabs + 4 LDS writes
+            if (j + 2 < N && !(ablate & 1)) {
                 slab_issue<G, 32>(pq, bQ, j + 2, i0, N, tid);
                 slab_issue<G, 32>(po, dO, j + 2, i0, N, tid);
                 slab_issue<G, KR>(pk, bK, j + 2, 0, N, tid);
@@ -370,6 +395,8 @@ __global__ void __launch_bounds__(HG * 64, OCC) __attribute__((amdgpu_waves_per_
                     slab_issue<G, KR>(curv, dV, j, 0, N, tid);
                 }
             }
+            TGT_PROBE_T(2);                // prefetch issue
+            if (!(ablate & 4)) {
             F fq[G::kDC], fo[G::kDC];
             read_frags<T, D, HG>(fq, sQ, wave, r, hi);
             read_frags<T, D, HG>(fo, sO, wave, r, hi);
@@ -506,8 +533,13 @@ __global__ void __launch_bounds__(HG * 64, OCC) __attribute__((amdgpu_waves_per_
                 write_rows<T, D, HG>(sV, dv, wave, 32 * kt + r, hi);
             }
             write_rows<T, D, HG>(sQ, dq, wave, r, hi);
+            }
+            TGT_PROBE_T(3);                // tile math (LDS fragment reads .. result rows written to LDS)
             __syncthreads();
+            TGT_PROBE_T(4);                // barrier
             bool plain = true;
+            if (ablate & 2) {
+            } else
             if constexpr (CS) {
                 slab_store_sum<G, 32, T, false>(sQ, pq, gQ, j, i0, N, tid, cs);
                 if constexpr (NT > 1) {
@@ -535,6 +567,7 @@ __global__ void __launch_bounds__(HG * 64, OCC) __attribute__((amdgpu_waves_per_
                     slab_store<G, KR>(sV, dV, j, 0, N, tid);
                 }
             }
+            TGT_PROBE_T(5);                // result stores (+ column sums)
         }
         __syncthreads();      // the next query-tile pass re-fills both sets
         // third-arm gradients of this query tile (summed over j in registers) leave through LDS
@@ -574,6 +607,13 @@ __global__ void __launch_bounds__(HG * 64, OCC) __attribute__((amdgpu_waves_per_
             }
         }
     }
+#ifdef TGT_PROBES
+    if (tid == 0 && blockIdx.x < 4096) {
+        pt[7] = probe_now() - t_begin;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g_tri_probe[blockIdx.x * 8 + i] = pt[i];
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -583,8 +623,14 @@ __global__ void __launch_bounds__(HG * 64, OCC) __attribute__((amdgpu_waves_per_
 #define TGT_NT2_OCC 1      // measured: capping the two-tile backward at 256 registers (2 waves per SIMD) spills -- 7.0 ms against 1.6 ms
 #endif
 template <typename T, int D, int HG, int NT>
-static int launch_tri_nt(const tgt_triplet_attention_args& a, bool bwd, hipStream_t st) {
+static int launch_tri_nt(const tgt_triplet_attention_args& a_in, bool bwd, hipStream_t st) {
     using G = TriGeo<T, D, HG>;
+#ifdef TGT_PROBES
+    tgt_triplet_attention_args a = a_in;
+    a._pad0 = getenv("TGT_TRI_BWD_ABLATE") ? atoi(getenv("TGT_TRI_BWD_ABLATE")) : 0;
+#else
+    const tgt_triplet_attention_args& a = a_in;
+#endif
     const int grid = a.B * 2 * (a.H / HG);
     constexpr int kArm = ArmStage<T, HG, NT>::kBytes;
     constexpr int kFwdLds = 2 * (1 + 2 * NT) * G::kSlabBytes > kArm ? 2 * (1 + 2 * NT) * G::kSlabBytes : kArm;
@@ -674,6 +720,14 @@ int tri_att_run_f32(const tgt_triplet_attention_args& a, bool bwd, hipStream_t s
 #endif
 #if TGT_TRI_INST & 2
 int tri_att_run_bf16(const tgt_triplet_attention_args& a, bool bwd, hipStream_t st) { return dispatch_d<bf16_t>(a, bwd, st); }
+#ifdef TGT_PROBES
+}  // namespace tgt
+// probe build only: the segment cycle totals the last bf16 backward launch left (8 per workgroup, see TGT_PROBE_T)
+extern "C" int tgt_probe_read(void* dst, int n_u64) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(tgt::g_tri_probe), (size_t)n_u64 * 8);
+}
+namespace tgt {
+#endif
 #endif
 #if TGT_TRI_INST & 4
 int tri_att_run_f16(const tgt_triplet_attention_args& a, bool bwd, hipStream_t st) { return dispatch_d<f16_t>(a, bwd, st); }
@@ -684,9 +738,12 @@ bool tri_att16_fwd_eligible(const tgt_triplet_attention_args& a);
 int tri_att16_fwd_run(const tgt_triplet_attention_args& a, hipStream_t st);
 bool tri_att16_bwd_eligible(const tgt_triplet_attention_args& a);
 int tri_att16_bwd_run(const tgt_triplet_attention_args& a, hipStream_t st);
+bool tri_att_bwd2_eligible(const tgt_triplet_attention_args& a);       // triplet_attention_bwd2.hip: 16-bit, D = 16, N <= 32, H % 8 == 0
+int tri_att_bwd2_run(const tgt_triplet_attention_args& a, hipStream_t st);
 
 int triplet_attention_run(const tgt_triplet_attention_args* a, bool bwd, hipStream_t st) {
     if (!a) return set_error(TGT_ERR_INVALID, "triplet attention: null args");
+
     if (a->B < 0 || a->N < 0 || a->H <= 0) return set_error(TGT_ERR_INVALID, "triplet attention: bad sizes B=%d N=%d H=%d", a->B, a->N, a->H);
     if (a->B == 0 || a->N == 0) return TGT_OK;                 // empty batch: nothing to do
     if (a->N > 64) return set_error(TGT_ERR_UNSUPPORTED, "triplet attention: N=%d > 64 not supported", a->N);
@@ -712,6 +769,7 @@ int triplet_attention_run(const tgt_triplet_attention_args* a, bool bwd, hipStre
     }
     if (!bwd && tri_att16_fwd_eligible(*a)) return tri_att16_fwd_run(*a, st);      // 33 <= N <= 64: 16-wide tiles (triplet_attention16.hip)
     if (bwd && tri_att16_bwd_eligible(*a)) return tri_att16_bwd_run(*a, st);
+    if (bwd && tri_att_bwd2_eligible(*a)) return tri_att_bwd2_run(*a, st);
     switch (a->dtype) {
         case TGT_F32: return tri_att_run_f32(*a, bwd, st);
         case TGT_BF16: return tri_att_run_bf16(*a, bwd, st);
