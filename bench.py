@@ -362,7 +362,9 @@ def main():
             if not pmc and summaries:
                 pmc_note = dict(file='profiles/' + summaries[-1], kernel_src_sha=sha, match=False,
                                 note='kernel sources changed since the last counter pass: traffic / mfma_util not quoted')
+            # (tools/pmc_summary.py's short names of the mangled kernels; the round-4 backward lives in namespace bwd2)
             for short, name in (('tri_att_fwd_kernel', 'tgt_triplet_attention_fwd'), ('tri_att_bwd_kernel', 'tgt_triplet_attention_bwd'),
+                                ('bwd219tri_att_bwd2_kernel', 'tgt_triplet_attention_bwd'),
                                 ('tri_att_proj_fwd_kernel', 'tgt_triplet_attention_proj_fwd')):
                 if short in pmc and 'hbm_bytes_per_launch' in pmc[short]:
                     traffic[name] = dict(traffic_bytes=pmc[short]['hbm_bytes_per_launch'])
@@ -378,20 +380,28 @@ def main():
                             share_of_step=round(tot / (dt * 1e3), 4),
                             # matrix-core utilisation of this kernel from the SQ counter pass (offline, same shape):
                             # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs); an HBM-bound core at 15.5 FLOP/B
-                            mfma_util=pmc.get({'tgt_triplet_attention_bwd': 'tri_att_bwd_kernel', 'tgt_triplet_attention_fwd': 'tri_att_fwd_kernel',
+                            mfma_util=pmc.get({'tgt_triplet_attention_bwd': ('bwd219tri_att_bwd2_kernel' if 'bwd219tri_att_bwd2_kernel' in pmc else 'tri_att_bwd_kernel'),
+                                               'tgt_triplet_attention_fwd': 'tri_att_fwd_kernel',
                                                'tgt_triplet_attention_proj_fwd': 'tri_att_proj_fwd_kernel'}[name], {}).get('mfma_util'),
                             other_kernels={k: dict(avg_launch_ms=round(v[1], 4),
                                                    achieved=round(v[2] / (v[1] * 1e-3) / 1e9, 1))
                                            for k, v in cand.items() if k != name})
             roofline['offline_pmc'] = pmc_note
             if prof_iso is not None and times_region.get(name):
+                # The top-level achieved / frac / avg_launch_ms are the ones the headline throughput is made of: event pairs INSIDE
+                # the timed region (the second stream's node kernels share the CUs there).  The kernel alone is under timing.alone.
                 reg = sum(times_region[name]) / len(times_region[name])
                 roofline['timing'] = dict(
-                    how=f'HIP events on the launch stream over {args.roofline_steps} extra steps after the timed region with the node '
-                        'channel and the parameter-gradient fork on the same stream (kernel alone; = TGT_NODE_STREAM=0 TGT_WGRAD_STREAM=0 rocprofv3 --stats of this command)',
+                    top_level='in_timed_region',
+                    alone=dict(avg_launch_ms=round(avg_ms, 4), achieved=round(ach, 1), frac=round(ach / HBM_PEAK_GBS, 4),
+                               how=f'HIP events on the launch stream over {args.roofline_steps} extra steps after the timed region with the node '
+                                   'channel and the parameter-gradient fork on the same stream (= TGT_NODE_STREAM=0 TGT_WGRAD_STREAM=0 '
+                                   'rocprofv3 --stats of this command)'),
                     in_timed_region=dict(avg_launch_ms=round(reg, 4), achieved=round(nbytes / (reg * 1e-3) / 1e9, 1),
                                          frac=round(nbytes / (reg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                          note='event pairs inside the timed region: the second stream\'s node kernels share the CUs'))
+                roofline.update(avg_launch_ms=round(reg, 4), achieved=round(nbytes / (reg * 1e-3) / 1e9, 1),
+                                frac=round(nbytes / (reg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), launches=len(times_region[name]))
                 roofline['share_of_step'] = round(sum(times_region[name]) / (dt * 1e3), 4)
             if skip_mode and drop_frac > 0:
                 roofline['droppath_skip'] = dict(kernels='forward+backward' if (skip_mode == '2' or proj_on) else 'forward',

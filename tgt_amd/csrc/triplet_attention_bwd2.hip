@@ -35,9 +35,20 @@ constexpr int kRow = 256;                  // bytes of one slab row (8 heads x 1
 constexpr int kSlab = 32 * kRow;           // 8 KB
 constexpr int kSet = 4 * kSlab;            // {Q | dO | K | V}
 constexpr int kXch = 2 * 2048;             // per wave: dS tile + A tile, each [2 key tiles][32 i][16 k] 16-bit
-constexpr int kOffXch = 2 * kSet;
-constexpr int kOffPart = kOffXch + HG * kXch;      // one dE / dG partial per thread
-constexpr int kLds = kOffPart + kThreads * 4;
+// LDS: NS slab sets | 8 exchange tiles | one dE / dG partial per thread.  NS = 2: slabs prefetched into registers and committed
+// by ds_write (one step ahead); NS = 3 (DMA): slabs land in LDS directly (buffer_load ... lds), two steps ahead.
+template <bool DMA> struct Lay {
+    static constexpr int kSets = DMA ? 3 : 2;
+    static constexpr int kOffXch = kSets * kSet;
+    static constexpr int kOffPart = kOffXch + HG * kXch;
+    static constexpr int kLds = kOffPart + kThreads * 4;
+};
+typedef __attribute__((address_space(3))) void lds_void;
+#if TGT_LD_AUX == 2
+#define TGT_BWD2_LD_POLICY " nt"           // the streaming-load policy of common.hpp, spelled for the inline-assembly loads
+#else
+#define TGT_BWD2_LD_POLICY ""
+#endif
 
 __device__ __forceinline__ int swz(int row) { return ((row & 7) << 1) | ((row >> 3) & 1); }
 // byte offset inside a slab of byte column `cb` of row `row`
@@ -76,9 +87,10 @@ __device__ __forceinline__ uint2 frag_half(const frag_t<T>& f, int h) {
 }
 
 // FL >= 0: BIASED / GATED compiled in (the training instantiation); FL < 0: read from the arguments
-template <typename T, bool CS, int FL>
+template <typename T, bool CS, int FL, bool DMA>
 __global__ void __launch_bounds__(kThreads, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) tri_att_bwd2_kernel(const tgt_triplet_attention_args a) {
     using F = frag_t<T>;
+    constexpr int kOffXch = Lay<DMA>::kOffXch, kOffPart = Lay<DMA>::kOffPart;
     using G = TriGeo<T, D, HG>;            // (third-arm staging only)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t sbase = (uint32_t)(uintptr_t)smem;
@@ -92,6 +104,11 @@ __global__ void __launch_bounds__(kThreads, 2) __attribute__((amdgpu_waves_per_e
     const bool biased = FL >= 0 ? (FL & TGT_TRI_BIASED) != 0 : ta.biased, gated = FL >= 0 ? (FL & TGT_TRI_GATED) != 0 : ta.gated;
     constexpr float kLog2e = 1.4426950408889634f;
     const float scale2 = a.scale * kLog2e;
+#ifdef TGT_PROBES
+    const int ablate = a._pad0;            // probe builds only (results are wrong): 1 no loads, 2 no stores, 4 no tile math
+#else
+    constexpr int ablate = 0;
+#endif
 
     const int64_t Nl = N;
     const int64_t ldq = a.ld_dqkv[c.dir] ? a.ld_dqkv[c.dir] : a.ld_qkv[c.dir];
@@ -108,22 +125,31 @@ __global__ void __launch_bounds__(kThreads, 2) __attribute__((amdgpu_waves_per_e
     const uint32_t oo = (uint32_t)(a.o_off[c.dir] * 2) + hch;
     // Q-type rows (i, j): row stride N*ld, j stride ld;  partner rows (j,k) inward / (k,j) outward
     const bool inward = c.dir == 0;
-    const uint32_t sQr = (uint32_t)N * lds_, sQj = lds_, sKr = inward ? lds_ : (uint32_t)N * lds_, sKj = inward ? (uint32_t)N * lds_ : lds_;
-    const uint32_t gQr = (uint32_t)N * ldg_, gQj = ldg_, gKr = inward ? ldg_ : (uint32_t)N * ldg_, gKj = inward ? (uint32_t)N * ldg_ : ldg_;
-    const uint32_t oQr = (uint32_t)N * ldo_, oQj = ldo_;
+#ifdef TGT_PROBES
+    const bool contig = (ablate & 8) != 0;       // probe: every slab = 32 CONSECUTIVE rows (wrong pairs; how much does the row stride cost?)
+#else
+    constexpr bool contig = false;
+#endif
+    const uint32_t sQr = contig ? lds_ : (uint32_t)N * lds_, sQj = contig ? (uint32_t)N * lds_ : lds_;
+    const uint32_t sKr = (inward || contig) ? lds_ : (uint32_t)N * lds_, sKj = (inward || contig) ? (uint32_t)N * lds_ : lds_;
+    const uint32_t gQr = contig ? ldg_ : (uint32_t)N * ldg_, gQj = contig ? (uint32_t)N * ldg_ : ldg_;
+    const uint32_t gKr = (inward || contig) ? ldg_ : (uint32_t)N * ldg_, gKj = (inward || contig) ? (uint32_t)N * ldg_ : ldg_;
+    const uint32_t oQr = contig ? ldo_ : (uint32_t)N * ldo_, oQj = contig ? (uint32_t)N * ldo_ : ldo_;
     ThirdArm dta = ta;
     dta.ld = lde;
 
-    // this thread's 16-byte chunk of every slab: row tid / 16, slot tid % 16; rows past N are out of range
+    // this thread's 16-byte chunk of every slab: row tid / 16, PHYSICAL slot tid % 16 of the LDS image (lane-linear inside a
+    // wave: what an LDS-DMA load writes), i.e. slot (tid % 16) ^ swz(row) of the row in memory; rows past N are out of range
     const int crow = tid >> 4, cslot = tid & 15;
+    const uint32_t lslot16 = (uint32_t)((cslot ^ swz(crow)) & 15) * 16u;
     const uint32_t kOOB = 0x80000000u;
     const bool rowok = crow < N;
-    const uint32_t vQ = rowok ? (uint32_t)crow * sQr + (uint32_t)cslot * 16u : kOOB;
-    const uint32_t vK = rowok ? (uint32_t)crow * sKr + (uint32_t)cslot * 16u : kOOB;
-    const uint32_t vO = rowok ? (uint32_t)crow * oQr + (uint32_t)cslot * 16u : kOOB;
-    const uint32_t wQ = rowok ? (uint32_t)crow * gQr + (uint32_t)cslot * 16u : kOOB;
-    const uint32_t wK = rowok ? (uint32_t)crow * gKr + (uint32_t)cslot * 16u : kOOB;
-    const int chunk = slab_off(crow, cslot * 16);
+    const uint32_t vQ = rowok ? (uint32_t)crow * sQr + lslot16 : kOOB;
+    const uint32_t vK = rowok ? (uint32_t)crow * sKr + lslot16 : kOOB;
+    const uint32_t vO = rowok ? (uint32_t)crow * oQr + lslot16 : kOOB;
+    const uint32_t wQ = rowok ? (uint32_t)crow * gQr + lslot16 : kOOB;
+    const uint32_t wK = rowok ? (uint32_t)crow * gKr + lslot16 : kOOB;
+    const int chunk = crow * kRow + cslot * 16;
 
     float* part = reinterpret_cast<float*>(smem + kOffPart);
 
@@ -206,7 +232,7 @@ __global__ void __launch_bounds__(kThreads, 2) __attribute__((amdgpu_waves_per_e
     }
 
     auto issue = [&](u32x4_t (&pre)[4], int jj) {
-        const bool live = jj < N;                                       // (scalar: past the end every load is out of range)
+        const bool live = jj < N && !(ablate & 1);                      // (scalar: past the end every load is out of range)
         const __amdgpu_buffer_rsrc_t rs = live ? r_src : r_src0, ro = live ? r_do : r_do0;
         pre[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)vQ, (int)(qo + (uint32_t)jj * sQj), TGT_LD_AUX);
         pre[1] = __builtin_amdgcn_raw_buffer_load_b128(ro, (int)vO, (int)(oo + (uint32_t)jj * oQj), TGT_LD_AUX);
@@ -218,28 +244,73 @@ __global__ void __launch_bounds__(kThreads, 2) __attribute__((amdgpu_waves_per_e
 #pragma unroll
         for (int t = 0; t < 4; ++t) *reinterpret_cast<u32x4_t*>(s + t * kSlab) = pre[t];
     };
-
-    u32x4_t pre[4];
-    issue(pre, 0);
-    commit(pre, 0);
-    issue(pre, 1);
-    {   // three dropped (out-of-range) stores: the loop is entered with the queue it has on its back edge -- 4 loads, then 3
-        // stores -- so the waits of the commit are exact counts on both paths instead of vmcnt(0)
+    // DMA: the four slabs of step jj straight into set `set` (each wave: its 4 rows x 256 B of every slab, lane-linear).
+    // Inline assembly on purpose: hipcc orders every later LDS read behind a builtin LDS-DMA load with s_waitcnt vmcnt(0)
+    // (it cannot tell the sets apart), which would serialise the walk; the waits are placed by hand at the barrier instead.
+    // (s_nop: one wait state between a SALU write of M0 and the LDS-DMA that uses it.)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const uint64_t src_base = (uint64_t)(uintptr_t)a.qkv[c.dir] + (uint64_t)c.b * (uint64_t)(Nl * Nl * a.ld_qkv[c.dir] * 2);
+    const uint64_t do_base = (uint64_t)(uintptr_t)a.d_out + (uint64_t)c.b * (uint64_t)(Nl * Nl * a.ld_out * 2);
+    const uint32_t src_bytes = (uint32_t)(Nl * Nl * a.ld_qkv[c.dir] * 2), do_bytes = (uint32_t)(Nl * Nl * a.ld_out * 2);
+    auto dma = [&](int jj, int set) {
+        const bool live = jj < N && !(ablate & 1);                      // (scalar: past the end every load is out of range)
+        const u32x4_t rs = {(uint32_t)src_base, (uint32_t)(src_base >> 32) & 0xffffu, live ? src_bytes : 0u, 0x00020000u};
+        const u32x4_t ro = {(uint32_t)do_base, (uint32_t)(do_base >> 32) & 0xffffu, live ? do_bytes : 0u, 0x00020000u};
+        const uint32_t l0 = sbase + (uint32_t)(set * kSet + wave_u * 1024);
+#define TGT_DMA16(LDSADDR, VOFF, RSRC, SOFF)                                                                                   \
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen" TGT_BWD2_LD_POLICY " lds"                                  \
+                     :: "s"(LDSADDR), "v"(VOFF), "s"(RSRC), "s"(SOFF) : "memory")      /* (M0 is not live across statements in this kernel: no other LDS-DMA, movrel or GDS use) */
+        TGT_DMA16(l0, vQ, rs, qo + (uint32_t)jj * sQj);
+        TGT_DMA16(l0 + kSlab, vO, ro, oo + (uint32_t)jj * oQj);
+        TGT_DMA16(l0 + 2 * kSlab, vK, rs, ko + (uint32_t)jj * sKj);
+        TGT_DMA16(l0 + 3 * kSlab, vK, rs, vo + (uint32_t)jj * sKj);
+#undef TGT_DMA16
+    };
+    auto dummy_stores = [&]() {
+        // three dropped (out-of-range) stores: the loop is entered with the queue it has on its back edge -- 4 loads, then 3
+        // stores -- so the waits of the walk are exact counts on both paths
         const u32x4_t z = {0, 0, 0, 0};
 #pragma unroll
         for (int t = 0; t < 3; ++t) __builtin_amdgcn_raw_buffer_store_b128(z, r_grd, (int)kOOB, 16 * t, TGT_ST_AUX);     // (distinct, or hipcc folds them)
-    }
-    __syncthreads();
+    };
 
+    u32x4_t pre[4];
+    if constexpr (DMA) {
+        // rows past N are never written by the loads (out of range) and stay zero through the walk (their results are zeros)
+        if (N < 32) {
+            const u32x4_t z = {0, 0, 0, 0};
+            for (int o = tid * 16; o < 3 * kSet; o += kThreads * 16) *reinterpret_cast<u32x4_t*>(smem + o) = z;
+            __syncthreads();
+        }
+        dma(0, 0);
+        dma(1, 1);
+        dummy_stores();
+        // the queue is: loads(0) x4, loads(1) x4, 3 stores
+        asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
+        issue(pre, 0);
+        commit(pre, 0);
+        issue(pre, 1);
+        dummy_stores();
+        __syncthreads();
+    }
+
+    int cur = 0;
     for (int j = 0; j < N; ++j) {
-        const int cur = j & 1;
-        // Hazards (one barrier per j, as in the old kernel): set cur^1 holds the results of step j-1; this thread read its
-        // own chunk of them for the stores at the end of step j-1 and now overwrites that same chunk.
-        commit(pre, cur ^ 1);
-        issue(pre, j + 2);
+        if constexpr (DMA) {
+            // set of step j + 2 = set of step j - 1: every wave finished reading it before the last barrier, and this thread's
+            // loads write the chunks this thread itself read for the stores of step j - 1
+            dma(j + 2, cur == 0 ? 2 : cur - 1);
+        } else {
+            // Hazards (one barrier per j, as in the old kernel): set cur^1 holds the results of step j-1; this thread read its
+            // own chunk of them for the stores at the end of step j-1 and now overwrites that same chunk.
+            commit(pre, cur ^ 1);
+            issue(pre, j + 2);
+        }
 
         const uint32_t sQ = sbase + (uint32_t)(cur * kSet), sO = sQ + kSlab, sK = sQ + 2 * kSlab, sV = sQ + 3 * kSlab;
         char* const gQs = smem + cur * kSet;
+        if (!(ablate & 4)) {
         const F fq = load_frag<T>(reinterpret_cast<const T*>(gQs + a_frag));
         const F fo = load_frag<T>(reinterpret_cast<const T*>(gQs + kSlab + a_frag));
         const F fk = load_frag<T>(reinterpret_cast<const T*>(gQs + 2 * kSlab + a_frag));
@@ -353,8 +424,14 @@ __global__ void __launch_bounds__(kThreads, 2) __attribute__((amdgpu_waves_per_e
                 csv[k] += f32x2{dv[0][2 * k], dv[0][2 * k + 1]} + f32x2{dv[1][2 * k], dv[1][2 * k + 1]};
             }
         }
-        __syncthreads();
-        {
+        }
+        if constexpr (DMA) {
+            // queue: loads(j+1) x4, stores(j-1) x3, loads(j+2) x4 -- the slabs of step j + 1 have landed for every wave behind this
+            asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else {
+            __syncthreads();
+        }
+        if (!(ablate & 2)) {
             const char* sres = smem + cur * kSet + chunk;
             const u32x4_t o0 = *reinterpret_cast<const u32x4_t*>(sres);
             const u32x4_t o2 = *reinterpret_cast<const u32x4_t*>(sres + 2 * kSlab);
@@ -362,8 +439,12 @@ __global__ void __launch_bounds__(kThreads, 2) __attribute__((amdgpu_waves_per_e
             __builtin_amdgcn_raw_buffer_store_b128(o0, r_grd, (int)wQ, (int)(qo + (uint32_t)j * gQj), TGT_ST_AUX);
             __builtin_amdgcn_raw_buffer_store_b128(o2, r_grd, (int)wK, (int)(ko + (uint32_t)j * gKj), TGT_ST_AUX);
             __builtin_amdgcn_raw_buffer_store_b128(o3, r_grd, (int)wK, (int)(vo + (uint32_t)j * gKj), TGT_ST_AUX);
+        } else if constexpr (DMA) {
+            dummy_stores();             // (probe builds: keep the queue shape the wait counts assume)
         }
+        if constexpr (DMA) cur = cur == 2 ? 0 : cur + 1; else cur ^= 1;
     }
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the out-of-range loads past the end of the walk)
     __syncthreads();
     // third-arm gradients (summed over j in registers) leave through LDS
     {
@@ -415,11 +496,27 @@ __global__ void __launch_bounds__(kThreads, 2) __attribute__((amdgpu_waves_per_e
 }
 
 template <typename T, bool CS, int FL>
-static int launch_one(const tgt_triplet_attention_args& a, hipStream_t st) {
-    static bool attr_set[16] = {};
-    if (!dyn_lds_once(attr_set, reinterpret_cast<const void*>(&tri_att_bwd2_kernel<T, CS, FL>), kLds))
-        return set_error(TGT_ERR_LAUNCH, "tri_att_bwd2_kernel: cannot reserve %d bytes of LDS", kLds);
-    hipLaunchKernelGGL((tri_att_bwd2_kernel<T, CS, FL>), dim3(a.B * 2 * (a.H / HG)), dim3(kThreads), kLds, st, a);
+static int launch_one(const tgt_triplet_attention_args& a_in, hipStream_t st) {
+#ifdef TGT_PROBES
+    tgt_triplet_attention_args a = a_in;
+    a._pad0 = getenv("TGT_TRI_BWD_ABLATE") ? atoi(getenv("TGT_TRI_BWD_ABLATE")) : 0;
+#else
+    const tgt_triplet_attention_args& a = a_in;
+#endif
+    static const bool dma = !(getenv("TGT_TRI_BWD2_DMA") && atoi(getenv("TGT_TRI_BWD2_DMA")) == 0);       // A/B knob
+    if (dma) {
+        static bool attr_set[16] = {};
+        constexpr int kLds = Lay<true>::kLds;
+        if (!dyn_lds_once(attr_set, reinterpret_cast<const void*>(&tri_att_bwd2_kernel<T, CS, FL, true>), kLds))
+            return set_error(TGT_ERR_LAUNCH, "tri_att_bwd2_kernel: cannot reserve %d bytes of LDS", kLds);
+        hipLaunchKernelGGL((tri_att_bwd2_kernel<T, CS, FL, true>), dim3(a.B * 2 * (a.H / HG)), dim3(kThreads), kLds, st, a);
+    } else {
+        static bool attr_set[16] = {};
+        constexpr int kLds = Lay<false>::kLds;
+        if (!dyn_lds_once(attr_set, reinterpret_cast<const void*>(&tri_att_bwd2_kernel<T, CS, FL, false>), kLds))
+            return set_error(TGT_ERR_LAUNCH, "tri_att_bwd2_kernel: cannot reserve %d bytes of LDS", kLds);
+        hipLaunchKernelGGL((tri_att_bwd2_kernel<T, CS, FL, false>), dim3(a.B * 2 * (a.H / HG)), dim3(kThreads), kLds, st, a);
+    }
     return check_launch("tri_att_bwd2_kernel");
 }
 template <typename T>
