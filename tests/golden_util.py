@@ -178,6 +178,19 @@ FULL_AT_CFG = dict(model_height=24, layer_multiplier=1, upto_hop=32, embed_3d_ty
                    node_act_dropout=0, edge_act_dropout=0)
 
 
+# BASELINE config 1: TGT-Agx2 12 shared layers x 2 distance predictor at full width (reference configs/pcqm/tgt_agx2_100m/dist_pred/
+# tgt_agx2_dp_nordkit.yaml: coords_input none, 256 bins, aggregate triplets) on an 8-graph ragged mini-batch, N <= 32
+FULL_AGX2_CFG = dict(model_height=12, layer_multiplier=2, upto_hop=32, embed_3d_type='none',
+                     num_3d_kernels=128, num_dist_bins=256, node_width=768, edge_width=256,
+                     num_heads=64, activation='gelu', scale_degree=True, triplet_heads=16,
+                     triplet_type='aggregate', triplet_dropout=0, node_ffn_multiplier=1.,
+                     edge_ffn_multiplier=1., source_dropout=0, drop_path=0,
+                     node_act_dropout=0, edge_act_dropout=0)
+FULL_AGX2_GEOM = dict(B=8, N=32, num_nodes=[32, 29, 27, 24, 21, 18, 14, 9])
+# the BASELINE config-2 architecture at the benchmark's node count: TGT-At 24L, B = 2, N = 32 (one ragged graph)
+FULL_AT_N32_GEOM = dict(B=2, N=32, num_nodes=[32, 27])
+
+
 def model_batch(geom, seed):
     """Synthetic batch + the two keys the scheme adds on device
     (reference lib/training_schemes/pcqm/pretrain/scheme.py:60-76), without

@@ -588,16 +588,60 @@ def test_layernorm_backward_fused_into_the_consumer_dgrad(producer, consumer, dt
         assert bool(torch.isfinite(a.float()).all()), name
 
 
-def test_lazy_dgrad_token_is_loud_when_misused():
-    """the token a consumer returns instead of dx reads as NaN everywhere: a consumer that treated it as a real gradient cannot go
-    unnoticed; writing into it is refused"""
+def test_lazy_dgrad_token_carries_its_product():
+    """the token a consumer returns instead of dx is a zero scalar expanded to the gradient's shape (no memory) that carries
+    (dz, W); materialising it gives the product; writing into it is refused"""
     dz, w = torch.randn(64, 128, device='cuda', dtype=torch.bfloat16), torch.randn(128, 256, device='cuda', dtype=torch.bfloat16)
     tok = ops._lazy_dgrad(dz, w, (4, 16, 256))
-    assert tok.shape == (4, 16, 256) and bool(torch.isnan(tok.float()).all())
+    assert tok.shape == (4, 16, 256) and tok.stride() == (0, 0, 0) and float(tok.float().abs().max()) == 0.0
     got = ops._materialize_dgrad(tok)
     assert rel(got.view(64, 256), dz.double() @ w.double()) < TOL[torch.bfloat16]
     plain = torch.randn(4, 16, 256, device='cuda')
     assert ops._materialize_dgrad(plain) is plain and ops._take_lazy_dgrad(plain) is None
+
+
+@pytest.mark.parametrize('consumers', ['one', 'two_linears', 'linear_and_other', 'retain_grad'])
+def test_lazy_dgrad_handover_is_safe_for_any_use_of_the_layernorm_output(consumers, monkeypatch):
+    """the LayerNorm entry offers the lazy data gradient on EVERY output y; a y with two consumers (two
+    Linears, a Linear and something else), retain_grad or another hook must still get the complete gradient.  Every variant
+    against the same graph with the hand-over switched off (TGT_EPI_LN_BWD=0 path), gradient by gradient."""
+    monkeypatch.setattr(ops, '_EDGE_MIN_ROWS', 1)
+    B, N, C = 3, 9, 256
+    dt = torch.bfloat16
+    g = torch.Generator(device='cuda').manual_seed(23)
+    mk = lambda *shape, scale=1.0: torch.randn(*shape, device='cuda', generator=g) * scale
+    x0, res0 = mk(B, N, N, C).to(dt), mk(B, N, N, C).to(dt)
+    lw0, lb0 = torch.rand(C, device='cuda', generator=g) + 0.5, mk(C, scale=0.2)
+    w10, b10, w20, b20 = mk(C, C, scale=C ** -0.5), mk(C, scale=0.1), mk(128, C, scale=C ** -0.5), mk(128, scale=0.1)
+    go1, go2, gs = mk(B, N, N, C).to(dt), mk(B, N, N, 128).to(dt), mk(B, N, N, C).to(dt)
+    outs = []
+    for lazy in (True, False):
+        monkeypatch.setattr(ops, '_EPI_LN_BWD', lazy)
+        ops._lazy_dgrads[:] = [0, 0, 0]
+        leaves = [t.clone().requires_grad_(True) for t in (x0, res0, lw0, lb0, w10, b10, w20, b20)]
+        x, res, lw, lb, w1, b1, w2, b2 = leaves
+        with torch.autocast('cuda', dtype=dt):
+            s, y = ops.add_layer_norm(x, res, None, lw, lb)
+            if consumers == 'retain_grad':
+                y.retain_grad()
+            loss = (ops.linear(y, w1, b1).float() * go1.float()).sum() + (s.float() * gs.float()).sum()
+            if consumers == 'two_linears':
+                loss = loss + (ops.linear(y, w2, b2).float() * go2.float()).sum()
+            elif consumers == 'linear_and_other':
+                loss = loss + (y.float() ** 2).sum() * 0.01
+        loss.backward()
+        if lazy:
+            assert ops._lazy_dgrads[0] >= 1                                  # the Linear(s) did hand over
+            if consumers == 'one':
+                assert ops._lazy_dgrads[1] == 1 and ops._lazy_dgrads[2] == 0       # ... and the entry fused the only token
+            if consumers in ('two_linears', 'linear_and_other'):
+                assert ops._lazy_dgrads[1] == 0 and ops._lazy_dgrads[2] >= 1       # ... or the hook completed the gradient
+        grads = [t.grad for t in leaves if t.grad is not None]
+        assert all(bool(torch.isfinite(t.float()).all()) for t in grads)
+        outs.append(grads + ([y.grad] if consumers == 'retain_grad' else []))
+    assert len(outs[0]) == len(outs[1])
+    for a, b_ in zip(*outs):
+        assert rel(a, b_) < 2 * TOL[dt], (consumers, rel(a, b_))
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])

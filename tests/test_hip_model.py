@@ -151,6 +151,82 @@ def test_full_width_24L_forward_vs_reference_golden():
     assert np.abs(gap16.double().cpu().numpy() - z['gap::full']).max() < 5e-2
 
 
+def _sampled_ok(t, z, key, tol):
+    """t against the golden's samples + norm of `key` (rel-L2 on the samples, relative norm)"""
+    flat = t.detach().double().cpu().numpy().reshape(-1)
+    if key + '::full' in z.files:
+        ref = z[key + '::full'].reshape(-1)
+        return np.linalg.norm(flat - ref) <= tol * max(np.linalg.norm(ref), 1e-30), (key, np.linalg.norm(flat - ref), np.linalg.norm(ref))
+    ref_s = z[key + '::samples']
+    s = flat[gu.sample_index(flat.size)]
+    ok = np.linalg.norm(s - ref_s) <= tol * np.linalg.norm(ref_s) and abs(np.linalg.norm(flat) - float(z[key + '::norm'])) <= tol * float(z[key + '::norm'])
+    return ok, (key, np.linalg.norm(s - ref_s) / np.linalg.norm(ref_s))
+
+
+def test_full_width_agx2_12x2_forward_vs_reference_golden():
+    """BASELINE config 1 exactly: TGT-Agx2 12 shared layers x 2 distance predictor at full width on the 8-graph ragged
+    mini-batch (N <= 32), eval forward, against the reference's fp32 CPU forward (lib/models/pcqm/distance_predictor.py:9-55);
+    fp32, and bf16 / fp16 autocast within the stated 24L tolerance (3e-2 rel-L2 on the logits)."""
+    from tgt_amd.pcqm import TGT_Distance
+    model = gu.fill_params(TGT_Distance(**gu.FULL_AGX2_CFG), seed=920).cuda().eval()
+    batch = {k: v.cuda() for k, v in gu.model_batch(gu.FULL_AGX2_GEOM, seed=921).items()}
+    z = np.load(os.path.join(gu.GOLDEN_DIR, 'model_full_agx2_12x2_fp32.npz'))
+    with torch.no_grad():
+        logits = model(batch)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            l_bf = model(batch)
+        with torch.autocast('cuda', dtype=torch.float16):
+            l_fp = model(batch)
+    ok, info = _sampled_ok(logits, z, 'logits', 2e-3)
+    assert ok, info
+    valid = (batch['edge_mask'] > 0).cpu().numpy()
+    agree = (logits.argmax(-1).cpu().numpy() == z['logits_argmax::full'])[valid].mean()
+    assert agree > 0.99, agree
+    for name, l16 in (('bf16', l_bf), ('fp16', l_fp)):
+        ok, info = _sampled_ok(l16, z, 'logits', 3e-2)
+        assert ok, (name, info)
+
+
+def test_full_width_24L_n32_vs_reference_golden():
+    """TGT-At 24L at BASELINE widths AND the benchmark's node count (B = 2, N = 32, one ragged graph): the kernels the bench
+    line runs (projection-fused triplet forward, the round-4 backward, the fused edge Linears) against the REFERENCE's fp32
+    run -- eval forward, then loss and parameter gradients in train mode with every dropout off (fp32 and bf16 autocast)."""
+    from tgt_amd.pcqm import TGT_Multi
+    from tgt_amd.training.step import pretrain_loss, StepConfig
+    z = np.load(os.path.join(gu.GOLDEN_DIR, 'model_full_at_24L_n32_fp32.npz'))
+    batch = {k: v.cuda() for k, v in gu.model_batch(gu.FULL_AT_N32_GEOM, seed=931).items()}
+    model = gu.fill_params(TGT_Multi(**gu.FULL_AT_CFG), seed=930).cuda().eval()
+    with torch.no_grad():
+        gap, logits = model(batch)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            gap16, logits16 = model(batch)
+    ok, info = _sampled_ok(logits, z, 'logits', 2e-3)
+    assert ok, info
+    assert np.abs(gap.double().cpu().numpy() - z['gap::full']).max() < 1e-3
+    valid = (batch['edge_mask'] > 0).cpu().numpy()
+    assert (logits.argmax(-1).cpu().numpy() == z['logits_argmax::full'])[valid].mean() > 0.99
+    ok, info = _sampled_ok(logits16, z, 'logits', 3e-2)
+    assert ok, info
+    assert np.abs(gap16.double().cpu().numpy() - z['gap::full']).max() < 5e-2
+    del model
+    cfg = StepConfig(num_dist_bins=512, mixed_precision=None)
+    loss_ref = float(z['loss::full'])
+    drift = gu.bf16_drift('full_at_24L')       # the reference's own bf16-autocast drift (B = 2, N = 12 case): the anchor of the bf16 tolerances
+    for mode, tol_loss, tol_grad in (('fp32', 2e-5, 5e-3), ('bf16', 1e-3, None)):
+        model = gu.fill_params(TGT_Multi(**gu.FULL_AT_CFG), seed=930).cuda().train()
+        ctx = torch.autocast('cuda', dtype=torch.bfloat16) if mode == 'bf16' else torch.autocast('cuda', enabled=False)
+        with ctx:
+            loss = pretrain_loss(model(batch), batch, cfg)
+        loss.backward()
+        assert abs(float(loss.detach()) - loss_ref) < tol_loss * abs(loss_ref), (mode, float(loss.detach()), loss_ref)
+        pm = dict(model.named_parameters())
+        for k in gu.FULL_GRAD_KEYS:
+            tol = tol_grad if tol_grad is not None else 2.0 * drift['pgrad.' + k]
+            ok, info = _sampled_ok(pm[k].grad, z, 'pgrad.' + k, tol)
+            assert ok, (mode, info, tol)
+        del model
+
+
 def test_state_dict_roundtrip_with_oracle():
     """A checkpoint written by the reference-schema model loads strictly."""
     from tgt_amd.pcqm import TGT_Multi

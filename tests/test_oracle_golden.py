@@ -103,6 +103,41 @@ def test_full_width_24L_fp32_forward():
     assert agree > 0.995
 
 
+def test_full_width_agx2_12x2_fp32_forward():
+    """BASELINE config 1 exactly: TGT-Agx2 12 shared layers x 2 distance predictor, full width, the 8-graph ragged mini-batch
+    (reference lib/models/pcqm/distance_predictor.py:9-55)."""
+    model = gu.fill_params(om.TGT_Distance(**gu.FULL_AGX2_CFG), seed=920).eval()
+    batch = gu.model_batch(gu.FULL_AGX2_GEOM, seed=921)
+    with torch.no_grad():
+        logits = model(batch)
+    gold = load('model_full_agx2_12x2_fp32')
+    check(logits, gold['logits'], 1e-3, 'logits')
+    assert (logits.argmax(-1).numpy() == gold['logits_argmax']['full']).mean() > 0.995
+
+
+def test_full_width_24L_n32_fp32_forward_and_gradients():
+    """TGT-At 24L at BASELINE widths and the benchmark's node count (B = 2, N = 32): eval forward, then loss and parameter
+    gradients in train mode with the dropouts off -- the oracle in fp32 against the reference's fp32 run."""
+    gold = load('model_full_at_24L_n32_fp32')
+    model = gu.fill_params(om.TGT_Multi(**gu.FULL_AT_CFG), seed=930)
+    batch = gu.model_batch(gu.FULL_AT_N32_GEOM, seed=931)
+    model.eval()
+    with torch.no_grad():
+        gap, logits = model(batch)
+    check(gap, gold['gap'], 1e-4, 'gap')
+    check(logits, gold['logits'], 1e-3, 'logits')
+    assert (logits.argmax(-1).numpy() == gold['logits_argmax']['full']).mean() > 0.995
+    model.train()
+    g, l = model(batch)
+    loss = torch.nn.functional.l1_loss(g, batch['target']) + 0.1 * core.binned_distance_xent(
+        l, core.pairwise_dist(batch['dft_coords']), batch['edge_mask'], 512, 8)
+    loss.backward()
+    check(loss, gold['loss'], 1e-5, 'loss')
+    named = dict(model.named_parameters())
+    for k in gu.FULL_GRAD_KEYS:
+        check(named[k].grad, gold['pgrad.' + k], 5e-3, k)
+
+
 def test_state_dict_manifest_matches_reference():
     gold = load('misc')
     sd = om.TGT_Multi(**gu.FULL_AT_CFG).state_dict()

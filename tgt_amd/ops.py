@@ -979,38 +979,73 @@ def _take_colsum(grad, C_):
 
 # LayerNorm backward as the epilogue of the data-gradient GEMM that produces its dy (tgt_edge_linear, TGT_EPI_LN_BWD): the Linear
 # that consumes a LayerNorm output does NOT compute dx = dz W in its backward when the LayerNorm entry that produced its input
-# has said it will (`_tgt_lazy_ok` on the forward tensor): it returns a TOKEN -- a NaN scalar expanded to the gradient's shape (no
-# memory; anything that consumed it as a real gradient would turn into NaNs, loudly) carrying (dz, W) -- and the entry's backward
-# runs GEMM + LayerNorm backward + stream-gradient add + dgamma / dbeta / bias-gradient sums as ONE launch: the 134 MB dy is neither
-# written nor read back (0.126 ms against 0.060 + 0.135 at the BASELINE shape).  Same object-identity hand-over as _hand_colsum.
+# has said it will (`_tgt_lazy_ok` on the forward tensor): it returns a TOKEN -- a ZERO scalar expanded to the gradient's shape (no
+# memory) carrying (dz, W) -- and the entry's backward runs GEMM + LayerNorm backward + stream-gradient add + dgamma / dbeta /
+# bias-gradient sums as ONE launch: the 134 MB dy is neither written nor read back (0.126 ms against 0.060 + 0.135 at the BASELINE
+# shape).  Same object-identity hand-over as _hand_colsum.
+# The hand-over is safe for ANY use of y (round 4; the round-3 token was a NaN that a second consumer of y turned into a silent NaN
+# gradient): the entry hangs a tensor hook on y (_LazyRec.hook) that sees the ACCUMULATED gradient of y before the entry's
+# backward does.  One consumer, token untouched: it passes, and the entry fuses the product.  Anything else -- two Linears on the same
+# y, a second non-lazy consumer, retain_grad, another hook -- and autograd has summed the (zero) tokens with whatever real gradients
+# there were: the hook adds the products the tokens stand for, so the entry receives the complete gradient (unfused, correct).
 _EPI_LN_BWD = os.environ.get('TGT_EPI_LN_BWD', '1') != '0'           # A/B knob
-_nan_scalars = {}
-_lazy_dgrads = [0, 0]              # [offered, fused]  (tests / diagnostics)
+_zero_scalars = {}
+_lazy_dgrads = [0, 0, 0]           # [offered, fused, materialized by the hook]  (tests / diagnostics)
+
+
+class _LazyRec:
+    """the tokens issued against one LayerNorm output y during a backward pass"""
+    __slots__ = ('issued',)
+
+    def __init__(self):
+        self.issued = []
+
+    def hook(self, grad):
+        issued, self.issued = self.issued, []
+        if not issued:
+            return None
+        if len(issued) == 1 and grad is issued[0] and _take_lazy_dgrad(grad) is not None:
+            return None                         # the untouched token of the only consumer: the entry's backward fuses it
+        total = grad
+        for tok in issued:
+            dz2, w, _ = tok._tgt_lazy
+            prod = (dz2 @ w).view(grad.shape).to(grad.dtype)
+            total = prod if total is None else total + prod
+        _lazy_dgrads[2] += len(issued)
+        return total
 
 
 def _lazy_ok(x, weight, cd):
-    """forward-time decision of a Linear: may its backward leave dx to the LayerNorm entry that produced x?"""
-    return (_EPI_LN_BWD and getattr(x, '_tgt_lazy_ok', False) and x.is_cuda and cd in (torch.bfloat16, torch.float16) and
+    """forward-time decision of a Linear: may its backward leave dx to the LayerNorm entry that produced x?  Returns the entry's
+    _LazyRec (the backward issues its token against it) or False."""
+    rec = getattr(x, '_tgt_lazy_ok', None)
+    if (_EPI_LN_BWD and rec is not None and x.is_cuda and cd in (torch.bfloat16, torch.float16) and
             x.dtype == cd and weight.shape[1] == 256 and weight.shape[0] in (64, 128, 256) and
-            x.numel() // 256 >= _EDGE_MIN_ROWS)
+            x.numel() // 256 >= _EDGE_MIN_ROWS):
+        return rec
+    return False
 
 
-def _lazy_dgrad(dz2, w, shape):
-    """the un-computed gradient dz2 @ w of `shape` (see above)"""
+def _lazy_dgrad(dz2, w, shape, rec=None):
+    """the un-computed gradient dz2 @ w of `shape` (see above); rec: the _LazyRec of the tensor it is the gradient of"""
     key = (dz2.device, dz2.dtype)
-    nan = _nan_scalars.get(key)
-    if nan is None:
-        nan = _nan_scalars[key] = torch.full((), float('nan'), dtype=dz2.dtype, device=dz2.device)
-    token = nan.expand(shape)
+    zero = _zero_scalars.get(key)
+    if zero is None:
+        zero = _zero_scalars[key] = torch.zeros((), dtype=dz2.dtype, device=dz2.device)
+    token = zero.expand(shape)
     token._tgt_lazy = (dz2, w, token._version)
+    if rec is not None:
+        rec.issued.append(token)
     _lazy_dgrads[0] += 1
     return token
 
 
 def _offer_lazy(s, y):
     """(s, y) of a residual + LayerNorm entry, y marked: this entry's backward accepts a lazy data gradient for y (_ln_backward)"""
-    if _EPI_LN_BWD and y.is_cuda and y.shape[-1] == 256 and y.dtype == s.dtype and y.dtype in (torch.bfloat16, torch.float16):
-        y._tgt_lazy_ok = True
+    if _EPI_LN_BWD and y.is_cuda and y.requires_grad and y.shape[-1] == 256 and y.dtype == s.dtype and y.dtype in (torch.bfloat16, torch.float16):
+        rec = _LazyRec()
+        y._tgt_lazy_ok = rec
+        y.register_hook(rec.hook)
     return s, y
 
 
@@ -1283,7 +1318,7 @@ def _linear_backward(x2, w, dy2, xs, xdt, wdt, bdt, need_dx, need_dw, need_db, l
     if need_dx:
         # lazy_dx: the LayerNorm entry that produced x runs this GEMM itself, fused with its own backward (_lazy_dgrad)
         if lazy_dx and xdt == dy2.dtype:
-            dx = _lazy_dgrad(dy2.contiguous(), w, xs)
+            dx = _lazy_dgrad(dy2.contiguous(), w, xs, lazy_dx if isinstance(lazy_dx, _LazyRec) else None)
         elif _EDGE_N512 and _edge_kernel_ok(dy2, w.shape[1], dy2.dtype) and \
                 ((w.shape[0] == 256 and w.shape[1] == 512) or w.shape[1] <= 128):
             # data gradients the weight-resident kernels win: lin_O's (256 -> 512 channels: 3 E at ~5 TB/s, library 3.5) on

@@ -124,6 +124,51 @@ def full_width_case():
     save('model_full_at_24L_fp32', out)
 
 
+def sampled(prefix, t, full=False):
+    return {f'{prefix}::{kk}': a for kk, a in gu.summarize(t, full).items()}
+
+
+def full_agx2_case():
+    """BASELINE config 1: TGT-Agx2 12L x 2 distance predictor at full width (lib/models/pcqm/distance_predictor.py:9-55), fp32
+    eval forward on the 8-graph ragged mini-batch; sampled logits + every argmax bin."""
+    torch.manual_seed(0)
+    model = gu.fill_params(TGT_Distance(**gu.FULL_AGX2_CFG), seed=920).eval()
+    batch = gu.model_batch(gu.FULL_AGX2_GEOM, seed=921)
+    t0 = time.time()
+    with torch.no_grad():
+        logits = model(batch)
+    print(f'full_agx2 fwd {time.time()-t0:.1f}s logits {tuple(logits.shape)}')
+    out = sampled('logits', logits)
+    out['logits_argmax::full'] = logits.argmax(-1).numpy().astype(np.int16)
+    save('model_full_agx2_12x2_fp32', out)
+
+
+def full_at_n32_case():
+    """TGT-At 24L at BASELINE widths AND the benchmark's node count (B = 2, N = 32, one ragged graph), fp32: eval forward,
+    then train mode with every dropout off: pretrain loss and the gradients of gu.FULL_GRAD_KEYS."""
+    torch.manual_seed(0)
+    model = gu.fill_params(TGT_Multi(**gu.FULL_AT_CFG), seed=930)
+    batch = gu.model_batch(gu.FULL_AT_N32_GEOM, seed=931)
+    model.eval()
+    t0 = time.time()
+    with torch.no_grad():
+        gap, logits = model(batch)
+    out = sampled('gap', gap, True)
+    out.update(sampled('logits', logits))
+    out['logits_argmax::full'] = logits.argmax(-1).numpy().astype(np.int16)
+    model.train()
+    outs = model(batch)
+    loss = pretrain_loss(outs, batch, gu.FULL_AT_CFG['num_dist_bins'])
+    loss.backward()
+    print(f'full_at_24L_n32 fwd+fwd/bwd {time.time()-t0:.1f}s loss={float(loss):.6f} dtype={loss.dtype}')
+    out.update(sampled('loss', loss.detach(), True))
+    named = dict(model.named_parameters())
+    for k in gu.FULL_GRAD_KEYS:
+        g = named[k].grad
+        out.update(sampled('pgrad.' + k, g, g.numel() <= 4096))
+    save('model_full_at_24L_n32_fp32', out)
+
+
 def misc_cases():
     rng = np.random.default_rng(4242)
     coords = torch.from_numpy(rng.standard_normal((2, 5, 3)).astype(np.float32))
@@ -279,7 +324,7 @@ def bf16_drift_cases():
 
 
 if __name__ == '__main__':
-    which = sys.argv[2:] or ['op', 'model', 'misc', 'full', 'drift', 'predict']
+    which = sys.argv[2:] or ['op', 'model', 'misc', 'full', 'full_agx2', 'full_n32', 'drift', 'predict']
     if 'op' in which:
         op_cases()
     if 'model' in which:
@@ -288,6 +333,10 @@ if __name__ == '__main__':
         misc_cases()
     if 'full' in which:
         full_width_case()
+    if 'full_agx2' in which:
+        full_agx2_case()
+    if 'full_n32' in which:
+        full_at_n32_case()
     if 'drift' in which:
         bf16_drift_cases()
     if 'predict' in which:
