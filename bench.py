@@ -291,13 +291,19 @@ def main():
     prof = ops.profile_kernels(True)
     fence()
     ms0 = torch.cuda.memory_stats(dev)
+    # one event per step on the step's stream (GPU-side step boundaries: the spread of the steps, e.g. one stalled by a
+    # synchronous device allocation, shows in step_ms below; `value` stays the wall time of the whole region)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         _, loss = step(args.warmup + i)
+        marks[i + 1].record()
         if args.sync_every and (i + 1) % args.sync_every == 0:
             trainer.mean_loss()                      # host read of the control block: synchronises this rank
     fence()
     dt = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     ms1 = torch.cuda.memory_stats(dev)
     ops.profile_kernels(False)
     # Kernel durations for `roofline`: inside the timed region the node channel runs on a second HIP stream and its kernels share
@@ -436,6 +442,8 @@ def main():
                         parallelism=f'dp{world}', precision=f'{args.precision} autocast, fp32 params/Adam',
                         **({'host_loss_read_every': args.sync_every} if args.sync_every else {})),
             final_loss=round(loss_val, 5),
+            step_ms=dict(min=round(step_ms[0], 3), median=round(step_ms[len(step_ms) // 2], 3), max=round(step_ms[-1], 3),
+                         note='GPU-side duration of each timed step (events on the step stream)'),
             roofline=roofline,
             # the caching allocator inside the timed region: device allocations / frees there are synchronous driver calls
             memory=dict(reserved_GB=round(ms1.get('reserved_bytes.all.current', 0) / 1e9, 2),

@@ -303,7 +303,9 @@ typedef struct tgt_edge_linear_args {
     const void* a;      int64_t lda;
     const void* w;      int64_t ldw;
     const void* bias;
-    const float* gamma; const float* beta; float eps; int32_t _pad0;
+    const float* gamma; const float* beta; float eps;
+    int32_t colsum_rows;   /* rows of colsum_partial the caller provides (ABI 28; 0 = tgt_edge_linear_parts(M, N) as of this call): with N = 256
+                              the launch uses EXACTLY this many persistent workgroups, so every provided row is written and none beyond */
     float* mean;        float* rstd;
     void* y;            int64_t ldy;
     void* out;          int64_t ldo;
@@ -443,6 +445,12 @@ int tgt_sum_planes(const float* x, int32_t planes, int64_t n, float* out, void* 
  * optimizer step, so the trainer refreshes every W^T of the model with this call instead of one copy kernel per Linear and
  * backward launch.  blocks_per_item: workgroups per matrix (each walks 32 x 32 tiles). */
 typedef struct tgt_transpose_item { const void* src; void* dst; int32_t rows, cols; } tgt_transpose_item;
+/* ABI 28: up to 64 plane sums (dst[i] (n) = sum over planes of src[i] (planes, n), float32, the fixed order of tgt_sum_planes: bit-identical
+ * to it) as ONE launch: the closing sums behind the split-M weight gradients and column-sum partials of a layer (reference:
+ * the reductions inside autograd's Linear / LayerNorm backward, lib/tgt/layers/layers.py:155-160,270-290).  `items` is a HOST array
+ * (the descriptors travel as kernel arguments; nothing is read from it after the call returns). */
+typedef struct tgt_sum_item { const float* src; float* dst; int32_t planes; int32_t _pad; int64_t n; } tgt_sum_item;
+int tgt_sum_many(const tgt_sum_item* items, int32_t n, void* stream);
 int tgt_transpose_many(const tgt_transpose_item* items, int32_t n, int32_t blocks_per_item, void* stream);
 
 /* Row-wise cross entropy of the binned-distance head: replaces

@@ -226,6 +226,51 @@ def test_forked_parameter_gradient_stream_changes_nothing(monkeypatch):
     assert torch.equal(runs[0], runs[1])
 
 
+def test_deferred_closing_sums_change_nothing(monkeypatch):
+    """ops.flush_deferred (round 4, the backward's launch diet): inside the Trainer's backward the closing sums of the split-M
+    weight gradients and of the column-sum / LayerNorm partials are only registered and run as ONE tgt_sum_many launch per <= 64
+    of them (+ the kernels that read them), flushed before the gradient collection reads anything.  tgt_sum_many does per item what
+    tgt_sum_planes does: three steps with the deferral equal three steps without it, bit for bit -- with and without the bucketed
+    gradient path (hooks read gradients in the middle of the backward), node side stream on."""
+    import torch.distributed as dist
+    from tgt_amd import ops
+    from tgt_amd.pcqm import TGT_Multi
+    from tgt_amd.training.step import Trainer, StepConfig
+    monkeypatch.setattr(ops, '_EDGE_MIN_ROWS', 1)
+    monkeypatch.setattr(ops, '_SPLIT_MIN_ROWS', 1)
+    kwargs = dict(gu.FULL_AT_CFG, model_height=3)
+    cfg = StepConfig(num_dist_bins=512, mixed_precision='bf16', coords_noise=0.0, lr_warmup_steps=10, lr_total_steps=100, bucket_mbytes=8)
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{_free_port()}', rank=0, world_size=1)
+    try:
+        for bucketed in (False, True):
+            runs = []
+            for deferred in (True, False):
+                monkeypatch.setattr(ops, '_DEFER_SUMS', deferred)
+                ops._deferred_stats[:] = [0, 0]
+                m1 = gu.fill_params(TGT_Multi(**kwargs), seed=3).cuda().eval()
+                with Trainer(m1, cfg, force_distributed=bucketed) as tr:
+                    for step in range(1, 4):
+                        tr.training_step(_batch(cfg, step))
+                    runs.append(_params(m1).clone())
+                assert not any(q[0] or q[1] for q in ops._deferred.values())          # nothing left registered
+                if deferred:
+                    # the closing sums of every backward were registered (the tiny batch has no split-M weight gradients: the
+                    # column-sum / LayerNorm partials only) and ran in fewer launches than there were sums
+                    assert ops._deferred_stats[0] >= 3 * 3 * 3 and ops._deferred_stats[1] < ops._deferred_stats[0]
+                else:
+                    assert ops._deferred_stats == [0, 0]
+            assert torch.equal(runs[0], runs[1]), bucketed
+    finally:
+        if own:
+            dist.destroy_process_group()
+    # outside a Trainer's backward nothing is deferred: the result is there when the call returns
+    part = torch.randn(16, 256, 64, device='cuda')
+    out = ops.sum_planes(part, torch.empty(256, 64, device='cuda'))
+    assert torch.allclose(out, part.sum(0), atol=1e-4) and ops._deferred_stats == [0, 0]
+
+
 # ---- world-size 2 on the GPU: two ranks share cuda:0 and exchange over gloo (device tensors staged through the host by
 # the backend).  RCCL refuses two ranks on one device and the test boxes have one GPU, so this is the closest a 1-GPU box gets
 # to the N > 1 path: autograd hooks -> bucket gather behind BOTH streams -> asynchronous all-reduce -> one-launch Adam, on

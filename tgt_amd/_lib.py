@@ -20,7 +20,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 SOURCES = ['capi.hip', 'optimizer.hip', 'edge_gemm.hip', 'params.hip', 'loss.hip', 'predict.hip', 'gaussian.hip', 'triplet_attention_proj.hip',
            ('triplet_attention.hip', ['-DTGT_TRI_INST=9'], '.f32'), ('triplet_attention.hip', ['-DTGT_TRI_INST=2'], '.bf16'),
            ('triplet_attention.hip', ['-DTGT_TRI_INST=4'], '.f16'), 'triplet_attention16.hip', 'triplet_attention_bwd2.hip', 'triplet_aggregate.hip', 'node_attention.hip', 'node_attention_mfma.hip', 'layernorm.hip', 'triangular_update.hip', 'elementwise.hip']
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 TGT_F32, TGT_BF16, TGT_F16 = 0, 1, 2
 TRI_BIASED, TRI_GATED, TRI_MASK_OUT = 1, 2, 4
@@ -81,7 +81,7 @@ class EdgeLinearArgs(C.Structure):
     _fields_ = [
         ('M', _i64), ('K', _i32), ('N', _i32), ('dtype', _i32), ('epilogue', _i32),
         ('a', _vp), ('lda', _i64), ('w', _vp), ('ldw', _i64), ('bias', _vp),
-        ('gamma', _vp), ('beta', _vp), ('eps', _f32), ('_pad0', _i32),
+        ('gamma', _vp), ('beta', _vp), ('eps', _f32), ('colsum_rows', _i32),
         ('mean', _vp), ('rstd', _vp), ('y', _vp), ('ldy', _i64),
         ('out', _vp), ('ldo', _i64), ('out2', _vp), ('ldo2', _i64),
         ('res', _vp), ('ldr', _i64), ('ds_in', _vp), ('ld_ds', _i64),
@@ -91,6 +91,11 @@ class EdgeLinearArgs(C.Structure):
     ]
 
 
+class SumItem(C.Structure):
+    _fields_ = [('src', _vp), ('dst', _vp), ('planes', _i32), ('_pad', _i32), ('n', _i64)]
+
+
+SUM_MANY_MAX = 64
 EPI_BIAS, EPI_GELU, EPI_RESID, EPI_GELU_BWD, EPI_LN_BWD = range(5)
 EDGE_BIAS_SCALED = 1
 
@@ -122,6 +127,7 @@ SYMBOLS = {
     'tgt_sum_rows': (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     'tgt_sum_planes': (C.c_int, [_vp, _i32, _i64, _vp, _vp]),
     'tgt_transpose_many': (C.c_int, [_vp, _i32, _i32, _vp]),
+    'tgt_sum_many': (C.c_int, [C.POINTER(SumItem), _i32, _vp]),
     'tgt_cross_entropy_fwd': (C.c_int, [_vp, _i32, _vp, _i64, _i32, _vp, _vp, _vp]),
     'tgt_cross_entropy_bwd': (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     'tgt_fuse_rows': (C.c_int, [C.POINTER(FuseRowsArgs), _vp]),
@@ -174,16 +180,28 @@ def build_library(force=False, verbose=False):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     # the compile commands (flags included) and the compiler's identity are part of the library's currency, not only mtimes:
     # their hash is kept next to the library (libtgt_hip.stamp travels with the .so; the objects under build/ do not)
+    def read(path):
+        with open(path) as fh:
+            return fh.read()
+
     try:
         hipcc_id = subprocess.run([hipcc, '--version'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode(errors='replace')
+        have_hipcc = True
     except OSError:
-        hipcc_id = 'unknown'
+        hipcc_id, have_hipcc = 'unknown', False
     lib_stamp = hashlib.sha256(repr([(u[0], u[1], u[2]) for u in units]).encode() + hipcc_id.encode()).hexdigest()
     stamp_path = LIB_PATH[:-3] + '.stamp'
-    if not force and os.path.exists(LIB_PATH) and \
-            os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps) and \
-            os.path.exists(stamp_path) and open(stamp_path).read() == lib_stamp:
+    current = os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps)
+    if not force and current and os.path.exists(stamp_path) and read(stamp_path) == lib_stamp:
         return LIB_PATH
+    if not have_hipcc:
+        # no compiler on this box (a prebuilt library travelled here): nothing can be rebuilt, so a library that is newer than
+        # every source is taken as it is -- lib() still checks its ABI version when it loads
+        if current and not force:
+            import warnings
+            warnings.warn(f'{hipcc} not found: using the prebuilt {LIB_PATH} without its build stamp')
+            return LIB_PATH
+        raise RuntimeError(f'{hipcc} not found and {LIB_PATH} is missing or older than its sources: cannot build the HIP kernels')
     objs = []
     stamps = []
     procs = []
@@ -199,7 +217,7 @@ def build_library(force=False, verbose=False):
         stamp = hashlib.sha256((' '.join(cmd) + '\n' + hipcc_id).encode()).hexdigest()
         stamp_file = os.path.join(d, 'unit.cmd')
         if not force and os.path.exists(o) and os.path.getmtime(o) >= max(shared, os.path.getmtime(s)) and \
-                os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+                os.path.exists(stamp_file) and read(stamp_file) == stamp:
             continue                                                    # this unit's object is current
         shutil.rmtree(d, ignore_errors=True)
         os.makedirs(d)

@@ -50,6 +50,7 @@ int fuse_rows_run(const tgt_fuse_rows_args* a, bool scatter, hipStream_t st);
 int permute_cols_run(const void* src, int sd, const int32_t* idx, void* dst, int dd, int rows, int cols, hipStream_t st);
 int sum_planes_run(const float* x, int planes, int64_t n, float* out, hipStream_t st);
 int transpose_many_run(const void* items, int n, int blocks_per_item, hipStream_t st);
+int sum_many_run(const void* items_host, int n, hipStream_t st);
 int xent_run(const void* x, int dtype, const int64_t* target, const float* lse_in, const float* w, int64_t rows, int C,
              float* lse, float* xent, void* dx, hipStream_t st);
 int edge_linear_supported(const tgt_edge_linear_args* a);
@@ -82,7 +83,7 @@ using namespace tgt;
 extern "C" {
 
 const char* tgt_last_error(void) { return g_err; }
-int tgt_abi_version(void) { return 27; }
+int tgt_abi_version(void) { return 28; }
 
 int tgt_triplet_attention_fwd(const tgt_triplet_attention_args* a, void* stream) {
     return triplet_attention_run(a, false, reinterpret_cast<hipStream_t>(stream));
@@ -172,6 +173,9 @@ int tgt_cross_entropy_bwd(const void* logits, int32_t dtype, const int64_t* targ
 }
 int tgt_sum_planes(const float* x, int32_t planes, int64_t n, float* out, void* stream) {
     return sum_planes_run(x, planes, n, out, reinterpret_cast<hipStream_t>(stream));
+}
+int tgt_sum_many(const tgt_sum_item* items, int32_t n, void* stream) {
+    return sum_many_run(items, n, reinterpret_cast<hipStream_t>(stream));
 }
 int tgt_transpose_many(const tgt_transpose_item* items, int32_t n, int32_t blocks_per_item, void* stream) {
     return transpose_many_run(items, n, blocks_per_item, reinterpret_cast<hipStream_t>(stream));

@@ -1212,6 +1212,13 @@ static int er_grid(int64_t M) {
     if (g_grid_cap && g > g_grid_cap) g = g_grid_cap;
     return (int)g;
 }
+// the grid of a row-phase launch: the caller's row count of colsum_partial when it states one (one row per persistent workgroup:
+// exactly the provided rows are written, whatever device / grid cap the sizing call saw), else the default
+static int er_grid(const tgt_edge_linear_args& a) {
+    const int64_t row_tiles = (a.M + 31) / 32;
+    if (a.colsum_partial && a.colsum_rows > 0) return (int)(a.colsum_rows < row_tiles ? a.colsum_rows : row_tiles);
+    return er_grid(a.M);
+}
 
 
 template <typename T, int KS, int EPI>
@@ -1222,7 +1229,7 @@ static int er_launch(const tgt_edge_linear_args& a, hipStream_t st) {
     static bool attr_set[16] = {};
     if (!dyn_lds_once(attr_set, reinterpret_cast<const void*>(&edge_rows_kernel<T, KS, EPI>), lds))
         return set_error(TGT_ERR_LAUNCH, "edge_rows_kernel: cannot reserve %d bytes of LDS", lds);
-    hipLaunchKernelGGL((edge_rows_kernel<T, KS, EPI>), dim3((unsigned)er_grid(a.M)), dim3(1024), lds, st, a);
+    hipLaunchKernelGGL((edge_rows_kernel<T, KS, EPI>), dim3((unsigned)er_grid(a)), dim3(1024), lds, st, a);
     return check_launch("edge_rows_kernel");
 }
 
@@ -1232,7 +1239,7 @@ static int er512_launch(const tgt_edge_linear_args& a, hipStream_t st) {
     static bool attr_set[16] = {};
     if (!dyn_lds_once(attr_set, reinterpret_cast<const void*>(&edge_rows512_kernel<T>), lds))
         return set_error(TGT_ERR_LAUNCH, "edge_rows512_kernel: cannot reserve %d bytes of LDS", lds);
-    hipLaunchKernelGGL((edge_rows512_kernel<T>), dim3((unsigned)er_grid(a.M)), dim3(1024), lds, st, a);
+    hipLaunchKernelGGL((edge_rows512_kernel<T>), dim3((unsigned)er_grid(a)), dim3(1024), lds, st, a);
     return check_launch("edge_rows512_kernel");
 }
 
@@ -1242,7 +1249,7 @@ static int ew512_launch(const tgt_edge_linear_args& a, hipStream_t st) {
     static bool attr_set[16] = {};
     if (!dyn_lds_once(attr_set, reinterpret_cast<const void*>(&edge_wide512_kernel<T>), lds))
         return set_error(TGT_ERR_LAUNCH, "edge_wide512_kernel: cannot reserve %d bytes of LDS", lds);
-    hipLaunchKernelGGL((edge_wide512_kernel<T>), dim3((unsigned)er_grid(a.M)), dim3(1024), lds, st, a);
+    hipLaunchKernelGGL((edge_wide512_kernel<T>), dim3((unsigned)er_grid(a)), dim3(1024), lds, st, a);
     return check_launch("edge_wide512_kernel");
 }
 // K = 256 -> N = 512 with the plain epilogue and nothing else attached
@@ -1388,6 +1395,9 @@ int edge_linear_run(const tgt_edge_linear_args* a, hipStream_t st) {
         return set_error(TGT_ERR_INVALID, "edge linear: rows_per_sample missing (or more than 2^31 rows with a per-sample scale)");
     if (a->gamma && a->epilogue != EPI_LN_BWD && !a->beta) return set_error(TGT_ERR_INVALID, "edge linear: beta missing");
     if (a->dropout_p < 0.f || a->dropout_p >= 1.f) return set_error(TGT_ERR_INVALID, "edge linear: dropout_p outside [0,1)");
+    if (a->colsum_partial && a->N == 256 && (a->colsum_rows < 0 || a->colsum_rows > (a->M + 31) / 32))
+        return set_error(TGT_ERR_INVALID, "edge linear: colsum_rows = %d, but a launch over %lld rows writes at most %lld rows of colsum_partial "
+                         "(size the buffer with tgt_edge_linear_parts)", a->colsum_rows, (long long)a->M, (long long)((a->M + 31) / 32));
     if (a->K == 512) return a->dtype == TGT_BF16 ? er512_launch<bf16_t>(*a, st) : er512_launch<f16_t>(*a, st);
     if (ew512_eligible(*a)) return a->dtype == TGT_BF16 ? ew512_launch<bf16_t>(*a, st) : ew512_launch<f16_t>(*a, st);
     if (er_eligible(*a)) return a->dtype == TGT_BF16 ? er_run<bf16_t>(*a, st) : er_run<f16_t>(*a, st);

@@ -589,21 +589,25 @@ template <typename T, int HG, int D>
 static int launch(const tgt_node_attention_args& a, bool bwd, hipStream_t st) {
     using L = Lay<HG>;
     const int grid = ((a.B + 7) / 8) * 8 * (a.H / HG);       // a multiple of 8: the XCD lists of unit_of_block cover every unit
-    static const int ablate = getenv("TGT_NODE_ABLATE") ? atoi(getenv("TGT_NODE_ABLATE")) : 0;    // micro-benchmark only: 1 no tile math, 2 no loads, 4 no stores
+#ifdef TGT_PROBES
+    static const int ablate = getenv("TGT_NODE_ABLATE") ? atoi(getenv("TGT_NODE_ABLATE")) : 0;    // probe builds only: 1 no tile math, 2 no loads, 4 no stores
+#else
+    constexpr int ablate = 0;                 // (the shipped library has no ablation switch: a stray environment variable cannot corrupt results)
+#endif
     if (!bwd) {
         constexpr int kLds = L::lds_bytes(D, false);
         static_assert(kLds <= kLdsMax, "forward LDS");
-        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&node_att_mfma_fwd_kernel<T, HG, D>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLds), true);
-        (void)once;
+        static bool attr_set[16] = {};                 // per device (common.hpp: dyn_lds_once)
+        if (!dyn_lds_once(attr_set, reinterpret_cast<const void*>(&node_att_mfma_fwd_kernel<T, HG, D>), kLds))
+            return set_error(TGT_ERR_LAUNCH, "node_att_mfma_fwd_kernel: cannot reserve %d bytes of LDS", kLds);
         hipLaunchKernelGGL((node_att_mfma_fwd_kernel<T, HG, D>), dim3(grid), dim3(HG * 64), kLds, st, a, ablate);
         return check_launch("node_att_mfma_fwd_kernel");
     } else {
         constexpr int kLds = L::lds_bytes(D, true);
         if constexpr (kLds <= kLdsMax) {
-            static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&node_att_mfma_bwd_kernel<T, HG, D>),
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, kLds), true);
-            (void)once;
+            static bool attr_set[16] = {};                 // per device (common.hpp: dyn_lds_once)
+            if (!dyn_lds_once(attr_set, reinterpret_cast<const void*>(&node_att_mfma_bwd_kernel<T, HG, D>), kLds))
+                return set_error(TGT_ERR_LAUNCH, "node_att_mfma_bwd_kernel: cannot reserve %d bytes of LDS", kLds);
             hipLaunchKernelGGL((node_att_mfma_bwd_kernel<T, HG, D>), dim3(grid), dim3(HG * 64), kLds, st, a, ablate);
             return check_launch("node_att_mfma_bwd_kernel");
         }

@@ -155,6 +155,87 @@ int sum_planes_run(const float* x, int planes, int64_t n, float* out, hipStream_
 }
 
 // ---------------------------------------------------------------------------
+// Many plane sums in ONE launch (round 4, the backward's launch diet): the closing fixed-order sums behind the split-M weight
+// gradients and the column-sum partials of a layer (13 + 8 launches of 4-9 us per backward layer, each with its dispatch gap)
+// are collected by the host (ops.DeferredSums) and run as one grid.  The descriptors travel as KERNEL ARGUMENTS (the pointers
+// change every step; no staging copy), each workgroup finds its item in the block prefix and then does exactly what
+// sum_planes_kernel does for it -- same slices, same order, bit-identical results.
+// ---------------------------------------------------------------------------
+constexpr int kSumManyMax = 64;
+struct SumManyArgs {
+    const float* src[kSumManyMax];
+    float* dst[kSumManyMax];
+    int64_t nv[kSumManyMax];             // elements (vec = 1) or float4 groups (vec = 4) per plane
+    int32_t planes[kSumManyMax];
+    int32_t first_block[kSumManyMax + 1];
+    uint64_t vec4;                       // bit i: item i is summed as float4
+    int32_t n;
+};
+template <int V>
+__device__ __forceinline__ void sum_planes_block(const float* x, int planes, int64_t nv, float* out, int block, void* lds) {
+    using VT = typename PlaneVec<V>::type;
+    VT (*red)[32] = reinterpret_cast<VT (*)[32]>(lds);
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int64_t col = (int64_t)block * 32 + cl;
+    const VT* xv = reinterpret_cast<const VT*>(x);
+    VT s0 = {}, s1 = {}, s2 = {}, s3 = {};
+    if (col < nv) {
+        int p = sl;
+        for (; p + 24 < planes; p += 32) {
+            const VT a = xv[(int64_t)p * nv + col], b = xv[(int64_t)(p + 8) * nv + col];
+            const VT c = xv[(int64_t)(p + 16) * nv + col], d = xv[(int64_t)(p + 24) * nv + col];
+            vadd(s0, a); vadd(s1, b); vadd(s2, c); vadd(s3, d);
+        }
+        for (; p < planes; p += 8) vadd(s0, xv[(int64_t)p * nv + col]);
+        vadd(s0, s1); vadd(s2, s3); vadd(s0, s2);
+    }
+    red[sl][cl] = s0;
+    __syncthreads();
+    if (sl == 0 && col < nv) {
+        VT t = red[0][cl];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) vadd(t, red[k][cl]);
+        reinterpret_cast<VT*>(out)[col] = t;
+    }
+}
+__global__ void __launch_bounds__(256) sum_many_kernel(const SumManyArgs a) {
+    __shared__ float4 red[8][32];
+    int it = 0;
+    while (it + 1 < a.n && (int)blockIdx.x >= a.first_block[it + 1]) ++it;          // (scalar: <= 64 steps)
+    const int block = (int)blockIdx.x - a.first_block[it];
+    if ((a.vec4 >> it) & 1) sum_planes_block<4>(a.src[it], a.planes[it], a.nv[it], a.dst[it], block, red);
+    else sum_planes_block<1>(a.src[it], a.planes[it], a.nv[it], a.dst[it], block, red);
+}
+struct SumItem { const float* src; float* dst; int32_t planes; int32_t _pad; int64_t n; };
+int sum_many_run(const void* items_host, int n, hipStream_t st) {
+    static_assert(sizeof(SumItem) == 32, "tgt_sum_item layout");
+    if (n < 0 || (n > 0 && !items_host)) return set_error(TGT_ERR_INVALID, "sum_many: bad arguments");
+    if (n > kSumManyMax) return set_error(TGT_ERR_UNSUPPORTED, "sum_many: at most %d sums per launch", kSumManyMax);
+    const SumItem* items = reinterpret_cast<const SumItem*>(items_host);
+    SumManyArgs a = {};
+    int blocks = 0, m = 0;
+    for (int i = 0; i < n; ++i) {
+        const SumItem& s = items[i];
+        if (!s.src || !s.dst || s.planes <= 0 || s.n < 0) return set_error(TGT_ERR_INVALID, "sum_many: bad item %d", i);
+        if (s.n == 0) continue;
+        const bool v4 = s.n % 4 == 0 && ((uintptr_t)s.src | (uintptr_t)s.dst) % 16 == 0;          // (the rule of sum_planes_run)
+        a.src[m] = s.src; a.dst[m] = s.dst; a.planes[m] = s.planes;
+        a.nv[m] = v4 ? s.n / 4 : s.n;
+        if (v4) a.vec4 |= (uint64_t)1 << m;
+        a.first_block[m] = blocks;
+        const int64_t nb = (a.nv[m] + 31) / 32;
+        if (nb > 0x3fffffff - blocks) return set_error(TGT_ERR_UNSUPPORTED, "sum_many: too many elements");
+        blocks += (int)nb;
+        ++m;
+    }
+    if (m == 0) return TGT_OK;
+    a.first_block[m] = blocks;
+    a.n = m;
+    hipLaunchKernelGGL(sum_many_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    return check_launch("sum_many_kernel");
+}
+
+// ---------------------------------------------------------------------------
 // Transposes of many small 16-bit matrices in ONE launch: the data-gradient kernels of csrc/edge_gemm.hip take the weight as
 // (N, K) = W^T of the nn.Linear they differentiate.  Per step that was one 4 us copy kernel per Linear (plus its dispatch gap)
 // in front of 96 backward launches; the weights only change in the optimizer step, so the trainer refreshes all of them at once.

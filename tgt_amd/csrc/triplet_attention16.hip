@@ -599,14 +599,14 @@ static int launch_bwd(const tgt_triplet_attention_args& a, hipStream_t st) {
     const bool cs = a.d_qkv_colsum[0] != nullptr;
     const int grid = a.B * 2 * (a.H / HG);
     if (cs) {
-        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tri_att16_bwd_kernel<T, HG, NQ, true>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLds), true);
-        (void)once;
+        static bool attr_set[16] = {};                 // per device (common.hpp: dyn_lds_once)
+        if (!dyn_lds_once(attr_set, reinterpret_cast<const void*>(&tri_att16_bwd_kernel<T, HG, NQ, true>), kLds))
+            return set_error(TGT_ERR_LAUNCH, "tri_att16_bwd_kernel: cannot reserve %d bytes of LDS", kLds);
         hipLaunchKernelGGL((tri_att16_bwd_kernel<T, HG, NQ, true>), dim3(grid), dim3(G::kThreads), kLds, st, a);
     } else {
-        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tri_att16_bwd_kernel<T, HG, NQ, false>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLds), true);
-        (void)once;
+        static bool attr_set[16] = {};                 // per device (common.hpp: dyn_lds_once)
+        if (!dyn_lds_once(attr_set, reinterpret_cast<const void*>(&tri_att16_bwd_kernel<T, HG, NQ, false>), kLds))
+            return set_error(TGT_ERR_LAUNCH, "tri_att16_bwd_kernel: cannot reserve %d bytes of LDS", kLds);
         hipLaunchKernelGGL((tri_att16_bwd_kernel<T, HG, NQ, false>), dim3(grid), dim3(G::kThreads), kLds, st, a);
     }
     return check_launch("tri_att16_bwd_kernel");
@@ -618,9 +618,9 @@ static int launch(const tgt_triplet_attention_args& a, hipStream_t st) {
     constexpr int kArm = Arm16<T, HG, NQ>::kBytes, kSlabs = 2 * 3 * G::kSlabBytes;
     constexpr int kLds = kArm > kSlabs ? kArm : kSlabs;
     static_assert(kLds <= 160 * 1024, "LDS");
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tri_att16_fwd_kernel<T, HG, NQ>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, kLds), true);
-    (void)once;
+    static bool attr_set[16] = {};                 // per device (common.hpp: dyn_lds_once)
+    if (!dyn_lds_once(attr_set, reinterpret_cast<const void*>(&tri_att16_fwd_kernel<T, HG, NQ>), kLds))
+        return set_error(TGT_ERR_LAUNCH, "tri_att16_fwd_kernel: cannot reserve %d bytes of LDS", kLds);
     hipLaunchKernelGGL((tri_att16_fwd_kernel<T, HG, NQ>), dim3(a.B * 2 * (a.H / HG)), dim3(G::kThreads), kLds, st, a);
     return check_launch("tri_att16_fwd_kernel");
 }

@@ -56,7 +56,11 @@ __device__ __forceinline__ void proj2_walk(const tgt_triplet_attention_args& a, 
     using G = TriGeo<T, D, HG>;
     using F = frag_t<T>;
     const int lane = tid & 63, wave = tid >> 6, r = lane & 31, hi = lane >> 5;
-    const uint32_t ablate = a._pad1;                   // probes (TGT_PROJ_ABLATE): 1 no X loads, 2 no stores, 4 no projection, 8 no attention math
+#ifdef TGT_PROBES
+    const uint32_t ablate = a._pad1;                   // probe builds only (TGT_PROJ_ABLATE): 1 no X loads, 2 no stores, 4 no projection, 8 no attention math
+#else
+    constexpr uint32_t ablate = 0;                     // (the shipped library ignores _pad1)
+#endif
     const bool attend = wave < 8;                      // role
     const int hw = wave & 7;                           // head inside the group
     const int N = c.N;
@@ -315,17 +319,15 @@ static int launch_proj(const tgt_triplet_attention_args& a, const void* x, const
     const int grid = a.B * 2 * (a.H / 8);
     static_assert(ArmStage<T, 8, 1>::kBytes <= proj2::kOffO, "arm stage must fit the aliased area");
     static bool attr_set[16] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
-    if (!attr_set[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&tri_att_proj_fwd_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                proj2::kLds) != hipSuccess)
-            return set_error(TGT_ERR_LAUNCH, "tri_att_proj_fwd_kernel: cannot reserve %d bytes of LDS", proj2::kLds);
-        attr_set[dev] = true;
-    }
+    if (!dyn_lds_once(attr_set, reinterpret_cast<const void*>(&tri_att_proj_fwd_kernel<T>), proj2::kLds))
+        return set_error(TGT_ERR_LAUNCH, "tri_att_proj_fwd_kernel: cannot reserve %d bytes of LDS", proj2::kLds);
+#ifdef TGT_PROBES
     static const int ablate = getenv("TGT_PROJ_ABLATE") ? atoi(getenv("TGT_PROJ_ABLATE")) : 0;
     tgt_triplet_attention_args aa = a;
     aa._pad1 = (uint32_t)ablate;
+#else
+    const tgt_triplet_attention_args& aa = a;          // (_pad1 is padding: never written, never read)
+#endif
     hipLaunchKernelGGL((tri_att_proj_fwd_kernel<T>), dim3(grid), dim3(1024), proj2::kLds, st, aa, reinterpret_cast<const T*>(x),
                        reinterpret_cast<const T*>(w), reinterpret_cast<const T*>(bias));
     return check_launch("tri_att_proj_fwd_kernel");

@@ -7,6 +7,7 @@ eager / CPU fallback (a missing library or a CPU tensor raises).
 import contextlib
 import ctypes as C
 import os
+import weakref
 
 import torch
 
@@ -212,26 +213,124 @@ def _colsum_workspace(B, width, used, device):
 _ATEN_PLANE_SUM = False       # settled (+0.3 % for the kernel; tests patch this): ATen's reduction instead of tgt_sum_planes
 
 
-def sum_planes(part, out):
-    """out <- part.sum(0) for contiguous fp32 part (P, ...) and out (...), fixed order (tgt_sum_planes)."""
-    _dev(part, out)
-    if _ATEN_PLANE_SUM:
-        return torch.sum(part, 0, out=out)
+# ---------------------------------------------------------------------------
+# The backward's launch diet (round 4): the closing sums of a layer as ONE launch -- built, measured, OPT-IN.
+# A backward layer ends 13 split-M weight gradients and 8 column-sum / LayerNorm partial buffers with a 4-9 us kernel each
+# (sum_planes / sum_rows).  Nothing on the step's chain reads their results: they are parameter gradients, read by the Trainer's
+# gradient collection.  With TGT_DEFER_SUMS=1, inside a Trainer's backward (ops.trainer_backward) sum_planes / sum_rows only
+# REGISTER (partials, result) and return the -- not yet filled -- result tensor; flush_deferred() runs everything registered so
+# far as one tgt_sum_many launch per <= 64 sums, followed by the few kernels that read those results (the column permutation of
+# lin_O's weight gradient, the scatter of the fused projection's gradient: _after_sums).  The Trainer flushes before it reads
+# gradients (FlatState.collect_grads, i.e. also before every bucket's all-reduce) and when the backward ends; a queue flushes
+# itself at TGT_DEFER_MAX entries.  One queue per stream: work registered from the node side stream is summed on that stream.
+# Bit-identical to the immediate path (tgt_sum_many does per item exactly what tgt_sum_planes does;
+# tests/test_hip_trainer.py::test_deferred_closing_sums_change_nothing).
+# Why it is off: ~370 launches fewer per step, and the step gets SLOWER -- per-step medians over 30 steps, same box, alternating
+# (profiles/r05g_ab_defer_sweep2.txt): 84.15 / 84.17 / 84.19 / 84.12 ms immediate against 84.76 / 84.79 (flush at 8) and 84.90 /
+# 84.84 (flush at 16).  The immediate sums read partials the GEMM has just written (L2 / MALL-resident, 4-5 us each, and their
+# dispatch gaps largely overlap the neighbouring kernels' tails); the collected launch reads them from HBM with little memory
+# parallelism.  The launch COUNT was the wrong target; what the boundary costs is ~1-2 us here, not the 5 us the trace suggests.
+# Contract of the deferral (why the queue holds aliases): autograd's AccumulateGrad adopts a gradient only when it is its single
+# owner and CLONES it otherwise; a clone taken before the flush copies unfilled memory.  Registered results therefore reach
+# autograd as fresh tensor objects (t.detach() where an object is also referenced elsewhere: _take_colsum), weight-shared stacks
+# and anything outside a Trainer's backward never defer.
+# ---------------------------------------------------------------------------
+_DEFER_SUMS = os.environ.get('TGT_DEFER_SUMS', '0') == '1'           # A/B knob (measured slower: see above)
+_DEFER_MAX = int(os.environ.get('TGT_DEFER_MAX', '56'))            # sums per queue before it flushes itself (<= 64: one launch)
+_deferred = {}                     # stream handle -> [ [ (part, out), ... ], [post callables] ]
+_deferred_stats = [0, 0]           # [sums registered, tgt_sum_many launches]  (tests / diagnostics)
+
+
+def _deferring():
+    return _DEFER_SUMS and _trainer_backward[0] > 0 and not _WGRAD_STREAM
+
+
+def _queue():
+    key = torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    q = _deferred.get(key)
+    if q is None:
+        q = _deferred[key] = [[], [], torch.cuda.current_stream()]
+    return q
+
+
+def _run_sums(pairs):
+    L = _lib.lib()
+    for i in range(0, len(pairs), _lib.SUM_MANY_MAX):
+        chunk = pairs[i:i + _lib.SUM_MANY_MAX]
+        items = (_lib.SumItem * len(chunk))()
+        for it, (part, out) in zip(items, chunk):
+            it.src, it.dst, it.planes, it.n = part.data_ptr(), out.data_ptr(), part.shape[0], out.numel()
+        _lib.check(L.tgt_sum_many(items, len(chunk), _stream()), 'tgt_sum_many')
+        _deferred_stats[1] += 1
+
+
+def _flush_queue(q):
+    pairs, posts = q[0], q[1]
+    q[0], q[1] = [], []
+    if pairs:
+        _run_sums(pairs)
+    for fn in posts:
+        fn()
+
+
+def flush_deferred():
+    """run every registered closing sum (and what was queued behind them), each queue on the stream it was registered from"""
+    if not _deferred:
+        return
+    cur = torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    for key, q in list(_deferred.items()):
+        if not (q[0] or q[1]):
+            continue
+        if key == cur:
+            _flush_queue(q)
+        else:
+            with torch.cuda.stream(q[2]):
+                _flush_queue(q)
+
+
+def _after_sums(fn):
+    """fn() reads results of sum_planes / sum_rows: now when nothing is pending on this stream, else right behind the sums"""
+    if _deferring():
+        q = _queue()
+        if q[0] or q[1]:
+            q[1].append(fn)
+            return
+    fn()
+
+
+def _check_planes(part, out):
     if part.dtype != torch.float32 or out.dtype != torch.float32 or not part.is_contiguous() or not out.is_contiguous() or \
             part.shape[1:] != out.shape:
         raise RuntimeError(f'sum_planes: contiguous float32 (P, ...) -> (...) expected, got {tuple(part.shape)} {part.dtype} -> '
                            f'{tuple(out.shape)} {out.dtype}')
+
+
+def sum_planes(part, out, defer=True):
+    """out <- part.sum(0) for contiguous fp32 part (P, ...) and out (...), fixed order (tgt_sum_planes).  Inside a Trainer's
+    backward the sum is only registered (see above): `out` is filled by the next flush_deferred() -- callers that read the
+    result themselves pass defer=False."""
+    _dev(part, out)
+    if _ATEN_PLANE_SUM:
+        return torch.sum(part, 0, out=out)
+    _check_planes(part, out)
+    if defer and _deferring():
+        q = _queue()
+        # (an ALIAS of out keeps its memory: holding the tensor object itself would make autograd's AccumulateGrad see a second
+        # owner of the gradient it is handed and CLONE it -- a copy of memory the flush has not filled yet -- instead of adopting it)
+        q[0].append((part, out.detach()))
+        _deferred_stats[0] += 1
+        if len(q[0]) >= _DEFER_MAX:
+            _flush_queue(q)
+        return out
     _lib.check(_lib.lib().tgt_sum_planes(_ptr(part), part.shape[0], out.numel(), _ptr(out), _stream()), 'tgt_sum_planes')
     return out
 
 
-def sum_rows(x):
-    """fp32 (rows, C) -> (C,) column sums, fixed order (tgt_sum_rows)."""
+def sum_rows(x, defer=True):
+    """fp32 (rows, C) -> (C,) column sums in the fixed order of tgt_sum_planes (rows = planes), deferrable like sum_planes."""
     _dev(x)
     assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
-    out = torch.empty(x.shape[1], dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().tgt_sum_rows(_ptr(x), x.shape[0], x.shape[1], _ptr(out), _stream()), 'tgt_sum_rows')
-    return out
+    return sum_planes(x, torch.empty(x.shape[1], dtype=torch.float32, device=x.device), defer)
 
 
 class ParamTable:
@@ -282,9 +381,16 @@ def _unfuse_grads(table, params, dW, db):
     """per-parameter gradients (dtype of each parameter) from the fused projection's fp32
     gradients in ONE launch"""
     grads = [torch.empty_like(p) for p in params]
-    dW, db = dW.contiguous(), db.to(dW.dtype).contiguous()
+    if not (dW.is_contiguous() and db.dtype == dW.dtype and db.is_contiguous()):
+        flush_deferred()                  # (a cast / copy reads them: they must not be pending sums)
+        dW, db = dW.contiguous(), db.to(dW.dtype).contiguous()
     a = _fuse_args(table, grads[0::2], grads[1::2], dW, db)
-    _lib.check(_lib.lib().tgt_unfuse_rows(C.byref(a), _stream()), 'tgt_unfuse_rows')
+    keep = [t.detach() for t in (dW, db, *grads)]       # aliases: the memory stays, the gradient objects keep ONE owner (see sum_planes)
+
+    def run():
+        _lib.check(_lib.lib().tgt_unfuse_rows(C.byref(a), _stream()), 'tgt_unfuse_rows')
+        keep.clear()
+    _after_sums(run)
     return grads
 
 
@@ -974,7 +1080,10 @@ def _take_colsum(grad, C_):
     if tag is None or tag[1] != grad._version or tag[0].numel() != C_ or grad.shape[-1] != C_:
         return None
     _colsum_handoffs[1] += 1
-    return tag[0]
+    # a FRESH alias: the tagged gradient tensor (and with it this tuple) can outlive the node -- e.g. d_res also flows down the
+    # residual stream -- and a second owner of the object would make AccumulateGrad clone the sums instead of adopting them;
+    # inside a Trainer's backward they may be registered sums that the flush has not computed yet (flush_deferred)
+    return tag[0].detach()
 
 
 # LayerNorm backward as the epilogue of the data-gradient GEMM that produces its dy (tgt_edge_linear, TGT_EPI_LN_BWD): the Linear
@@ -995,16 +1104,19 @@ _lazy_dgrads = [0, 0, 0]           # [offered, fused, materialized by the hook] 
 
 class _LazyRec:
     """the tokens issued against one LayerNorm output y during a backward pass"""
-    __slots__ = ('issued',)
+    __slots__ = ('issued', 'y')
 
-    def __init__(self):
+    def __init__(self, y):
         self.issued = []
+        self.y = weakref.ref(y)
 
     def hook(self, grad):
         issued, self.issued = self.issued, []
         if not issued:
             return None
-        if len(issued) == 1 and grad is issued[0] and _take_lazy_dgrad(grad) is not None:
+        y = self.y()
+        watched = y is not None and (y.retains_grad or len(y._backward_hooks or ()) > 1)      # someone else looks at y's gradient
+        if len(issued) == 1 and grad is issued[0] and _take_lazy_dgrad(grad) is not None and not watched:
             return None                         # the untouched token of the only consumer: the entry's backward fuses it
         total = grad
         for tok in issued:
@@ -1043,7 +1155,7 @@ def _lazy_dgrad(dz2, w, shape, rec=None):
 def _offer_lazy(s, y):
     """(s, y) of a residual + LayerNorm entry, y marked: this entry's backward accepts a lazy data gradient for y (_ln_backward)"""
     if _EPI_LN_BWD and y.is_cuda and y.requires_grad and y.shape[-1] == 256 and y.dtype == s.dtype and y.dtype in (torch.bfloat16, torch.float16):
-        rec = _LazyRec()
+        rec = _LazyRec(y)
         y._tgt_lazy_ok = rec
         y.register_hook(rec.hook)
     return s, y
@@ -1166,6 +1278,8 @@ class trainer_backward:
         _trainer_backward[0] += 1
 
     def __exit__(self, *exc):
+        if _trainer_backward[0] == 1:
+            flush_deferred()               # (before the count drops: nothing stays registered past the backward)
         _trainer_backward[0] -= 1
         return False
 
@@ -1209,6 +1323,7 @@ def _param_grad(t, dtype):
     cast kernel first (parameters that are not float32), that kernel runs on the current stream and has to wait."""
     if t is None or t.dtype == dtype:
         return t
+    flush_deferred()                      # (t may be a registered, not yet computed sum)
     wait_side_streams(t.device)
     return t.to(dtype)
 
@@ -1334,7 +1449,10 @@ def _linear_backward(x2, w, dy2, xs, xdt, wdt, bdt, need_dx, need_dw, need_db, l
                 part = torch.bmm(dy2.view(P, M // P, -1).transpose(1, 2), x2.view(P, M // P, -1),
                                  out_dtype=torch.float32) if dy2.dtype != torch.float32 else \
                     torch.bmm(dy2.view(P, M // P, -1).transpose(1, 2), x2.view(P, M // P, -1))
-                dw = sum_planes(part, torch.empty(part.shape[1:], dtype=torch.float32, device=part.device)).to(wdt)
+                dw = sum_planes(part, torch.empty(part.shape[1:], dtype=torch.float32, device=part.device))
+                if wdt != torch.float32:
+                    flush_deferred()
+                    dw = dw.to(wdt)
             else:
                 dw = (dy2.t() @ x2).to(wdt)
             if dw_post is not None:
@@ -1370,10 +1488,19 @@ class _Linear(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
-def _permute_cols(src, idx, dtype):
+def _permute_cols(src, idx, dtype, after_sums=False):
+    """src[:, idx] as `dtype`; after_sums: src may be a pending sum (see flush_deferred): the launch queues behind it"""
     out = torch.empty(src.shape, dtype=dtype, device=src.device)
-    _lib.check(_lib.lib().tgt_permute_cols(_ptr(src), _DT[src.dtype], _ptr(idx), _ptr(out), _DT[dtype],
-                                           src.shape[0], src.shape[1], _stream()), 'tgt_permute_cols')
+    keep = [src.detach(), out.detach()]                 # aliases (see sum_planes): `out` itself must keep a single owner
+    args = (_ptr(src), _DT[src.dtype], _ptr(idx), _ptr(out), _DT[dtype], src.shape[0], src.shape[1])
+
+    def run():
+        _lib.check(_lib.lib().tgt_permute_cols(*args, _stream()), 'tgt_permute_cols')
+        keep.clear()
+    if after_sums:
+        _after_sums(run)
+    else:
+        run()
     return out
 
 
@@ -1398,7 +1525,7 @@ class _LinearPermutedCols(torch.autograd.Function):
         cs = _take_colsum(dy, dy.shape[-1]) if need_db else None
         dx, dw, db = _linear_backward(x2, w, dy.reshape(-1, dy.shape[-1]), xs, xdt, torch.float32, bdt,
                                       ctx.needs_input_grad[0], ctx.needs_input_grad[1], need_db and cs is None,
-                                      dw_post=lambda t: _permute_cols(t.contiguous(), inv, wdt))
+                                      dw_post=lambda t: _permute_cols(t.contiguous(), inv, wdt, after_sums=True))
         if cs is not None:
             db = _param_grad(cs, bdt)
         return dx, dw, db, None, None, None
@@ -1505,6 +1632,7 @@ def edge_linear_raw(a, w, bias=None, epilogue=_lib.EPI_BIAS, *, ln=None, y=None,
     g.flags = int(flags)
     if colsum_partial is not None:
         g.colsum_partial = colsum_partial.data_ptr()
+        g.colsum_rows = colsum_partial.shape[0]          # (N = 256: the launch uses exactly this many workgroups, one row each)
     _call('tgt_edge_linear', _lib.lib().tgt_edge_linear, g)
     return out
 
@@ -1759,7 +1887,7 @@ class _LinearResidualLN(torch.autograd.Function):
                         _hand_colsum(d_pre, sum_rows(part))
         dx, dw, db = _linear_backward(x2, w, d_z.reshape(rows, N), xs, xdt, torch.float32 if ctx.col_inv is not None else wdt, bdt,
                                       need_dx, ctx.needs_input_grad[1], need_db and cs is None,
-                                      dw_post=None if ctx.col_inv is None else (lambda t: _permute_cols(t.contiguous(), ctx.col_inv, wdt)))
+                                      dw_post=None if ctx.col_inv is None else (lambda t: _permute_cols(t.contiguous(), ctx.col_inv, wdt, after_sums=True)))
         if need_db and cs is not None:
             db = _param_grad(cs, bdt)
         return (dx, dw, db, d_res if rdt == d_res.dtype else d_res.to(rdt), None,
@@ -1976,7 +2104,7 @@ class _GaussianBasis(torch.autograd.Function):
         partial = torch.empty(L.tgt_gaussian_basis_parts(pairs), 2 * K, dtype=torch.float32, device=g.device)
         _lib.check(L.tgt_gaussian_basis_bwd(_ptr(xf), _ptr(mf), _ptr(bf), _ptr(mw), _ptr(sw), pairs, K, _DT[out_dtype], _ptr(g), _ptr(dt),
                                             _ptr(partial), _stream()), 'tgt_gaussian_basis_bwd')
-        dms = sum_rows(partial)
+        dms = sum_rows(partial, defer=False)          # (sliced and cast right below)
         dx = (dt * mf).view(xs) if ctx.needs_input_grad[0] else None
         return dx, (dt * xf).view(ms), dt.view(bs), dms[:K].view(mws).to(pdt), dms[K:].view(sws).to(pdt), None
 

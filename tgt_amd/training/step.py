@@ -181,6 +181,7 @@ class FlatState:
         883 accumulate kernels); parameters without a gradient contribute zeros."""
         idx = range(len(self.params)) if indices is None else indices
         if self.param.is_cuda:
+            ops.flush_deferred()                           # the closing sums of the backward so far (ops.DeferredSums), per stream
             ops.wait_side_streams(self.param.device)       # node-FFN gradients come from a second stream
         src, dst = [], []
         for i in idx:
