@@ -246,7 +246,14 @@ def main():
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=dev)
+        # RCCL on its own HIGH-PRIORITY stream: a bucket's all-reduce is dispatched ahead of the next workgroups of the backward
+        # kernels it overlaps (two priority levels are all HIP offers; the node side stream uses the same one)
+        opts = None
+        try:
+            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+        except Exception:
+            pass
+        dist.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=dev, pg_options=opts)
 
     from tgt_amd import ops
     from tgt_amd.pcqm import TGT_Multi
@@ -322,10 +329,18 @@ def main():
         ops.profile_kernels(False)
         ops.side_stream.enabled = True
         ops._WGRAD_STREAM = forked
+    comm_ms = trainer.comm_exposed_ms()             # per timed step: what of the gradient exchange the backward did not hide
+    comm_ms = comm_ms[-args.steps:] if comm_ms else []
+    rank_ms = [dt / args.steps * 1e3]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        mine = torch.tensor([dt, sum(comm_ms) / max(1, len(comm_ms))], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_ms = [float(t[0]) / args.steps * 1e3 for t in every]
+        rank_comm = [float(t[1]) for t in every]
+        dt = max(float(t[0]) for t in every)
+    else:
+        rank_comm = [0.0]
     loss_val = float(loss.detach())
 
     if rank == 0:
@@ -441,6 +456,13 @@ def main():
                         global_batch=args.batch * world, nodes=args.nodes,
                         parallelism=f'dp{world}', precision=f'{args.precision} autocast, fp32 params/Adam',
                         **({'host_loss_read_every': args.sync_every} if args.sync_every else {})),
+            # the exchange, so that a scaling curve explains itself: per-rank step time, and the milliseconds per step the step's
+            # stream sat waiting for the last gradient buckets after the backward had ended (0 with one rank: nothing to exchange)
+            ms_per_step_by_rank=[round(v, 3) for v in rank_ms],
+            comm_exposed_ms=round(max(rank_comm), 3), comm_exposed_ms_by_rank=[round(v, 3) for v in rank_comm],
+            grad_exchange=dict(buckets=(len(trainer.buckets) if trainer.buckets else 0), bucket_mbytes=cfg.bucket_mbytes,
+                               launch_order_last_step=trainer.bucket_order[:16], mode=cfg.grad_exchange,
+                               wire_dtype=cfg.grad_comm_dtype or 'fp32', rccl_stream='high priority' if world > 1 else None),
             final_loss=round(loss_val, 5),
             step_ms=dict(min=round(step_ms[0], 3), median=round(step_ms[len(step_ms) // 2], 3), max=round(step_ms[-1], 3),
                          note='GPU-side duration of each timed step (events on the step stream)'),

@@ -58,6 +58,9 @@ def _worker(rank, world, port, kwargs, bucket_mb, result, comm=None, exchange='a
         result['grad'] = (tr.flat.grad / world).clone()
         result['param'] = tr.flat.param.clone()
         result['nbuckets'] = -1 if tr.buckets is None else len(tr.buckets)
+        result['bucket_order'] = list(tr.bucket_order)
+        result['layer_of_bucket'] = [] if tr.buckets is None else [
+            [n for n, p in model.named_parameters() if p.requires_grad][b[3]] for b in tr.buckets]
     dist.barrier()
     dist.destroy_process_group()
 
@@ -83,6 +86,17 @@ def test_two_rank_gradients_equal_single_rank(variant):
     assert err < 1e-5, err
     if variant == 'bucketed':
         assert result['nbuckets'] > 10
+        # the exchange overlaps the backward because buckets close -- and their all-reduce is launched -- in the order the
+        # backward produces gradients: the LAST layers' buckets first.  Every bucket once; the encoder layers strictly from the
+        # top of the stack down (buckets are laid out in parameter = forward order, so that is descending bucket index).
+        order = result['bucket_order']
+        assert sorted(order) == list(range(result['nbuckets']))
+        layer = []
+        for k in order:
+            name = result['layer_of_bucket'][k]
+            if '.TGT_layers.' in name:
+                layer.append(int(name.split('.TGT_layers.')[1].split('.')[0]))
+        assert len(set(layer)) >= 3 and layer == sorted(layer, reverse=True), layer
     else:
         assert result['nbuckets'] == -1
 

@@ -213,6 +213,9 @@ class Trainer:
         self.world = dist.get_world_size(process_group) if self.distributed else 1
         self._handles = []
         self._armed = False
+        self.buckets = None                # [start, end, n_params, first_param_index] per bucket (distributed runs: _setup_buckets)
+        self.bucket_order = []             # bucket indices in the order their all-reduce was launched during the last backward
+        self._comm_events = []             # (before, after) event pairs around the waits for the gradient exchange, one per step
         dev = self.flat.param.device
         self.dynamic_scale = self.cfg.mixed_precision == 'fp16'
         # the device control block drives the step whenever a per-step decision exists
@@ -339,6 +342,7 @@ class Trainer:
 
     def _reduce_bucket(self, k):
         s, e, n, first = self.buckets[k]
+        self.bucket_order.append(k)
         self.flat.collect_grads(range(first, first + n))
         self._handles.append(self._all_reduce_async(self.flat.grad[s:e]))
 
@@ -354,10 +358,31 @@ class Trainer:
         for k, left in enumerate(self._pending):
             if left > 0:
                 self._reduce_bucket(k)
+        # What of the exchange is NOT hidden behind the backward: the time the step's stream spends blocked on the collectives'
+        # completion (an event before and after the waits; nothing else is queued in between).  Read later, off the step's path
+        # (comm_exposed_ms): no host synchronisation here.
+        timed = self.flat.param.is_cuda and len(self._comm_events) < 4096
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for h in self._handles:
             h.wait()
+        if timed:
+            e1.record()
+            self._comm_events.append((e0, e1))
         self._handles.clear()
         self._pending = [b[2] for b in self.buckets]
+
+    def comm_exposed_ms(self, reset=True):
+        """per-step milliseconds the step's stream waited for the gradient exchange after the backward had ended (the part of the
+        all-reduce that the backward did not hide), for the steps since the last call; synchronises (call it when logging)"""
+        if not self._comm_events:
+            return []
+        torch.cuda.synchronize(self.flat.param.device)
+        out = [a.elapsed_time(b) for a, b in self._comm_events]
+        if reset:
+            self._comm_events.clear()
+        return out
 
     def refresh_shadow(self):
         """the 16-bit parameter shadows <- the float32 parameters.  Runs by itself after
@@ -381,6 +406,7 @@ class Trainer:
         cfg, f = self.cfg, self.flat
         f.clear_grads()
         self._armed = True
+        self.bucket_order = []
         with self.autocast():
             outputs = self.model(batch)
             loss = self.loss_fn(outputs, batch, cfg)
@@ -391,6 +417,14 @@ class Trainer:
             (loss * self.ctl[ops.CTL_SCALE].to(loss.dtype) if self.dynamic_scale else loss).backward()
         self._armed = False
         self._finish_reduce()
+        # Hand back values, not graph roots.  A caller that keeps last step's loss keeps that step's autograd nodes alive through
+        # it -- including every parameter's AccumulateGrad node, which the NEXT forward then re-uses with the stream it was created
+        # on; with the node channel on its own stream that is torch's "AccumulateGrad node's stream does not match" situation: an
+        # extra cross-stream wait per parameter in every backward, and a capture hazard.  Detached, the nodes die with the backward
+        # and each forward creates them on the stream that uses the parameter.
+        loss = loss.detach()
+        outputs = tuple(o.detach() if torch.is_tensor(o) else o for o in outputs) if isinstance(outputs, (tuple, list)) else \
+            (outputs.detach() if torch.is_tensor(outputs) else outputs)
         return outputs, loss
 
     def apply_gradients(self):

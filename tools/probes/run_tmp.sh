@@ -1,3 +1,3 @@
-mkdir -p gpurun_out/r05g
-run() { env "$@" python bench.py --no-cpu-baseline --steps 30 --warmup 8 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('$*', d['value'], d['ms_per_step'], d['step_ms'], d['memory']['device_allocs_in_timed_region'], d['memory']['reserved_GB'])"; }
-for rep in 1 2; do for k in "TGT_DEFER_SUMS=0" "TGT_DEFER_MAX=8" "TGT_DEFER_MAX=16" "TGT_DEFER_SUMS=0 PYTORCH_CUDA_ALLOC_CONF=expandable_segments:True" "TGT_DEFER_MAX=8 PYTORCH_CUDA_ALLOC_CONF=expandable_segments:True"; do run $k; done; done 2>&1 | tee gpurun_out/r05g/ab_defer_sweep2.txt
+mkdir -p gpurun_out/r05h
+run() { env "$@" python bench.py --no-cpu-baseline --steps 30 --warmup 8 2>gpurun_out/r05h/stderr.txt | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('$*', d['value'], d['ms_per_step'], d['step_ms']['median'], r['avg_launch_ms'], r['frac'], d['comm_exposed_ms'], d['memory']['device_allocs_in_timed_region'])"; grep -c "AccumulateGrad" gpurun_out/r05h/stderr.txt; }
+for k in "A=1" "TGT_TRI_BWD2_DMA=0" "A=1" "TGT_TRI_BWD2_DMA=0"; do run $k; done | tee gpurun_out/r05h/ab.txt
