@@ -385,7 +385,7 @@ def main():
                                 note='kernel sources changed since the last counter pass: traffic / mfma_util not quoted')
             # (tools/pmc_summary.py's short names of the mangled kernels; the round-4 backward lives in namespace bwd2)
             for short, name in (('tri_att_fwd_kernel', 'tgt_triplet_attention_fwd'), ('tri_att_bwd_kernel', 'tgt_triplet_attention_bwd'),
-                                ('bwd219tri_att_bwd2_kernel', 'tgt_triplet_attention_bwd'),
+                                ('tri_att_bwd2_kernel', 'tgt_triplet_attention_bwd'),
                                 ('tri_att_proj_fwd_kernel', 'tgt_triplet_attention_proj_fwd')):
                 if short in pmc and 'hbm_bytes_per_launch' in pmc[short]:
                     traffic[name] = dict(traffic_bytes=pmc[short]['hbm_bytes_per_launch'])
@@ -401,7 +401,7 @@ def main():
                             share_of_step=round(tot / (dt * 1e3), 4),
                             # matrix-core utilisation of this kernel from the SQ counter pass (offline, same shape):
                             # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs); an HBM-bound core at 15.5 FLOP/B
-                            mfma_util=pmc.get({'tgt_triplet_attention_bwd': ('bwd219tri_att_bwd2_kernel' if 'bwd219tri_att_bwd2_kernel' in pmc else 'tri_att_bwd_kernel'),
+                            mfma_util=pmc.get({'tgt_triplet_attention_bwd': ('tri_att_bwd2_kernel' if 'tri_att_bwd2_kernel' in pmc else 'tri_att_bwd_kernel'),
                                                'tgt_triplet_attention_fwd': 'tri_att_fwd_kernel',
                                                'tgt_triplet_attention_proj_fwd': 'tri_att_proj_fwd_kernel'}[name], {}).get('mfma_util'),
                             other_kernels={k: dict(avg_launch_ms=round(v[1], 4),
@@ -437,7 +437,7 @@ def main():
                                                             achieved=round(nb / (avg * 1e-3) / 1e9, 1),
                                                             frac=round(nb / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
                     # (the matrix-core kernels of csrc/node_attention_mfma.hip: one launch each way)
-                    shorts = ('nmf24node_att_mfma_fwd_kernel',) if kind == 'fwd' else ('nmf24node_att_mfma_bwd_kernel',)
+                    shorts = ('node_att_mfma_fwd_kernel',) if kind == 'fwd' else ('node_att_mfma_bwd_kernel',)
                     if all(k in pmc and 'hbm_bytes_per_launch' in pmc[k] for k in shorts):
                         roofline['other_kernels'][kname]['traffic'] = sum(pmc[k]['hbm_bytes_per_launch'] for k in shorts)
                         roofline['other_kernels'][kname]['algorithmic_bytes_per_launch'] = nb

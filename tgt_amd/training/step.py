@@ -417,6 +417,8 @@ class Trainer:
             (loss * self.ctl[ops.CTL_SCALE].to(loss.dtype) if self.dynamic_scale else loss).backward()
         self._armed = False
         self._finish_reduce()
+        if self.flat.param.is_cuda:
+            ops.release_stream_keepalive(self.flat.param.device)      # both streams joined: cross-stream tensors may go back to their pools
         # Hand back values, not graph roots.  A caller that keeps last step's loss keeps that step's autograd nodes alive through
         # it -- including every parameter's AccumulateGrad node, which the NEXT forward then re-uses with the stream it was created
         # on; with the node channel on its own stream that is torch's "AccumulateGrad node's stream does not match" situation: an

@@ -16,8 +16,22 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r'tgt\d*(\w+?_kernel)', name)
-    return m.group(1) if m else name[:60]
+    """the kernel's own identifier (`tri_att_bwd2_kernel`) from a mangled (`_ZN3tgt4bwd219tri_att_bwd2_kernelI...`) or a demangled
+    (`void tgt::bwd2::tri_att_bwd2_kernel<...>`) trace name"""
+    m = re.search(r'([A-Za-z_][A-Za-z0-9_]*_kernel)', name)
+    if not m:
+        return name[:60]
+    s = m.group(1)
+    # Itanium mangling: <length><identifier>; take the identifier whose length prefix fits
+    for i in range(len(s) - 1, 0, -1):
+        if s[i - 1].isdigit() and not s[i].isdigit():
+            j = i - 1
+            while j > 0 and s[j - 1].isdigit():
+                j -= 1
+            for k in range(j, i):
+                if int(s[k:i]) == len(s) - i:
+                    return s[i:]
+    return s
 
 
 def kernel_source_sha(root=None):
