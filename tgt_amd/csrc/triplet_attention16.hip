@@ -34,13 +34,16 @@ template <typename T> using frag4_t = typename F4<T>::type;
 __device__ __forceinline__ f32x4 mma16(s16x4 a, s16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 mma16(h16x4 a, h16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
 
+template <typename T> struct V4;
+template <> struct V4<bf16_t> { typedef __attribute__((ext_vector_type(4))) __bf16 type; };
+template <> struct V4<f16_t> { typedef __attribute__((ext_vector_type(4))) _Float16 type; };
 template <typename T>
 __device__ __forceinline__ frag4_t<T> pack4(const f32x4& v) {
-    T t[4];
+    typename V4<T>::type t;                 // (vector element assignment: hipcc pairs the conversions into two v_cvt_pk)
 #pragma unroll
     for (int i = 0; i < 4; ++i) t[i] = from_f32<T>(v[i]);
     frag4_t<T> f;
-    __builtin_memcpy(&f, t, 8);
+    __builtin_memcpy(&f, &t, 8);
     return f;
 }
 template <typename T>
@@ -52,6 +55,21 @@ __device__ __forceinline__ frag4_t<T> ident4(int x, int g) {     // B[kk][n] = (
     __builtin_memcpy(&f, t, 8);
     return f;
 }
+
+// gfx950's transposed LDS read: a 16-lane group reads a [4 rows][16 columns] block of 16-bit elements (lane p supplies the address of
+// row p >> 2, columns 4 (p & 3) ..) and lane p receives COLUMN p of it -- an operand fragment of the transposed tile, straight
+// from a row-major image (round 4: replaces the X . I matrix-core transposes and the 2-byte transposed exchange stores)
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+template <typename T>
+__device__ __forceinline__ frag4_t<T> tr_frag(const char* p) {
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s16x4*>((uint32_t)(uintptr_t)p));
+    frag4_t<T> f;
+    __builtin_memcpy(&f, &v, 8);
+    return f;
+}
+// exchange block [16 rows][16 columns] of 16-bit values, 8-byte quads XOR-swizzled with (row >> 2): conflict-free for the 8-byte
+// stores in accumulator layout (lane = row) and for the transposed reads (lane = column)
+__device__ __forceinline__ int xblk_off(int row, int quad) { return row * 32 + ((quad ^ ((row >> 2) & 3)) << 3); }
 
 // slab geometry: 16 * NQ rows of HG heads x 16 channels; the slab_* templates of triplet_common.hpp take it as they take TriGeo
 template <typename T, int HG, int NQ>
@@ -261,14 +279,17 @@ __global__ void __launch_bounds__(HG * NQ * 64) tri_att16_bwd_kernel(const tgt_t
     using G = Geo16<T, HG, NQ>;
     using A = Arm16<T, HG, NQ>;
     using F = frag4_t<T>;
-    constexpr int R = G::kRows, kSet = 4 * G::kSlabBytes;        // {Q | dO | K | V}, two sets
+    constexpr int R = G::kRows, kSet = 4 * G::kSlabBytes;        // {Q | dO | K | V}, THREE sets: the slabs land in LDS two steps ahead (LDS-DMA)
     constexpr int kBlk = 16 * 16 * (int)sizeof(T);               // one 16x16 exchange block
     constexpr int kXWave = (2 + 2 * NQ) * kBlk;                  // per (head, query block): Q^T, dO^T, dS[kb], A[kb]
-    constexpr int kOffX = 2 * kSet;
+    constexpr int kOffX = 3 * kSet;
+    constexpr int kPieces = G::kSlabBytes / 1024;                // 1 KB (one wave instruction) pieces per slab
+    static_assert(G::kSlabBytes % 1024 == 0 && 4 * kPieces == 2 * HG * NQ, "every wave loads exactly two pieces of a set");
     constexpr int E = 16 / (int)sizeof(T);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int x16 = lane & 15, g = lane >> 4, hw = wave % HG, qb = wave / HG;
+    const int pr = x16 >> 2, c2 = x16 & 3;          // the address a lane supplies to a transposed read: row pr, column quad c2 of its group's block
     const int ngroups = a.H / HG;
     int bid = blockIdx.x;
     const int grp = bid % ngroups;
@@ -336,15 +357,9 @@ __global__ void __launch_bounds__(HG * NQ * 64) tri_att16_bwd_kernel(const tgt_t
     static_assert(SlabIO<G, R>::kIters == 1, "one chunk per thread");
     const bool has_chunk = tid < SlabIO<G, R>::kChunks;
     const int crow = tid / G::kSlots, cslot = tid % G::kSlots;
-    // column sums of dQ, dK, dV over this thread's chunk column: fp32 accumulators in LDS behind the exchange area (this thread's
-    // own 96 bytes, plain read-modify-write; 24 more registers would push the tile math into scratch)
-    float* csl = reinterpret_cast<float*>(smem + kOffX + HG * NQ * kXWave) + tid * 3 * E;
-    if constexpr (CS) {
-        if (has_chunk)
-#pragma unroll
-            for (int e = 0; e < 3 * E; ++e) csl[e] = 0.f;
-    }
-
+    // column sums of dQ, dK, dV (the projection's bias gradient) in registers, from the fp32 accumulators: dQ^T of this wave's
+    // query block (lane = query, d = 4g + q), dK^T / dV^T of its key block (lane = key); lanes and blocks are summed after the walk
+    f32x4 cq = {0.f, 0.f, 0.f, 0.f}, ck = {0.f, 0.f, 0.f, 0.f}, cv = {0.f, 0.f, 0.f, 0.f};
     // a graph DropPath dropped (graph_scale[b] == 0) receives an all-zero d_out: zeros to its gradient rows, nothing read or
     // computed; dE / dG (zero-initialised above) and the column sums leave through the common tail below
     const bool dead = a.graph_scale && a.graph_scale[b] == 0.f;          // workgroup-uniform
@@ -355,56 +370,82 @@ __global__ void __launch_bounds__(HG * NQ * 64) tri_att16_bwd_kernel(const tgt_t
             slab_store_zero<G, R>(gV, j, 0, N, tid);
         }
     } else {
-    uint4 pq[1], po[1], pk[1], pv[1];
-    slab_issue<G, R>(pq, bQ, 0, 0, N, tid);
-    slab_issue<G, R>(po, bO, 0, 0, N, tid);
-    slab_issue<G, R>(pk, bK, 0, 0, N, tid);
-    slab_issue<G, R>(pv, bV, 0, 0, N, tid);
-    slab_commit<G, R>(pq, smem, tid);
-    slab_commit<G, R>(po, smem + G::kSlabBytes, tid);
-    slab_commit<G, R>(pk, smem + 2 * G::kSlabBytes, tid);
-    slab_commit<G, R>(pv, smem + 3 * G::kSlabBytes, tid);
-    if (N > 1) {
-        slab_issue<G, R>(pq, bQ, 1, 0, N, tid);
-        slab_issue<G, R>(po, bO, 1, 0, N, tid);
-        slab_issue<G, R>(pk, bK, 1, 0, N, tid);
-        slab_issue<G, R>(pv, bV, 1, 0, N, tid);
+    // Loads (round 4, as triplet_attention_bwd2.hip): buffer_load ... lds straight into set (step % 3), two steps ahead; each wave
+    // owns two 1 KB pieces of a set (piece t = wave and wave + #waves of the 4 * kPieces pieces {Q | dO | K | V}); a lane's 16 bytes
+    // land at physical chunk (row, slot'), i.e. it fetches slot' ^ swizzle(row) of the row (the LDS image keeps Geo16's layout);
+    // rows past N and steps past the end are out of range (no bytes written: the sets are zero-filled first when N < R).
+    // Inline assembly with hand-placed waits: hipcc would order every LDS read behind a builtin LDS-DMA with vmcnt(0).
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const uint32_t sbase = (uint32_t)(uintptr_t)smem;
+    const uint64_t src_base = (uint64_t)(uintptr_t)a.qkv[dir] + (uint64_t)b * (uint64_t)(Nl * Nl * a.ld_qkv[dir] * sz);
+    const uint64_t do_base = (uint64_t)(uintptr_t)a.d_out + (uint64_t)b * (uint64_t)(Nl * Nl * a.ld_out * sz);
+    const uint32_t src_bytes = (uint32_t)(Nl * Nl * a.ld_qkv[dir] * sz), do_bytes = (uint32_t)(Nl * Nl * a.ld_out * sz);
+    uint32_t l_off[2], l_voff[2], l_chan[2], l_js[2];
+    bool l_do[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int t = wave_u + u * HG * NQ, slab = t / kPieces, piece = t % kPieces;      // (wave-uniform)
+        const int c = piece * 64 + lane, row = c / G::kSlots, pslot = c % G::kSlots;
+        const int f = (row / G::kRowsPerBankRow) & G::kSwzMask;
+        const SlabBuf& sb = slab == 0 ? bQ : (slab == 1 ? bO : (slab == 2 ? bK : bV));
+        l_off[u] = (uint32_t)(slab * G::kSlabBytes + piece * 1024);
+        l_voff[u] = row < N ? (uint32_t)row * sb.row_stride + (uint32_t)((pslot ^ f) << 4) : 0x80000000u;
+        l_chan[u] = sb.chan;
+        l_js[u] = sb.j_stride;
+        l_do[u] = slab == 1;
     }
-    __syncthreads();
+    auto dma = [&](int jj, int set) {
+        const bool live = jj < N;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint64_t base = l_do[u] ? do_base : src_base;
+            const u32x4_t rs = {(uint32_t)base, (uint32_t)(base >> 32) & 0xffffu, live ? (l_do[u] ? do_bytes : src_bytes) : 0u, 0x00020000u};
+            const uint32_t lds = sbase + (uint32_t)(set * kSet) + l_off[u];
+            const uint32_t so = l_chan[u] + (uint32_t)jj * l_js[u];
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds"
+                         :: "s"(lds), "v"(l_voff[u]), "s"(rs), "s"(so) : "memory");
+        }
+    };
+    // every thread issues three result stores per step (out of range where it owns no chunk / no row): the wait counts below
+    // are the same number in every wave
+    const bool own = has_chunk && crow < N;
+    const uint32_t kOOB = 0x80000000u;
+    const uint32_t wQ = own ? (uint32_t)crow * gQ.row_stride + (uint32_t)cslot * 16u : kOOB;
+    const uint32_t wK = own ? (uint32_t)crow * gK.row_stride + (uint32_t)cslot * 16u : kOOB;
+    const int chunk = has_chunk ? G::lds_off(crow, cslot) : 0;
+    if (N < R) {
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
+        for (int o = tid * 16; o < 3 * kSet; o += G::kThreads * 16) *reinterpret_cast<uint4*>(smem + o) = z4;
+        __syncthreads();
+    }
+    dma(0, 0);
+    dma(1, 1);
+    {
+        const u32x4_t z4 = {0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 3; ++t) __builtin_amdgcn_raw_buffer_store_b128(z4, r_grd, (int)kOOB, 16 * t, TGT_ST_AUX);
+    }
+    // queue: loads(0) x2, loads(1) x2, 3 stores
+    asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
-    const F ident = ident4<T>(x16, g);
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     char* xw = smem + kOffX + (hw * NQ + qb) * kXWave;          // this wave's exchange blocks (phase 1)
+    int cur = 0;
     for (int j = 0; j < N; ++j) {
-        char* sQ = smem + (j & 1) * kSet;
+        char* sQ = smem + cur * kSet;
         char* sO = sQ + G::kSlabBytes;
         char* sK = sQ + 2 * G::kSlabBytes;
         char* sV = sQ + 3 * G::kSlabBytes;
-        if (j + 1 < N) {
-            char* nQ = smem + ((j + 1) & 1) * kSet;
-            slab_commit<G, R>(pq, nQ, tid);
-            slab_commit<G, R>(po, nQ + G::kSlabBytes, tid);
-            slab_commit<G, R>(pk, nQ + 2 * G::kSlabBytes, tid);
-            slab_commit<G, R>(pv, nQ + 3 * G::kSlabBytes, tid);
-        }
-        if (j + 2 < N) {
-            slab_issue<G, R>(pq, bQ, j + 2, 0, N, tid);
-            slab_issue<G, R>(po, bO, j + 2, 0, N, tid);
-            slab_issue<G, R>(pk, bK, j + 2, 0, N, tid);
-            slab_issue<G, R>(pv, bV, j + 2, 0, N, tid);
-        }
         // ---- phase 1: (head, query block) ----
         {
             const F fq = frag_of<T, G>(sQ, 16 * qb + x16, hw, g), fo = frag_of<T, G>(sO, 16 * qb + x16, hw, g);
             f32x4 s[NQ], da[NQ];
-            F kTf[NQ];
             float mx = -INFINITY;
 #pragma unroll
             for (int kb = 0; kb < NQ; ++kb) {
                 const F fk = frag_of<T, G>(sK, 16 * kb + x16, hw, g), fv = frag_of<T, G>(sV, 16 * kb + x16, hw, g);
                 s[kb] = mma16(fk, fq, z);                 // S^T[key][query]
                 da[kb] = mma16(fv, fo, z);                // dA^T[key][query]
-                kTf[kb] = pack4<T>(mma16(fk, ident, z));  // K^T: lane d, keys 4g..4g+3
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     s[kb][q] = s[kb][q] * a.scale + biasM[kb][q];
@@ -438,9 +479,11 @@ __global__ void __launch_bounds__(HG * NQ * 64) tri_att16_bwd_kernel(const tgt_t
                 }
             delta = xor16_sum(delta);
             delta += xhalf(delta);
-            // Q^T, dO^T in operand layout (lane d, queries 4g..4g+3) for phase 2
+            // Q^T, dO^T in operand layout (lane d, queries 4g..4g+3) for phase 2: a copy, because this wave's dQ rows replace its
+            // Q rows in the slab before the other waves of the head get there
             {
-                const F qTf = pack4<T>(mma16(fq, ident, z)), oTf = pack4<T>(mma16(fo, ident, z));
+                const F qTf = tr_frag<T>(sQ + G::lds_elem(16 * qb + 4 * g + pr, hw * 16 + 4 * c2));
+                const F oTf = tr_frag<T>(sO + G::lds_elem(16 * qb + 4 * g + pr, hw * 16 + 4 * c2));
                 uint2 r0, r1;
                 __builtin_memcpy(&r0, &qTf, 8);
                 __builtin_memcpy(&r1, &oTf, 8);
@@ -450,7 +493,7 @@ __global__ void __launch_bounds__(HG * NQ * 64) tri_att16_bwd_kernel(const tgt_t
             f32x4 dq = z;
 #pragma unroll
             for (int kb = 0; kb < NQ; ++kb) {
-                f32x4 dsv;
+                f32x4 dsv, atv;
                 char* xs = xw + (2 + kb) * kBlk;
                 char* xa = xw + (2 + NQ + kb) * kBlk;
 #pragma unroll
@@ -458,18 +501,28 @@ __global__ void __launch_bounds__(HG * NQ * 64) tri_att16_bwd_kernel(const tgt_t
                     const float ds = s[kb][q] * (da[kb][q] - delta);
                     if (biased) dE[kb][q] += ds;
                     dsv[q] = ds * a.scale;
-                    // transposed on the way out: block[key][query]
-                    *reinterpret_cast<T*>(xs + ((4 * g + q) * 16 + x16) * (int)sizeof(T)) = from_f32<T>(dsv[q]);
-                    *reinterpret_cast<T*>(xa + ((4 * g + q) * 16 + x16) * (int)sizeof(T)) = from_f32<T>(s[kb][q] * gate[kb][q]);
+                    atv[q] = s[kb][q] * gate[kb][q];
                 }
-                dq = mma16(kTf[kb], pack4<T>(dsv), dq);          // dQ^T[d][query]
+                // block[query][key], as the accumulator holds it (lane = query, keys 4g..4g+3): one 8-byte store each; phase 2
+                // reads them transposed
+                const F dsf = pack4<T>(dsv), atf = pack4<T>(atv);
+                uint2 w0, w1;
+                __builtin_memcpy(&w0, &dsf, 8);
+                __builtin_memcpy(&w1, &atf, 8);
+                *reinterpret_cast<uint2*>(xs + xblk_off(x16, g)) = w0;
+                *reinterpret_cast<uint2*>(xa + xblk_off(x16, g)) = w1;
+                // K^T of the key block (lane d, keys 4g..4g+3) straight from the slab, transposed by the read
+                dq = mma16(tr_frag<T>(sK + G::lds_elem(16 * kb + 4 * g + pr, hw * 16 + 4 * c2)), dsf, dq);          // dQ^T[d][query]
             }
             const F dqf = pack4<T>(dq);
             uint2 raw;
             __builtin_memcpy(&raw, &dqf, 8);
             *reinterpret_cast<uint2*>(sQ + G::lds_elem(16 * qb + x16, hw * 16 + 4 * g)) = raw;
+            if constexpr (CS) cq += dq;
         }
         __syncthreads();
+        // the slabs of step j + 2 into the set of step j - 1: every thread read its result chunks of that set before it got here
+        dma(j + 2, cur == 0 ? 2 : cur - 1);
         // ---- phase 2: (head, KEY block = this wave's block index) ----
         {
             const int kb = qb;
@@ -480,12 +533,11 @@ __global__ void __launch_bounds__(HG * NQ * 64) tri_att16_bwd_kernel(const tgt_t
                 F qTf, oTf, dsb, ab;
                 const uint2 r0 = *reinterpret_cast<const uint2*>(xo + (x16 * 16 + 4 * g) * (int)sizeof(T));
                 const uint2 r1 = *reinterpret_cast<const uint2*>(xo + kBlk + (x16 * 16 + 4 * g) * (int)sizeof(T));
-                const uint2 r2 = *reinterpret_cast<const uint2*>(xo + (2 + kb) * kBlk + (x16 * 16 + 4 * g) * (int)sizeof(T));
-                const uint2 r3 = *reinterpret_cast<const uint2*>(xo + (2 + NQ + kb) * kBlk + (x16 * 16 + 4 * g) * (int)sizeof(T));
                 __builtin_memcpy(&qTf, &r0, 8);
                 __builtin_memcpy(&oTf, &r1, 8);
-                __builtin_memcpy(&dsb, &r2, 8);
-                __builtin_memcpy(&ab, &r3, 8);
+                // dS / A of (query block q2, key block kb) as the B operand: lane = key, queries 4g..4g+3 -- transposed reads
+                dsb = tr_frag<T>(xo + (2 + kb) * kBlk + xblk_off(4 * g + pr, c2));
+                ab = tr_frag<T>(xo + (2 + NQ + kb) * kBlk + xblk_off(4 * g + pr, c2));
                 dk = mma16(qTf, dsb, dk);                 // dK^T[d][key] += Q^T[d][queries] dS[queries][key]
                 dv = mma16(oTf, ab, dv);                  // dV^T[d][key] += dO^T[d][queries] A[queries][key]
             }
@@ -495,37 +547,21 @@ __global__ void __launch_bounds__(HG * NQ * 64) tri_att16_bwd_kernel(const tgt_t
             __builtin_memcpy(&r1, &dvf, 8);
             *reinterpret_cast<uint2*>(sK + G::lds_elem(16 * kb + x16, hw * 16 + 4 * g)) = r0;
             *reinterpret_cast<uint2*>(sV + G::lds_elem(16 * kb + x16, hw * 16 + 4 * g)) = r1;
+            if constexpr (CS) { ck += dk; cv += dv; }
         }
-        __syncthreads();
-        if (has_chunk && crow < N) {
-            const char* slabs[3] = {sQ, sK, sV};
-            const SlabBuf* dst[3] = {&gQ, &gK, &gV};
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                const uint4 v = *reinterpret_cast<const uint4*>(slabs[p] + G::lds_off(crow, cslot));
-                if constexpr (CS) {
-                    T xa[E];
-                    __builtin_memcpy(xa, &v, 16);
-                    float4* acc = reinterpret_cast<float4*>(csl + p * E);
-#pragma unroll
-                    for (int e4 = 0; e4 < E / 4; ++e4) {
-                        float4 t = acc[e4];
-                        t.x += to_f32(xa[4 * e4]); t.y += to_f32(xa[4 * e4 + 1]); t.z += to_f32(xa[4 * e4 + 2]); t.w += to_f32(xa[4 * e4 + 3]);
-                        acc[e4] = t;
-                    }
-                }
-                const uint32_t so = dst[p]->chan + (uint32_t)j * dst[p]->j_stride;
-                buf_store16(*dst[p], v, (uint32_t)crow * dst[p]->row_stride + (uint32_t)cslot * 16u, so);
-                // A 128-bit store reads its data registers a cycle or two AFTER it issues; hipcc pads that hazard only for
-                // stores without a scalar offset, and here the fp16 column-sum code that follows wrote a conversion result
-                // into the first data register right behind the store (seen: the first dword of stored chunks replaced by
-                // fp32 bit patterns, tools/probes/dbg_tri16.py).  Two wait states, fenced against the scheduler:
-                __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_nop 1" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        // queue: loads(j+1) x2, stores(j-1) x3, loads(j+2) x2 -- the slabs of step j + 1 have landed for every wave behind this
+        asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        {
+            const u32x4_t o0 = *reinterpret_cast<const u32x4_t*>(sQ + chunk);
+            const u32x4_t o2 = *reinterpret_cast<const u32x4_t*>(sK + chunk);
+            const u32x4_t o3 = *reinterpret_cast<const u32x4_t*>(sV + chunk);
+            __builtin_amdgcn_raw_buffer_store_b128(o0, r_grd, (int)wQ, (int)(gQ.chan + (uint32_t)j * gQ.j_stride), TGT_ST_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(o2, r_grd, (int)wK, (int)(gK.chan + (uint32_t)j * gK.j_stride), TGT_ST_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(o3, r_grd, (int)wK, (int)(gV.chan + (uint32_t)j * gV.j_stride), TGT_ST_AUX);
         }
+        cur = cur == 2 ? 0 : cur + 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the out-of-range loads past the end of the walk)
     }      // (!dead)
     __syncthreads();
     // ---- third-arm gradients: through the stage image, then 2-byte scatter (as arm_stage_store_grad) ----
@@ -559,27 +595,31 @@ __global__ void __launch_bounds__(HG * NQ * 64) tri_att16_bwd_kernel(const tgt_t
         }
     }
     if constexpr (CS) {
-        float csum[3][E];
+        __syncthreads();                                         // the stage image is dead: its space takes the fold
+        float* cs = reinterpret_cast<float*>(smem);              // [tensor][head][block][16 d], then one dE / dG partial per thread
+        constexpr int kFold = 3 * HG * NQ * 16;
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int e = 0; e < E; ++e) csum[p][e] = has_chunk ? csl[p * E + e] : 0.f;
-        __syncthreads();                                         // the stage image and the accumulators are dead: their space takes the fold
-        constexpr int kPlane = G::kThreads * E;
-        float* cs = reinterpret_cast<float*>(smem);
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int e = 0; e < E; ++e) cs[p * kPlane + tid * E + e] = csum[p][e];
-        cs[3 * kPlane + tid] = part;
+        for (int q = 0; q < 4; ++q) {
+            const float vq = group_sum<16>(cq[q]), vk = group_sum<16>(ck[q]), vv = group_sum<16>(cv[q]);
+            if (x16 == 0) {
+                cs[((0 * HG + hw) * NQ + qb) * 16 + 4 * g + q] = vq;
+                cs[((1 * HG + hw) * NQ + qb) * 16 + 4 * g + q] = vk;
+                cs[((2 * HG + hw) * NQ + qb) * 16 + 4 * g + q] = vv;
+            }
+        }
+        cs[kFold + tid] = part;
         __syncthreads();
         float* row = a.d_qkv_colsum[dir] + (int64_t)b * ldq + grp * HG * 16;
-        slab_colsum_finish<G, T>(cs, row + a.q_off[dir], tid);
-        slab_colsum_finish<G, T>(cs + kPlane, row + a.k_off[dir], tid);
-        slab_colsum_finish<G, T>(cs + 2 * kPlane, row + a.v_off[dir], tid);
+        if (tid < 3 * HG * 16) {
+            const int t = tid / (HG * 16), col = tid % (HG * 16), h = col / 16, d = col % 16;
+            float v = 0.f;
+#pragma unroll
+            for (int blk = 0; blk < NQ; ++blk) v += cs[((t * HG + h) * NQ + blk) * 16 + d];
+            row[(t == 0 ? a.q_off[dir] : (t == 1 ? a.k_off[dir] : a.v_off[dir])) + col] = v;
+        }
         if ((biased || gated) && tid < A::kVals) {
             float v = 0.f;
-            for (int t = tid; t < G::kThreads; t += A::kVals) v += cs[3 * kPlane + t];
+            for (int t = tid; t < G::kThreads; t += A::kVals) v += cs[kFold + t];
             float* erow = a.d_eg_colsum[dir] + (int64_t)b * lde;
             if (tid < HG) { if (biased) erow[a.e_off[dir] + grp * HG + tid] = v; }
             else if (gated) erow[a.g_off[dir] + grp * HG + tid - HG] = v;
@@ -592,8 +632,8 @@ static int launch_bwd(const tgt_triplet_attention_args& a, hipStream_t st) {
     using G = Geo16<T, HG, NQ>;
     constexpr int E = 16 / (int)sizeof(T);
     constexpr int kArm = Arm16<T, HG, NQ>::kBytes;
-    constexpr int kWalk = 2 * 4 * G::kSlabBytes + HG * NQ * (2 + 2 * NQ) * 16 * 16 * (int)sizeof(T) + SlabIO<G, G::kRows>::kChunks * 3 * E * 4;      // (+ the column-sum accumulators of the chunk-owning threads)
-    constexpr int kCs = (3 * G::kThreads * E + G::kThreads) * 4;
+    constexpr int kWalk = 3 * 4 * G::kSlabBytes + HG * NQ * (2 + 2 * NQ) * 16 * 16 * (int)sizeof(T);
+    constexpr int kCs = (3 * HG * NQ * 16 + G::kThreads) * 4;
     constexpr int kLds = (kArm > kWalk ? kArm : kWalk) > kCs ? (kArm > kWalk ? kArm : kWalk) : kCs;
     static_assert(kLds <= 160 * 1024, "LDS");
     const bool cs = a.d_qkv_colsum[0] != nullptr;

@@ -1,4 +1,4 @@
-mkdir -p gpurun_out/r05j
-timeout 1500 python -m pytest tests/test_hip_trainer.py tests/test_hip_model.py -x -q -m gpu 2>&1 | tail -3
-run() { env "$@" python bench.py --no-cpu-baseline --steps 30 --warmup 8 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('$*', d['value'], d['ms_per_step'], d['step_ms'], d['memory'])"; }
-for k in "TGT_STREAM_KEEPALIVE=1" "TGT_STREAM_KEEPALIVE=0" "TGT_STREAM_KEEPALIVE=1" "TGT_STREAM_KEEPALIVE=0"; do run $k; done | tee gpurun_out/r05j/ab_keepalive.txt
+mkdir -p gpurun_out/r05k
+python bench.py --no-cpu-baseline --nodes 48 --batch 128 --steps 20 --warmup 6 2>/dev/null | tail -1 > gpurun_out/r05k/bench_n48_b128.json
+python -c "
+import json; d=json.load(open('gpurun_out/r05k/bench_n48_b128.json')); r=d['roofline']; print(d['value'], d['ms_per_step'], d['step_ms'], r['kernel'], r['avg_launch_ms'], r['frac'], r['timing']['alone'], {k:v['avg_launch_ms'] for k,v in r['other_kernels'].items()})"
