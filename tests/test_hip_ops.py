@@ -979,6 +979,50 @@ def test_baseline_size_projection_bias_gradient():
     assert rel(ys, y1[100:102]) < 1e-3 and rel(dxs, dx1[100:102]) < 1e-3
 
 
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+def test_baseline_size_projection_fused_forward_slices(dt, monkeypatch):
+    """tgt_triplet_attention_proj_fwd -- the forward the benchmark runs -- at BASELINE size (B = 256, N = 32, ragged masks, a tenth
+    of the graphs DropPath-dropped): graphs [s:e] of the full launch equal a launch on that slice alone BIT FOR BIT (the output
+    and the Q / K / V rows the kernel leaves for the backward: compared through the backward kernel's gradient rows), dropped
+    graphs give exact zeros, everything is finite.  The slice shapes are the ones test_projection_fused_triplet_attention_vs_oracle
+    holds to the float64 oracle.  """
+    from tgt_amd import ops
+    monkeypatch.setattr(ops, '_SPLIT_MIN_ROWS', 1)            # the 3-graph slices take the projection-fused kernel too
+    B, N, C, Ht = 256, 32, 256, 16
+    L = ops.TripletLayout(C, Ht)
+    rng = np.random.default_rng(15)
+    m3, _ = _ragged_mask3(B, N, rng)
+    g = torch.Generator(device='cuda').manual_seed(21)
+    randn = lambda *s: torch.randn(*s, device='cuda', generator=g)
+    x = randn(B, N, N, C).to(dt)
+    w = (randn(L.width, C) * C ** -0.5).to(dt)
+    b = (randn(L.width) * 0.1).to(dt)
+    d_out = randn(B, N, N, 2 * C).to(dt)
+    scale = ((torch.rand(B, device='cuda', generator=g) > 0.1).float() / 0.9)
+    scale[1], scale[B - 2] = 0.0, 0.0                          # dropped graphs inside the compared slices
+
+    def run(sl):
+        xs = x[sl].clone().requires_grad_(True)
+        with torch.autocast('cuda', dtype=dt):
+            y = ops.projected_triplet_attention(xs, w, b, m3[sl], L, graph_scale=scale[sl].contiguous())
+        assert type(y.grad_fn).__name__ == '_ProjectedTripletAttentionBackward'
+        q = y.grad_fn.saved_tensors[2] if hasattr(y.grad_fn, 'saved_tensors') else None
+        dx, = torch.autograd.grad(y, xs, d_out[sl] * (scale[sl] > 0).to(dt).view(-1, 1, 1, 1))
+        return y.detach(), q, dx
+    prof = ops.profile_kernels(True)
+    full = run(slice(None))
+    ops.profile_kernels(False)
+    assert 'tgt_triplet_attention_proj_fwd' in ops.kernel_times_ms(prof)           # the fused kernel ran (not GEMM + attention)
+    for s_, e_ in ((0, 3), (B // 2 - 27, B // 2 - 24), (B - 3, B)):
+        part = run(slice(s_, e_))
+        assert torch.equal(full[0][s_:e_], part[0])
+        if full[1] is not None and part[1] is not None and full[1].shape[1:] == part[1].shape[1:]:
+            live = (scale[s_:e_] > 0)
+            assert torch.equal(full[1][s_:e_][live], part[1][live])              # the Q / K / V rows written for the backward
+    assert float(full[0][1].abs().max()) == 0.0 and float(full[0][B - 2].abs().max()) == 0.0
+    assert torch.isfinite(full[0]).all() and torch.isfinite(full[2]).all()
+
+
 @pytest.mark.parametrize('shape', [(8, 768, 768), (128, 256, 256), (32, 1536, 256), (128, 64, 256), (3, 5, 7), (1, 16), (33, 1030)])
 def test_sum_planes(shape):
     """closing sum of the chunked weight gradients (tgt_sum_planes): fixed order, so two launches agree
