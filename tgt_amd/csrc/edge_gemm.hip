@@ -655,6 +655,8 @@ __global__ void __launch_bounds__(1024, 4) edge_rows_kernel(const tgt_edge_linea
     if (blockIdx.x >= row_tiles) return;
     const int n_tiles = (int)((row_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x);       // tiles of this workgroup
     auto tile_of = [&](int s) { return (int64_t)blockIdx.x + (int64_t)s * gridDim.x; };    // (s >= n_tiles: past the last row -> empty buffers)
+    // (static wave priority for either role -- what gave the projection-fused triplet forward 8 % -- measured neutral here:
+    // profiles/r05o_ab_prio.txt)
 
     if (wave < 8) {
         // ------------------------------------------------------------------------------------------------ GEMM role

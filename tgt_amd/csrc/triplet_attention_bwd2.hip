@@ -152,6 +152,7 @@ __global__ void __launch_bounds__(kThreads, 2) __attribute__((amdgpu_waves_per_e
     const int chunk = crow * kRow + cslot * 16;
 
     float* part = reinterpret_cast<float*>(smem + kOffPart);
+    // (s_setprio 1 for the younger half of the workgroup: measured neutral, profiles/r05o_ab_prio.txt -- the kernel is memory-bound)
 
     // a graph DropPath dropped (graph_scale[b] == 0) receives an all-zero d_out: zeros to its gradient rows and column sums
     const bool dead = a.graph_scale && a.graph_scale[c.b] == 0.f;          // workgroup-uniform

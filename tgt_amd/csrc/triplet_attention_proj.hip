@@ -130,6 +130,14 @@ __device__ __forceinline__ void proj2_walk(const tgt_triplet_attention_args& a, 
     //    read it in iteration j-1 (before B_{j-1}).  X tile (j+1)&1, read in iteration j, was committed before B_{j-1}.
     //  * O slab j&1 is written in iteration j and stored after B_j; it is written again in iteration j+2, after B_{j+1}.
     const int l16 = lane & 15, l4 = lane >> 4;
+    // Static wave priority (round 4): the projection role -- the younger half of the workgroup, which loses the per-SIMD issue
+    // arbitration by age, and the matrix-pipe-heavy one -- runs at s_setprio 1 for the whole walk: 0.459 -> 0.420 ms at B = 256
+    // (profiles/r05n_proj_prio.txt; 2 = the attention role instead: no change).  The condition must be provably wave-uniform
+    // (readfirstlane): s_setprio ignores EXEC.
+#ifndef TGT_PROJ_PRIO
+#define TGT_PROJ_PRIO 1
+#endif
+    if (TGT_PROJ_PRIO != 0 && __builtin_amdgcn_readfirstlane(wave) >= 8 == (TGT_PROJ_PRIO == 1)) __builtin_amdgcn_s_setprio(1);
     if (attend) {
         // ------------------------------------------------------------------------------------------- attention role
         float biasM[16], gate[16];

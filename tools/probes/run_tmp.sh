@@ -1,4 +1,3 @@
-mkdir -p gpurun_out/r05k
-python bench.py --no-cpu-baseline --nodes 48 --batch 128 --steps 20 --warmup 6 2>/dev/null | tail -1 > gpurun_out/r05k/bench_n48_b128.json
-python -c "
-import json; d=json.load(open('gpurun_out/r05k/bench_n48_b128.json')); r=d['roofline']; print(d['value'], d['ms_per_step'], d['step_ms'], r['kernel'], r['avg_launch_ms'], r['frac'], r['timing']['alone'], {k:v['avg_launch_ms'] for k,v in r['other_kernels'].items()})"
+mkdir -p gpurun_out/r05o
+run() { TGT_HIP_LIB=${1:+$PWD/$1} python bench.py --no-cpu-baseline --steps 30 --warmup 8 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('lib=$1', d['value'], d['step_ms']['median'], r['avg_launch_ms'], {k:v['avg_launch_ms'] for k,v in r['other_kernels'].items()})"; }
+for rep in 1 2; do for lib in "" tools/probes/lib_er1.so tools/probes/lib_er2.so tools/probes/lib_b2p.so; do run $lib; done; done | tee gpurun_out/r05o/ab_prio.txt
