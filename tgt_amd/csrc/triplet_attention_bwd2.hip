@@ -86,6 +86,55 @@ __device__ __forceinline__ uint2 frag_half(const frag_t<T>& f, int h) {
     return v;
 }
 
+// Third-arm staging with 16-byte global accesses.  A pair's record [E of the 8 heads | G of the 8 heads] is two 16-byte pieces of
+// its E/G row; the generic arm_stage_load / arm_stage_store_grad of triplet_common.hpp move them as sixteen 2-byte values per pair
+// (256 + 256 wave instructions per workgroup around a walk of 768 16-byte stores).  The LDS image is ArmStage's (records 4-byte
+// aligned: four dword accesses per piece), so arm_stage_read / arm_stage_put_grad work on it unchanged.
+// Requires 16-byte aligned pieces: tri_att_bwd2_eligible checks the row lengths and offsets.
+template <typename T>
+__device__ __forceinline__ void arm_load16(const ThirdArm& ta, int b, int dir, int g, int N, char* lds, int tid) {
+    using A = ArmStage<T, HG, 1>;
+    const int pitch = A::pitch(dir), mpitch = A::mpitch(dir);
+    const char* eg = reinterpret_cast<const char*>(ta.eg);
+    for (int idx = tid; idx < 32 * 32 * 2; idx += kThreads) {
+        const int half = idx & 1, pr = idx >> 1, yy = pr & 31, xx = pr >> 5;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (xx < N && yy < N && (half == 0 ? ta.biased : ta.gated))
+            v = *reinterpret_cast<const uint4*>(eg + ((((int64_t)b * N + xx) * N + yy) * ta.ld + (half == 0 ? ta.e_off : ta.g_off) + g * HG) * 2);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(lds + xx * pitch + yy * A::kPairBytes + half * 16);
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    }
+    for (int idx = tid; idx < 32 * 32; idx += kThreads) {
+        const int yy = idx & 31, xx = idx >> 5;
+        float m = 0.f;
+        if (xx < N && yy < N && ta.mask) m = ta.mask[((int64_t)b * N + xx) * N + yy];
+        *reinterpret_cast<float*>(lds + A::kOffM + xx * mpitch + yy * 4) = m;
+    }
+}
+// the gradient records back to the E/G gradient rows; sums[h] += what this thread stored for head h of ITS piece (tid & 1: 0 = E, 1 = G;
+// the stored, i.e. rounded, values)
+template <typename T>
+__device__ __forceinline__ void arm_store16(const ThirdArm& ta, void* d_eg, int b, int dir, int g, int N, const char* lds, int tid,
+                                            float (&sums)[HG]) {
+    using A = ArmStage<T, HG, 1>;
+    const int pitch = A::pitch(dir);
+    char* deg = reinterpret_cast<char*>(d_eg);
+    static_assert(kThreads % 2 == 0, "a thread must own one piece (E or G)");
+#pragma nounroll
+    for (int idx = tid; idx < 32 * 32 * 2; idx += kThreads) {
+        const int half = idx & 1, pr = idx >> 1, yy = pr & 31, xx = pr >> 5;
+        if (xx < N && yy < N && (half == 0 ? ta.biased : ta.gated)) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(lds + xx * pitch + yy * A::kPairBytes + half * 16);
+            const uint4 v = make_uint4(src[0], src[1], src[2], src[3]);
+            *reinterpret_cast<uint4*>(deg + ((((int64_t)b * N + xx) * N + yy) * ta.ld + (half == 0 ? ta.e_off : ta.g_off) + g * HG) * 2) = v;
+            T t[HG];
+            __builtin_memcpy(t, &v, 16);
+#pragma unroll
+            for (int h = 0; h < HG; ++h) sums[h] += to_f32(t[h]);
+        }
+    }
+}
+
 // FL >= 0: BIASED / GATED compiled in (the training instantiation); FL < 0: read from the arguments
 template <typename T, bool CS, int FL, bool DMA>
 __global__ void __launch_bounds__(kThreads, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) tri_att_bwd2_kernel(const tgt_triplet_attention_args a) {
@@ -151,7 +200,7 @@ __global__ void __launch_bounds__(kThreads, 2) __attribute__((amdgpu_waves_per_e
     const uint32_t wK = rowok ? (uint32_t)crow * gKr + lslot16 : kOOB;
     const int chunk = crow * kRow + cslot * 16;
 
-    float* part = reinterpret_cast<float*>(smem + kOffPart);
+    float* part = reinterpret_cast<float*>(smem + kOffXch);        // after the walk: [thread][head] partial dE / dG column sums (16 KB of the dead exchange tiles)
     // (s_setprio 1 for the younger half of the workgroup: measured neutral, profiles/r05o_ab_prio.txt -- the kernel is memory-bound)
 
     // a graph DropPath dropped (graph_scale[b] == 0) receives an all-zero d_out: zeros to its gradient rows and column sums
@@ -166,7 +215,8 @@ __global__ void __launch_bounds__(kThreads, 2) __attribute__((amdgpu_waves_per_e
         const float zero16[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         arm_stage_put_grad<T, HG, 1>(smem, c.dir, wave, r, hi, 0, zero16, zero16);
         __syncthreads();
-        arm_stage_store_grad<T, HG, 1>(dta, a.d_eg[c.dir], c.b, c.dir, c.g, N, 0, smem, tid);
+        float unused[HG] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        arm_store16<T>(dta, a.d_eg[c.dir], c.b, c.dir, c.g, N, smem, tid, unused);
         if constexpr (CS) {
             float* row = a.d_qkv_colsum[c.dir] + (int64_t)c.b * ldq + c.g * HG * D;
             if (tid < HG * D) {
@@ -185,7 +235,7 @@ __global__ void __launch_bounds__(kThreads, 2) __attribute__((amdgpu_waves_per_e
 
     // third-arm tile of this head (accumulator layout), staged through LDS once (aliases the slab sets)
     f32x2 biasM[8], gate[8], dE[8], dG[8];
-    arm_stage_load<T, HG, 1>(ta, c.b, c.dir, c.g, N, 0, smem, tid);
+    arm_load16<T>(ta, c.b, c.dir, c.g, N, smem, tid);
     __syncthreads();
     {
         float b16[16], g16[16];
@@ -461,8 +511,13 @@ __global__ void __launch_bounds__(kThreads, 2) __attribute__((amdgpu_waves_per_e
     }
     __syncthreads();
     {
-        const float pv = arm_stage_store_grad<T, HG, 1>(dta, a.d_eg[c.dir], c.b, c.dir, c.g, N, 0, smem, tid);
-        if constexpr (CS) part[tid] = pv;
+        float pv[HG] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        arm_store16<T>(dta, a.d_eg[c.dir], c.b, c.dir, c.g, N, smem, tid, pv);
+        if constexpr (CS) {
+            // (the exchange tiles are dead: their space takes one partial per thread and head)
+#pragma unroll
+            for (int h = 0; h < HG; ++h) part[tid * HG + h] = pv[h];
+        }
     }
     if constexpr (CS) {
         float* row = a.d_qkv_colsum[c.dir] + (int64_t)c.b * ldq + c.g * HG * D + wave * D;
@@ -487,7 +542,7 @@ __global__ void __launch_bounds__(kThreads, 2) __attribute__((amdgpu_waves_per_e
             constexpr int kVals = 2 * HG;                  // E of the 8 heads, then G
             if (tid < kVals) {
                 float v = 0.f;
-                for (int t = tid; t < kThreads; t += kVals) v += part[t];
+                for (int t = tid / HG; t < kThreads; t += 2) v += part[t * HG + tid % HG];        // threads of this piece (t & 1), fixed order
                 float* erow = a.d_eg_colsum[c.dir] + (int64_t)c.b * lde;
                 if (tid < HG) { if (biased) erow[a.e_off[c.dir] + c.g * HG + tid] = v; }
                 else if (gated) erow[a.g_off[c.dir] + c.g * HG + tid - HG] = v;
@@ -533,7 +588,15 @@ static int launch(const tgt_triplet_attention_args& a, hipStream_t st) {
 
 bool tri_att_bwd2_eligible(const tgt_triplet_attention_args& a) {
     static const bool off = getenv("TGT_TRI_BWD2") && atoi(getenv("TGT_TRI_BWD2")) == 0;      // A/B knob: 0 = the round-1..3 kernel
-    return !off && (a.dtype == TGT_BF16 || a.dtype == TGT_F16) && a.D == 16 && a.N <= 32 && a.H % 8 == 0 && !(a.dropout_p > 0.f);
+    if (off || !((a.dtype == TGT_BF16 || a.dtype == TGT_F16) && a.D == 16 && a.N <= 32 && a.H % 8 == 0 && !(a.dropout_p > 0.f))) return false;
+    // the third-arm tiles travel as 16-byte pieces (arm_load16 / arm_store16): row lengths and column offsets in whole pieces
+    if (a.flags & (TGT_TRI_BIASED | TGT_TRI_GATED))
+        for (int dir = 0; dir < 2; ++dir) {
+            const int64_t lde = a.ld_deg[dir] ? a.ld_deg[dir] : a.ld_eg[dir];
+            if (a.ld_eg[dir] % 8 || lde % 8 || a.e_off[dir] % 8 || a.g_off[dir] % 8 || ((uintptr_t)a.eg[dir] | (uintptr_t)a.d_eg[dir]) % 16)
+                return false;
+        }
+    return true;
 }
 int tri_att_bwd2_run(const tgt_triplet_attention_args& a, hipStream_t st) {
     return a.dtype == TGT_BF16 ? bwd2::launch<bf16_t>(a, st) : bwd2::launch<f16_t>(a, st);
