@@ -464,6 +464,7 @@ def main():
                                launch_order_last_step=trainer.bucket_order[:16], mode=cfg.grad_exchange,
                                wire_dtype=cfg.grad_comm_dtype or 'fp32', rccl_stream='high priority' if world > 1 else None),
             final_loss=round(loss_val, 5),
+            knobs_not_default=__import__('tgt_amd.knobs', fromlist=['K']).K.non_default(),      # {} = the default path
             step_ms=dict(min=round(step_ms[0], 3), median=round(step_ms[len(step_ms) // 2], 3), max=round(step_ms[-1], 3),
                          note='GPU-side duration of each timed step (events on the step stream)'),
             roofline=roofline,

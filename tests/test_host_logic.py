@@ -2,6 +2,7 @@
 the reference's separate nn.Linear parameters, and the numpy restatement of the kernels'
 attention-dropout generator."""
 import numpy as np
+import pytest
 import torch
 
 import golden_util as gu
@@ -60,3 +61,26 @@ def test_dropout_generator_restatement_is_deterministic_and_calibrated():
     assert abs(keep.mean() - 0.8) < 0.01 and abs(scale - 1.25) < 1e-6
     # neighbouring keys share one hash word but not their decision
     assert (keep[:, :, 0::2] != keep[:, :, 1::2]).mean() > 0.2
+
+
+def test_knobs_are_read_once_in_one_place(monkeypatch):
+    """tgt_amd/knobs.py: every host-side A/B switch in one record; flags that default on go off with "0", flags that default off go
+    on with "1", and non_default() names exactly what differs (bench.py prints it)"""
+    from tgt_amd import knobs
+    for var, *_ in knobs._SPEC.values():
+        monkeypatch.delenv(var, raising=False)
+    for var in knobs.ENV_OF_LIBRARY:
+        monkeypatch.delenv(var, raising=False)
+    base = knobs.Knobs.from_env()
+    assert base.non_default() == {}
+    assert base.tri_proj and base.node_stream and not base.defer_sums and base.side_prio == -1 and base.tri_skip == 1
+    monkeypatch.setenv('TGT_TRI_PROJ', '0')
+    monkeypatch.setenv('TGT_DEFER_SUMS', '1')
+    monkeypatch.setenv('TGT_WGRAD_STREAM', '0')          # a default-off flag set to its default: not reported
+    monkeypatch.setenv('TGT_TRI_SKIP', '2')
+    monkeypatch.setenv('TGT_TRI_BWD2_DMA', '0')          # read by the library, listed in the report
+    k = knobs.Knobs.from_env()
+    assert k.non_default() == {'TGT_TRI_PROJ': False, 'TGT_DEFER_SUMS': True, 'TGT_TRI_SKIP': 2, 'TGT_TRI_BWD2_DMA': '0'}
+    import dataclasses
+    with pytest.raises(dataclasses.FrozenInstanceError):
+        k.tri_proj = True

@@ -12,6 +12,7 @@ import weakref
 import torch
 
 from . import _lib
+from .knobs import K
 
 _DT = {torch.float32: _lib.TGT_F32, torch.bfloat16: _lib.TGT_BF16, torch.float16: _lib.TGT_F16}
 
@@ -20,14 +21,14 @@ _DT = {torch.float32: _lib.TGT_F32, torch.bfloat16: _lib.TGT_BF16, torch.float16
 _PROFILE = None
 
 
-_TRI_SPLIT = os.environ.get('TGT_TRI_SPLIT', '1') != '0'        # A/B knobs, read once
-_TRI_PROJ = os.environ.get('TGT_TRI_PROJ', '1') != '0'
-_TRI_COLSUM = os.environ.get('TGT_TRI_COLSUM', '1') != '0'
+_TRI_SPLIT = K.tri_split        # A/B knobs: tgt_amd/knobs.py reads the environment once; tests patch these names
+_TRI_PROJ = K.tri_proj
+_TRI_COLSUM = K.tri_colsum
 # graph_scale (DropPath-dropped graphs skipped by the triplet kernels) reaches the BACKWARD kernel only with TGT_TRI_SKIP=2: at the
 # BASELINE shapes the backward is 1024 workgroups in exactly four rounds on 256 CUs (one workgroup per CU), and with ~10 % of them
 # finishing early the last round is still a round -- measured 0.474 vs 0.476 ms -- so by default it keeps computing every graph (the
 # forward, two workgroups per CU, gains 4 %)
-_TRI_SKIP_BWD = os.environ.get('TGT_TRI_SKIP', '1') == '2'
+_TRI_SKIP_BWD = K.tri_skip == 2
 
 
 def profile_kernels(enable=True):
@@ -235,8 +236,8 @@ _ATEN_PLANE_SUM = False       # settled (+0.3 % for the kernel; tests patch this
 # autograd as fresh tensor objects (t.detach() where an object is also referenced elsewhere: _take_colsum), weight-shared stacks
 # and anything outside a Trainer's backward never defer.
 # ---------------------------------------------------------------------------
-_DEFER_SUMS = os.environ.get('TGT_DEFER_SUMS', '0') == '1'           # A/B knob (measured slower: see above)
-_DEFER_MAX = int(os.environ.get('TGT_DEFER_MAX', '56'))            # sums per queue before it flushes itself (<= 64: one launch)
+_DEFER_SUMS = K.defer_sums           # A/B knob (measured slower: see above)
+_DEFER_MAX = K.defer_max            # sums per queue before it flushes itself (<= 64: one launch)
 _deferred = {}                     # stream handle -> [ [ (part, out), ... ], [post callables] ]
 _deferred_stats = [0, 0]           # [sums registered, tgt_sum_many launches]  (tests / diagnostics)
 
@@ -1097,7 +1098,7 @@ def _take_colsum(grad, C_):
 # backward does.  One consumer, token untouched: it passes, and the entry fuses the product.  Anything else -- two Linears on the same
 # y, a second non-lazy consumer, retain_grad, another hook -- and autograd has summed the (zero) tokens with whatever real gradients
 # there were: the hook adds the products the tokens stand for, so the entry receives the complete gradient (unfused, correct).
-_EPI_LN_BWD = os.environ.get('TGT_EPI_LN_BWD', '1') != '0'           # A/B knob
+_EPI_LN_BWD = K.epi_ln_bwd           # A/B knob
 _zero_scalars = {}
 _lazy_dgrads = [0, 0, 0]           # [offered, fused, materialized by the hook]  (tests / diagnostics)
 
@@ -1263,7 +1264,7 @@ def _as_dtype_view(p, cd):
 
 # opt-in (TGT_WGRAD_STREAM=1): weight gradients of the edge Linears on a third stream.  Measured over 20 same-box pairs on five boxes:
 # +1.7 % on one, -1.9 % on another, occasional runs 5-10 % low -- two equal-priority queues of HBM-bound kernels; the mean is ~0
-_WGRAD_STREAM = os.environ.get('TGT_WGRAD_STREAM', '0') == '1'
+_WGRAD_STREAM = K.wgrad_stream
 _wgrad_streams = {}
 _trainer_backward = [0]           # > 0 while a Trainer runs its backward: the only caller that joins the forked stream afterwards
 
@@ -1309,7 +1310,7 @@ def _on_stream(ws):
     return torch.cuda.stream(ws) if ws is not None else contextlib.nullcontext()
 
 
-_TERMINAL_SUMS = os.environ.get('TGT_TERMINAL_SUMS', '1') != '0'     # A/B knob: the closing sums of parameter gradients on the forked stream too
+_TERMINAL_SUMS = K.terminal_sums     # A/B knob: the closing sums of parameter gradients on the forked stream too
 
 
 def _terminal_fork(rows, *tensors):
@@ -1328,7 +1329,7 @@ def _param_grad(t, dtype):
     return t.to(dtype)
 
 
-_SIDE_PRIO = int(os.environ.get('TGT_SIDE_PRIO', '-1'))           # A/B knob: HIP priority of the node side stream (-1 = high: its short kernels are
+_SIDE_PRIO = K.side_prio           # A/B knob: HIP priority of the node side stream (-1 = high: its short kernels are
 #                                                                    dispatched ahead of the edge kernels' next workgroups; +0.5 % over 5 same-box pairs)
 
 
@@ -1374,7 +1375,7 @@ class WeightTransposes:
         _lib.check(_lib.lib().tgt_transpose_many(_ptr(self.table), len(self.entries), 16, _stream()), 'tgt_transpose_many')
 
 
-_WT_CACHE = os.environ.get('TGT_WT_CACHE', '1') != '0'          # A/B knob
+_WT_CACHE = K.wt_cache          # A/B knob
 
 
 def weight_t(w):
@@ -1387,8 +1388,8 @@ def weight_t(w):
     return w.t().contiguous()
 
 
-_EDGE_GEMM = os.environ.get('TGT_EDGE_GEMM', '1') != '0'          # A/B knob: the weight-resident slice kernel where it wins
-_EDGE_N512 = os.environ.get('TGT_EDGE_N512', '1') != '0'          # A/B knob: lin_O's (256 -> 512) and the narrow (-> <= 128) data gradients on the weight-resident kernels
+_EDGE_GEMM = K.edge_gemm          # A/B knob: the weight-resident slice kernel where it wins
+_EDGE_N512 = K.edge_n512          # A/B knob: lin_O's (256 -> 512) and the narrow (-> <= 128) data gradients on the weight-resident kernels
 _EDGE_MIN_ROWS = 65536                                            # (tests lower it)
 
 
@@ -1654,12 +1655,12 @@ def edge_linear_supported(K, N, dtype, epilogue=_lib.EPI_BIAS, ln=False, row_sca
 # it LOSES 0.25 % (2496 / 2498 vs 2501 / 2505 graphs/s same-box): the 4096-workgroup grid-stride form and the eight accumulators per
 # vector cost the streaming kernel more than the 22 us column-sum pass they replace.  Off by default.
 _GELU_BWD_COLSUM = False       # settled off (-0.25 % in the step); tests patch this to cover the ABI entry
-_FFN_GELU_EPI = os.environ.get('TGT_FFN_GELU_EPI', '1') != '0'     # A/B knob: lin_W1 + GELU + dropout as one launch on the edge rows
+_FFN_GELU_EPI = K.ffn_gelu_epi     # A/B knob: lin_W1 + GELU + dropout as one launch on the edge rows
 # A/B knob: GELU backward as the epilogue of lin_W2's data-gradient GEMM (the closing node takes the activation detached and returns the
 # gradient of the pre-activation).  Round 2: neutral (the row phase of that epilogue was instruction-bound, 0.122 ms against 0.068 + 0.072
 # for GEMM + activation pass).  Round 3, after the row-phase rewrite (0.101 ms): +1.5 % graphs/s same-box (2749.7 / 2750.0 against
 # 2709.9 / 2708.8, profiles/r03e_ab.txt): on by default
-_FFN_GELU_BWD_EPI = os.environ.get('TGT_FFN_GELU_BWD_EPI', '1') != '0'
+_FFN_GELU_BWD_EPI = K.ffn_gelu_bwd_epi
 
 
 class _LinearGeluDropout(torch.autograd.Function):
@@ -1894,8 +1895,8 @@ class _LinearResidualLN(torch.autograd.Function):
                 _param_grad(dg, lndt), _param_grad(dbeta, lndt), None, None, None, None, d_pre, None, None)
 
 
-_GELU_BWD_EPI_COLSUM = os.environ.get('TGT_GELU_BWD_EPI_COLSUM', '1') != '0'      # A/B knob: lin_W1's bias gradient from the GELU_BWD epilogue
-_EDGE_K512 = os.environ.get('TGT_EDGE_K512', '1') != '0'        # A/B knob: lin_O (K = 512) + residual + LayerNorm as one launch
+_GELU_BWD_EPI_COLSUM = K.gelu_bwd_epi_colsum      # A/B knob: lin_W1's bias gradient from the GELU_BWD epilogue
+_EDGE_K512 = K.edge_k512        # A/B knob: lin_O (K = 512) + residual + LayerNorm as one launch
 
 
 def _residual_fusable(x, weight, res, cd):
@@ -1905,7 +1906,7 @@ def _residual_fusable(x, weight, res, cd):
     return N <= 256 and res.is_cuda and _edge_kernel_ok(x2, N, cd, ks) and res.dtype in (cd,) and res.is_contiguous()
 
 
-_PRESCALE = os.environ.get('TGT_PRESCALE', '1') != '0'       # A/B knob: DropPath factor folded into the branch's producer
+_PRESCALE = K.prescale       # A/B knob: DropPath factor folded into the branch's producer
 
 
 def can_prescale(rows, in_features, out_features, dtype):
@@ -1963,7 +1964,7 @@ _main_streams = {}          # the stream the side stream was last forked from, p
 # Measured (profiles/r05j_ab_keepalive.txt, same box, alternating, 30 steps): device allocations 0 / 0 against 73 / 0, but the
 # per-step median is 83.53 / 83.48 ms against 83.12 / 83.06 and single steps stall (max 110 / 116 ms against 96 / 85) -- the
 # allocations cost less than holding every cross-stream activation to the end of the step.  Opt-in.
-_KEEPALIVE = os.environ.get('TGT_STREAM_KEEPALIVE', '0') == '1'       # A/B knob (default: Tensor.record_stream)
+_KEEPALIVE = K.stream_keepalive       # A/B knob (default: Tensor.record_stream)
 _stream_keepalive = []
 
 
@@ -2004,7 +2005,7 @@ class side_stream:
     reducer when these modules are aliased into the reference's run_training.py -- only orders its
     collectives after the stream of the hook that closed a bucket, and would race with gradients still
     being produced on the side stream; without an owner the block therefore runs on the current stream."""
-    enabled = os.environ.get('TGT_NODE_STREAM', '1') != '0'
+    enabled = K.node_stream
     _owners = 0
 
     @classmethod

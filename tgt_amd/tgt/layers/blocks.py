@@ -9,11 +9,12 @@ from torch import nn
 import torch.nn.functional as F
 
 from ... import ops
+from ...knobs import K
 from .triplet import get_triplet_layer
 
 
-_CHAIN_NODE_STREAM = __import__('os').environ.get('TGT_NODE_CHAIN', '1') != '0'      # A/B knob
-_TRI_SKIP = __import__('os').environ.get('TGT_TRI_SKIP', '1') != '0'      # A/B knob: triplet kernels skip DropPath-dropped graphs
+_CHAIN_NODE_STREAM = K.node_chain      # A/B knob (tgt_amd/knobs.py)
+_TRI_SKIP = K.tri_skip != 0      # A/B knob: triplet kernels skip DropPath-dropped graphs
 
 
 def _keep(module, **kw):

@@ -1,15 +1,14 @@
 """The layer stack (`TGT_Encoder`) and the attribute-style batch container (`Graph`).
 Same public behaviour and state_dict prefixes (`TGT_layers.{i}.`) as the reference's
 lib/tgt/encoder.py."""
-import os
-
 from torch import nn
 
+from ..knobs import K
 from .layers import TGT_Layer
 from .layers.blocks import PendingResidual
 
 
-_DEFER_EDGE = os.environ.get('TGT_DEFER_EDGE', '1') != '0'      # A/B knob
+_DEFER_EDGE = K.defer_edge      # A/B knob (tgt_amd/knobs.py)
 
 
 class Graph(dict):
