@@ -253,7 +253,12 @@ def main():
             opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
         except Exception:
             pass
-        dist.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=dev, pg_options=opts)
+        try:
+            dist.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=dev, pg_options=opts)
+        except (TypeError, ValueError, RuntimeError):
+            if dist.is_initialized():
+                raise
+            dist.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=dev)     # (this torch does not take the options)
 
     from tgt_amd import ops
     from tgt_amd.pcqm import TGT_Multi

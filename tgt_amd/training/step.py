@@ -214,6 +214,7 @@ class Trainer:
         self._handles = []
         self._armed = False
         self.buckets = None                # [start, end, n_params, first_param_index] per bucket (distributed runs: _setup_buckets)
+        self._hooks_registered = False
         self.bucket_order = []             # bucket indices in the order their all-reduce was launched during the last backward
         self._comm_events = []             # (before, after) event pairs around the waits for the gradient exchange, one per step
         dev = self.flat.param.device
@@ -299,8 +300,12 @@ class Trainer:
                 self.buckets.append([start, ends[i], count, first])
                 start, count, first = ends[i], 0, i + 1
         self._pending = [b[2] for b in self.buckets]
-        for p in f.params:
-            p.register_post_accumulate_grad_hook(self._grad_ready)
+        # The hooks are registered AFTER the first forward (compute_gradients), not here: a post-accumulate hook keeps the
+        # parameter's AccumulateGrad node alive for good, and that node runs on the stream that was current when it was CREATED.
+        # Created here, every node would sit on the default stream while the node channel's gradients are produced on the side
+        # stream -- torch's "AccumulateGrad node's stream does not match" case: one cross-stream wait per node-channel parameter in
+        # every backward.  The first forward creates each node on the stream that uses its parameter; the hook then pins THAT one.
+        self._hooks_registered = False
 
     def _grad_ready(self, p):
         if not self._armed:
@@ -413,6 +418,10 @@ class Trainer:
         # GradScaler.scale(loss): the scale is a device scalar, so a changed scale costs no sync
         # parameter gradients may come from a forked stream (collect_grads joins it) -- unless a parameter takes part in the graph
         # more than once (weight-shared stacks): autograd then ADDS into .grad on the current stream, unordered with the fork
+        if self.buckets is not None and not self._hooks_registered:
+            for p in f.params:
+                p.register_post_accumulate_grad_hook(self._grad_ready)
+            self._hooks_registered = True
         with (ops.trainer_backward() if not self._shared else contextlib.nullcontext()):
             (loss * self.ctl[ops.CTL_SCALE].to(loss.dtype) if self.dynamic_scale else loss).backward()
         self._armed = False
