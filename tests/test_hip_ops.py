@@ -48,6 +48,7 @@ CASES = [  # B, N, num_nodes, C, H
     (2, 33, [33, 20], 256, 16),   # one node past a tile, BASELINE width
     (2, 64, [64, 50], 64, 4),     # N = 64, D = 16: four 16-wide blocks (the 16-wide forward kernel)
     (1, 57, [57], 128, 8),        # ragged last block, two head groups
+    (2, 11, [11, 7], 128, 8),     # ONE 8-head group, odd N < 32: the round-4 backward with zero-filled slab rows (LDS-DMA writes nothing past N)
 ]
 
 
