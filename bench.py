@@ -211,6 +211,9 @@ def main():
     ap.add_argument('--ragged', action='store_true',
                     help='SURVEY 8(d) secondary: num_nodes ~ U{nodes/2..nodes} with the first graph at `nodes` (padded batch)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--settle-steps', type=int, default=45,
+                    help='untimed steps BEFORE the warm-up steps that let the caching allocator reach its steady state (it keeps adding '
+                         '12-54 MB segments on the node side stream for ~50 steps, then never again: tools/probes/mem_growth_probe.py); 0: none')
     ap.add_argument('--roofline-steps', type=int, default=3,
                     help='untimed single-stream steps after the timed region that measure the roofline kernels alone (0: use the timed region)')
     ap.add_argument('--cpu-baseline-worker', type=int, default=0, help=argparse.SUPPRESS)
@@ -298,8 +301,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Allocator settle: same steps as the warm-up, run until the caching allocator stops asking the driver for memory (at most
+    # --settle-steps of them).  Not part of the contract's W warm-up steps and not timed; it only moves the allocator's own
+    # start-up transient (synchronous hipMalloc calls during the first ~50 steps of any run) out of the timed region.
+    settled = 0
+    if args.settle_steps > 0:
+        quiet, last = 0, torch.cuda.memory_stats(dev).get('num_device_alloc', 0)
+        while settled < args.settle_steps and quiet < 8:
+            step(settled)
+            settled += 1
+            now = torch.cuda.memory_stats(dev).get('num_device_alloc', 0)
+            quiet = quiet + 1 if now == last else 0
+            last = now
     for i in range(args.warmup):
         step(i)
+    # The host queues a step ~20 ms ahead of the GPU.  A generation-2 collection of Python's garbage collector walks every tracked
+    # object of the process -- 40-65 ms here (tools/probes/gc_probe.py), once every ~50 steps -- and when it lands on a thin
+    # margin the stream runs dry: single steps of 120-130 ms in a 20-step region.  Freezing what exists after the warm-up (model,
+    # trainer, batches: all of it lives for the whole run) keeps later collections to the few objects a step creates.  The
+    # collector stays ON.
+    import gc
+    gc.collect()
+    gc.freeze()
     prof = ops.profile_kernels(True)
     fence()
     ms0 = torch.cuda.memory_stats(dev)
@@ -474,6 +497,7 @@ def main():
                          note='GPU-side duration of each timed step (events on the step stream)'),
             roofline=roofline,
             # the caching allocator inside the timed region: device allocations / frees there are synchronous driver calls
+            allocator_settle_steps=settled,
             memory=dict(reserved_GB=round(ms1.get('reserved_bytes.all.current', 0) / 1e9, 2),
                         peak_allocated_GB=round(ms1.get('allocated_bytes.all.peak', 0) / 1e9, 2),
                         device_allocs_in_timed_region=ms1.get('num_device_alloc', 0) - ms0.get('num_device_alloc', 0),

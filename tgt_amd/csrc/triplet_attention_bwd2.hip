@@ -38,10 +38,14 @@ constexpr int kXch = 2 * 2048;             // per wave: dS tile + A tile, each [
 // LDS: NS slab sets | 8 exchange tiles | one dE / dG partial per thread.  NS = 2: slabs prefetched into registers and committed
 // by ds_write (one step ahead); NS = 3 (DMA): slabs land in LDS directly (buffer_load ... lds), two steps ahead.
 template <bool DMA> struct Lay {
-    static constexpr int kSets = DMA ? 3 : 2;
+#ifndef TGT_BWD2_DEPTH
+#define TGT_BWD2_DEPTH 2             // LDS-DMA: slabs land this many steps ahead (DEPTH + 1 slab sets; 3 = all 160 KB of LDS)
+#endif
+    static constexpr int kDepth = TGT_BWD2_DEPTH;
+    static constexpr int kSets = DMA ? kDepth + 1 : 2;
     static constexpr int kOffXch = kSets * kSet;
     static constexpr int kOffPart = kOffXch + HG * kXch;
-    static constexpr int kLds = kOffPart + kThreads * 4;
+    static constexpr int kLds = kOffPart;          // (the per-thread dE / dG partials of the epilogue live in the dead exchange tiles)
 };
 typedef __attribute__((address_space(3))) void lds_void;
 #if TGT_LD_AUX == 2
@@ -330,14 +334,18 @@ __global__ void __launch_bounds__(kThreads, 2) __attribute__((amdgpu_waves_per_e
         // rows past N are never written by the loads (out of range) and stay zero through the walk (their results are zeros)
         if (N < 32) {
             const u32x4_t z = {0, 0, 0, 0};
-            for (int o = tid * 16; o < 3 * kSet; o += kThreads * 16) *reinterpret_cast<u32x4_t*>(smem + o) = z;
+            for (int o = tid * 16; o < Lay<true>::kSets * kSet; o += kThreads * 16) *reinterpret_cast<u32x4_t*>(smem + o) = z;
             __syncthreads();
         }
+        // the loop is entered with the queue it has on its back edge: {4 loads, 3 stores} per step in flight
         dma(0, 0);
-        dma(1, 1);
-        dummy_stores();
-        // the queue is: loads(0) x4, loads(1) x4, 3 stores
-        asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int d = 1; d < Lay<true>::kDepth; ++d) {
+            dma(d, d);
+            dummy_stores();
+        }
+        // queue: loads(0) x4, then {loads(d) x4, 3 stores} for d = 1 .. DEPTH-1
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(7 * (Lay<true>::kDepth - 1)) : "memory");
     } else {
         issue(pre, 0);
         commit(pre, 0);
@@ -351,7 +359,7 @@ __global__ void __launch_bounds__(kThreads, 2) __attribute__((amdgpu_waves_per_e
         if constexpr (DMA) {
             // set of step j + 2 = set of step j - 1: every wave finished reading it before the last barrier, and this thread's
             // loads write the chunks this thread itself read for the stores of step j - 1
-            dma(j + 2, cur == 0 ? 2 : cur - 1);
+            dma(j + Lay<true>::kDepth, cur == 0 ? Lay<true>::kSets - 1 : cur - 1);
         } else {
             // Hazards (one barrier per j, as in the old kernel): set cur^1 holds the results of step j-1; this thread read its
             // own chunk of them for the stores at the end of step j-1 and now overwrites that same chunk.
@@ -478,7 +486,7 @@ __global__ void __launch_bounds__(kThreads, 2) __attribute__((amdgpu_waves_per_e
         }
         if constexpr (DMA) {
             // queue: loads(j+1) x4, stores(j-1) x3, loads(j+2) x4 -- the slabs of step j + 1 have landed for every wave behind this
-            asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(7 * (Lay<true>::kDepth - 1)) : "memory");
         } else {
             __syncthreads();
         }
@@ -493,7 +501,7 @@ __global__ void __launch_bounds__(kThreads, 2) __attribute__((amdgpu_waves_per_e
         } else if constexpr (DMA) {
             dummy_stores();             // (probe builds: keep the queue shape the wait counts assume)
         }
-        if constexpr (DMA) cur = cur == 2 ? 0 : cur + 1; else cur ^= 1;
+        if constexpr (DMA) cur = cur == Lay<true>::kSets - 1 ? 0 : cur + 1; else cur ^= 1;
     }
     if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the out-of-range loads past the end of the walk)
     __syncthreads();
