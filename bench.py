@@ -307,7 +307,8 @@ def main():
     settled = 0
     if args.settle_steps > 0:
         quiet, last = 0, torch.cuda.memory_stats(dev).get('num_device_alloc', 0)
-        while settled < args.settle_steps and quiet < 8:
+        # (every step runs the ranks' gradient exchange: with more than one rank the COUNT must not depend on a rank's own allocator)
+        while settled < args.settle_steps and (quiet < 8 or world > 1):
             step(settled)
             settled += 1
             now = torch.cuda.memory_stats(dev).get('num_device_alloc', 0)
