@@ -1013,6 +1013,7 @@ def test_baseline_size_projection_fused_forward_slices(dt, monkeypatch):
     prof = ops.profile_kernels(True)
     full = run(slice(None))
     ops.profile_kernels(False)
+    torch.cuda.synchronize()
     assert 'tgt_triplet_attention_proj_fwd' in ops.kernel_times_ms(prof)           # the fused kernel ran (not GEMM + attention)
     for s_, e_ in ((0, 3), (B // 2 - 27, B // 2 - 24), (B - 3, B)):
         part = run(slice(s_, e_))
