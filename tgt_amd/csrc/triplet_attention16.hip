@@ -428,6 +428,10 @@ __global__ void __launch_bounds__(HG * NQ * 64) tri_att16_bwd_kernel(const tgt_t
     // queue: loads(0) x2, loads(1) x2, 3 stores
     asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
+#ifndef TGT_T16_PRIO
+#define TGT_T16_PRIO 1             // static wave priority: the younger half of the workgroup at s_setprio 1 (three alternating pairs at N = 48: 0.692 / 0.690 / 0.699 against 0.697 / 0.714 / 0.704 ms)
+#endif
+    if (TGT_T16_PRIO == 1 && wave_u >= HG * NQ / 2) __builtin_amdgcn_s_setprio(1);
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     char* xw = smem + kOffX + (hw * NQ + qb) * kXWave;          // this wave's exchange blocks (phase 1)
     int cur = 0;
