@@ -198,7 +198,6 @@ __global__ void __launch_bounds__(HG * NQ * 64) tri_att16_fwd_kernel(const tgt_t
     }
     __syncthreads();
 
-    const F ident = ident4<T>(x16, g);
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     // one barrier per j: hazards as in triplet_attention.hip (the other set is rewritten at the top of the iteration by the
     // thread that last read those chunks; O goes into this wave's own rows / columns of the Q slab)
@@ -218,13 +217,12 @@ __global__ void __launch_bounds__(HG * NQ * 64) tri_att16_fwd_kernel(const tgt_t
             slab_issue<G, R>(pv, bV, j + 2, 0, N, tid);
         }
         const F fq = frag_of<T, G>(sQ, 16 * qb + x16, hw, g);
-        f32x4 s[NQ], vt[NQ];
+        f32x4 s[NQ];
         float mx = -INFINITY;
 #pragma unroll
         for (int kb = 0; kb < NQ; ++kb) {
-            const F fk = frag_of<T, G>(sK, 16 * kb + x16, hw, g), fv = frag_of<T, G>(sV, 16 * kb + x16, hw, g);
+            const F fk = frag_of<T, G>(sK, 16 * kb + x16, hw, g);
             s[kb] = mma16(fk, fq, z);             // S^T[key][query]
-            vt[kb] = mma16(fv, ident, z);         // V[key][d] -> lane d
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 s[kb][q] = s[kb][q] * a.scale + biasM[kb][q];
@@ -249,7 +247,8 @@ __global__ void __launch_bounds__(HG * NQ * 64) tri_att16_fwd_kernel(const tgt_t
         for (int kb = 0; kb < NQ; ++kb) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) s[kb][q] = s[kb][q] * inv * gate[kb][q];
-            o = mma16(pack4<T>(vt[kb]), pack4<T>(s[kb]), o);          // O^T[d][query]
+            // V^T of the key block (lane d, keys 4g..4g+3) straight from the slab, transposed by the read (round 4: was V . I on the matrix core + a pack)
+            o = mma16(tr_frag<T>(sV + G::lds_elem(16 * kb + 4 * g + (x16 >> 2), hw * 16 + 4 * (x16 & 3))), pack4<T>(s[kb]), o);          // O^T[d][query]
         }
         {   // lane (query, g) holds channels 4g .. 4g+3 of its query: 8 bytes into the head's columns of the Q slab
             const F of = pack4<T>(o);
