@@ -189,6 +189,8 @@ FULL_AGX2_CFG = dict(model_height=12, layer_multiplier=2, upto_hop=32, embed_3d_
 FULL_AGX2_GEOM = dict(B=8, N=32, num_nodes=[32, 29, 27, 24, 21, 18, 14, 9])
 # the BASELINE config-2 architecture at the benchmark's node count: TGT-At 24L, B = 2, N = 32 (one ragged graph)
 FULL_AT_N32_GEOM = dict(B=2, N=32, num_nodes=[32, 27])
+# ... and of BASELINE config 4: N up to 48 (the 16-wide triplet kernels, the lane-per-head node attention)
+FULL_AT_N48_GEOM = dict(B=2, N=48, num_nodes=[48, 39])
 
 
 def model_batch(geom, seed):

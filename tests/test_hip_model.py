@@ -187,15 +187,19 @@ def test_full_width_agx2_12x2_forward_vs_reference_golden():
         assert ok, (name, info)
 
 
-def test_full_width_24L_n32_vs_reference_golden():
-    """TGT-At 24L at BASELINE widths AND the benchmark's node count (B = 2, N = 32, one ragged graph): the kernels the bench
-    line runs (projection-fused triplet forward, the round-4 backward, the fused edge Linears) against the REFERENCE's fp32
-    run -- eval forward, then loss and parameter gradients in train mode with every dropout off (fp32 and bf16 autocast)."""
+@pytest.mark.parametrize('which', ['n32', 'n48'])
+def test_full_width_24L_n32_vs_reference_golden(which):
+    """TGT-At 24L at BASELINE widths AND the benchmarks' node counts (B = 2, one ragged graph; N = 32: the kernels the bench
+    line runs -- projection-fused triplet forward, the round-4 backward, the fused edge Linears; N = 48 = BASELINE config 4: the
+    16-wide triplet kernels and the lane-per-head node attention) against the REFERENCE's fp32 run -- eval forward, then loss and
+    parameter gradients in train mode with every dropout off (fp32 and bf16 autocast)."""
     from tgt_amd.pcqm import TGT_Multi
     from tgt_amd.training.step import pretrain_loss, StepConfig
-    z = np.load(os.path.join(gu.GOLDEN_DIR, 'model_full_at_24L_n32_fp32.npz'))
-    batch = {k: v.cuda() for k, v in gu.model_batch(gu.FULL_AT_N32_GEOM, seed=931).items()}
-    model = gu.fill_params(TGT_Multi(**gu.FULL_AT_CFG), seed=930).cuda().eval()
+    name, geom, seeds = {'n32': ('model_full_at_24L_n32_fp32.npz', gu.FULL_AT_N32_GEOM, (930, 931)),
+                         'n48': ('model_full_at_24L_n48_fp32.npz', gu.FULL_AT_N48_GEOM, (940, 941))}[which]
+    z = np.load(os.path.join(gu.GOLDEN_DIR, name))
+    batch = {k: v.cuda() for k, v in gu.model_batch(geom, seed=seeds[1]).items()}
+    model = gu.fill_params(TGT_Multi(**gu.FULL_AT_CFG), seed=seeds[0]).cuda().eval()
     with torch.no_grad():
         gap, logits = model(batch)
         with torch.autocast('cuda', dtype=torch.bfloat16):
@@ -213,7 +217,7 @@ def test_full_width_24L_n32_vs_reference_golden():
     loss_ref = float(z['loss::full'])
     drift = gu.bf16_drift('full_at_24L')       # the reference's own bf16-autocast drift (B = 2, N = 12 case): the anchor of the bf16 tolerances
     for mode, tol_loss, tol_grad in (('fp32', 2e-5, 5e-3), ('bf16', 1e-3, None)):
-        model = gu.fill_params(TGT_Multi(**gu.FULL_AT_CFG), seed=930).cuda().train()
+        model = gu.fill_params(TGT_Multi(**gu.FULL_AT_CFG), seed=seeds[0]).cuda().train()
         ctx = torch.autocast('cuda', dtype=torch.bfloat16) if mode == 'bf16' else torch.autocast('cuda', enabled=False)
         with ctx:
             loss = pretrain_loss(model(batch), batch, cfg)

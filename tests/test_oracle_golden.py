@@ -115,12 +115,18 @@ def test_full_width_agx2_12x2_fp32_forward():
     assert (logits.argmax(-1).numpy() == gold['logits_argmax']['full']).mean() > 0.995
 
 
-def test_full_width_24L_n32_fp32_forward_and_gradients():
-    """TGT-At 24L at BASELINE widths and the benchmark's node count (B = 2, N = 32): eval forward, then loss and parameter
-    gradients in train mode with the dropouts off -- the oracle in fp32 against the reference's fp32 run."""
-    gold = load('model_full_at_24L_n32_fp32')
-    model = gu.fill_params(om.TGT_Multi(**gu.FULL_AT_CFG), seed=930)
-    batch = gu.model_batch(gu.FULL_AT_N32_GEOM, seed=931)
+FULL_AT_GOLDENS = {'n32': ('model_full_at_24L_n32_fp32', gu.FULL_AT_N32_GEOM, (930, 931)),
+                   'n48': ('model_full_at_24L_n48_fp32', gu.FULL_AT_N48_GEOM, (940, 941))}
+
+
+@pytest.mark.parametrize('which', list(FULL_AT_GOLDENS))
+def test_full_width_24L_n32_fp32_forward_and_gradients(which):
+    """TGT-At 24L at BASELINE widths and the benchmark's node counts (B = 2; N = 32: config 2, N = 48: config 4): eval forward,
+    then loss and parameter gradients in train mode with the dropouts off -- the oracle in fp32 against the reference's fp32 run."""
+    name, geom, seeds = FULL_AT_GOLDENS[which]
+    gold = load(name)
+    model = gu.fill_params(om.TGT_Multi(**gu.FULL_AT_CFG), seed=seeds[0])
+    batch = gu.model_batch(geom, seed=seeds[1])
     model.eval()
     with torch.no_grad():
         gap, logits = model(batch)

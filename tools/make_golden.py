@@ -143,12 +143,13 @@ def full_agx2_case():
     save('model_full_agx2_12x2_fp32', out)
 
 
-def full_at_n32_case():
+def full_at_n32_case(geom=None, name='model_full_at_24L_n32_fp32', seeds=(930, 931)):
     """TGT-At 24L at BASELINE widths AND the benchmark's node count (B = 2, N = 32, one ragged graph), fp32: eval forward,
-    then train mode with every dropout off: pretrain loss and the gradients of gu.FULL_GRAD_KEYS."""
+    then train mode with every dropout off: pretrain loss and the gradients of gu.FULL_GRAD_KEYS.  (geom = gu.FULL_AT_N48_GEOM:
+    the same at BASELINE config 4's node count.)"""
     torch.manual_seed(0)
-    model = gu.fill_params(TGT_Multi(**gu.FULL_AT_CFG), seed=930)
-    batch = gu.model_batch(gu.FULL_AT_N32_GEOM, seed=931)
+    model = gu.fill_params(TGT_Multi(**gu.FULL_AT_CFG), seed=seeds[0])
+    batch = gu.model_batch(geom or gu.FULL_AT_N32_GEOM, seed=seeds[1])
     model.eval()
     t0 = time.time()
     with torch.no_grad():
@@ -166,7 +167,7 @@ def full_at_n32_case():
     for k in gu.FULL_GRAD_KEYS:
         g = named[k].grad
         out.update(sampled('pgrad.' + k, g, g.numel() <= 4096))
-    save('model_full_at_24L_n32_fp32', out)
+    save(name, out)
 
 
 def misc_cases():
@@ -324,7 +325,7 @@ def bf16_drift_cases():
 
 
 if __name__ == '__main__':
-    which = sys.argv[2:] or ['op', 'model', 'misc', 'full', 'full_agx2', 'full_n32', 'drift', 'predict']
+    which = sys.argv[2:] or ['op', 'model', 'misc', 'full', 'full_agx2', 'full_n32', 'full_n48', 'drift', 'predict']
     if 'op' in which:
         op_cases()
     if 'model' in which:
@@ -337,6 +338,8 @@ if __name__ == '__main__':
         full_agx2_case()
     if 'full_n32' in which:
         full_at_n32_case()
+    if 'full_n48' in which:
+        full_at_n32_case(gu.FULL_AT_N48_GEOM, 'model_full_at_24L_n48_fp32', (940, 941))
     if 'drift' in which:
         bf16_drift_cases()
     if 'predict' in which:
