@@ -403,7 +403,7 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, 'tools'))
             from pmc_summary import kernel_source_sha
             sha = kernel_source_sha(ROOT)
-            summaries = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_pmc_summary.json'))
+            summaries = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_pmc_summary.json') and '_n48_' not in f)     # (N = 48 passes: another shape)
             for f in reversed(summaries):
                 cand_pmc = json.load(open(os.path.join(ROOT, 'profiles', f)))
                 if cand_pmc.get('_kernel_src_sha') == sha:
