@@ -11,12 +11,12 @@ enable_gemm_tuning(online=True)
 dev = torch.device('cuda', 0)
 torch.manual_seed(0)
 model = TGT_Multi(**tgt_at_24l()).to(dev).train()
-cfg = StepConfig()
+cfg = StepConfig(mixed_precision='bf16')
 tr = Trainer(model, cfg)
-pool = [{k: v.to(dev) for k, v in make_batch(256, 32, batch_seed(s)).items()} for s in range(2)]
+pool = [{k: v.to(dev) for k, v in make_batch(int(os.environ.get('PROBE_B', '256')), 32, batch_seed(s)).items()} for s in range(2)]
 def step(i):
     return tr.training_step(preprocess_batch(pool[i % 2], dev, cfg, training=True))
-for i in range(3): step(i)
+for i in range(12): step(i)
 torch.cuda.synchronize()
 pr = cProfile.Profile()
 # (single-threaded autograd so that the Python backward functions run in THIS thread and show up in the profile)
@@ -27,3 +27,4 @@ with torch.autograd.set_multithreading_enabled(False):
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
 st.sort_stats('tottime').print_stats(int(sys.argv[1]) if len(sys.argv) > 1 else 45)
+st.sort_stats('cumtime').print_stats(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
