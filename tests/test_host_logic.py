@@ -84,3 +84,31 @@ def test_knobs_are_read_once_in_one_place(monkeypatch):
     import dataclasses
     with pytest.raises(dataclasses.FrozenInstanceError):
         k.tri_proj = True
+
+
+def test_parameter_reuse_is_found_in_the_graph():
+    """the forked parameter-gradient stream / deferred closing sums are only safe when every parameter that one of the
+    package's own autograd Functions differentiates enters the graph once; the Trainer looks for reuse of ANY kind in the graph
+    of its first step (not only layer_multiplier > 1)"""
+    import torch
+    from tgt_amd.training.step import _parameter_reused
+
+    class Lin(torch.autograd.Function):                 # stands for the package's Functions (a Python-defined node)
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x, w)
+            return x @ w.t()
+
+        @staticmethod
+        def backward(ctx, dy):
+            x, w = ctx.saved_tensors
+            return dy @ w, dy.t() @ x
+
+    lin, other = torch.nn.Linear(4, 4), torch.nn.Linear(4, 4)
+    params = list(lin.parameters()) + list(other.parameters())
+    x = torch.randn(3, 4)
+    assert not _parameter_reused(Lin.apply(Lin.apply(x, lin.weight), other.weight).sum(), params)
+    assert _parameter_reused(Lin.apply(Lin.apply(x, lin.weight), lin.weight).sum(), params)     # a module applied twice
+    assert _parameter_reused((Lin.apply(x, lin.weight) @ lin.weight).sum(), params)             # a tied weight, one own edge
+    assert not _parameter_reused(lin(lin(x)).sum(), params)            # library nodes only: autograd orders those itself
+    assert not _parameter_reused(x.sum().requires_grad_(), params)     # no graph at all

@@ -195,6 +195,34 @@ class FlatState:
             torch._foreach_copy_(dst, src)
 
 
+def _parameter_reused(root, params):
+    """True when a parameter enters the autograd graph under `root` through more than one edge, at least one of them from one of
+    this package's own autograd Functions.  autograd then SUMS the incoming gradients in the input buffer of the parameter's
+    AccumulateGrad node on a stream of its choosing: neither a gradient produced on the forked parameter-gradient stream nor a
+    registered-but-not-yet-computed closing sum (ops.trainer_backward) may take part in that.  (Library nodes produce their
+    gradients on the stream autograd knows about: the two look-ups of the 3-D kernel's per-edge-type tables are fine.)  One walk
+    over the graph of the first step."""
+    ids = {id(p) for p in params}
+    uses, own, seen, stack = {}, set(), set(), [root.grad_fn]
+    while stack:
+        fn = stack.pop()
+        if fn is None or fn in seen:
+            continue
+        seen.add(fn)                      # (the node objects themselves: they stay alive, one Python wrapper per graph node)
+        custom = isinstance(fn, torch.autograd.function.BackwardCFunction)
+        for nxt, _ in fn.next_functions:
+            if nxt is None:
+                continue
+            v = getattr(nxt, 'variable', None)
+            if v is not None and id(v) in ids:
+                uses[id(v)] = uses.get(id(v), 0) + 1
+                if custom:
+                    own.add(id(v))
+            else:
+                stack.append(nxt)
+    return any(n > 1 and k in own for k, n in uses.items())
+
+
 class Trainer:
     """The reference's per-step sequence (lib/training/training.py:439-470 + the loop body of
     :520-532) on flat buffers.  Everything the reference decides on the host per step -- GradScaler's
@@ -230,6 +258,7 @@ class Trainer:
             self._setup_buckets()
         self._wt = None
         self._shared = getattr(model, 'layer_multiplier', 1) > 1 or getattr(getattr(model, 'encoder', None), 'layer_multiplier', 1) > 1
+        self._reuse_checked = False        # the first backward walks its graph once for parameters that enter it more than once
         if self.cfg.mixed_precision in ('bf16', 'fp16') and self.flat.param.is_cuda:
             self.flat.make_shadow(torch.bfloat16 if self.cfg.mixed_precision == 'bf16' else torch.float16)
             # W^T of the shadowed weights for the data-gradient kernels, refreshed in one launch after every optimizer step
@@ -422,6 +451,10 @@ class Trainer:
             for p in f.params:
                 p.register_post_accumulate_grad_hook(self._grad_ready)
             self._hooks_registered = True
+        if not self._shared and not self._reuse_checked:
+            # any OTHER parameter reuse (tied weights, a module applied twice): found in the graph of the first step
+            self._shared = _parameter_reused(loss, f.params)
+            self._reuse_checked = True
         with (ops.trainer_backward() if not self._shared else contextlib.nullcontext()):
             (loss * self.ctl[ops.CTL_SCALE].to(loss.dtype) if self.dynamic_scale else loss).backward()
         self._armed = False
