@@ -67,8 +67,10 @@ class NonLinear(nn.Module):
     def __init__(self, input, output_size, hidden=None):
         super().__init__()
         hidden = input if hidden is None else hidden
-        self.layer1 = nn.Linear(input, hidden)
-        self.layer2 = nn.Linear(hidden, output_size)
+        # (blocks.Linear: the weight gradients contract over B*N*N rows -- as plain library GEMMs they were 0.29 + 0.27 ms of a
+        #  TGT-At step on a handful of workgroups, split over row chunks 0.03 ms each)
+        self.layer1 = Linear(input, hidden)
+        self.layer2 = Linear(hidden, output_size)
 
     def forward(self, x):
         return self.layer2(F.gelu(self.layer1(x)))
