@@ -225,6 +225,7 @@ def main():
                     help='read the running mean loss on the host every K steps (K = 1: the reference loop, which pays a '
                          '.item() per step, tgt_training.py:153-157); 0 = never inside the timed steps (default)')
     ap.add_argument('--no-gemm-tuning', action='store_true', help='library default GEMM heuristics')
+    ap.add_argument('--no-numa-bind', action='store_true', help='leave the CPU affinity of the rank alone (default: the NUMA node of its GPU)')
     ap.add_argument('--write-gemm-tuning', default='', help='tune online and write the TunableOp file here')
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -247,6 +248,10 @@ def main():
         raise SystemExit('bench.py needs an MI355X: the TGT kernels have no CPU path')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    # this rank's threads on the socket its GPU hangs on (the CPU baseline below gets the whole host back)
+    from tgt_amd.training.affinity import bind_to_gpu_numa
+    host_mask = os.sched_getaffinity(0) if hasattr(os, 'sched_getaffinity') else None
+    host_affinity = bind_to_gpu_numa(local_rank, enabled=not args.no_numa_bind)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         # RCCL on its own HIGH-PRIORITY stream: a bucket's all-reduce is dispatched ahead of the next workgroups of the backward
@@ -494,6 +499,7 @@ def main():
                                wire_dtype=cfg.grad_comm_dtype or 'fp32', rccl_stream='high priority' if world > 1 else None),
             final_loss=round(loss_val, 5),
             knobs_not_default=__import__('tgt_amd.knobs', fromlist=['K']).K.non_default(),      # {} = the default path
+            host_affinity=host_affinity,
             step_ms=dict(min=round(step_ms[0], 3), median=round(step_ms[len(step_ms) // 2], 3), max=round(step_ms[-1], 3),
                          note='GPU-side duration of each timed step (events on the step stream)'),
             roofline=roofline,
@@ -506,6 +512,11 @@ def main():
                         alloc_retries=ms1.get('num_alloc_retries', 0)),
         )
         if world == 1 and not args.no_cpu_baseline:
+            if host_mask is not None:
+                try:
+                    os.sched_setaffinity(0, host_mask)      # the oracle's step runs on all of the host's cores again
+                except OSError:
+                    pass
             out['cpu_baseline'] = cpu_baseline(full=args.cpu_baseline_full)
         print(json.dumps(out), flush=True)
     if world > 1:

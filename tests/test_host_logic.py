@@ -112,3 +112,25 @@ def test_parameter_reuse_is_found_in_the_graph():
     assert _parameter_reused((Lin.apply(x, lin.weight) @ lin.weight).sum(), params)             # a tied weight, one own edge
     assert not _parameter_reused(lin(lin(x)).sum(), params)            # library nodes only: autograd orders those itself
     assert not _parameter_reused(x.sum().requires_grad_(), params)     # no graph at all
+
+
+def test_numa_affinity_helper_parses_and_declines_gracefully():
+    """bench.py binds a rank to the CPUs of its GPU's NUMA node (tgt_amd/training/affinity.py); without the topology it must
+    leave the process alone and say why"""
+    import os
+    from tgt_amd.training import affinity
+    assert affinity._cpulist('0-3,8,10-11\n') == {0, 1, 2, 3, 8, 10, 11}
+    assert affinity._cpulist('') == set()
+    assert affinity.bind_to_gpu_numa(0, enabled=False) == {'bound': False, 'why': 'disabled'}
+    before = os.sched_getaffinity(0)
+    real = affinity.gpu_numa_node
+    try:
+        affinity.gpu_numa_node = lambda i: None              # a container that hides the PCI topology
+        rep = affinity.bind_to_gpu_numa(0)
+        assert rep['bound'] is False and 'NUMA' in rep['why']
+        affinity.gpu_numa_node = lambda i: 10 ** 6           # a node without a cpulist
+        rep = affinity.bind_to_gpu_numa(0)
+        assert rep['bound'] is False
+    finally:
+        affinity.gpu_numa_node = real
+    assert os.sched_getaffinity(0) == before

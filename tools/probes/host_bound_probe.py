@@ -13,6 +13,9 @@ from tgt_amd.training.synthetic import make_batch, batch_seed
 from tgt_amd.training.gemm_tuning import enable_gemm_tuning
 enable_gemm_tuning(online=True)
 dev = torch.device('cuda', 0)
+if os.environ.get('PROBE_BIND') == '1':
+    from tgt_amd.training.affinity import bind_to_gpu_numa
+    print('affinity', bind_to_gpu_numa(0))
 torch.manual_seed(0)
 model = TGT_Multi(**tgt_at_24l()).to(dev).train()
 cfg = StepConfig(mixed_precision='bf16')
