@@ -271,6 +271,52 @@ def test_deferred_closing_sums_change_nothing(monkeypatch):
     assert torch.allclose(out, part.sum(0), atol=1e-4) and ops._deferred_stats == [0, 0]
 
 
+def test_flat_gradient_destinations_change_nothing(monkeypatch):
+    """ops._grad_dst (round 4): inside the Trainer's backward the kernels that end a weight gradient write it into the parameter's
+    slice of the flat gradient buffer; AccumulateGrad adopts the alias and the gradient collection skips the copy.  Same kernels,
+    same order: three steps with the destinations equal three steps without, bit for bit, with and without the bucketed path
+    (whose hooks collect in the middle of the backward); and most of the gradient bytes are in place when the backward ends."""
+    import torch.distributed as dist
+    from tgt_amd import ops
+    from tgt_amd.pcqm import TGT_Multi
+    from tgt_amd.training.step import Trainer, StepConfig
+    monkeypatch.setattr(ops, '_EDGE_MIN_ROWS', 1)
+    monkeypatch.setattr(ops, '_SPLIT_MIN_ROWS', 1)
+    kwargs = dict(gu.FULL_AT_CFG, model_height=3)
+    cfg = StepConfig(num_dist_bins=512, mixed_precision='bf16', coords_noise=0.0, lr_warmup_steps=10, lr_total_steps=100, bucket_mbytes=8)
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{_free_port()}', rank=0, world_size=1)
+    try:
+        for bucketed in (False, True):
+            runs = []
+            for in_place in (True, False):
+                monkeypatch.setattr(ops, '_FLAT_GRAD_ON', in_place)
+                m1 = gu.fill_params(TGT_Multi(**kwargs), seed=3).cuda().eval()
+                with Trainer(m1, cfg, force_distributed=bucketed) as tr:
+                    for step in range(1, 4):
+                        tr.training_step(_batch(cfg, step))
+                    placed = sum(p.numel() for p, v in zip(tr.flat.params, tr.flat.grad_views)
+                                 if p.grad is not None and p.grad.data_ptr() == v.data_ptr())
+                    total = sum(p.numel() for p in tr.flat.params if p.grad is not None)
+                    runs.append(_params(m1).clone())
+                    mine = [p.data_ptr() for p in tr.flat.params]
+                    assert all(q in ops._FLAT_GRAD for q in mine)
+                assert not any(q in ops._FLAT_GRAD for q in mine)          # a closed trainer takes its slices out of the registry
+                if in_place:
+                    assert placed > 0.5 * total, (placed, total)          # the large matrices; biases / LayerNorm vectors still travel
+                else:
+                    assert placed == 0
+            assert torch.equal(runs[0], runs[1]), bucketed
+    finally:
+        if own:
+            dist.destroy_process_group()
+    # outside a Trainer's backward gradients are ordinary tensors
+    m2 = gu.fill_params(TGT_Multi(**kwargs), seed=3).cuda().eval()
+    with Trainer(m2, cfg) as tr:
+        assert ops._grad_dst(tr.flat.params[0].data_ptr(), tr.flat.params[0].shape, torch.float32) is None
+
+
 # ---- world-size 2 on the GPU: two ranks share cuda:0 and exchange over gloo (device tensors staged through the host by
 # the backend).  RCCL refuses two ranks on one device and the test boxes have one GPU, so this is the closest a 1-GPU box gets
 # to the N > 1 path: autograd hooks -> bucket gather behind BOTH streams -> asynchronous all-reduce -> one-launch Adam, on

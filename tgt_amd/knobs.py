@@ -34,6 +34,7 @@ _SPEC = {
     'stream_keepalive': ('TGT_STREAM_KEEPALIVE', False, 'flag', 'keep cross-stream tensors referenced instead of record_stream'),
     'node_stream': ('TGT_NODE_STREAM', True, 'flag', 'node channel on a second HIP stream'),
     'node_chain': ('TGT_NODE_CHAIN', True, 'flag', "the next layer's node projections chained on the side stream"),
+    'flat_grad_dst': ('TGT_FLAT_GRAD_DST', True, 'flag', 'weight gradients written into the flat gradient buffer inside a Trainer backward'),
     'defer_edge': ('TGT_DEFER_EDGE', True, 'flag', 'closing edge residual performed by the next layer entry'),
 }
 ENV_OF_LIBRARY = ('TGT_TRI_BWD2', 'TGT_TRI_BWD2_DMA', 'TGT_HIP_LIB', 'TGT_NODE_MFMA', 'TGT_TUNING_FILE')
@@ -72,6 +73,7 @@ class Knobs:
     stream_keepalive: bool
     node_stream: bool
     node_chain: bool
+    flat_grad_dst: bool
     defer_edge: bool
 
     @classmethod

@@ -381,7 +381,10 @@ def _fuse_params(table, params, cd):
 def _unfuse_grads(table, params, dW, db):
     """per-parameter gradients (dtype of each parameter) from the fused projection's fp32
     gradients in ONE launch"""
-    grads = [torch.empty_like(p) for p in params]
+    grads = []
+    for p in params:                      # (inside a Trainer's backward: straight into the flat gradient buffer, see _grad_dst)
+        dst = _grad_dst(p.data_ptr(), p.shape, p.dtype)
+        grads.append(dst if dst is not None else torch.empty_like(p))
     if not (dW.is_contiguous() and db.dtype == dW.dtype and db.is_contiguous()):
         flush_deferred()                  # (a cast / copy reads them: they must not be pending sums)
         dW, db = dW.contiguous(), db.to(dW.dtype).contiguous()
@@ -1269,6 +1272,39 @@ _wgrad_streams = {}
 _trainer_backward = [0]           # > 0 while a Trainer runs its backward: the only caller that joins the forked stream afterwards
 
 
+# Gradients written where the optimizer reads them.  A Trainer keeps one flat float32 gradient buffer; autograd hands every
+# parameter its own gradient tensor, and the Trainer's gradient collection then copies all of them into the buffer (414 MB each
+# way, 0.34 ms of multi-tensor copies and ~1 ms of host time per step).  Inside a Trainer's backward the kernels that END a
+# weight gradient (the fixed-order plane sum of a split-M product, the scatter of a fused projection's gradient) write into the
+# parameter's slice of that buffer instead and return a fresh alias of it: AccumulateGrad adopts the alias (single owner, same
+# layout), the collection finds the gradient already in place and skips it.  Only there: any other backward (tests,
+# torch.autograd.grad) gets ordinary tensors, and a Trainer whose parameters enter the graph more than once never opens the
+# context (step.py: _parameter_reused) -- autograd would add into the slice a second time.
+_FLAT_GRAD = {}                   # parameter data_ptr -> (float32 view of the flat gradient buffer shaped like the parameter)
+_FLAT_GRAD_ON = K.flat_grad_dst
+
+
+def register_flat_grads(params, views):
+    for p_, v in zip(params, views):
+        _FLAT_GRAD[p_.data_ptr()] = v
+
+
+def unregister_flat_grads(ptrs):
+    for q in ptrs:
+        _FLAT_GRAD.pop(q, None)
+
+
+def _grad_dst(ptr, shape, dtype):
+    """a fresh alias of the flat-buffer slice that belongs to the parameter at `ptr`, or None (not inside a Trainer's backward,
+    not registered, another shape / dtype)"""
+    if not (_FLAT_GRAD_ON and _trainer_backward[0] > 0 and ptr is not None):
+        return None
+    v = _FLAT_GRAD.get(ptr)
+    if v is None or v.dtype != dtype or tuple(v.shape) != tuple(shape):
+        return None
+    return v.detach()
+
+
 class trainer_backward:
     """`with ops.trainer_backward():` around loss.backward() -- inside, parameter gradients may be produced on a forked stream
     (autograd does not know about it: the stream switch happens inside a node).  The caller MUST order its reads of the
@@ -1421,7 +1457,7 @@ def _linear_forward(x, weight, bias, cd):
     return x2, w, y
 
 
-def _linear_backward(x2, w, dy2, xs, xdt, wdt, bdt, need_dx, need_dw, need_db, lazy_dx=False, dw_post=None, fork=True):
+def _linear_backward(x2, w, dy2, xs, xdt, wdt, bdt, need_dx, need_dw, need_db, lazy_dx=False, dw_post=None, fork=True, dw_ptr=None):
     """(dx, dW, db) of y = x W^T + b.  dW = dY^T X contracts over M = B*N*N = 262144 rows into a
     tiny (out,in) result; as one GEMM the library runs it on a handful of workgroups
     (0.4-0.8 ms), as 64-128 independent chunk products + an fp32 sum it is HBM-bound (57 us for
@@ -1450,12 +1486,16 @@ def _linear_backward(x2, w, dy2, xs, xdt, wdt, bdt, need_dx, need_dw, need_db, l
                 part = torch.bmm(dy2.view(P, M // P, -1).transpose(1, 2), x2.view(P, M // P, -1),
                                  out_dtype=torch.float32) if dy2.dtype != torch.float32 else \
                     torch.bmm(dy2.view(P, M // P, -1).transpose(1, 2), x2.view(P, M // P, -1))
-                dw = sum_planes(part, torch.empty(part.shape[1:], dtype=torch.float32, device=part.device))
+                # (dw_ptr: the parameter this gradient belongs to -- inside a Trainer's backward the sum lands in its slice of the
+                #  flat gradient buffer, see _grad_dst)
+                dst = _grad_dst(dw_ptr, part.shape[1:], torch.float32) if (dw_post is None and wdt == torch.float32) else None
+                dw = sum_planes(part, dst if dst is not None else torch.empty(part.shape[1:], dtype=torch.float32, device=part.device))
                 if wdt != torch.float32:
                     flush_deferred()
                     dw = dw.to(wdt)
             else:
-                dw = (dy2.t() @ x2).to(wdt)
+                dst = _grad_dst(dw_ptr, (dy2.shape[1], x2.shape[1]), wdt) if dw_post is None else None
+                dw = (dy2.t() @ x2).to(wdt) if dst is None else dst.copy_(dy2.t() @ x2)      # (the same cast, into the slice)
             if dw_post is not None:
                 dw = dw_post(dw)
     if need_db:
@@ -1474,6 +1514,7 @@ class _Linear(torch.autograd.Function):
         ctx.save_for_backward(x2, w)
         ctx.meta = (x.shape, x.dtype, weight.dtype, None if bias is None else bias.dtype)
         ctx.lazy = lazy
+        ctx.wptr = weight.data_ptr()
         return y
 
     @staticmethod
@@ -1483,7 +1524,8 @@ class _Linear(torch.autograd.Function):
         need_db = bdt is not None and ctx.needs_input_grad[2]
         cs = _take_colsum(dy, dy.shape[-1]) if need_db else None
         dx, dw, db = _linear_backward(x2, w, dy.reshape(-1, dy.shape[-1]), xs, xdt, wdt, bdt,
-                                      ctx.needs_input_grad[0], ctx.needs_input_grad[1], need_db and cs is None, ctx.lazy)
+                                      ctx.needs_input_grad[0], ctx.needs_input_grad[1], need_db and cs is None, ctx.lazy,
+                                      dw_ptr=ctx.wptr)
         if cs is not None:
             db = _param_grad(cs, bdt)
         return dx, dw, db, None, None
@@ -1687,6 +1729,7 @@ class _LinearGeluDropout(torch.autograd.Function):
                         row_scale=sample_scale, rows_per_sample=rps)
         ctx.save_for_backward(x2, w, pre, sample_scale)
         ctx.meta = (xs, x.dtype, weight.dtype, None if bias is None else bias.dtype, float(p), seed, rps * N)
+        ctx.wptr = weight.data_ptr()
         ctx.set_materialize_grads(False)
         # TWO outputs: the activation, and the pre-activation as a differentiable value of its own -- a consumer that owns the
         # activation's derivative (linear_residual_layer_norm: GELU backward as the epilogue of its data-gradient GEMM) reads
@@ -1726,7 +1769,7 @@ class _LinearGeluDropout(torch.autograd.Function):
         if d_pre is None:
             return None, None, None, None, None, None, None, None
         dx, dw, db = _linear_backward(x2, w, d_pre.view(-1, d_pre.shape[-1]), xs, xdt, wdt, bdt, ctx.needs_input_grad[0],
-                                      ctx.needs_input_grad[1], need_db and cs is None, ctx.lazy)
+                                      ctx.needs_input_grad[1], need_db and cs is None, ctx.lazy, dw_ptr=ctx.wptr)
         if need_db and cs is not None:
             db = _param_grad(cs, bdt)
         return dx, dw, db, None, None, None, None, None
@@ -1845,6 +1888,7 @@ class _LinearResidualLN(torch.autograd.Function):
             ctx.save_for_backward(x2, w, s, g, mean, rstd, scale)
         ctx.meta = (xs, x.dtype, weight.dtype, None if bias is None else bias.dtype, ln_w.dtype, res.dtype, rps)
         ctx.prescaled = bool(prescaled and scale is not None)
+        ctx.wptr = weight.data_ptr()
         return s, y
 
     @staticmethod
@@ -1888,7 +1932,8 @@ class _LinearResidualLN(torch.autograd.Function):
                         _hand_colsum(d_pre, sum_rows(part))
         dx, dw, db = _linear_backward(x2, w, d_z.reshape(rows, N), xs, xdt, torch.float32 if ctx.col_inv is not None else wdt, bdt,
                                       need_dx, ctx.needs_input_grad[1], need_db and cs is None,
-                                      dw_post=None if ctx.col_inv is None else (lambda t: _permute_cols(t.contiguous(), ctx.col_inv, wdt, after_sums=True)))
+                                      dw_post=None if ctx.col_inv is None else (lambda t: _permute_cols(t.contiguous(), ctx.col_inv, wdt, after_sums=True)),
+                                      dw_ptr=ctx.wptr)
         if need_db and cs is not None:
             db = _param_grad(cs, bdt)
         return (dx, dw, db, d_res if rdt == d_res.dtype else d_res.to(rdt), None,

@@ -154,6 +154,16 @@ class FlatState:
             self.grad_views.append(self.grad[o:o + p.numel()].view_as(p))
             p.grad = None
         self.shadow = None
+        self._registered = []
+        if dev.type == 'cuda':
+            # kernels that end a weight gradient inside a Trainer's backward write it into these slices (ops._grad_dst)
+            ops.register_flat_grads(self.params, self.grad_views)
+            self._registered = [p.data_ptr() for p in self.params]
+            weakref.finalize(self, ops.unregister_flat_grads, list(self._registered))      # (the registry holds views of self.grad)
+
+    def release(self):
+        ops.unregister_flat_grads(self._registered)
+        self._registered = []
 
     def views(self, flat):
         """per-parameter views of a flat buffer laid out like self.param"""
@@ -188,7 +198,7 @@ class FlatState:
             g = self.params[i].grad
             if g is None:
                 self.grad_views[i].zero_()
-            else:
+            elif g.data_ptr() != self.grad_views[i].data_ptr():     # (else: the kernel that ended this gradient wrote it in place, ops._grad_dst)
                 src.append(g if g.dtype == torch.float32 else g.float())
                 dst.append(self.grad_views[i])
         if src:
@@ -278,15 +288,16 @@ class Trainer:
         # (or garbage collection of the trainer) gives the ownership back.
         ops.side_stream.owner_present(True)
         self._closed = False
-        self._finalizer = weakref.finalize(self, Trainer._release, self._hooks, self._wt)
+        self._finalizer = weakref.finalize(self, Trainer._release, self._hooks, self._wt, list(self.flat._registered))
 
     @staticmethod
-    def _release(hooks, wt=None):
+    def _release(hooks, wt=None, grad_ptrs=()):
         for h in hooks:
             h.remove()
         hooks.clear()
         if wt is not None:
             wt.close()
+        ops.unregister_flat_grads(grad_ptrs)        # (the registry holds views of this trainer's gradient buffer)
         ops.side_stream.owner_present(False)
 
     def close(self):
