@@ -21,6 +21,8 @@ _SPEC = {
     'defer_max': ('TGT_DEFER_MAX', 56, 'int', 'sums per queue before it flushes itself'),
     'epi_ln_bwd': ('TGT_EPI_LN_BWD', True, 'flag', 'LayerNorm backward as the epilogue of the data-gradient GEMM'),
     'wgrad_stream': ('TGT_WGRAD_STREAM', False, 'flag', 'parameter gradients on a third stream inside the Trainer backward'),
+    'wgrad_keep': ('TGT_WGRAD_KEEP', True, 'flag', 'forked operands kept referenced in a window instead of record_stream (with wgrad_stream)'),
+    'wgrad_depth': ('TGT_WGRAD_DEPTH', 8, 'int', 'forks whose operands stay referenced before their origin stream waits for them'),
     'terminal_sums': ('TGT_TERMINAL_SUMS', True, 'flag', 'closing sums on the forked stream too (with wgrad_stream)'),
     'side_prio': ('TGT_SIDE_PRIO', -1, 'int', 'HIP priority of the node side stream (-1 = high)'),
     'wt_cache': ('TGT_WT_CACHE', True, 'flag', 'cached W^T for the data-gradient kernels'),
@@ -60,6 +62,8 @@ class Knobs:
     defer_max: int
     epi_ln_bwd: bool
     wgrad_stream: bool
+    wgrad_keep: bool
+    wgrad_depth: int
     terminal_sums: bool
     side_prio: int
     wt_cache: bool

@@ -4,6 +4,7 @@ These functions are the only way the tgt_amd modules do the hot-path
 arithmetic.  They require HIP device tensors and libtgt_hip.so; there is no
 eager / CPU fallback (a missing library or a CPU tensor raises).
 """
+import collections
 import contextlib
 import ctypes as C
 import os
@@ -1268,7 +1269,10 @@ def _as_dtype_view(p, cd):
 # opt-in (TGT_WGRAD_STREAM=1): weight gradients of the edge Linears on a third stream.  Measured over 20 same-box pairs on five boxes:
 # +1.7 % on one, -1.9 % on another, occasional runs 5-10 % low -- two equal-priority queues of HBM-bound kernels; the mean is ~0
 _WGRAD_STREAM = K.wgrad_stream
+_WGRAD_KEEP = K.wgrad_keep            # forked operands kept referenced in a window instead of Tensor.record_stream
+_WGRAD_DEPTH = K.wgrad_depth
 _wgrad_streams = {}
+_wgrad_window = {}                    # device -> deque of [event on the forked stream | None, operands, origin stream]
 _trainer_backward = [0]           # > 0 while a Trainer runs its backward: the only caller that joins the forked stream afterwards
 
 
@@ -1336,9 +1340,26 @@ def _wgrad_fork(*tensors, rows=None):
     if ws is None:
         ws = _wgrad_streams[dev] = torch.cuda.Stream(dev, priority=0)
     ws.wait_stream(cur)
-    for t in tensors:
-        t.record_stream(ws)
     _main_streams.setdefault(dev, cur)
+    if not _WGRAD_KEEP:
+        for t in tensors:
+            t.record_stream(ws)
+        return ws
+    # The operands must outlive the forked work.  record_stream would do it, but then the allocator holds every freed operand
+    # until an event on the forked stream completes, the host runs many layers ahead of the GPU and asks for fresh memory
+    # instead: the reserve grew from 69 to 130-200 GB and one run in eight lost 10 % (profiles/r05y_ab_wgrad_stream.txt).
+    # Instead the operands of the last _WGRAD_DEPTH forks stay referenced here; the stream they came from is made to wait for
+    # the work of the fork that falls out of the window and only then is that fork's reference dropped: whatever reuses the
+    # memory on that stream is ordered behind the forked kernels that read it.
+    q = _wgrad_window.setdefault(dev, collections.deque())
+    if q and q[-1][0] is None:               # close the previous fork: an event on ws behind everything it was given
+        ev = torch.cuda.Event()
+        ev.record(ws)
+        q[-1][0] = ev
+    q.append([None, tensors, cur])
+    while len(q) > _WGRAD_DEPTH:
+        ev, _old, origin = q.popleft()
+        origin.wait_event(ev)
     return ws
 
 
@@ -2104,6 +2125,12 @@ def wait_side_streams(device=None):
             for other in (_side_streams.get(dev), _wgrad_streams.get(dev), _main_streams.get(dev)):
                 if other is not None and other != cur:
                     cur.wait_stream(other)
+            q = _wgrad_window.get(dev)
+            if q:
+                # everything forked so far is behind `cur` now; operands that came from `cur` may go (the others wait for their turn)
+                keep = [e for e in q if e[2] != cur or e[0] is None]      # (an open fork may still be given work)
+                q.clear()
+                q.extend(keep)
 
 
 def drop_path_scale(x, drop_prob, training):
