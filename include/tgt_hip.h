@@ -243,7 +243,9 @@ int tgt_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
  * ---------------------------------------------------------------------- */
 enum { TGT_CTL_SCALE = 0, TGT_CTL_TRACKER = 1, TGT_CTL_FOUND_INF = 2, TGT_CTL_STEPS = 3, TGT_CTL_MULT = 4,
        TGT_CTL_COEF = 5, TGT_CTL_NORM = 6, TGT_CTL_SKIPPED = 7, TGT_CTL_LOSS = 8, TGT_CTL_SAMPLES = 9,
-       TGT_CTL_NAN = 10, TGT_CTL_LOSS_LO = 11, TGT_CTL_PAIR = 12, TGT_CTL_SAMPLES_LO = 14, TGT_CTL_SIZE = 16 };
+       TGT_CTL_NAN = 10, TGT_CTL_LOSS_LO = 11, TGT_CTL_PAIR = 12, TGT_CTL_SAMPLES_LO = 14, TGT_CTL_LR = 15, TGT_CTL_SIZE = 16 };
+/* TGT_CTL_LR (ABI 29): tgt_adam_step called with ctl != NULL and lr < 0 reads the learning rate from ctl[15] -- a captured
+ * (hipGraph) step cannot take a new host argument per replay; the schedule's value is written into the block before each one. */
 /* TGT_CTL_LOSS / TGT_CTL_SAMPLES are (value, low-order part) float pairs with TGT_CTL_LOSS_LO / TGT_CTL_SAMPLES_LO: the running sums
  * are value + low part (read both, add in float64).  TGT_CTL_STEPS is an exact float32 count up to 2^24 optimizer steps (the
  * reference's longest schedule is 3e5).  TGT_CTL_COEF follows torch's clip_grad_norm_: NaN when the gradient norm is NaN. */
@@ -451,6 +453,14 @@ typedef struct tgt_transpose_item { const void* src; void* dst; int32_t rows, co
  * (the descriptors travel as kernel arguments; nothing is read from it after the call returns). */
 typedef struct tgt_sum_item { const float* src; float* dst; int32_t planes; int32_t _pad; int64_t n; } tgt_sum_item;
 int tgt_sum_many(const tgt_sum_item* items, int32_t n, void* stream);
+
+/* ABI 29.  A device-resident 64-bit step counter mixed into every dropout seed of tgt_gelu_dropout_* and tgt_edge_linear
+ * (seed' = seed + *counter * 0x9E3779B97F4A7C15): a training step captured in a hipGraph bakes the seeds its host drew into the
+ * graph; the counter -- incremented by the graph itself once per replay -- gives each replay its own drop patterns, forward and
+ * backward of one step seeing the same value.  Process-wide, read at launch time; NULL (the default) = seeds as given.  The
+ * attention-dropout seeds of tgt_triplet_attention_* / tgt_node_attention_* are NOT covered (the captured step refuses p > 0 there).
+ * Replaces nothing in the reference: torch's own graph-safe Philox offsets play this role for its dropout under CUDA graphs. */
+int tgt_set_seed_counter(const void* device_counter);
 int tgt_transpose_many(const tgt_transpose_item* items, int32_t n, int32_t blocks_per_item, void* stream);
 
 /* Row-wise cross entropy of the binned-distance head: replaces

@@ -317,6 +317,59 @@ def test_flat_gradient_destinations_change_nothing(monkeypatch):
         assert ops._grad_dst(tr.flat.params[0].data_ptr(), tr.flat.params[0].shape, torch.float32) is None
 
 
+def test_graphed_training_step_equals_eager():
+    """training/graphed.py: Trainer.training_step captured in a hipGraph and replayed.  What a replay must not inherit from the
+    capture is a device value -- the dropout step counter the kernels mix into their seeds (tgt_set_seed_counter), torch's
+    capture-aware generator for the DropPath / source-dropout draws, the learning rate in the optimizer's control block -- so in
+    graph-safe mode an eager step and a replay launch the same kernels with the same arguments: after three warm-up steps and
+    three more steps on fresh batches the parameters are bit-identical, dropouts ON; and successive replays do not repeat their
+    drop patterns."""
+    from tgt_amd import ops
+    from tgt_amd.pcqm import TGT_Multi
+    from tgt_amd.training.step import Trainer, StepConfig
+    from tgt_amd.training.graphed import GraphedTrainingStep
+    kwargs = dict(gu.FULL_AT_CFG, model_height=2, source_dropout=0.3, drop_path=0.2, node_act_dropout=0.1, edge_act_dropout=0.1)
+    cfg = StepConfig(num_dist_bins=512, mixed_precision='bf16', coords_noise=0.0, lr_warmup_steps=4, lr_total_steps=100)
+    batches = [_batch(cfg, s) for s in range(4)]
+    runs, losses = [], []
+    try:
+        for graphed in (False, True):
+            torch.manual_seed(77)
+            ops.reset_random_pools()
+            m = gu.fill_params(TGT_Multi(**kwargs), seed=3).cuda().train()
+            with Trainer(m, cfg) as tr:
+                if graphed:
+                    with GraphedTrainingStep(tr, batches[0], warmup=3) as gs:
+                        for b in batches[1:]:
+                            out, loss = gs.step(b)
+                            losses.append(float(loss))
+                        # the same batch twice more: a new counter value, a new DropPath draw -> another loss
+                        again = [float(gs.step(batches[1])[1]) for _ in range(2)]
+                        assert gs.replays == 5 and int(gs.counter) == 3 + 5
+                else:
+                    ctr = torch.zeros(1, dtype=torch.int64, device='cuda')
+                    ops.graph_safe_rng(True)
+                    ops.set_seed_counter(ctr)
+                    tr.set_device_lr(True)
+                    for b in [batches[0]] * 3 + batches[1:] + [batches[1]] * 2:
+                        tr.global_step += 1
+                        tr.write_device_lr()
+                        ctr.add_(1)
+                        tr.compute_gradients(b)
+                        tr.apply_gradients()
+                    ops.set_seed_counter(None)
+                    ops.graph_safe_rng(False)
+                runs.append(_params(m).clone())
+                steps = tr.global_step
+            assert steps == 8
+    finally:
+        ops.set_seed_counter(None)
+        ops.graph_safe_rng(False)
+    assert torch.isfinite(runs[0]).all()
+    assert torch.equal(runs[0], runs[1])
+    assert again[0] != again[1] and losses[0] != again[0]          # replays of one batch differ: the drop patterns moved on
+
+
 # ---- world-size 2 on the GPU: two ranks share cuda:0 and exchange over gloo (device tensors staged through the host by
 # the backend).  RCCL refuses two ranks on one device and the test boxes have one GPU, so this is the closest a 1-GPU box gets
 # to the N > 1 path: autograd hooks -> bucket gather behind BOTH streams -> asynchronous all-reduce -> one-launch Adam, on

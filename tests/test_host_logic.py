@@ -134,3 +134,28 @@ def test_numa_affinity_helper_parses_and_declines_gracefully():
     finally:
         affinity.gpu_numa_node = real
     assert os.sched_getaffinity(0) == before
+
+
+def test_graph_safe_host_seeds_are_a_function_of_the_call_position():
+    """training/graphed.py: a captured step bakes its host-drawn dropout seeds into the graph, so in graph-safe mode they are a fixed
+    function of the call's position inside the step (the step enters through the device counter instead): every step draws the
+    same sequence, every call of a step another seed; outside the mode seeds come from torch's CPU generator again"""
+    import torch
+    from tgt_amd import ops
+    try:
+        ops.graph_safe_rng(True)
+        ops.begin_step()
+        a = [ops.draw_dropout(0.1, True)[1] for _ in range(50)]
+        ops.begin_step()
+        b = [ops.draw_dropout(0.1, True)[1] for _ in range(50)]
+        assert a == b and len(set(a)) == 50 and all(0 <= s < 2 ** 63 for s in a)
+        assert ops.draw_dropout(0.1, False) == (0.0, 0)            # not training: no dropout, no position consumed
+        assert ops.draw_dropout(0.0, True) == (0.0, 0)
+        ops.begin_step()
+        assert ops.draw_dropout(0.1, True)[1] == a[0]
+    finally:
+        ops.graph_safe_rng(False)
+    torch.manual_seed(5)
+    c = ops.draw_dropout(0.1, True)[1]
+    torch.manual_seed(5)
+    assert ops.draw_dropout(0.1, True)[1] == c and c not in a

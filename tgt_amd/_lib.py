@@ -20,7 +20,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 SOURCES = ['capi.hip', 'optimizer.hip', 'edge_gemm.hip', 'params.hip', 'loss.hip', 'predict.hip', 'gaussian.hip', 'triplet_attention_proj.hip',
            ('triplet_attention.hip', ['-DTGT_TRI_INST=9'], '.f32'), ('triplet_attention.hip', ['-DTGT_TRI_INST=2'], '.bf16'),
            ('triplet_attention.hip', ['-DTGT_TRI_INST=4'], '.f16'), 'triplet_attention16.hip', 'triplet_attention_bwd2.hip', 'triplet_aggregate.hip', 'node_attention.hip', 'node_attention_mfma.hip', 'layernorm.hip', 'triangular_update.hip', 'elementwise.hip']
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 TGT_F32, TGT_BF16, TGT_F16 = 0, 1, 2
 TRI_BIASED, TRI_GATED, TRI_MASK_OUT = 1, 2, 4
@@ -128,6 +128,7 @@ SYMBOLS = {
     'tgt_sum_planes': (C.c_int, [_vp, _i32, _i64, _vp, _vp]),
     'tgt_transpose_many': (C.c_int, [_vp, _i32, _i32, _vp]),
     'tgt_sum_many': (C.c_int, [C.POINTER(SumItem), _i32, _vp]),
+    'tgt_set_seed_counter': (C.c_int, [_vp]),
     'tgt_cross_entropy_fwd': (C.c_int, [_vp, _i32, _vp, _i64, _i32, _vp, _vp, _vp]),
     'tgt_cross_entropy_bwd': (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     'tgt_fuse_rows': (C.c_int, [C.POINTER(FuseRowsArgs), _vp]),

@@ -78,12 +78,21 @@ int bins_to_dist_run(const void* bins, int kind, int64_t R, int N, const int64_t
 
 }  // namespace tgt
 
+namespace tgt {
+static const uint64_t* g_seed_counter = nullptr;
+const uint64_t* seed_counter() { return g_seed_counter; }
+}  // namespace tgt
+
 using namespace tgt;
 
 extern "C" {
 
 const char* tgt_last_error(void) { return g_err; }
-int tgt_abi_version(void) { return 28; }
+int tgt_abi_version(void) { return 29; }
+int tgt_set_seed_counter(const void* device_counter) {
+    g_seed_counter = reinterpret_cast<const uint64_t*>(device_counter);
+    return TGT_OK;
+}
 
 int tgt_triplet_attention_fwd(const tgt_triplet_attention_args* a, void* stream) {
     return triplet_attention_run(a, false, reinterpret_cast<hipStream_t>(stream));

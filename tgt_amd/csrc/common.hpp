@@ -215,6 +215,14 @@ struct FastDiv {
     }
 };
 
+// A device-resident step counter mixed into every dropout seed (tgt_set_seed_counter, ABI 29).  A captured (hipGraph) training
+// step bakes its host-drawn seeds into the graph; the counter -- bumped by the graph itself once per replay -- gives every replay
+// its own drop patterns, and forward and backward of one step see the same value.  NULL (the default): seeds are used as given.
+const uint64_t* seed_counter();                    // host side: what tgt_set_seed_counter registered (capi.hip)
+__device__ __forceinline__ uint64_t step_seed(uint64_t seed, const uint64_t* ctr) {
+    return ctr ? seed + *ctr * 0x9E3779B97F4A7C15ull : seed;
+}
+
 // keep/drop of the V consecutive elements of vector `vec` (= first element index / V): one hash
 // of (seed, vec), then one 32-bit word per TWO elements, 16 bits each;
 // P(keep) = 1 - thresh16 / 65536.

@@ -151,7 +151,7 @@ static int eg_num_cus();
 // ---------------------------------------------------------------------------------------------------------------
 // RB = 32-row blocks per tile (rows per tile kBM = 32*RB): 4, or 2 for the register-hungry epilogues
 template <typename T, int KS, int WN, int EPI, int RB>
-__global__ void __launch_bounds__(512, 2) edge_slice_kernel(const tgt_edge_linear_args a, int groups) {
+__global__ void __launch_bounds__(512, 2) edge_slice_kernel(const tgt_edge_linear_args a, int groups, const uint64_t* seed_ctr) {
     using F = frag_t<T>;
     constexpr int WM = 8 / WN, MB = RB / WM, kBM = 32 * RB, K = KS * 16, kRowBytes = K * 2, kBufBytes = kBM * kRowBytes, NT = WN * 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(512, 2) edge_slice_kernel(const tgt_edge_linea
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
                         bool keep[4] = {true, true, true, true};
-                        if (thresh) keep4(a.dropout_seed, m, N, n0 + 8 * gq + 4 * hi, thresh, keep);
+                        if (thresh) keep4(step_seed(a.dropout_seed, seed_ctr), m, N, n0 + 8 * gq + 4 * hi, thresh, keep);
 #pragma unroll
                         for (int jj = 0; jj < 4; ++jj) {
                             const float x = to_f32(from_f32<T>(v[4 * gq + jj]));      // gelu of the value as stored
@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(512, 2) edge_slice_kernel(const tgt_edge_linea
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
                         bool keep[4] = {true, true, true, true};
-                        if (thresh) keep4(a.dropout_seed, m, N, n0 + 8 * gq + 4 * hi, thresh, keep);
+                        if (thresh) keep4(step_seed(a.dropout_seed, seed_ctr), m, N, n0 + 8 * gq + 4 * hi, thresh, keep);
 #pragma unroll
                         for (int jj = 0; jj < 4; ++jj) {
                             const float x = pv[4 * gq + jj];
@@ -640,7 +640,7 @@ __device__ __forceinline__ void rp_st_f32(__amdgpu_buffer_rsrc_t r, uint32_t off
 }
 
 template <typename T, int KS, int EPI>
-__global__ void __launch_bounds__(1024, 4) edge_rows_kernel(const tgt_edge_linear_args a) {
+__global__ void __launch_bounds__(1024, 4) edge_rows_kernel(const tgt_edge_linear_args a, const uint64_t* seed_ctr) {
     using F = frag_t<T>;
     constexpr int K = KS * 16, N = 256, kBM = 32, kABytes = kBM * K * 2, kSBytes = kBM * N * 2, kPass = 2;
     constexpr bool kOperand = EPI == EPI_RESID || EPI == EPI_GELU_BWD || EPI == EPI_LN_BWD;
@@ -832,7 +832,7 @@ __global__ void __launch_bounds__(1024, 4) edge_rows_kernel(const tgt_edge_linea
             if constexpr (EPI == EPI_GELU) {
                 rp_st16(rs_out2, o_out2 + po * (uint32_t)ldo2_b, rp_pack<T>(v));                  // the pre-activation
                 bool keep[8] = {true, true, true, true, true, true, true, true};
-                if (thresh) keep_vector<8>(a.dropout_seed, (m * N + ch * 8) >> 3, thresh, keep);
+                if (thresh) keep_vector<8>(step_seed(a.dropout_seed, seed_ctr), (m * N + ch * 8) >> 3, thresh, keep);
                 f32x2 gl[4];
                 const float ik = inv_keep * sc_i;       // (row_scale: the DropPath factor of the branch, folded into the activation)
 #pragma unroll
@@ -849,7 +849,7 @@ __global__ void __launch_bounds__(1024, 4) edge_rows_kernel(const tgt_edge_linea
                 f32x2 pv[4], o[4];
                 rp_unpack<T>(cur.o1[i], pv);
                 bool keep[8] = {true, true, true, true, true, true, true, true};
-                if (thresh) keep_vector<8>(a.dropout_seed, (m * N + ch * 8) >> 3, thresh, keep);
+                if (thresh) keep_vector<8>(step_seed(a.dropout_seed, seed_ctr), (m * N + ch * 8) >> 3, thresh, keep);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     f32x2 e;
@@ -1231,7 +1231,7 @@ static int er_launch(const tgt_edge_linear_args& a, hipStream_t st) {
     static bool attr_set[16] = {};
     if (!dyn_lds_once(attr_set, reinterpret_cast<const void*>(&edge_rows_kernel<T, KS, EPI>), lds))
         return set_error(TGT_ERR_LAUNCH, "edge_rows_kernel: cannot reserve %d bytes of LDS", lds);
-    hipLaunchKernelGGL((edge_rows_kernel<T, KS, EPI>), dim3((unsigned)er_grid(a)), dim3(1024), lds, st, a);
+    hipLaunchKernelGGL((edge_rows_kernel<T, KS, EPI>), dim3((unsigned)er_grid(a)), dim3(1024), lds, st, a, seed_counter());
     return check_launch("edge_rows_kernel");
 }
 
@@ -1303,7 +1303,7 @@ static int es_launch(const tgt_edge_linear_args& a, hipStream_t st) {
     if (groups > row_tiles) groups = row_tiles;
     if (g_grid_cap && groups > g_grid_cap) groups = g_grid_cap;
     const int64_t blocks = ((groups + 7) / 8) * n_slices * 8;
-    hipLaunchKernelGGL((edge_slice_kernel<T, KS, WN, EPI, RB>), dim3((unsigned)blocks), dim3(512), lds, st, a, (int)groups);
+    hipLaunchKernelGGL((edge_slice_kernel<T, KS, WN, EPI, RB>), dim3((unsigned)blocks), dim3(512), lds, st, a, (int)groups, seed_counter());
     return check_launch("edge_slice_kernel");
 }
 

@@ -19,8 +19,10 @@ template <typename T, bool BWD, bool CS = false>
 __global__ void __launch_bounds__(256) gelu_dropout_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                           T* __restrict__ out, int64_t n, uint64_t seed,
                                                           uint32_t thresh, float inv_keep, const float* __restrict__ row_scale,
-                                                          int64_t elems_per_sample, int cols = 0, float* __restrict__ cs_partial = nullptr) {
+                                                          int64_t elems_per_sample, int cols = 0, float* __restrict__ cs_partial = nullptr,
+                                                          const uint64_t* __restrict__ seed_ctr = nullptr) {
     constexpr int V = 16 / (int)sizeof(T);
+    seed = step_seed(seed, seed_ctr);
     float csum[CS ? V : 1];
     if constexpr (CS)
         for (int t = 0; t < V; ++t) csum[t] = 0.f;
@@ -93,11 +95,12 @@ static int gd_launch(const void* x, const void* dy, void* out, int64_t n, float 
     if (blocks < 1) blocks = 1;
     if (!bwd)
         hipLaunchKernelGGL((gelu_dropout_kernel<T, false>), dim3((unsigned)blocks), dim3(256), 0, st,
-                           reinterpret_cast<const T*>(x), nullptr, reinterpret_cast<T*>(out), n, seed, thresh, inv_keep, row_scale, eps_);
+                           reinterpret_cast<const T*>(x), nullptr, reinterpret_cast<T*>(out), n, seed, thresh, inv_keep, row_scale, eps_, 0,
+                           (float*)nullptr, seed_counter());
     else
         hipLaunchKernelGGL((gelu_dropout_kernel<T, true>), dim3((unsigned)blocks), dim3(256), 0, st,
                            reinterpret_cast<const T*>(x), reinterpret_cast<const T*>(dy), reinterpret_cast<T*>(out), n,
-                           seed, thresh, inv_keep, row_scale, eps_);
+                           seed, thresh, inv_keep, row_scale, eps_, 0, (float*)nullptr, seed_counter());
     return check_launch(bwd ? "gelu_dropout_bwd_kernel" : "gelu_dropout_fwd_kernel");
 }
 
@@ -118,7 +121,8 @@ static int gd_colsum_launch(const void* x, const void* dy, void* out, int64_t n,
     if (blocks > kGdColsumParts) blocks = kGdColsumParts;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL((gelu_dropout_kernel<T, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const T*>(x),
-                       reinterpret_cast<const T*>(dy), reinterpret_cast<T*>(out), n, seed, thresh, inv_keep, row_scale, eps_, cols, partial);
+                       reinterpret_cast<const T*>(dy), reinterpret_cast<T*>(out), n, seed, thresh, inv_keep, row_scale, eps_, cols, partial,
+                       seed_counter());
     if (int e = check_launch("gelu_dropout_bwd_colsum_kernel")) return e;
     return sum_rows_run(partial, (int)blocks, cols, colsum, st);
 }

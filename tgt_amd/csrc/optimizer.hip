@@ -13,7 +13,7 @@
 namespace tgt {
 
 enum { CTL_SCALE = 0, CTL_TRACKER = 1, CTL_FOUND_INF = 2, CTL_STEPS = 3, CTL_MULT = 4, CTL_COEF = 5, CTL_NORM = 6,
-       CTL_SKIPPED = 7, CTL_LOSS = 8, CTL_SAMPLES = 9, CTL_NAN = 10, CTL_LOSS_LO = 11, CTL_PAIR = 12, CTL_SAMPLES_LO = 14 };
+       CTL_SKIPPED = 7, CTL_LOSS = 8, CTL_SAMPLES = 9, CTL_NAN = 10, CTL_LOSS_LO = 11, CTL_PAIR = 12, CTL_SAMPLES_LO = 14, CTL_LR = 15 };
 
 // running sums of update_losses as float32 PAIRS (value, low-order part): an error-free two-sum per step, so that the sample
 // count stays exact far beyond 2^24 and the loss sum keeps ~48 bits (a plain float32 sum stops counting samples at 16.7 M)
@@ -48,6 +48,7 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
     float mult = gscale, coef = 1.f;
     if (ctl) {
         if (ctl[CTL_FOUND_INF] != 0.f) return;
+        if (lr < 0.f) lr = ctl[CTL_LR];          // (a captured step: the schedule's value is written into the block before each replay)
         mult = ctl[CTL_MULT];
         coef = ctl[CTL_COEF];
         const double t = (double)ctl[CTL_STEPS];

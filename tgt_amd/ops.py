@@ -158,11 +158,56 @@ def _tri_args(fused, mask3, out, L, d_out=None, d_fused=None, colsum=None, dropo
     return a
 
 
+# ---- randomness that survives a hipGraph capture (training/graphed.py) --------------------------------------------------
+# A captured step replays the kernel ARGUMENTS of the capture: a dropout seed drawn on the host would give every replay the
+# same drop pattern, and a vector taken from a pre-drawn pool the same DropPath draw.  In graph-safe mode
+#   * host seeds are a fixed function of the call's position inside the step (begin_step() resets the position), and the step
+#     itself enters through a 64-bit DEVICE counter the kernels mix into the seed (tgt_set_seed_counter, ABI 29) -- the captured
+#     graph increments it once per replay;
+#   * DropPath factors / source-dropout masks are drawn by torch where they are needed (torch's generator is capture-aware: the
+#     Philox offset of a replay comes from device memory), not from the pools.
+# An eager step in this mode computes exactly what a replay computes (tests/test_hip_trainer.py).
+_GRAPH_SAFE = [False]
+_site = [0]
+_seed_counter = [None]            # the registered device counter (kept alive here)
+
+
+def graph_safe_rng(on):
+    _GRAPH_SAFE[0] = bool(on)
+    _site[0] = 0
+    if on:
+        reset_random_pools()
+
+
+def begin_step():
+    """start of a training step in graph-safe mode: the per-call seed positions start over"""
+    _site[0] = 0
+
+
+def set_seed_counter(counter):
+    """counter: a 1-element int64 device tensor (or None); see graph_safe_rng"""
+    if counter is not None:
+        assert counter.is_cuda and counter.dtype == torch.int64 and counter.numel() == 1
+    _seed_counter[0] = counter
+    _lib.check(_lib.lib().tgt_set_seed_counter(_ptr(counter)), 'tgt_set_seed_counter')
+
+
+def _host_seed():
+    """a 64-bit dropout seed: from torch's CPU generator (no device sync; torch.manual_seed makes it reproducible), or -- graph-safe
+    mode -- the position of this call inside the step, spread over 64 bits"""
+    if _GRAPH_SAFE[0]:
+        _site[0] += 1
+        x = (_site[0] * 0x9E3779B97F4A7C15 + 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        x ^= x >> 31
+        return (x * 0xBF58476D1CE4E5B9) & 0x7FFFFFFFFFFFFFFF
+    return int(torch.empty((), dtype=torch.int64).random_().item())
+
+
 def draw_dropout(p, training):
     """(p, seed) of a counter-based in-kernel dropout: p forced to 0 outside training, the seed
     drawn from torch's CPU generator (no device sync; torch.manual_seed makes it reproducible)"""
     p = float(p) if training else 0.0
-    return (p, int(torch.empty((), dtype=torch.int64).random_().item()) if p > 0 else 0)
+    return (p, _host_seed() if p > 0 else 0)
 
 
 class _TripletAttention(torch.autograd.Function):
@@ -772,7 +817,7 @@ def adam_step_(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), e
 
 # layout of the optimizer control block (include/tgt_hip.h TGT_CTL_*)
 CTL_SCALE, CTL_TRACKER, CTL_FOUND_INF, CTL_STEPS, CTL_MULT, CTL_COEF, CTL_NORM, CTL_SKIPPED = range(8)
-CTL_LOSS, CTL_SAMPLES, CTL_NAN, CTL_LOSS_LO, CTL_PAIR, CTL_SAMPLES_LO, CTL_SIZE = 8, 9, 10, 11, 12, 14, 16
+CTL_LOSS, CTL_SAMPLES, CTL_NAN, CTL_LOSS_LO, CTL_PAIR, CTL_SAMPLES_LO, CTL_LR, CTL_SIZE = 8, 9, 10, 11, 12, 14, 15, 16
 
 
 def grad_scaler_step_(grad, ctl, world=1, clip_value=0.0, clip_norm=0.0, dynamic=False, growth_factor=2.0,
@@ -910,6 +955,8 @@ class _ScalePool:
     def take(cls, B, keep, device):
         """one pool per stream (a refill and the reads of its rows stay on one stream) AND per keep probability: the DropPath
         rate ramps over the layers, and a pool keyed by the stream alone was refilled by every layer (two launches each)"""
+        if _GRAPH_SAFE[0]:
+            return torch.empty(B, dtype=torch.float32, device=device).bernoulli_(keep).div_(keep)
         sid = torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0
         pool = cls._pools.get((sid, B, keep))
         if pool is None:
@@ -934,6 +981,8 @@ class _DropMaskPool:
 
     @classmethod
     def take(cls, B, N, p, fill, device):
+        if _GRAPH_SAFE[0]:
+            return torch.empty(B, 1, N, dtype=torch.float32, device=device).bernoulli_(p).mul_(fill)
         sid = torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0
         key = (sid, B, N, p, fill, device)
         st = cls._pools.get(key)
@@ -999,7 +1048,7 @@ def gelu_dropout(x, p, training, sample_scale=None):
     sample_scale (B,) float32: the result is multiplied by sample_scale[b] -- the DropPath factor of the residual
     branch, folded in here (see linear_residual_layer_norm(prescaled=True))."""
     p = float(p) if training else 0.0
-    seed = int(torch.empty((), dtype=torch.int64).random_().item()) if p > 0 else 0
+    seed = _host_seed() if p > 0 else 0
     if sample_scale is not None and (x.numel() // x.shape[0]) % 8:
         raise RuntimeError('gelu_dropout: sample_scale needs a multiple of 8 elements per sample')
     return _GeluDropout.apply(x, p, seed, sample_scale)
@@ -1812,7 +1861,7 @@ def linear_gelu_dropout(x, weight, bias, p, training, sample_scale=None):
     """dropout(gelu(linear(x, weight, bias)), p) [* sample_scale per graph] in one launch; see linear_gelu_dropout_ok"""
     cd = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled('cuda') else x.dtype
     p = float(p) if training else 0.0
-    seed = int(torch.empty((), dtype=torch.int64).random_().item()) if p > 0 else 0
+    seed = _host_seed() if p > 0 else 0
     act, pre = _LinearGeluDropout.apply(x, weight, bias, cd, p, seed, sample_scale, _lazy_ok(x, weight, cd))
     # rides on the tensor object (as _tgt_colsum does): what a consumer needs to take over the activation's backward
     act._tgt_gelu = (pre, p, seed, sample_scale)

@@ -1,0 +1,118 @@
+"""The training step as a hipGraph replay -- for the shapes where the HOST is the bottleneck.
+
+The eager step costs the host ~65 ms of enqueue time whatever the batch (2100 launches from Python); at the BASELINE batch
+(256 graphs of 32 nodes) the GPU needs 80 ms and hides it, at 64 graphs it needs 28 ms and at 8 graphs 16 ms -- the eager step
+still takes 58-61 ms there (tools/probes/graph_step_probe.py).  `GraphedTrainingStep` captures ONE `Trainer.training_step`
+(reference lib/training/training.py:439-470: forward, loss, backward, clipping, optimizer) on fixed-shape batches and replays
+it; what a replay must not take from the capture is made a DEVICE value first:
+
+  * dropout patterns: the kernels mix a device step counter into their seeds (ops.set_seed_counter, tgt_set_seed_counter); the
+    graph starts with `counter += 1`.  DropPath factors and source-dropout masks are drawn by torch inside the graph (its
+    generator is capture-aware).  Attention dropout inside the triplet / node attention kernels is not covered: refused.
+  * the learning rate: Adam reads it from the optimizer's control block (Trainer.set_device_lr), refreshed before every replay;
+    the bias corrections already use the device-side count of applied steps.
+  * the batch: copied into the static tensors the capture saw.
+
+Single rank (the bucketed all-reduce hooks are host callbacks).  Same kernels, same arguments: in graph-safe mode an eager step
+and a replay give bit-identical parameters (tests/test_hip_trainer.py::test_graphed_training_step_equals_eager).
+"""
+import torch
+
+from .. import ops
+from .step import Trainer
+
+
+def _attention_dropout(model):
+    """largest attention-dropout probability inside the model's triplet / node attention modules"""
+    worst = 0.0
+    for m in model.modules():
+        for name in ('attention_dropout', 'attn_dropout', 'triplet_dropout'):
+            v = getattr(m, name, None)
+            if isinstance(v, (int, float)):
+                worst = max(worst, float(v))
+    return worst
+
+
+class GraphedTrainingStep:
+    """step(batch) -> (outputs, loss) like Trainer.training_step, as a graph replay.
+
+    trainer: a single-rank Trainer on the GPU; example_batch: a preprocessed batch (preprocess_batch) of the shapes every later
+    batch will have; warmup: eager steps on it before the capture (allocator, GEMM tuning, autograd hooks) -- they are REAL
+    optimizer steps.  The outputs / loss returned by step() are the capture's static tensors (overwritten by the next replay)."""
+
+    def __init__(self, trainer, example_batch, warmup=3, update_losses=False):
+        if not isinstance(trainer, Trainer) or trainer.distributed:
+            raise RuntimeError('GraphedTrainingStep: a single-rank tgt_amd Trainer is required')
+        dev = trainer.flat.param.device
+        if dev.type != 'cuda':
+            raise RuntimeError('GraphedTrainingStep needs the GPU')
+        if trainer.model.training and _attention_dropout(trainer.model) > 0:
+            raise RuntimeError('GraphedTrainingStep: attention dropout inside the attention kernels is seeded from the host; '
+                               'a captured step would repeat its pattern (use the eager Trainer)')
+        self.trainer, self.update_losses = trainer, update_losses
+        self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()}
+        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        ops.graph_safe_rng(True)
+        ops.set_seed_counter(self.counter)
+        trainer.set_device_lr(True)
+        self._closed = False
+        self.stream = torch.cuda.Stream(dev)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(self.stream):
+            for _ in range(max(1, warmup)):
+                self._eager()
+        torch.cuda.current_stream(dev).wait_stream(self.stream)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=self.stream):
+            self.out = self._body()
+        self.replays = 0
+
+    # what the graph holds: the counter bump and the trainer's own step on the static batch
+    def _body(self):
+        tr = self.trainer
+        self.counter.add_(1)
+        outputs, loss = tr.compute_gradients(self.static)
+        tr.apply_gradients()
+        if self.update_losses:
+            tr.update_losses(loss, self.static)
+        return outputs, loss
+
+    def _eager(self):
+        tr = self.trainer
+        tr.global_step += 1
+        tr.write_device_lr()
+        return self._body()
+
+    def step(self, batch):
+        if self._closed:
+            raise RuntimeError('GraphedTrainingStep is closed')
+        tr = self.trainer
+        for k, v in batch.items():
+            if torch.is_tensor(v):
+                dst = self.static[k]
+                if dst.shape != v.shape or dst.dtype != v.dtype:
+                    raise RuntimeError(f'GraphedTrainingStep: batch[{k!r}] is {tuple(v.shape)} {v.dtype}, the capture saw '
+                                       f'{tuple(dst.shape)} {dst.dtype} (one graph per shape)')
+                dst.copy_(v, non_blocking=True)
+        tr.global_step += 1
+        tr.write_device_lr()
+        self.graph.replay()
+        self.replays += 1
+        return self.out
+
+    def close(self):
+        """back to eager: host seeds, pooled DropPath draws, the learning rate as an argument"""
+        if not self._closed:
+            self._closed = True
+            ops.set_seed_counter(None)
+            ops.graph_safe_rng(False)
+            self.trainer.device_lr = False
+            self.graph = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False

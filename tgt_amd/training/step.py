@@ -269,6 +269,7 @@ class Trainer:
         self._wt = None
         self._shared = getattr(model, 'layer_multiplier', 1) > 1 or getattr(getattr(model, 'encoder', None), 'layer_multiplier', 1) > 1
         self._reuse_checked = False        # the first backward walks its graph once for parameters that enter it more than once
+        self.device_lr = False             # True: Adam takes the learning rate from ctl[CTL_LR] (set_device_lr)
         if self.cfg.mixed_precision in ('bf16', 'fp16') and self.flat.param.is_cuda:
             self.flat.make_shadow(torch.bfloat16 if self.cfg.mixed_precision == 'bf16' else torch.float16)
             # W^T of the shadowed weights for the data-gradient kernels, refreshed in one launch after every optimizer step
@@ -452,6 +453,7 @@ class Trainer:
         f.clear_grads()
         self._armed = True
         self.bucket_order = []
+        ops.begin_step()                   # (graph-safe randomness: the per-call seed positions start over; a no-op otherwise)
         with self.autocast():
             outputs = self.model(batch)
             loss = self.loss_fn(outputs, batch, cfg)
@@ -487,7 +489,9 @@ class Trainer:
         [GradScaler.update], the order of training.py:451-469, as (at most) two passes over the flat
         gradient and one over the optimizer state; averages over ranks via the gradient multiplier."""
         cfg, f = self.cfg, self.flat
-        lr = lr_at(self.global_step, cfg)
+        # device_lr (a captured step, training/graphed.py): the kernel reads the rate from the control block, which the owner of
+        # the graph refreshes before every replay
+        lr = -1.0 if self.device_lr else lr_at(self.global_step, cfg)
         if self.use_ctl:
             ops.grad_scaler_step_(f.grad, self.ctl, self.world, cfg.clip_grad_value, cfg.clip_grad_norm, self.dynamic_scale,
                                   cfg.growth_factor, cfg.backoff_factor, cfg.growth_interval)
@@ -500,6 +504,19 @@ class Trainer:
                            shadow=f.shadow, clip_value=cfg.clip_grad_value)
         if self._wt is not None:
             self._wt.refresh()              # (the shadow just changed: every registered W^T follows, one launch)
+
+    def set_device_lr(self, on=True):
+        """the learning rate as a device value (ctl[CTL_LR]) instead of a kernel argument; needs the control-block path of the
+        optimizer, which is switched on with it"""
+        self.device_lr = bool(on)
+        if on:
+            if not self.use_ctl:           # the applied-step count moves to the device with it
+                self.ctl[ops.CTL_STEPS] = float(self._applied_steps)
+            self.use_ctl = True
+            self.write_device_lr()
+
+    def write_device_lr(self):
+        self.ctl[ops.CTL_LR] = lr_at(max(self.global_step, 1), self.cfg)
 
     def training_step(self, batch):
         """batch: device tensors incl. edge_mask / dist_input (see preprocess_batch).
