@@ -16,6 +16,8 @@ rm -rf /tmp/pstats
 grep "^{" /tmp/pstats.log | tail -1 > $O/bench_under_rocprof.json
 cp $(find /tmp/pstats -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
 cd $R
+# (bench.py quotes `traffic` / `mfma_util` from a sha-matched summary under profiles/: hand it the one this run has just measured)
+cp $O/pmc_summary.json profiles/${tag}_pmc_summary.json 2>/dev/null || true
 python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --steps 50 --warmup 10 --no-cpu-baseline > $O/bench_50steps.json 2>> $O/bench.err
 python bench.py --no-cpu-baseline --batch 128 --nodes 48 > $O/bench_n48_b128.json 2>> $O/bench.err
