@@ -370,6 +370,36 @@ def test_graphed_training_step_equals_eager():
     assert again[0] != again[1] and losses[0] != again[0]          # replays of one batch differ: the drop patterns moved on
 
 
+def test_graphed_training_step_refuses_what_it_cannot_replay():
+    """one graph per batch shape; attention dropout inside the attention kernels is host-seeded: both are errors, not silent
+    repetitions; close() hands the process back to host seeds and pooled draws"""
+    import pytest
+    from tgt_amd import ops
+    from tgt_amd.pcqm import TGT_Multi
+    from tgt_amd.training.step import Trainer, StepConfig, preprocess_batch
+    from tgt_amd.training.synthetic import make_batch
+    from tgt_amd.training.graphed import GraphedTrainingStep
+    cfg = StepConfig(num_dist_bins=512, mixed_precision='bf16', coords_noise=0.0, lr_warmup_steps=4, lr_total_steps=100)
+    kwargs = dict(gu.FULL_AT_CFG, model_height=2, node_act_dropout=0.1)
+    m = gu.fill_params(TGT_Multi(**kwargs), seed=3).cuda().train()
+    with Trainer(m, cfg) as tr:
+        with GraphedTrainingStep(tr, _batch(cfg, 0), warmup=1) as gs:
+            assert ops._GRAPH_SAFE[0] and ops._seed_counter[0] is gs.counter and tr.device_lr
+            other = preprocess_batch(make_batch(2, 7, seed=1, ragged=True), 'cuda', cfg, add_noise=False)      # another batch size
+            with pytest.raises(RuntimeError, match='one graph per shape'):
+                gs.step(other)
+            gs.step(_batch(cfg, 1))
+        assert not ops._GRAPH_SAFE[0] and ops._seed_counter[0] is None and not tr.device_lr
+        with pytest.raises(RuntimeError, match='closed'):
+            gs.step(_batch(cfg, 1))
+        tr.training_step(_batch(cfg, 2))                     # the eager trainer goes on (learning rate as an argument again)
+    m2 = gu.fill_params(TGT_Multi(**dict(kwargs, triplet_dropout=0.1)), seed=3).cuda().train()
+    with Trainer(m2, cfg) as tr2:
+        with pytest.raises(RuntimeError, match='attention dropout'):
+            GraphedTrainingStep(tr2, _batch(cfg, 0), warmup=1)
+    assert not ops._GRAPH_SAFE[0]
+
+
 # ---- world-size 2 on the GPU: two ranks share cuda:0 and exchange over gloo (device tensors staged through the host by
 # the backend).  RCCL refuses two ranks on one device and the test boxes have one GPU, so this is the closest a 1-GPU box gets
 # to the N > 1 path: autograd hooks -> bucket gather behind BOTH streams -> asynchronous all-reduce -> one-launch Adam, on
