@@ -328,8 +328,30 @@ def test_graphed_training_step_equals_eager():
     from tgt_amd.pcqm import TGT_Multi
     from tgt_amd.training.step import Trainer, StepConfig
     from tgt_amd.training.graphed import GraphedTrainingStep
+    _graphed_equals_eager(bucketed=False)
+
+
+def test_graphed_training_step_captures_the_bucketed_all_reduce():
+    """the same equality with the distributed path on (nccl backend, world size 1, small buckets): the gradient hooks run at capture
+    time, their RCCL all-reduces on the high-priority stream become nodes of the graph"""
+    import torch.distributed as dist
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{_free_port()}', rank=0, world_size=1)
+    try:
+        _graphed_equals_eager(bucketed=True)
+    finally:
+        if own:
+            dist.destroy_process_group()
+
+
+def _graphed_equals_eager(bucketed):
+    from tgt_amd import ops
+    from tgt_amd.pcqm import TGT_Multi
+    from tgt_amd.training.step import Trainer, StepConfig
+    from tgt_amd.training.graphed import GraphedTrainingStep
     kwargs = dict(gu.FULL_AT_CFG, model_height=2, source_dropout=0.3, drop_path=0.2, node_act_dropout=0.1, edge_act_dropout=0.1)
-    cfg = StepConfig(num_dist_bins=512, mixed_precision='bf16', coords_noise=0.0, lr_warmup_steps=4, lr_total_steps=100)
+    cfg = StepConfig(num_dist_bins=512, mixed_precision='bf16', coords_noise=0.0, lr_warmup_steps=4, lr_total_steps=100, bucket_mbytes=8)
     batches = [_batch(cfg, s) for s in range(4)]
     runs, losses = [], []
     try:
@@ -337,9 +359,14 @@ def test_graphed_training_step_equals_eager():
             torch.manual_seed(77)
             ops.reset_random_pools()
             m = gu.fill_params(TGT_Multi(**kwargs), seed=3).cuda().train()
-            with Trainer(m, cfg) as tr:
+            with Trainer(m, cfg, force_distributed=bucketed) as tr:
+                assert tr.distributed == bucketed
                 if graphed:
-                    with GraphedTrainingStep(tr, batches[0], warmup=3) as gs:
+                    if bucketed:
+                        import pytest
+                        with pytest.raises(RuntimeError, match='single-rank'):
+                            GraphedTrainingStep(tr, batches[0], warmup=1)
+                    with GraphedTrainingStep(tr, batches[0], warmup=3, allow_distributed=bucketed) as gs:
                         for b in batches[1:]:
                             out, loss = gs.step(b)
                             losses.append(float(loss))

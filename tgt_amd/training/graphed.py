@@ -13,7 +13,8 @@ it; what a replay must not take from the capture is made a DEVICE value first:
     the bias corrections already use the device-side count of applied steps.
   * the batch: copied into the static tensors the capture saw.
 
-Single rank (the bucketed all-reduce hooks are host callbacks).  Same kernels, same arguments: in graph-safe mode an eager step
+Single rank by default; `allow_distributed=True` captures the bucketed RCCL all-reduces with the step (their hooks run at capture
+time, the collectives become graph nodes): exercised with the nccl backend at world size 1 only.  Same kernels, same arguments: in graph-safe mode an eager step
 and a replay give bit-identical parameters (tests/test_hip_trainer.py::test_graphed_training_step_equals_eager).
 """
 import torch
@@ -40,9 +41,15 @@ class GraphedTrainingStep:
     batch will have; warmup: eager steps on it before the capture (allocator, GEMM tuning, autograd hooks) -- they are REAL
     optimizer steps.  The outputs / loss returned by step() are the capture's static tensors (overwritten by the next replay)."""
 
-    def __init__(self, trainer, example_batch, warmup=3, update_losses=False):
-        if not isinstance(trainer, Trainer) or trainer.distributed:
-            raise RuntimeError('GraphedTrainingStep: a single-rank tgt_amd Trainer is required')
+    def __init__(self, trainer, example_batch, warmup=3, update_losses=False, allow_distributed=False):
+        if not isinstance(trainer, Trainer):
+            raise RuntimeError('GraphedTrainingStep: a tgt_amd Trainer is required')
+        if trainer.distributed and not allow_distributed:
+            # The bucketed RCCL all-reduces ARE capturable (the hooks run at capture time and their collectives become graph nodes:
+            # verified with the nccl backend at world size 1, tests/test_hip_trainer.py) -- but no multi-GPU box has replayed
+            # such a graph yet, and every rank must capture and replay in lock-step.  Opt in explicitly.
+            raise RuntimeError('GraphedTrainingStep: a single-rank Trainer is required (allow_distributed=True captures the '
+                               'bucketed all-reduce as well: untested beyond one rank)')
         dev = trainer.flat.param.device
         if dev.type != 'cuda':
             raise RuntimeError('GraphedTrainingStep needs the GPU')
