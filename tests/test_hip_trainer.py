@@ -331,6 +331,12 @@ def test_graphed_training_step_equals_eager():
     _graphed_equals_eager(bucketed=False)
 
 
+def test_graphed_training_step_fp16_loss_scaling_and_fp32():
+    """the device-side GradScaler (found_inf / skip / scale update in the control block) replays with the step; fp32 likewise"""
+    _graphed_equals_eager(bucketed=False, precision='fp16')
+    _graphed_equals_eager(bucketed=False, precision=None)
+
+
 def test_graphed_training_step_captures_the_bucketed_all_reduce():
     """the same equality with the distributed path on (nccl backend, world size 1, small buckets): the gradient hooks run at capture
     time, their RCCL all-reduces on the high-priority stream become nodes of the graph"""
@@ -345,13 +351,13 @@ def test_graphed_training_step_captures_the_bucketed_all_reduce():
             dist.destroy_process_group()
 
 
-def _graphed_equals_eager(bucketed):
+def _graphed_equals_eager(bucketed, precision='bf16'):
     from tgt_amd import ops
     from tgt_amd.pcqm import TGT_Multi
     from tgt_amd.training.step import Trainer, StepConfig
     from tgt_amd.training.graphed import GraphedTrainingStep
     kwargs = dict(gu.FULL_AT_CFG, model_height=2, source_dropout=0.3, drop_path=0.2, node_act_dropout=0.1, edge_act_dropout=0.1)
-    cfg = StepConfig(num_dist_bins=512, mixed_precision='bf16', coords_noise=0.0, lr_warmup_steps=4, lr_total_steps=100, bucket_mbytes=8)
+    cfg = StepConfig(num_dist_bins=512, mixed_precision=precision, coords_noise=0.0, lr_warmup_steps=4, lr_total_steps=100, bucket_mbytes=8)
     batches = [_batch(cfg, s) for s in range(4)]
     runs, losses = [], []
     try:
