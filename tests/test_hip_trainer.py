@@ -433,6 +433,50 @@ def test_graphed_training_step_refuses_what_it_cannot_replay():
     assert not ops._GRAPH_SAFE[0]
 
 
+def test_graphed_step_cache_one_graph_per_shape():
+    """GraphedStepCache: batches of two shapes, interleaved; every step() is exactly one optimizer step (the first `warmup` of a
+    shape eagerly in graph-safe mode, then a captured replay), one dropout counter for all graphs, least recently used evicted:
+    the parameters equal those of the same batch sequence stepped eagerly in graph-safe mode, bit for bit"""
+    from tgt_amd import ops
+    from tgt_amd.pcqm import TGT_Multi
+    from tgt_amd.training.step import Trainer, StepConfig, preprocess_batch
+    from tgt_amd.training.synthetic import make_batch
+    from tgt_amd.training.graphed import GraphedStepCache, eager_graph_safe_step
+    kwargs = dict(gu.FULL_AT_CFG, model_height=2, source_dropout=0.3, drop_path=0.2, node_act_dropout=0.1, edge_act_dropout=0.1)
+    cfg = StepConfig(num_dist_bins=512, mixed_precision='bf16', coords_noise=0.0, lr_warmup_steps=4, lr_total_steps=100)
+    shapes = [(3, 7), (2, 9), (4, 5)]
+    seq = [0, 1, 0, 0, 1, 1, 2, 0, 2, 2, 1, 0]            # with max_graphs = 2 the third shape evicts the least recently used one
+    batches = [preprocess_batch(make_batch(*shapes[k], seed=60 + i, ragged=True), 'cuda', cfg, add_noise=False) for i, k in enumerate(seq)]
+    runs = []
+    try:
+        for cached in (False, True):
+            torch.manual_seed(78)
+            ops.reset_random_pools()
+            m = gu.fill_params(TGT_Multi(**kwargs), seed=3).cuda().train()
+            with Trainer(m, cfg) as tr:
+                if cached:
+                    with GraphedStepCache(tr, warmup=1, max_graphs=2) as cache:
+                        for b in batches:
+                            cache.step(b)
+                        assert cache.captures >= 3 and cache.evictions >= 1 and len(cache.graphs) <= 2
+                        assert int(cache.counter) == len(seq)
+                else:
+                    ctr = torch.zeros(1, dtype=torch.int64, device='cuda')
+                    ops.graph_safe_rng(True)
+                    ops.set_seed_counter(ctr)
+                    tr.set_device_lr(True)
+                    for b in batches:
+                        eager_graph_safe_step(tr, ctr, b)
+                    ops.set_seed_counter(None)
+                    ops.graph_safe_rng(False)
+                assert tr.global_step == len(seq)
+                runs.append(_params(m).clone())
+    finally:
+        ops.set_seed_counter(None)
+        ops.graph_safe_rng(False)
+    assert torch.isfinite(runs[0]).all() and torch.equal(runs[0], runs[1])
+
+
 # ---- world-size 2 on the GPU: two ranks share cuda:0 and exchange over gloo (device tensors staged through the host by
 # the backend).  RCCL refuses two ranks on one device and the test boxes have one GPU, so this is the closest a 1-GPU box gets
 # to the N > 1 path: autograd hooks -> bucket gather behind BOTH streams -> asynchronous all-reduce -> one-launch Adam, on

@@ -41,7 +41,7 @@ class GraphedTrainingStep:
     batch will have; warmup: eager steps on it before the capture (allocator, GEMM tuning, autograd hooks) -- they are REAL
     optimizer steps.  The outputs / loss returned by step() are the capture's static tensors (overwritten by the next replay)."""
 
-    def __init__(self, trainer, example_batch, warmup=3, update_losses=False, allow_distributed=False):
+    def __init__(self, trainer, example_batch, warmup=3, update_losses=False, allow_distributed=False, counter=None):
         if not isinstance(trainer, Trainer):
             raise RuntimeError('GraphedTrainingStep: a tgt_amd Trainer is required')
         if trainer.distributed and not allow_distributed:
@@ -58,15 +58,20 @@ class GraphedTrainingStep:
                                'a captured step would repeat its pattern (use the eager Trainer)')
         self.trainer, self.update_losses = trainer, update_losses
         self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()}
-        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
-        ops.graph_safe_rng(True)
-        ops.set_seed_counter(self.counter)
-        trainer.set_device_lr(True)
+        # counter given: this graph is one of several on the trainer (GraphedStepCache owns the mode and the counter); warmup may
+        # then be 0 -- the trainer has already run eager steps of this shape in graph-safe mode
+        self._owns_mode = counter is None
+        self.counter = torch.zeros(1, dtype=torch.int64, device=dev) if counter is None else counter
+        if self._owns_mode:
+            ops.graph_safe_rng(True)
+            ops.set_seed_counter(self.counter)
+            trainer.set_device_lr(True)
+            warmup = max(1, warmup)
         self._closed = False
         self.stream = torch.cuda.Stream(dev)
         self.stream.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(self.stream):
-            for _ in range(max(1, warmup)):
+            for _ in range(warmup):
                 self._eager()
         torch.cuda.current_stream(dev).wait_stream(self.stream)
         torch.cuda.synchronize(dev)
@@ -112,10 +117,91 @@ class GraphedTrainingStep:
         """back to eager: host seeds, pooled DropPath draws, the learning rate as an argument"""
         if not self._closed:
             self._closed = True
+            if self._owns_mode:
+                ops.set_seed_counter(None)
+                ops.graph_safe_rng(False)
+                self.trainer.device_lr = False
+            self.graph = None
+            self.static = self.out = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+
+def eager_graph_safe_step(trainer, counter, batch, update_losses=False):
+    """one eager Trainer step in graph-safe mode -- exactly what a replay of a graph captured in that mode computes"""
+    trainer.global_step += 1
+    trainer.write_device_lr()
+    counter.add_(1)
+    outputs, loss = trainer.compute_gradients(batch)
+    trainer.apply_gradients()
+    if update_losses:
+        trainer.update_losses(loss, batch)
+    return outputs, loss
+
+
+class GraphedStepCache:
+    """One captured step per batch SHAPE (datasets whose padded sizes vary: PCQM batches are padded to their largest molecule,
+    reference lib/data/...padded_collate), at most `max_graphs` of them (least recently used goes first), all on one Trainer and one
+    dropout counter.  step(batch) is always exactly ONE optimizer step: the first `warmup` batches of a shape run eagerly (in
+    graph-safe mode: the same arithmetic a replay performs), the next one is captured and replayed.  Bucket the padding (e.g. to
+    multiples of 8 nodes) to keep the number of shapes small -- every graph owns the activations of its shape."""
+
+    def __init__(self, trainer, warmup=2, max_graphs=4, update_losses=False, allow_distributed=False):
+        if not isinstance(trainer, Trainer):
+            raise RuntimeError('GraphedStepCache: a tgt_amd Trainer is required')
+        if trainer.distributed and not allow_distributed:
+            raise RuntimeError('GraphedStepCache: a single-rank Trainer is required (see GraphedTrainingStep)')
+        dev = trainer.flat.param.device
+        if trainer.model.training and _attention_dropout(trainer.model) > 0:
+            raise RuntimeError('GraphedStepCache: attention dropout inside the attention kernels is seeded from the host')
+        self.trainer, self.warmup, self.max_graphs = trainer, max(1, warmup), max(1, max_graphs)
+        self.update_losses, self.allow_distributed = update_losses, allow_distributed
+        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        ops.graph_safe_rng(True)
+        ops.set_seed_counter(self.counter)
+        trainer.set_device_lr(True)
+        self.graphs, self.seen = {}, {}            # shape key -> GraphedTrainingStep (insertion order = recency) / eager steps so far
+        self.captures = self.evictions = 0
+        self._closed = False
+
+    @staticmethod
+    def _key(batch):
+        return tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(batch.items()) if torch.is_tensor(v))
+
+    def step(self, batch):
+        if self._closed:
+            raise RuntimeError('GraphedStepCache is closed')
+        key = self._key(batch)
+        gs = self.graphs.pop(key, None)
+        if gs is None:
+            n = self.seen.get(key, 0)
+            if n < self.warmup:
+                self.seen[key] = n + 1
+                return eager_graph_safe_step(self.trainer, self.counter, batch, self.update_losses)
+            while len(self.graphs) >= self.max_graphs:
+                old_key = next(iter(self.graphs))
+                self.graphs.pop(old_key).close()
+                self.evictions += 1
+            gs = GraphedTrainingStep(self.trainer, batch, warmup=0, update_losses=self.update_losses,
+                                     allow_distributed=self.allow_distributed, counter=self.counter)
+            self.captures += 1
+        self.graphs[key] = gs                      # most recently used last
+        return gs.step(batch)
+
+    def close(self):
+        if not self._closed:
+            self._closed = True
+            for gs in self.graphs.values():
+                gs.close()
+            self.graphs.clear()
             ops.set_seed_counter(None)
             ops.graph_safe_rng(False)
             self.trainer.device_lr = False
-            self.graph = None
 
     def __enter__(self):
         return self
