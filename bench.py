@@ -227,6 +227,11 @@ def main():
     ap.add_argument('--no-gemm-tuning', action='store_true', help='library default GEMM heuristics')
     ap.add_argument('--no-numa-bind', action='store_true', help='leave the CPU affinity of the rank alone (default: the NUMA node of its GPU)')
     ap.add_argument('--write-gemm-tuning', default='', help='tune online and write the TunableOp file here')
+    ap.add_argument('--share-device', action='store_true',
+                    help='multi-rank dress rehearsal on ONE GPU: every rank runs on cuda:0 and the ranks exchange over gloo (RCCL refuses '
+                         'two ranks on one device).  Walks the exact multi-rank branch of this file -- rendezvous, rank-0 broadcast, '
+                         'bucketed gradient exchange from the hooks, settle-step count, all_gather of the timings, per-rank NUMA binding, '
+                         'per-rank TunableOp files -- on a 1-GPU box; the number it prints is NOT a scaling figure (config says so)')
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         cpu_baseline_worker(args.cpu_baseline_worker, full=args.cpu_baseline_full)
@@ -246,13 +251,18 @@ def main():
         return launcher_selftest(rank, world)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the TGT kernels have no CPU path')
+    if args.share_device:
+        local_rank = 0                      # (every rank on the one GPU of the box)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     # this rank's threads on the socket its GPU hangs on (the CPU baseline below gets the whole host back)
     from tgt_amd.training.affinity import bind_to_gpu_numa
     host_mask = os.sched_getaffinity(0) if hasattr(os, 'sched_getaffinity') else None
     host_affinity = bind_to_gpu_numa(local_rank, enabled=not args.no_numa_bind)
-    if world > 1:
+    if world > 1 and args.share_device:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+    elif world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         # RCCL on its own HIGH-PRIORITY stream: a bucket's all-reduce is dispatched ahead of the next workgroups of the backward
         # kernels it overlaps (two priority levels are all HIP offers; the node side stream uses the same one)
@@ -335,16 +345,25 @@ def main():
     # one event per step on the step's stream (GPU-side step boundaries: the spread of the steps, e.g. one stalled by a
     # synchronous device allocation, shows in step_ms below; `value` stays the wall time of the whole region)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    host_ms, lead = [], []                  # per step: host enqueue time; was the GPU still busy with the PREVIOUS step when the host finished queueing this one?
+    n_comm_before = len(trainer._comm_events)
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
+        h0 = time.perf_counter()
         _, loss = step(args.warmup + i)
         marks[i + 1].record()
+        host_ms.append((time.perf_counter() - h0) * 1e3)
+        # (a non-blocking query: True = the GPU had already finished the previous step when the host finished queueing this one,
+        #  i.e. the stream ran dry at some point of this step -- the host, not the GPU, set its duration)
+        lead.append(bool(marks[i].query()))
         if args.sync_every and (i + 1) % args.sync_every == 0:
             trainer.mean_loss()                      # host read of the control block: synchronises this rank
     fence()
     dt = time.perf_counter() - t0
-    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    step_gpu = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    step_ms = sorted(step_gpu)
+    n_comm_timed = len(trainer._comm_events) - n_comm_before
     ms1 = torch.cuda.memory_stats(dev)
     ops.profile_kernels(False)
     # Kernel durations for `roofline`: inside the timed region the node channel runs on a second HIP stream and its kernels share
@@ -363,8 +382,8 @@ def main():
         ops.profile_kernels(False)
         ops.side_stream.enabled = True
         ops._WGRAD_STREAM = forked
-    comm_ms = trainer.comm_exposed_ms()             # per timed step: what of the gradient exchange the backward did not hide
-    comm_ms = comm_ms[-args.steps:] if comm_ms else []
+    comm_ms = trainer.comm_exposed_ms()             # per step: what of the gradient exchange the backward did not hide
+    comm_ms = comm_ms[n_comm_before:n_comm_before + n_comm_timed] if comm_ms else []       # (the timed steps only: not the roofline steps behind them)
     rank_ms = [dt / args.steps * 1e3]
     if world > 1:
         mine = torch.tensor([dt, sum(comm_ms) / max(1, len(comm_ms))], dtype=torch.float64, device=dev)
@@ -488,7 +507,8 @@ def main():
                                  f'{args.batch} synthetic N={args.nodes} graphs per GPU' + (f' (ragged: num_nodes ~ U{{{max(1, args.nodes // 2)}..{args.nodes}}}, padded)' if args.ragged else '') +
                                  '; dropouts of tgt_at_tp.yaml on',
                         global_batch=args.batch * world, nodes=args.nodes,
-                        parallelism=f'dp{world}', precision=f'{args.precision} autocast, fp32 params/Adam',
+                        parallelism=f'dp{world}' + (' (REHEARSAL: all ranks share one GPU, gloo exchange; not a scaling figure)' if args.share_device else ''),
+                        precision=f'{args.precision} autocast, fp32 params/Adam',
                         **({'host_loss_read_every': args.sync_every} if args.sync_every else {})),
             # the exchange, so that a scaling curve explains itself: per-rank step time, and the milliseconds per step the step's
             # stream sat waiting for the last gradient buckets after the backward had ended (0 with one rank: nothing to exchange)
@@ -496,12 +516,22 @@ def main():
             comm_exposed_ms=round(max(rank_comm), 3), comm_exposed_ms_by_rank=[round(v, 3) for v in rank_comm],
             grad_exchange=dict(buckets=(len(trainer.buckets) if trainer.buckets else 0), bucket_mbytes=cfg.bucket_mbytes,
                                launch_order_last_step=trainer.bucket_order[:16], mode=cfg.grad_exchange,
-                               wire_dtype=cfg.grad_comm_dtype or 'fp32', rccl_stream='high priority' if world > 1 else None),
+                               wire_dtype=cfg.grad_comm_dtype or 'fp32',
+                               rccl_stream=('high priority' if (world > 1 and not args.share_device) else None)),
             final_loss=round(loss_val, 5),
             knobs_not_default=__import__('tgt_amd.knobs', fromlist=['K']).K.non_default(),      # {} = the default path
             host_affinity=host_affinity,
             step_ms=dict(min=round(step_ms[0], 3), median=round(step_ms[len(step_ms) // 2], 3), max=round(step_ms[-1], 3),
-                         note='GPU-side duration of each timed step (events on the step stream)'),
+                         note='GPU-side duration of each timed step (events on the step stream)',
+                         # every step slower than 1.2x the median, with what the host was doing: its enqueue time for that step and
+                         # whether the stream had run dry (the GPU finished the previous step before the host finished queueing this one)
+                         stragglers=[dict(step=i, gpu_ms=round(step_gpu[i], 2), host_enqueue_ms=round(host_ms[i], 2), stream_ran_dry=lead[i])
+                                     for i in range(args.steps) if step_gpu[i] > 1.2 * step_ms[len(step_ms) // 2]][:8],
+                         host_enqueue_ms=dict(median=round(sorted(host_ms)[len(host_ms) // 2], 2), max=round(max(host_ms), 2)),
+                         steps_stream_ran_dry=sum(lead)),
+            # conditions of the timed region a plain Trainer loop does not get by itself: stated, not hidden
+            timed_region_policy=dict(gc_frozen=True, allocator_settle='up to --settle-steps untimed steps until 8 in a row make no device allocation',
+                                     numa_bound=bool(host_affinity.get('bound')), per_kernel_events=True),
             roofline=roofline,
             # the caching allocator inside the timed region: device allocations / frees there are synchronous driver calls
             allocator_settle_steps=settled,
@@ -513,10 +543,8 @@ def main():
         )
         if world == 1 and not args.no_cpu_baseline:
             if host_mask is not None:
-                try:
-                    os.sched_setaffinity(0, host_mask)      # the oracle's step runs on all of the host's cores again
-                except OSError:
-                    pass
+                from tgt_amd.training.affinity import restore_affinity
+                restore_affinity(host_mask)                 # the oracle's step runs on all of the host's cores again (every thread)
             out['cpu_baseline'] = cpu_baseline(full=args.cpu_baseline_full)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -16,6 +16,12 @@ def pytest_configure(config):
 def pytest_collection_modifyitems(config, items):
     """GPU tests are skipped (not failed) when no GPU is visible and they were
     not explicitly selected away with -m 'not gpu'."""
+    # the RCCL-with-two-ranks tests first: on a box with >= 2 GPUs a broken multi-rank path fails within the first seconds of
+    # the run instead of after the 900 single-GPU tests (they skip at once on the 1-GPU boxes)
+    first = [it for it in items if 'over_rccl' in it.name]
+    if first:
+        rest = [it for it in items if 'over_rccl' not in it.name]
+        items[:] = first + rest
     try:
         import torch
         has_gpu = torch.cuda.is_available()
@@ -27,3 +33,15 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if 'gpu' in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _parity_log_scope():
+    import parity_log
+    parity_log.new_test()
+    yield
+
+
+def pytest_sessionfinish(session, exitstatus):
+    import parity_log
+    parity_log.dump()

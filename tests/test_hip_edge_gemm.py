@@ -9,16 +9,18 @@ import math
 import pytest
 import torch
 
+import parity_log
+
 from tgt_amd import _lib, ops
 
 pytestmark = pytest.mark.gpu
 
-TOL = {torch.bfloat16: 4e-3, torch.float16: 5e-4}
+TOL = parity_log.Tol({torch.bfloat16: 4e-3, torch.float16: 5e-4})
 
 
 def rel(a, b):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
-    return float((a - b).norm() / (b.norm() + 1e-30))
+    return parity_log.record(float((a - b).norm() / (b.norm() + 1e-30)))
 
 
 def _mk(M, K, N, dtype, seed, bias=True):

@@ -10,17 +10,18 @@ import pytest
 import torch
 
 import golden_util as gu
+import parity_log
 from oracle import core
 
 pytestmark = pytest.mark.gpu
 
-TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2, torch.float16: 5e-3}
+TOL = parity_log.Tol({torch.float32: 2e-5, torch.bfloat16: 2e-2, torch.float16: 5e-3})
 
 
 def rel(a, b):
     a, b = a.double().cpu(), b.double().cpu()
     a, b = a.detach(), b.detach()
-    return float((a - b).norm() / (b.norm() + 1e-30))
+    return parity_log.record(float((a - b).norm() / (b.norm() + 1e-30)))
 
 
 def rnd(rng, *shape, scale=1.0):

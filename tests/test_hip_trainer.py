@@ -433,6 +433,105 @@ def test_graphed_training_step_refuses_what_it_cannot_replay():
     assert not ops._GRAPH_SAFE[0]
 
 
+def test_graph_mode_is_given_back_when_capture_fails_or_the_owner_is_dropped(monkeypatch):
+    """GraphedTrainingStep / GraphedStepCache switch process-global state (graph-safe randomness, the device
+    seed counter) and Trainer state (device learning rate).  A capture that raises, or an owner that is garbage-collected without
+    close(), must hand all of it back -- a Trainer silently left in that mode repeats dropout patterns on a stale learning rate."""
+    import gc
+    import pytest
+    from tgt_amd import ops
+    from tgt_amd.pcqm import TGT_Multi
+    from tgt_amd.training.step import Trainer, StepConfig
+    from tgt_amd.training import graphed
+    cfg = StepConfig(num_dist_bins=512, mixed_precision='bf16', coords_noise=0.0, lr_warmup_steps=4, lr_total_steps=100)
+    kwargs = dict(gu.FULL_AT_CFG, model_height=2, node_act_dropout=0.1)
+    m = gu.fill_params(TGT_Multi(**kwargs), seed=3).cuda().train()
+    with Trainer(m, cfg) as tr:
+        calls = [0]
+        real = graphed.GraphedTrainingStep._body
+
+        def failing(self):
+            calls[0] += 1
+            if calls[0] == 2:                         # the warm-up step passes, the capture raises
+                raise RuntimeError('boom inside the capture')
+            return real(self)
+        monkeypatch.setattr(graphed.GraphedTrainingStep, '_body', failing)
+        with pytest.raises(RuntimeError, match='boom'):
+            graphed.GraphedTrainingStep(tr, _batch(cfg, 0), warmup=1)
+        assert not ops._GRAPH_SAFE[0] and ops._seed_counter[0] is None and not tr.device_lr
+        monkeypatch.setattr(graphed.GraphedTrainingStep, '_body', real)
+        torch.cuda.synchronize()
+        tr.training_step(_batch(cfg, 1))              # the eager trainer goes on
+        gs = graphed.GraphedTrainingStep(tr, _batch(cfg, 0), warmup=1)
+        assert ops._GRAPH_SAFE[0] and tr.device_lr
+        del gs                                        # dropped without close()
+        gc.collect()
+        assert not ops._GRAPH_SAFE[0] and ops._seed_counter[0] is None and not tr.device_lr
+        cache = graphed.GraphedStepCache(tr, warmup=1, max_graphs=1)
+        assert ops._GRAPH_SAFE[0]
+        del cache
+        gc.collect()
+        assert not ops._GRAPH_SAFE[0] and not tr.device_lr
+
+
+def test_eager_step_on_a_graph_owned_trainer_advances_rate_and_counter():
+    """ADVICE r4 (medium), second half: Trainer.training_step called directly while a graph owns the trainer (the odd-shaped
+    last batch the one-graph-per-shape owner refuses) does what a replay does around the body -- refreshes the device learning
+    rate and bumps the dropout counter -- and equals eager_graph_safe_step bit for bit."""
+    from tgt_amd import ops
+    from tgt_amd.pcqm import TGT_Multi
+    from tgt_amd.training.step import Trainer, StepConfig, lr_at
+    from tgt_amd.training.graphed import GraphedTrainingStep, eager_graph_safe_step
+    kwargs = dict(gu.FULL_AT_CFG, model_height=2, source_dropout=0.3, drop_path=0.2, node_act_dropout=0.1, edge_act_dropout=0.1)
+    cfg = StepConfig(num_dist_bins=512, mixed_precision='bf16', coords_noise=0.0, lr_warmup_steps=4, lr_total_steps=100)
+    runs = []
+    for direct in (True, False):
+        torch.manual_seed(79)
+        ops.reset_random_pools()
+        m = gu.fill_params(TGT_Multi(**kwargs), seed=3).cuda().train()
+        with Trainer(m, cfg) as tr:
+            with GraphedTrainingStep(tr, _batch(cfg, 0), warmup=1) as gs:
+                gs.step(_batch(cfg, 1))
+                c0 = int(gs.counter)
+                if direct:
+                    tr.training_step(_batch(cfg, 2))
+                else:
+                    eager_graph_safe_step(tr, gs.counter, _batch(cfg, 2))
+                assert int(gs.counter) == c0 + 1
+                assert abs(float(tr.ctl[ops.CTL_LR]) - lr_at(tr.global_step, cfg)) < 1e-12 + 1e-6 * lr_at(tr.global_step, cfg)
+                gs.step(_batch(cfg, 3))
+            torch.cuda.synchronize()
+            runs.append(tr.flat.param.clone())
+    assert torch.equal(runs[0], runs[1])
+
+
+def test_graphed_step_cache_stops_capturing_when_it_thrashes():
+    """more live batch shapes than max_graphs would evict and re-capture on every step; the cache notices that
+    captures outnumber replays, warns once and runs the remaining steps eagerly in graph-safe mode (same arithmetic).  A
+    Python-valued batch entry is part of the key."""
+    import pytest
+    from tgt_amd import ops
+    from tgt_amd.pcqm import TGT_Multi
+    from tgt_amd.training.step import Trainer, StepConfig, preprocess_batch
+    from tgt_amd.training.synthetic import make_batch
+    from tgt_amd.training.graphed import GraphedStepCache
+    kwargs = dict(gu.FULL_AT_CFG, model_height=1, node_act_dropout=0.1)
+    cfg = StepConfig(num_dist_bins=512, mixed_precision='bf16', coords_noise=0.0, lr_warmup_steps=4, lr_total_steps=100)
+    shapes = [(2, 5), (2, 6), (2, 7)]
+    m = gu.fill_params(TGT_Multi(**kwargs), seed=3).cuda().train()
+    with Trainer(m, cfg) as tr:
+        with GraphedStepCache(tr, warmup=1, max_graphs=1) as cache:
+            assert cache._key({'a': torch.zeros(2), 'flag': 1}) != cache._key({'a': torch.zeros(2), 'flag': 2})
+            cache.thrash_window = 6
+            with pytest.warns(RuntimeWarning, match='falling back to eager'):
+                for i in range(24):
+                    b = preprocess_batch(make_batch(*shapes[i % 3], seed=60 + i, ragged=True), 'cuda', cfg, add_noise=False)
+                    cache.step(b)
+            assert cache.eager_fallback and not cache.graphs and cache.captures <= 8
+            assert int(cache.counter) == 24              # every step() was exactly one optimizer step
+    assert not ops._GRAPH_SAFE[0]
+
+
 def test_graphed_step_cache_one_graph_per_shape():
     """GraphedStepCache: batches of two shapes, interleaved; every step() is exactly one optimizer step (the first `warmup` of a
     shape eagerly in graph-safe mode, then a captured replay), one dropout counter for all graphs, least recently used evicted:

@@ -159,3 +159,57 @@ def test_graph_safe_host_seeds_are_a_function_of_the_call_position():
     c = ops.draw_dropout(0.1, True)[1]
     torch.manual_seed(5)
     assert ops.draw_dropout(0.1, True)[1] == c and c not in a
+
+
+def test_flat_gradient_destination_refuses_a_second_gradient_for_one_parameter():
+    """inside one Trainer backward a parameter's slice of the flat gradient buffer is handed out ONCE; a graph
+    that starts re-using a parameter after the first step (which is the only one the Trainer walks) is an error, not a silent
+    double write"""
+    import pytest
+    import torch
+    from tgt_amd import ops
+    v = torch.zeros(4, 3)
+    ops.register_flat_grads([v], [v])
+    try:
+        assert ops._grad_dst(v.data_ptr(), (4, 3), torch.float32) is None          # outside a Trainer backward: ordinary tensors
+        with ops.trainer_backward():
+            a = ops._grad_dst(v.data_ptr(), (4, 3), torch.float32)
+            assert a is not None and a.data_ptr() == v.data_ptr()
+            with pytest.raises(RuntimeError, match='second weight gradient'):
+                ops._grad_dst(v.data_ptr(), (4, 3), torch.float32)
+        with ops.trainer_backward():                                                # the next backward starts clean
+            assert ops._grad_dst(v.data_ptr(), (4, 3), torch.float32) is not None
+    finally:
+        ops.unregister_flat_grads([v.data_ptr()])
+
+
+def test_affinity_binds_every_thread_of_the_process():
+    """sched_setaffinity(0, ..) binds the calling thread only; torch's thread pools exist before bench.py binds"""
+    import os
+    import threading
+    import pytest
+    from tgt_amd.training import affinity
+    if not hasattr(os, 'sched_setaffinity'):
+        pytest.skip('no sched_setaffinity')
+    before = os.sched_getaffinity(0)
+    if len(before) < 2:
+        pytest.skip('one CPU')
+    stop = threading.Event()
+    seen = {}
+
+    def worker():
+        stop.wait()
+        seen['mask'] = os.sched_getaffinity(0)
+    t = threading.Thread(target=worker)
+    t.start()
+    target = set(sorted(before)[:1])
+    try:
+        done, total = affinity._bind_all_threads(target)
+        assert done >= 2 and total >= 2
+        stop.set()
+        t.join()
+        assert seen['mask'] == target and os.sched_getaffinity(0) == target
+    finally:
+        stop.set()
+        affinity.restore_affinity(before)
+    assert os.sched_getaffinity(0) == before

@@ -38,6 +38,7 @@ _SPEC = {
     'node_chain': ('TGT_NODE_CHAIN', True, 'flag', "the next layer's node projections chained on the side stream"),
     'flat_grad_dst': ('TGT_FLAT_GRAD_DST', True, 'flag', 'weight gradients written into the flat gradient buffer inside a Trainer backward'),
     'defer_edge': ('TGT_DEFER_EDGE', True, 'flag', 'closing edge residual performed by the next layer entry'),
+    'gate_node_bwd': ('TGT_GATE_NODE_BWD', 0, 'int', "the node side stream's backward chain of a layer waits for that layer's triplet backward kernel (1) / for the projection's data-gradient GEMM behind it (2)"),
 }
 ENV_OF_LIBRARY = ('TGT_TRI_BWD2', 'TGT_TRI_BWD2_DMA', 'TGT_HIP_LIB', 'TGT_NODE_MFMA', 'TGT_TUNING_FILE')
 
@@ -79,6 +80,7 @@ class Knobs:
     node_chain: bool
     flat_grad_dst: bool
     defer_edge: bool
+    gate_node_bwd: int
 
     @classmethod
     def from_env(cls):

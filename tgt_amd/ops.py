@@ -192,6 +192,12 @@ def set_seed_counter(counter):
     _lib.check(_lib.lib().tgt_set_seed_counter(_ptr(counter)), 'tgt_set_seed_counter')
 
 
+def bump_seed_counter():
+    """counter += 1 on the registered device counter (what a captured step does first); a no-op without one"""
+    if _seed_counter[0] is not None:
+        _seed_counter[0].add_(1)
+
+
 def _host_seed():
     """a 64-bit dropout seed: from torch's CPU generator (no device sync; torch.manual_seed makes it reproducible), or -- graph-safe
     mode -- the position of this call inside the step, spread over 64 bits"""
@@ -462,6 +468,32 @@ def _proj_fused_ok(x, N, L, cd):
             cd in (torch.bfloat16, torch.float16) and L.C == 256 and x.numel() // L.C >= _SPLIT_MIN_ROWS)
 
 
+# A/B knob (round 5): keep the node side stream's backward chain of a layer off the HBM-bound triplet backward
+# kernel of that layer.  The host enqueues a layer's node-FFN backward AFTER the layer's triplet backward (lower sequence numbers),
+# but on the GPU the chain starts as soon as dh arrives from the layer above -- i.e. under the edge FFN's backward and, with its
+# tail, under tri_att_bwd2 (0.40 ms alone, 0.45-0.47 inside the step).  Gated, the side stream waits for an event recorded behind
+# the triplet backward kernel (1) or behind the projection's data-gradient GEMM that follows it (2), so the chain runs under the
+# projection's GEMMs instead.  Consumed by the first Linear backward that runs on the side stream afterwards.
+_GATE_NODE_BWD = K.gate_node_bwd
+_tri_gate = {}                    # device index -> event recorded on the step's stream behind the latest triplet backward
+
+
+def _gate_record(dev):
+    if _GATE_NODE_BWD and side_stream.enabled and side_stream._owners > 0 and _trainer_backward[0] > 0:
+        ev = torch.cuda.Event()
+        ev.record()
+        _tri_gate[dev.index] = ev
+
+
+def _gate_wait(t):
+    if _tri_gate and t.is_cuda:
+        side = _side_streams.get(t.device)
+        if side is not None and torch._C._cuda_getCurrentRawStream(t.device.index) == side.cuda_stream:
+            ev = _tri_gate.pop(t.device.index, None)
+            if ev is not None:
+                side.wait_event(ev)
+
+
 class _ProjectedTripletAttention(torch.autograd.Function):
     """fused projection GEMM + triplet attention core as ONE autograd node, so that the backward
     kernel can hand the projection its bias gradient (column sums of d_fused, accumulated while
@@ -541,6 +573,8 @@ class _ProjectedTripletAttention(torch.autograd.Function):
         colsum = _colsum_workspace(fused.shape[0], L.width, L.used, fused.device)
         a = _tri_args(fused, mask3, out, L, d_out, d_fused, colsum, dropout=ctx.dropout, eg=eg, graph_scale=ctx.graph_scale)
         _call('tgt_triplet_attention_bwd', _lib.lib().tgt_triplet_attention_bwd, a)
+        if _GATE_NODE_BWD == 1:
+            _gate_record(d_fused.device)
         need_p = any(ctx.needs_input_grad[7:])
         d2 = d_fused.view(-1, L.width)
         if eg is not None and need_p:
@@ -555,6 +589,8 @@ class _ProjectedTripletAttention(torch.autograd.Function):
             # 1600-row product (tools/wgrad_chunk_probe.py); dx stays one GEMM over the fused row
             ws = _wgrad_fork(d2, x2, db)
             dx, _, _ = _linear_backward(x2, w, d2, xs, xdt, torch.float32, None, ctx.needs_input_grad[0], False, False)
+            if _GATE_NODE_BWD == 2:
+                _gate_record(d_fused.device)
             with _on_stream(ws):
                 dw = torch.empty(L.width, L.C, dtype=torch.float32, device=d2.device)
                 _wgrad_into(dw[:6 * L.C], d2[:, :6 * L.C], x2, 32)
@@ -1334,6 +1370,7 @@ _trainer_backward = [0]           # > 0 while a Trainer runs its backward: the o
 # torch.autograd.grad) gets ordinary tensors, and a Trainer whose parameters enter the graph more than once never opens the
 # context (step.py: _parameter_reused) -- autograd would add into the slice a second time.
 _FLAT_GRAD = {}                   # parameter data_ptr -> (float32 view of the flat gradient buffer shaped like the parameter)
+_grad_dst_seen = set()            # parameter data_ptrs handed a destination during the current Trainer backward (see _grad_dst)
 _FLAT_GRAD_ON = K.flat_grad_dst
 
 
@@ -1355,6 +1392,14 @@ def _grad_dst(ptr, shape, dtype):
     v = _FLAT_GRAD.get(ptr)
     if v is None or v.dtype != dtype or tuple(v.shape) != tuple(shape):
         return None
+    # One gradient per parameter and backward: the Trainer checked the graph of its FIRST step for parameters that enter it twice
+    # (step.py: _parameter_reused); a graph that changes later (a module applied twice in some steps, weights tied after step 1)
+    # would have two kernels write this slice and autograd sum two aliases of it -- silently wrong.  Caught here, every step.
+    if ptr in _grad_dst_seen:
+        raise RuntimeError('tgt_amd: a parameter received a second weight gradient inside one Trainer backward (it enters the '
+                           'autograd graph more than once: weight sharing that the first step did not show).  Construct the '
+                           'Trainer after tying the weights, or set TGT_FLAT_GRAD_DST=0')
+    _grad_dst_seen.add(ptr)
     return v.detach()
 
 
@@ -1365,6 +1410,8 @@ class trainer_backward:
     test, another optimizer) gets every gradient on the current stream."""
 
     def __enter__(self):
+        if _trainer_backward[0] == 0:
+            _grad_dst_seen.clear()
         _trainer_backward[0] += 1
 
     def __exit__(self, *exc):
@@ -1535,6 +1582,7 @@ def _linear_backward(x2, w, dy2, xs, xdt, wdt, bdt, need_dx, need_dw, need_db, l
     if dy2.dtype != w.dtype:
         dy2 = dy2.to(w.dtype)
     dx = dw = db = None
+    _gate_wait(dy2)
     # dw_post: what the caller still does to dW (it must run where dW was computed); fork=False: the caller reads dW itself
     ws = _wgrad_fork(dy2, x2) if (need_dw and fork) else None  # (forked BEFORE the data gradient is queued: it waits for dy only)
     if need_dx:

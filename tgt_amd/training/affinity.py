@@ -32,9 +32,38 @@ def gpu_numa_node(device_index):
     return node if node >= 0 else None
 
 
+def _bind_all_threads(cpus):
+    """sched_setaffinity on EVERY thread of this process.  On Linux the call binds one thread (pid 0 = the caller); threads that
+    already exist -- torch's intra-op / OpenMP pools are created at import -- keep their old mask, threads started later inherit
+    the caller's.  Returns (threads bound, threads seen)."""
+    try:
+        tids = [int(t) for t in os.listdir('/proc/self/task')]
+    except OSError:
+        tids = []
+    done = 0
+    for tid in tids:
+        try:
+            os.sched_setaffinity(tid, cpus)
+            done += 1
+        except OSError:
+            pass                      # (a thread that exited meanwhile)
+    os.sched_setaffinity(0, cpus)     # the caller last: what new threads inherit
+    return done, len(tids)
+
+
+def restore_affinity(cpus):
+    """give every thread of the process the mask `cpus` back (bench.py: the CPU baseline runs on the whole host)"""
+    if hasattr(os, 'sched_setaffinity') and cpus:
+        try:
+            _bind_all_threads(cpus)
+        except OSError:
+            pass
+
+
 def bind_to_gpu_numa(device_index, enabled=True):
-    """Restrict this process (and the threads it starts from now on) to the CPUs of the GPU's NUMA node.
-    Returns a small report for the benchmark line: {'numa_node', 'cpus', 'bound'} or {'bound': False, 'why': ...}."""
+    """Restrict EVERY existing thread of this process (and, by inheritance, the ones it starts from now on) to the CPUs of the
+    GPU's NUMA node.  Returns a small report for the benchmark line: {'numa_node', 'cpus', 'threads', 'bound'} or
+    {'bound': False, 'why': ...}."""
     if not enabled:
         return {'bound': False, 'why': 'disabled'}
     if not hasattr(os, 'sched_setaffinity'):
@@ -54,7 +83,7 @@ def bind_to_gpu_numa(device_index, enabled=True):
     if target == allowed:
         return {'bound': True, 'numa_node': node, 'cpus': len(target), 'note': 'mask already inside the node'}
     try:
-        os.sched_setaffinity(0, target)
+        done, seen = _bind_all_threads(target)
     except OSError as e:
         return {'bound': False, 'why': f'sched_setaffinity: {e}'}
-    return {'bound': True, 'numa_node': node, 'cpus': len(target)}
+    return {'bound': True, 'numa_node': node, 'cpus': len(target), 'threads': f'{done}/{seen}'}

@@ -17,10 +17,24 @@ Single rank by default; `allow_distributed=True` captures the bucketed RCCL all-
 time, the collectives become graph nodes): exercised with the nccl backend at world size 1 only.  Same kernels, same arguments: in graph-safe mode an eager step
 and a replay give bit-identical parameters (tests/test_hip_trainer.py::test_graphed_training_step_equals_eager).
 """
+import warnings
+import weakref
+
 import torch
 
 from .. import ops
 from .step import Trainer
+
+
+def _leave_graph_mode(trainer_ref):
+    """back to eager: host seeds, pooled DropPath draws, the learning rate as a kernel argument.  Shared by close(), by the
+    failure path of a capture and by the finalizer of an owner that was dropped without close() -- a Trainer left in graph-safe /
+    device-lr mode by accident would silently repeat dropout patterns and keep a stale learning rate."""
+    ops.set_seed_counter(None)
+    ops.graph_safe_rng(False)
+    tr = trainer_ref() if isinstance(trainer_ref, weakref.ReferenceType) else trainer_ref
+    if tr is not None:
+        tr.device_lr = False
 
 
 def _attention_dropout(model):
@@ -62,22 +76,33 @@ class GraphedTrainingStep:
         # then be 0 -- the trainer has already run eager steps of this shape in graph-safe mode
         self._owns_mode = counter is None
         self.counter = torch.zeros(1, dtype=torch.int64, device=dev) if counter is None else counter
+        self._closed = False
+        self._finalizer = None
         if self._owns_mode:
             ops.graph_safe_rng(True)
             ops.set_seed_counter(self.counter)
             trainer.set_device_lr(True)
             warmup = max(1, warmup)
-        self._closed = False
-        self.stream = torch.cuda.Stream(dev)
-        self.stream.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(self.stream):
-            for _ in range(warmup):
-                self._eager()
-        torch.cuda.current_stream(dev).wait_stream(self.stream)
-        torch.cuda.synchronize(dev)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=self.stream):
-            self.out = self._body()
+            # an owner dropped without close() must not leave the process in graph-safe mode
+            self._finalizer = weakref.finalize(self, _leave_graph_mode, weakref.ref(trainer))
+        try:
+            self.stream = torch.cuda.Stream(dev)
+            self.stream.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(self.stream):
+                for _ in range(warmup):
+                    self._eager()
+            torch.cuda.current_stream(dev).wait_stream(self.stream)
+            torch.cuda.synchronize(dev)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=self.stream):
+                self.out = self._body()
+        except BaseException:
+            # warm-up or capture failed: give the mode back before the error travels on (the Trainer stays usable eagerly)
+            self._closed = True
+            self.graph = self.static = self.out = None
+            if self._finalizer is not None:
+                self._finalizer()
+            raise
         self.replays = 0
 
     # what the graph holds: the counter bump and the trainer's own step on the static batch
@@ -117,10 +142,8 @@ class GraphedTrainingStep:
         """back to eager: host seeds, pooled DropPath draws, the learning rate as an argument"""
         if not self._closed:
             self._closed = True
-            if self._owns_mode:
-                ops.set_seed_counter(None)
-                ops.graph_safe_rng(False)
-                self.trainer.device_lr = False
+            if self._finalizer is not None:
+                self._finalizer()            # runs _leave_graph_mode once; a later garbage collection does nothing
             self.graph = None
             self.static = self.out = None
 
@@ -165,23 +188,60 @@ class GraphedStepCache:
         ops.graph_safe_rng(True)
         ops.set_seed_counter(self.counter)
         trainer.set_device_lr(True)
+        self._finalizer = weakref.finalize(self, _leave_graph_mode, weakref.ref(trainer))
         self.graphs, self.seen = {}, {}            # shape key -> GraphedTrainingStep (insertion order = recency) / eager steps so far
-        self.captures = self.evictions = 0
+        self.captures = self.evictions = self.replays = self.eager_steps = 0
+        self.thrash_window = 8 * self.max_graphs   # steps over which captures are compared with replays
+        self._recent = []                          # 1 = this step captured a graph, 0 = it replayed one
+        self.eager_fallback = False                # set once captures dominate: every later step runs eagerly (graph-safe mode)
         self._closed = False
 
     @staticmethod
     def _key(batch):
-        return tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(batch.items()) if torch.is_tensor(v))
+        """tensors by shape / dtype, anything else by VALUE: a captured graph bakes a Python-valued batch entry into its launch
+        arguments, so a changed value must select (or capture) another graph, never replay a stale one"""
+        key = []
+        for k, v in sorted(batch.items()):
+            if torch.is_tensor(v):
+                key.append((k, tuple(v.shape), str(v.dtype)))
+            else:
+                try:
+                    hash(v)
+                    key.append((k, 'py', v))
+                except TypeError:
+                    key.append((k, 'py', repr(v)))
+        return tuple(key)
 
     def step(self, batch):
         if self._closed:
             raise RuntimeError('GraphedStepCache is closed')
+        if self.eager_fallback:
+            self.eager_steps += 1
+            return eager_graph_safe_step(self.trainer, self.counter, batch, self.update_losses)
         key = self._key(batch)
         gs = self.graphs.pop(key, None)
         if gs is None:
             n = self.seen.get(key, 0)
             if n < self.warmup:
+                if len(self.seen) >= 64 * self.max_graphs and key not in self.seen:
+                    self.seen.pop(next(iter(self.seen)))          # (bounded: the oldest shape starts its warm-up over)
                 self.seen[key] = n + 1
+                self.eager_steps += 1
+                return eager_graph_safe_step(self.trainer, self.counter, batch, self.update_losses)
+            # Thrash guard: with more live shapes than max_graphs every step evicts a graph and captures another one -- a capture
+            # costs a multiple of an eager step and a private activation pool.  When captures outnumber replays over the last
+            # `thrash_window` graph steps, stop capturing: eager steps in graph-safe mode compute exactly what a replay would.
+            self._recent.append(1)
+            del self._recent[:-self.thrash_window]
+            if len(self._recent) >= self.thrash_window and 2 * sum(self._recent) > len(self._recent):
+                warnings.warn(f'GraphedStepCache: {sum(self._recent)} captures in the last {len(self._recent)} graph steps with '
+                              f'max_graphs={self.max_graphs}: more live batch shapes than graphs -- falling back to eager steps '
+                              '(bucket the padding or raise max_graphs)', RuntimeWarning, stacklevel=2)
+                self.eager_fallback = True
+                for g_ in self.graphs.values():
+                    g_.close()
+                self.graphs.clear()
+                self.eager_steps += 1
                 return eager_graph_safe_step(self.trainer, self.counter, batch, self.update_losses)
             while len(self.graphs) >= self.max_graphs:
                 old_key = next(iter(self.graphs))
@@ -190,7 +250,11 @@ class GraphedStepCache:
             gs = GraphedTrainingStep(self.trainer, batch, warmup=0, update_losses=self.update_losses,
                                      allow_distributed=self.allow_distributed, counter=self.counter)
             self.captures += 1
+        else:
+            self._recent.append(0)
+            del self._recent[:-self.thrash_window]
         self.graphs[key] = gs                      # most recently used last
+        self.replays += 1
         return gs.step(batch)
 
     def close(self):
@@ -199,9 +263,7 @@ class GraphedStepCache:
             for gs in self.graphs.values():
                 gs.close()
             self.graphs.clear()
-            ops.set_seed_counter(None)
-            ops.graph_safe_rng(False)
-            self.trainer.device_lr = False
+            self._finalizer()
 
     def __enter__(self):
         return self

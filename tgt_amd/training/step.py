@@ -407,7 +407,9 @@ class Trainer:
         # What of the exchange is NOT hidden behind the backward: the time the step's stream spends blocked on the collectives'
         # completion (an event before and after the waits; nothing else is queued in between).  Read later, off the step's path
         # (comm_exposed_ms): no host synchronisation here.
-        timed = self.flat.param.is_cuda and len(self._comm_events) < 4096
+        # (not under a hipGraph capture: an event recorded while capturing cannot be passed to elapsed_time, and replays would
+        #  add no pairs -- a captured step reports no exposed-communication time)
+        timed = self.flat.param.is_cuda and len(self._comm_events) < 4096 and not torch.cuda.is_current_stream_capturing()
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -522,6 +524,12 @@ class Trainer:
         """batch: device tensors incl. edge_mask / dist_input (see preprocess_batch).
         Returns (outputs, loss) like the reference's training_step (training.py:439-470)."""
         self.global_step += 1
+        if self.device_lr:
+            # graph-safe mode (training/graphed.py owns this trainer) and somebody steps it EAGERLY -- e.g. the odd-shaped last
+            # batch of an epoch that the one-graph-per-shape owner refused: do what a replay does around the captured body, so
+            # that the step neither runs on a stale learning rate nor repeats the previous step's dropout patterns
+            self.write_device_lr()
+            ops.bump_seed_counter()
         outputs, loss = self.compute_gradients(batch)
         self.apply_gradients()
         return outputs, loss
