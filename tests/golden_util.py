@@ -191,6 +191,30 @@ FULL_AGX2_GEOM = dict(B=8, N=32, num_nodes=[32, 29, 27, 24, 21, 18, 14, 9])
 FULL_AT_N32_GEOM = dict(B=2, N=32, num_nodes=[32, 27])
 # ... and of BASELINE config 4: N up to 48 (the 16-wide triplet kernels, the lane-per-head node attention)
 FULL_AT_N48_GEOM = dict(B=2, N=48, num_nodes=[48, 39])
+# BASELINE config 4 as a mini-batch: 8 ragged graphs, N <= 48, Gaussian 3-D embedding of (RDKit-like) coordinates
+FULL_AT_N48_B8_GEOM = dict(B=8, N=48, num_nodes=[48, 45, 41, 37, 33, 30, 24, 17])
+# BASELINE config 5, second stage: the TGT-Agx2 12 x 2 GAP predictor at full width (reference configs/pcqm/tgt_agx2_100m/gap_pred/
+# tgt_agx2_tp_nordkit.yaml; lib/models/pcqm/gap_predictor.py:10-63), fed with distances that went through the bins format
+# (bins2dist of 256-bin indices, lib/training_schemes/pcqm/gap_pred/scheme.py:70-73), 8 ragged graphs
+FULL_GAP_AGX2_CFG = dict(model_height=12, layer_multiplier=2, upto_hop=32, embed_3d_type='gaussian',
+                         num_3d_kernels=128, node_width=768, edge_width=256,
+                         num_heads=64, activation='gelu', scale_degree=True, triplet_heads=16,
+                         triplet_type='aggregate', triplet_dropout=0, node_ffn_multiplier=1.,
+                         edge_ffn_multiplier=1., source_dropout=0, drop_path=0,
+                         node_act_dropout=0, edge_act_dropout=0)
+
+
+def binned_dist_input(batch, num_bins=256, range_bins=8.0):
+    """the gap stage's distance input as the reference builds it: distances -> bin indices (commons.discrete_dist, float32
+    arithmetic) -> upper triangle kept (bin_ops packs triu only) -> bins2dist with shift_half and zero_diag
+    (commons.BinsProcessor.bins2dist: (bins + 0.5) * bin_size, symmetrised, zero diagonal)"""
+    d = batch['dist_input'].float()
+    bins = (d * ((num_bins - 1) / range_bins)).long().clamp(0, num_bins - 1)
+    bins = torch.triu(bins, 1).float()
+    bin_size = range_bins / (num_bins - 1)
+    dist = (bins + 0.5) * bin_size                   # (every element, the empty lower triangle included: commons.py:72-82)
+    dist = dist + dist.transpose(-2, -1)
+    return dist * (1 - torch.eye(dist.size(-1), dtype=dist.dtype))
 
 
 def model_batch(geom, seed):

@@ -187,7 +187,7 @@ def test_full_width_agx2_12x2_forward_vs_reference_golden():
         assert ok, (name, info)
 
 
-@pytest.mark.parametrize('which', ['n32', 'n48'])
+@pytest.mark.parametrize('which', ['n32', 'n48', 'n48_b8'])
 def test_full_width_24L_n32_vs_reference_golden(which):
     """TGT-At 24L at BASELINE widths AND the benchmarks' node counts (B = 2, one ragged graph; N = 32: the kernels the bench
     line runs -- projection-fused triplet forward, the round-4 backward, the fused edge Linears; N = 48 = BASELINE config 4: the
@@ -196,7 +196,9 @@ def test_full_width_24L_n32_vs_reference_golden(which):
     from tgt_amd.pcqm import TGT_Multi
     from tgt_amd.training.step import pretrain_loss, StepConfig
     name, geom, seeds = {'n32': ('model_full_at_24L_n32_fp32.npz', gu.FULL_AT_N32_GEOM, (930, 931)),
-                         'n48': ('model_full_at_24L_n48_fp32.npz', gu.FULL_AT_N48_GEOM, (940, 941))}[which]
+                         'n48': ('model_full_at_24L_n48_fp32.npz', gu.FULL_AT_N48_GEOM, (940, 941)),
+                         # BASELINE config 4 as a mini-batch: 8 ragged graphs (17..48 nodes), Gaussian 3-D embedding
+                         'n48_b8': ('model_full_at_24L_n48_b8_fp32.npz', gu.FULL_AT_N48_B8_GEOM, (960, 961))}[which]
     z = np.load(os.path.join(gu.GOLDEN_DIR, name))
     batch = {k: v.cuda() for k, v in gu.model_batch(geom, seed=seeds[1]).items()}
     model = gu.fill_params(TGT_Multi(**gu.FULL_AT_CFG), seed=seeds[0]).cuda().eval()
@@ -229,6 +231,40 @@ def test_full_width_24L_n32_vs_reference_golden(which):
             ok, info = _sampled_ok(pm[k].grad, z, 'pgrad.' + k, tol)
             assert ok, (mode, info, tol)
         del model
+
+
+def test_full_width_gap_agx2_12x2_vs_reference_golden():
+    """BASELINE config 5, second stage, at full width: the TGT-Agx2 12 shared layers x 2 GAP predictor (aggregate triplets,
+    Gaussian 3-D embedding) on 8 ragged graphs whose distance input went through the bins format (tgt_bins_to_dist on the device,
+    bit-equal to the reference's BinsProcessor.bins2dist), eval forward against the REFERENCE's fp32 CPU forward
+    (lib/models/pcqm/gap_predictor.py:48-63): fp32, and fp16 / bf16 autocast (`mixed_precision: true` of the gap_pred YAMLs) within
+    a stated multiple of the reference's OWN autocast drift on this very batch (stored with the golden)."""
+    from tgt_amd import ops
+    from tgt_amd.pcqm import TGT_Gap, predict
+    z = np.load(os.path.join(gu.GOLDEN_DIR, 'model_full_gap_agx2_12x2_fp32.npz'))
+    cpu = gu.model_batch(gu.FULL_AGX2_GEOM, seed=951)
+    batch = {k: v.cuda() for k, v in cpu.items()}
+    bins = torch.triu((batch['dist_input'].float() * (255 / 8)).long().clamp(0, 255), 1)
+    ref_dist = torch.from_numpy(z['dist_input::full'])
+    assert torch.equal(predict.bins2dist(bins, 8 / 255).cpu(), ref_dist)              # the device-side bins2dist (tgt_bins_to_dist), bit for bit
+    batch['dist_input'] = ref_dist.cuda()
+    model = gu.fill_params(TGT_Gap(**gu.FULL_GAP_AGX2_CFG), seed=950).cuda().eval()
+    ref = z['gap::full']
+    with torch.no_grad():
+        gap = model(batch)
+        with torch.autocast('cuda', dtype=torch.float16):
+            gap16 = model(batch)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            gapbf = model(batch)
+    e32 = np.abs(gap.double().cpu().numpy() - ref).max()
+    e16 = np.abs(gap16.double().cpu().numpy() - ref).max()
+    ebf = np.abs(gapbf.double().cpu().numpy() - ref).max()
+    d16, dbf = float(z['fp16_drift::full']), float(z['bf16_drift::full'])
+    print(f'gap agx2 12x2: fp32 {e32:.2e}; fp16 {e16:.2e} (reference drift {d16:.2e}); bf16 {ebf:.2e} (reference drift {dbf:.2e})')
+    assert e32 < 2e-4, e32
+    assert torch.isfinite(gap16).all() and torch.isfinite(gapbf).all()
+    assert e16 < 4 * d16, (e16, d16)
+    assert ebf < 2 * dbf, (ebf, dbf)
 
 
 def test_state_dict_roundtrip_with_oracle():

@@ -1,9 +1,11 @@
 """Parity of the HIP kernels (through the C ABI) against the oracle, on the GPU.
 
-fp32 kernels: <= 2e-5 rel-L2 vs the float64 oracle (exact-f32 matrix core +
-fast exp/rcp).  bf16/fp16 kernels: <= 2e-2 / 5e-3 (the reference's own
-bf16-autocast drift on one TripletAttention is 4.5e-3); gradients
-2x the forward tolerance.
+Stated tolerances (rel-L2 against the float64 oracle), set from MEASURED errors: profiles/parity_errors.json holds the largest
+error of every comparison this file makes (TGT_PARITY_LOG=<file> pytest ..., tests/parity_log.py) -- fp32 7.9e-7, bf16 4.2e-3,
+fp16 5.3e-4 over all cases, gradients included -- and the bar is the smaller of SURVEY 8c's proposal (fp32 1e-5, bf16 1e-2) and
+2x that measured maximum: fp32 kernels <= 2e-6 (exact-f32 matrix core + fast exp / rcp), bf16 <= 8e-3 (the reference's own
+bf16-autocast drift on one TripletAttention is 4.5e-3), fp16 <= 1e-3; gradients 2x the forward tolerance.
+(Rounds 1-4 ran with 2e-5 / 2e-2 / 5e-3: 2-25x looser than what the kernels deliver.)
 """
 import numpy as np
 import pytest
@@ -15,7 +17,9 @@ from oracle import core
 
 pytestmark = pytest.mark.gpu
 
-TOL = parity_log.Tol({torch.float32: 2e-5, torch.bfloat16: 2e-2, torch.float16: 5e-3})
+TOL = parity_log.Tol({torch.float32: 2e-6, torch.bfloat16: 8e-3, torch.float16: 1e-3})
+# gradient of the cross entropy w.r.t. logits STORED in dtype: the storage rounding of the result dominates (measured 1.9e-3 in bf16)
+XENT_GRAD_TOL = parity_log.Tol({torch.float32: 2e-6, torch.bfloat16: 3e-3, torch.float16: 5e-4})
 
 
 def rel(a, b):
@@ -1067,7 +1071,8 @@ def test_cross_entropy_rows(shape, dtype):
     loss.backward()
     assert rel(xent, xent_ref) < 2e-6
     assert abs(float(loss) - float(loss_ref)) < 2e-6 * abs(float(loss_ref))
-    assert x.grad.dtype == dtype and rel(x.grad, ref_in.grad) < TOL[dtype] / 4
+    tol_g = XENT_GRAD_TOL[dtype]
+    assert x.grad.dtype == dtype and rel(x.grad, ref_in.grad) < tol_g
     assert (x.grad[m == 0] == 0).all()            # masked pairs: exact zeros
 
 

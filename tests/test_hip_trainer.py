@@ -515,7 +515,7 @@ def test_graphed_step_cache_stops_capturing_when_it_thrashes():
     from tgt_amd.training.step import Trainer, StepConfig, preprocess_batch
     from tgt_amd.training.synthetic import make_batch
     from tgt_amd.training.graphed import GraphedStepCache
-    kwargs = dict(gu.FULL_AT_CFG, model_height=1, node_act_dropout=0.1)
+    kwargs = dict(gu.FULL_AT_CFG, model_height=2, node_act_dropout=0.1)
     cfg = StepConfig(num_dist_bins=512, mixed_precision='bf16', coords_noise=0.0, lr_warmup_steps=4, lr_total_steps=100)
     shapes = [(2, 5), (2, 6), (2, 7)]
     m = gu.fill_params(TGT_Multi(**kwargs), seed=3).cuda().train()

@@ -116,7 +116,9 @@ def test_full_width_agx2_12x2_fp32_forward():
 
 
 FULL_AT_GOLDENS = {'n32': ('model_full_at_24L_n32_fp32', gu.FULL_AT_N32_GEOM, (930, 931)),
-                   'n48': ('model_full_at_24L_n48_fp32', gu.FULL_AT_N48_GEOM, (940, 941))}
+                   'n48': ('model_full_at_24L_n48_fp32', gu.FULL_AT_N48_GEOM, (940, 941)),
+                   # BASELINE config 4 as a mini-batch: 8 ragged graphs, N <= 48, Gaussian 3-D embedding
+                   'n48_b8': ('model_full_at_24L_n48_b8_fp32', gu.FULL_AT_N48_B8_GEOM, (960, 961))}
 
 
 @pytest.mark.parametrize('which', list(FULL_AT_GOLDENS))
@@ -142,6 +144,22 @@ def test_full_width_24L_n32_fp32_forward_and_gradients(which):
     named = dict(model.named_parameters())
     for k in gu.FULL_GRAD_KEYS:
         check(named[k].grad, gold['pgrad.' + k], 5e-3, k)
+
+
+def test_full_width_gap_agx2_12x2_forward():
+    """BASELINE config 5, second stage: the TGT-Agx2 12 x 2 gap predictor at full width on 8 ragged graphs whose distance input
+    went through the bins format -- the oracle against the reference's fp32 forward (lib/models/pcqm/gap_predictor.py:48-63), and
+    the bins -> distance step against the reference's BinsProcessor output stored with the golden"""
+    gold = load('model_full_gap_agx2_12x2_fp32')
+    batch = gu.model_batch(gu.FULL_AGX2_GEOM, seed=951)
+    bins = torch.triu((batch['dist_input'].float() * (255 / 8)).long().clamp(0, 255), 1)
+    assert torch.equal(core.bins_to_dist(bins, 8 / 255), torch.from_numpy(gold['dist_input']['full']))      # bit for bit
+    batch['dist_input'] = gu.binned_dist_input(batch)
+    assert torch.equal(batch['dist_input'], torch.from_numpy(gold['dist_input']['full']))
+    model = gu.fill_params(om.TGT_Gap(**gu.FULL_GAP_AGX2_CFG), seed=950).eval()
+    with torch.no_grad():
+        gap = model(batch)
+    check(gap, gold['gap'], 1e-4, 'gap')
 
 
 def test_state_dict_manifest_matches_reference():

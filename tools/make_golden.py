@@ -170,6 +170,41 @@ def full_at_n32_case(geom=None, name='model_full_at_24L_n32_fp32', seeds=(930, 9
     save(name, out)
 
 
+def full_gap_agx2_case():
+    """BASELINE config 5, second stage: TGT-Agx2 12 x 2 gap predictor at full width (lib/models/pcqm/gap_predictor.py:10-63) on 8
+    ragged graphs whose distance input went through the bins format; fp32 eval forward = the golden; and the reference's OWN
+    fp16-autocast result on the same batch (CPU autocast: Linear / matmul in half, LayerNorm / softmax fp32) as the anchor of the
+    fp16 tolerance."""
+    torch.manual_seed(0)
+    model = gu.fill_params(TGT_Gap(**gu.FULL_GAP_AGX2_CFG), seed=950).eval()
+    batch = gu.model_batch(gu.FULL_AGX2_GEOM, seed=951)
+    batch['dist_input'] = gu.binned_dist_input(batch)
+    # (cross-check of the helper against the reference's own BinsProcessor arithmetic)
+    bp = ref_commons.BinsProcessor.__new__(ref_commons.BinsProcessor)
+    bp.shift_half, bp.zero_diag, bp.bin_size = True, True, 8 / 255
+    bins = torch.triu((gu.model_batch(gu.FULL_AGX2_GEOM, seed=951)['dist_input'].float() * (255 / 8)).long().clamp(0, 255), 1)
+    assert torch.equal(bp.bins2dist(bins.float()), batch['dist_input']), 'binned_dist_input != BinsProcessor.bins2dist'
+    t0 = time.time()
+    with torch.no_grad():
+        gap = model(batch)
+        try:
+            with torch.autocast('cpu', dtype=torch.float16):
+                gap16 = model(batch).float()
+        except Exception as e:                      # (a CPU op without a half kernel: the anchor falls back to bf16's)
+            print('  fp16 CPU autocast failed:', repr(e)[:200])
+            gap16 = None
+        with torch.autocast('cpu', dtype=torch.bfloat16):
+            gapbf = model(batch).float()
+    print(f'full_gap_agx2 fwd {time.time()-t0:.1f}s gap={gap.tolist()}')
+    out = sampled('gap', gap, True)
+    out['dist_input::full'] = batch['dist_input'].numpy()
+    if gap16 is not None:
+        out['fp16_drift::full'] = np.array(float((gap16 - gap).abs().max()))
+    out['bf16_drift::full'] = np.array(float((gapbf - gap).abs().max()))
+    print('  drift (max abs): fp16', None if gap16 is None else float((gap16 - gap).abs().max()), 'bf16', float((gapbf - gap).abs().max()))
+    save('model_full_gap_agx2_12x2_fp32', out)
+
+
 def misc_cases():
     rng = np.random.default_rng(4242)
     coords = torch.from_numpy(rng.standard_normal((2, 5, 3)).astype(np.float32))
@@ -325,7 +360,7 @@ def bf16_drift_cases():
 
 
 if __name__ == '__main__':
-    which = sys.argv[2:] or ['op', 'model', 'misc', 'full', 'full_agx2', 'full_n32', 'full_n48', 'drift', 'predict']
+    which = sys.argv[2:] or ['op', 'model', 'misc', 'full', 'full_agx2', 'full_n32', 'full_n48', 'full_n48_b8', 'full_gap_agx2', 'drift', 'predict']
     if 'op' in which:
         op_cases()
     if 'model' in which:
@@ -340,6 +375,10 @@ if __name__ == '__main__':
         full_at_n32_case()
     if 'full_n48' in which:
         full_at_n32_case(gu.FULL_AT_N48_GEOM, 'model_full_at_24L_n48_fp32', (940, 941))
+    if 'full_n48_b8' in which:
+        full_at_n32_case(gu.FULL_AT_N48_B8_GEOM, 'model_full_at_24L_n48_b8_fp32', (960, 961))
+    if 'full_gap_agx2' in which:
+        full_gap_agx2_case()
     if 'drift' in which:
         bf16_drift_cases()
     if 'predict' in which:
