@@ -345,6 +345,7 @@ def main():
     # one event per step on the step's stream (GPU-side step boundaries: the spread of the steps, e.g. one stalled by a
     # synchronous device allocation, shows in step_ms below; `value` stays the wall time of the whole region)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    ahead = []                              # per step: how many steps the host was ahead of the GPU when it finished queueing (0..6)
     host_ms, lead = [], []                  # per step: host enqueue time; was the GPU still busy with the PREVIOUS step when the host finished queueing this one?
     n_comm_before = len(trainer._comm_events)
     t0 = time.perf_counter()
@@ -357,6 +358,7 @@ def main():
         # (a non-blocking query: True = the GPU had already finished the previous step when the host finished queueing this one,
         #  i.e. the stream ran dry at some point of this step -- the host, not the GPU, set its duration)
         lead.append(bool(marks[i].query()))
+        ahead.append(sum(0 if marks[j].query() else 1 for j in range(max(0, i - 5), i + 1)))     # step-end marks the GPU has not reached yet
         if args.sync_every and (i + 1) % args.sync_every == 0:
             trainer.mean_loss()                      # host read of the control block: synchronises this rank
     fence()
@@ -528,7 +530,9 @@ def main():
                          stragglers=[dict(step=i, gpu_ms=round(step_gpu[i], 2), host_enqueue_ms=round(host_ms[i], 2), stream_ran_dry=lead[i])
                                      for i in range(args.steps) if step_gpu[i] > 1.2 * step_ms[len(step_ms) // 2]][:8],
                          host_enqueue_ms=dict(median=round(sorted(host_ms)[len(host_ms) // 2], 2), max=round(max(host_ms), 2)),
-                         steps_stream_ran_dry=sum(lead)),
+                         steps_stream_ran_dry=sum(lead),
+                         host_lead_steps=dict(min=min(ahead), median=sorted(ahead)[len(ahead) // 2], max=max(ahead),
+                                              note='step-end marks (of the last 6) the GPU had not reached when the host finished queueing a step: 0 = the stream ran dry')),
             # conditions of the timed region a plain Trainer loop does not get by itself: stated, not hidden
             timed_region_policy=dict(gc_frozen=True, allocator_settle='up to --settle-steps untimed steps until 8 in a row make no device allocation',
                                      numa_bound=bool(host_affinity.get('bound')), per_kernel_events=True),

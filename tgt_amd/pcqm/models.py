@@ -41,6 +41,15 @@ class GaussianLayer(nn.Module):
         """mul/bias summed over the (i-type, j-type) pair, built from PER-NODE gathers and a
         broadcast add: same value as embedding the (B,N,N,2) pair tensor, N times fewer
         indices through the embedding backward."""
+        if type_i.is_cuda:
+            # Both tables through ONE count-matrix GEMM per node role (ops.multi_hot_embed): nn.Embedding's backward
+            # (embedding_dense_backward) sorts the indices and reads the number of distinct ones back on the HOST -- four
+            # hipStreamSynchronize per step at the very end of the backward (rocprim radix sort + ~200 us of idle GPU each,
+            # profiles/r05y_trace_edges.txt), which also threw away the lead the host had built up over the step.
+            w2 = torch.cat([self.mul.weight, self.bias.weight], dim=1)             # (types, 2): [mul | bias]
+            both = ops.multi_hot_embed(type_i.unsqueeze(-1), w2, padding_idx=0).unsqueeze(2) + \
+                ops.multi_hot_embed(type_j.unsqueeze(-1), w2, padding_idx=0).unsqueeze(1)  # (B,N,N,2)
+            return both[..., :1], both[..., 1:]
         mul = self.mul(type_i).unsqueeze(2) + self.mul(type_j).unsqueeze(1)        # (B,N,N,1)
         bias = self.bias(type_i).unsqueeze(2) + self.bias(type_j).unsqueeze(1)
         return mul, bias
