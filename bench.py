@@ -339,7 +339,12 @@ def main():
     import gc
     gc.collect()
     gc.freeze()
-    prof = ops.profile_kernels(True)
+    # (events around the kernels the roofline leg reports, and only those: timing every launch costs the host ~3 us x 1400 per step)
+    ROOFLINE_KERNELS = ('tgt_triplet_attention_bwd', 'tgt_triplet_attention_fwd', 'tgt_triplet_attention_proj_fwd',
+                        'tgt_node_attention_fwd', 'tgt_node_attention_bwd')
+    if os.environ.get('TGT_BENCH_PROFILE_ALL') == '1':          # (A/B: events around every launch, as rounds 1-4 did)
+        ROOFLINE_KERNELS = None
+    prof = ops.profile_kernels(True, only=ROOFLINE_KERNELS)
     fence()
     ms0 = torch.cuda.memory_stats(dev)
     # one event per step on the step's stream (GPU-side step boundaries: the spread of the steps, e.g. one stalled by a
@@ -377,7 +382,7 @@ def main():
         ops.side_stream.enabled = False
         forked, ops._WGRAD_STREAM = ops._WGRAD_STREAM, False      # (the forked parameter-gradient stream as well: one stream, kernels alone)
         step(args.warmup + args.steps)                    # (one step for the allocator to settle on the new stream pattern)
-        prof_iso = ops.profile_kernels(True)
+        prof_iso = ops.profile_kernels(True, only=ROOFLINE_KERNELS)
         for i in range(args.roofline_steps):
             step(args.warmup + args.steps + 1 + i)
         fence()
@@ -425,11 +430,12 @@ def main():
         # from a tracked summary -- but ONLY from one measured on exactly these kernel sources (`_kernel_src_sha`, written by
         # tools/pmc_summary.py) at this shape; anything else is reported as stale, not as a measurement.
         traffic, pmc, pmc_note = {}, {}, None
-        if args.batch == 256 and args.nodes == 32 and args.precision == 'bf16':
+        n48 = args.batch == 128 and args.nodes == 48 and args.precision == 'bf16'          # BASELINE config 4's shape has its own counter pass (profiles/*_n48_pmc_summary.json)
+        if ((args.batch == 256 and args.nodes == 32) or n48) and args.precision == 'bf16':
             sys.path.insert(0, os.path.join(ROOT, 'tools'))
             from pmc_summary import kernel_source_sha
             sha = kernel_source_sha(ROOT)
-            summaries = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_pmc_summary.json') and '_n48_' not in f)     # (N = 48 passes: another shape)
+            summaries = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_pmc_summary.json') and (('_n48_' in f) == n48))     # (N = 48 passes: another shape)
             for f in reversed(summaries):
                 cand_pmc = json.load(open(os.path.join(ROOT, 'profiles', f)))
                 if cand_pmc.get('_kernel_src_sha') == sha:
@@ -441,7 +447,9 @@ def main():
             # (tools/pmc_summary.py's short names of the mangled kernels; the round-4 backward lives in namespace bwd2)
             for short, name in (('tri_att_fwd_kernel', 'tgt_triplet_attention_fwd'), ('tri_att_bwd_kernel', 'tgt_triplet_attention_bwd'),
                                 ('tri_att_bwd2_kernel', 'tgt_triplet_attention_bwd'),
-                                ('tri_att_proj_fwd_kernel', 'tgt_triplet_attention_proj_fwd')):
+                                ('tri_att_proj_fwd_kernel', 'tgt_triplet_attention_proj_fwd'),
+                                # (N in 33..64: the 16-wide kernels of csrc/triplet_attention16.hip)
+                                ('tri_att16_fwd_kernel', 'tgt_triplet_attention_fwd'), ('tri_att16_bwd_kernel', 'tgt_triplet_attention_bwd')):
                 if short in pmc and 'hbm_bytes_per_launch' in pmc[short]:
                     traffic[name] = dict(traffic_bytes=pmc[short]['hbm_bytes_per_launch'])
         roofline = None
@@ -456,8 +464,8 @@ def main():
                             share_of_step=round(tot / (dt * 1e3), 4),
                             # matrix-core utilisation of this kernel from the SQ counter pass (offline, same shape):
                             # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs); an HBM-bound core at 15.5 FLOP/B
-                            mfma_util=pmc.get({'tgt_triplet_attention_bwd': ('tri_att_bwd2_kernel' if 'tri_att_bwd2_kernel' in pmc else 'tri_att_bwd_kernel'),
-                                               'tgt_triplet_attention_fwd': 'tri_att_fwd_kernel',
+                            mfma_util=pmc.get({'tgt_triplet_attention_bwd': next((k for k in ('tri_att_bwd2_kernel', 'tri_att16_bwd_kernel') if k in pmc), 'tri_att_bwd_kernel'),
+                                               'tgt_triplet_attention_fwd': 'tri_att16_fwd_kernel' if 'tri_att16_fwd_kernel' in pmc else 'tri_att_fwd_kernel',
                                                'tgt_triplet_attention_proj_fwd': 'tri_att_proj_fwd_kernel'}[name], {}).get('mfma_util'),
                             other_kernels={k: dict(avg_launch_ms=round(v[1], 4),
                                                    achieved=round(v[2] / (v[1] * 1e-3) / 1e9, 1))
@@ -535,7 +543,7 @@ def main():
                                               note='step-end marks (of the last 6) the GPU had not reached when the host finished queueing a step: 0 = the stream ran dry')),
             # conditions of the timed region a plain Trainer loop does not get by itself: stated, not hidden
             timed_region_policy=dict(gc_frozen=True, allocator_settle='up to --settle-steps untimed steps until 8 in a row make no device allocation',
-                                     numa_bound=bool(host_affinity.get('bound')), per_kernel_events=True),
+                                     numa_bound=bool(host_affinity.get('bound')), per_kernel_events='roofline kernels only'),
             roofline=roofline,
             # the caching allocator inside the timed region: device allocations / frees there are synchronous driver calls
             allocator_settle_steps=settled,

@@ -32,10 +32,16 @@ _TRI_COLSUM = K.tri_colsum
 _TRI_SKIP_BWD = K.tri_skip == 2
 
 
-def profile_kernels(enable=True):
-    """Start (returns the dict that will fill with name -> [(start,end) events]) or stop."""
-    global _PROFILE
+_PROFILE_ONLY = None     # names to time (None: every kernel that offers itself)
+
+
+def profile_kernels(enable=True, only=None):
+    """Start (returns the dict that will fill with name -> [(start,end) events]) or stop.  only: an iterable of kernel names --
+    every other launch goes out without events (two hipEventRecord + two event objects per launch are ~3 us of HOST time, 1400
+    launches a step: bench.py times just the kernels its roofline leg reports)."""
+    global _PROFILE, _PROFILE_ONLY
     _PROFILE = {} if enable else None
+    _PROFILE_ONLY = frozenset(only) if (enable and only is not None) else None
     return _PROFILE
 
 
@@ -45,7 +51,7 @@ def kernel_times_ms(prof):
 
 
 def _call(name, fn, args):
-    if _PROFILE is None:
+    if _PROFILE is None or (_PROFILE_ONLY is not None and name not in _PROFILE_ONLY):
         _lib.check(fn(C.byref(args), _stream()), name)
         return
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -527,7 +533,7 @@ class _ProjectedTripletAttention(torch.autograd.Function):
             else:
                 eg = torch.addmm(be, x2, we.t()).view(B, N, N, L.used - 6 * L.C)
             a = _tri_args(fused, mask3, out, L, eg=eg, graph_scale=graph_scale)
-            s0, s1 = _prof_begin()
+            s0, s1 = _prof_begin('tgt_triplet_attention_proj_fwd')
             _lib.check(_lib.lib().tgt_triplet_attention_proj_fwd(C.byref(a), _ptr(x2), L.C, _ptr(w), _ptr(b), _stream()),
                        'tgt_triplet_attention_proj_fwd')
             _prof_end('tgt_triplet_attention_proj_fwd', s0, s1)
@@ -924,8 +930,8 @@ class _LayerNorm(torch.autograd.Function):
         return dx, dgb[0].to(ctx.wdtype), dgb[1].to(ctx.wdtype), None, None
 
 
-def _prof_begin():
-    if _PROFILE is None:
+def _prof_begin(name=None):
+    if _PROFILE is None or (_PROFILE_ONLY is not None and name not in _PROFILE_ONLY):
         return None, None
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()

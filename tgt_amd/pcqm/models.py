@@ -14,6 +14,8 @@ from .. import ops
 from ..tgt import TGT_Encoder, Graph
 from ..tgt.layers.blocks import LayerNorm, Linear
 
+import os
+_EMBED_GEMM = os.environ.get('TGT_EMBED_GEMM', '1') != '0'      # A/B knob (round 5): per-node mul / bias lookups as count-matrix GEMMs
 NODE_FEATURES_OFFSET = 128      # reference lib/models/pcqm/consts.py:1-7
 NUM_NODE_FEATURES = 9
 EDGE_FEATURES_OFFSET = 8
@@ -41,7 +43,7 @@ class GaussianLayer(nn.Module):
         """mul/bias summed over the (i-type, j-type) pair, built from PER-NODE gathers and a
         broadcast add: same value as embedding the (B,N,N,2) pair tensor, N times fewer
         indices through the embedding backward."""
-        if type_i.is_cuda:
+        if type_i.is_cuda and _EMBED_GEMM:
             # Both tables through ONE count-matrix GEMM per node role (ops.multi_hot_embed): nn.Embedding's backward
             # (embedding_dense_backward) sorts the indices and reads the number of distinct ones back on the HOST -- four
             # hipStreamSynchronize per step at the very end of the backward (rocprim radix sort + ~200 us of idle GPU each,
