@@ -344,7 +344,7 @@ def main():
                         'tgt_node_attention_fwd', 'tgt_node_attention_bwd')
     if os.environ.get('TGT_BENCH_PROFILE_ALL') == '1':          # (A/B: events around every launch, as rounds 1-4 did)
         ROOFLINE_KERNELS = None
-    prof = ops.profile_kernels(True, only=ROOFLINE_KERNELS)
+    prof = ops.profile_kernels(True, only=ROOFLINE_KERNELS, stride=1 if ROOFLINE_KERNELS is None else 5)
     fence()
     ms0 = torch.cuda.memory_stats(dev)
     # one event per step on the step's stream (GPU-side step boundaries: the spread of the steps, e.g. one stalled by a
@@ -368,6 +368,7 @@ def main():
             trainer.mean_loss()                      # host read of the control block: synchronises this rank
     fence()
     dt = time.perf_counter() - t0
+    seen_region = ops.profile_launch_counts()          # launches per kernel name inside the timed region (one in five carries events)
     step_gpu = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     step_ms = sorted(step_gpu)
     n_comm_timed = len(trainer._comm_events) - n_comm_before
@@ -382,7 +383,7 @@ def main():
         ops.side_stream.enabled = False
         forked, ops._WGRAD_STREAM = ops._WGRAD_STREAM, False      # (the forked parameter-gradient stream as well: one stream, kernels alone)
         step(args.warmup + args.steps)                    # (one step for the allocator to settle on the new stream pattern)
-        prof_iso = ops.profile_kernels(True, only=ROOFLINE_KERNELS)
+        prof_iso = ops.profile_kernels(True, only=ROOFLINE_KERNELS, stride=1 if ROOFLINE_KERNELS is None else 5)
         for i in range(args.roofline_steps):
             step(args.warmup + args.steps + 1 + i)
         fence()
@@ -423,7 +424,7 @@ def main():
                 if skip_mode and (kind != 'bwd' or skip_mode == '2' or proj_on):
                     # the kernel does not move the bytes of the graphs DropPath drops: count what it moves (expected fraction)
                     nbytes_k = int(nbytes_k * dropped_graph_discount(kind, args.nodes, C, Ht, drop_frac, esz))
-                cand[name] = (sum(times[name]), avg_ms, nbytes_k)
+                cand[name] = (avg_ms * seen_region.get(name, len(times[name])), avg_ms, nbytes_k)      # (total time in the timed region: mean of the timed launches x all launches)
         # HBM bytes per launch from the PMC passes (collected offline with rocprofv3 --pmc, see
         # profiles/README.md); only valid for the shape they were measured at
         # The counters cannot be collected inside this run (rocprofv3 --pmc wraps the process), so `traffic` / `mfma_util` come
@@ -459,7 +460,7 @@ def main():
             ach = nbytes / (avg_ms * 1e-3) / 1e9
             roofline = dict(bound='hbm', kernel=name, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
                             frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic.get(name, {}).get('traffic_bytes'),
-                            avg_launch_ms=round(avg_ms, 4), launches=len(times[name]),
+                            avg_launch_ms=round(avg_ms, 4), launches=seen_region.get(name, len(times[name])), launches_timed=len(times[name]),
                             algorithmic_bytes_per_launch=nbytes,
                             share_of_step=round(tot / (dt * 1e3), 4),
                             # matrix-core utilisation of this kernel from the SQ counter pass (offline, same shape):
@@ -485,8 +486,9 @@ def main():
                                          frac=round(nbytes / (reg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                          note='event pairs inside the timed region: the second stream\'s node kernels share the CUs'))
                 roofline.update(avg_launch_ms=round(reg, 4), achieved=round(nbytes / (reg * 1e-3) / 1e9, 1),
-                                frac=round(nbytes / (reg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), launches=len(times_region[name]))
-                roofline['share_of_step'] = round(sum(times_region[name]) / (dt * 1e3), 4)
+                                frac=round(nbytes / (reg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), launches=seen_region.get(name, len(times_region[name])),
+                                launches_timed=len(times_region[name]))
+                roofline['share_of_step'] = round(reg * seen_region.get(name, len(times_region[name])) / (dt * 1e3), 4)
             if skip_mode and drop_frac > 0:
                 roofline['droppath_skip'] = dict(kernels='forward+backward' if (skip_mode == '2' or proj_on) else 'forward',
                                                  expected_dropped_fraction=drop_frac,
@@ -540,10 +542,11 @@ def main():
                          host_enqueue_ms=dict(median=round(sorted(host_ms)[len(host_ms) // 2], 2), max=round(max(host_ms), 2)),
                          steps_stream_ran_dry=sum(lead),
                          host_lead_steps=dict(min=min(ahead), median=sorted(ahead)[len(ahead) // 2], max=max(ahead),
+                                              per_step=ahead[:64],
                                               note='step-end marks (of the last 6) the GPU had not reached when the host finished queueing a step: 0 = the stream ran dry')),
             # conditions of the timed region a plain Trainer loop does not get by itself: stated, not hidden
             timed_region_policy=dict(gc_frozen=True, allocator_settle='up to --settle-steps untimed steps until 8 in a row make no device allocation',
-                                     numa_bound=bool(host_affinity.get('bound')), per_kernel_events='roofline kernels only'),
+                                     numa_bound=bool(host_affinity.get('bound')), per_kernel_events='roofline kernels only, one launch in five'),
             roofline=roofline,
             # the caching allocator inside the timed region: device allocations / frees there are synchronous driver calls
             allocator_settle_steps=settled,

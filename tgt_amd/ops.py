@@ -33,16 +33,38 @@ _TRI_SKIP_BWD = K.tri_skip == 2
 
 
 _PROFILE_ONLY = None     # names to time (None: every kernel that offers itself)
+_PROFILE_STRIDE = 1      # every k-th launch of a name is timed
+_profile_seen = {}
 
 
-def profile_kernels(enable=True, only=None):
+def profile_kernels(enable=True, only=None, stride=1):
     """Start (returns the dict that will fill with name -> [(start,end) events]) or stop.  only: an iterable of kernel names --
-    every other launch goes out without events (two hipEventRecord + two event objects per launch are ~3 us of HOST time, 1400
-    launches a step: bench.py times just the kernels its roofline leg reports)."""
-    global _PROFILE, _PROFILE_ONLY
+    every other launch goes out without events; stride: of those, every stride-th launch per name is timed.  An event pair is not
+    free: two marker packets in the queue and ~3 us of host time per launch -- with all 1400 launches of a step timed the step
+    measured 81.66 ms, with the roofline kernels only 79.53 (same box, alternating: profiles/r06e_ab_host.txt); bench.py therefore
+    times just the kernels its roofline leg reports, one launch in five (a stride coprime with the 24 layers)."""
+    global _PROFILE, _PROFILE_ONLY, _PROFILE_STRIDE
     _PROFILE = {} if enable else None
     _PROFILE_ONLY = frozenset(only) if (enable and only is not None) else None
+    _PROFILE_STRIDE = max(1, int(stride)) if enable else 1
+    _profile_seen.clear()
     return _PROFILE
+
+
+def profile_launch_counts():
+    """name -> launches seen since profile_kernels(True, stride > 1) (timed or not); empty with stride 1"""
+    return dict(_profile_seen)
+
+
+def _timed(name):
+    """is this launch of `name` one the running profile wants events around?"""
+    if _PROFILE is None or (_PROFILE_ONLY is not None and name not in _PROFILE_ONLY):
+        return False
+    if _PROFILE_STRIDE == 1:
+        return True
+    n = _profile_seen.get(name, 0)
+    _profile_seen[name] = n + 1
+    return n % _PROFILE_STRIDE == 0
 
 
 def kernel_times_ms(prof):
@@ -51,7 +73,7 @@ def kernel_times_ms(prof):
 
 
 def _call(name, fn, args):
-    if _PROFILE is None or (_PROFILE_ONLY is not None and name not in _PROFILE_ONLY):
+    if _PROFILE is None or not _timed(name):
         _lib.check(fn(C.byref(args), _stream()), name)
         return
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -931,7 +953,7 @@ class _LayerNorm(torch.autograd.Function):
 
 
 def _prof_begin(name=None):
-    if _PROFILE is None or (_PROFILE_ONLY is not None and name not in _PROFILE_ONLY):
+    if _PROFILE is None or not _timed(name):
         return None, None
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
