@@ -35,7 +35,7 @@ HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 T
 
 
 def node_algorithmic_bytes(kind, B, N, W, Hn, esz=2):
-    """node attention (bias/softmax path), DESIGN.md §4.3: fwd reads Q,K,V (3NW), E,G (2N^2 Hn), writes
+    """node attention (bias/softmax path), DESIGN.md §4 (node attention row): fwd reads Q,K,V (3NW), E,G (2N^2 Hn), writes
     V_att (NW), H_hat (N^2 Hn); bwd reads Q,K,V,V_att,dV_att (5NW), E,G,dH_hat (3N^2 Hn), writes dQ,dK,dV (3NW),
     dE,dG (2N^2 Hn); + mask."""
     n2 = N * N
@@ -48,7 +48,7 @@ def _per_graph_bytes(kind, N, C, Ht, esz):
     n2 = N * N
     if kind == 'fwd':            # Q,K,V in + O out = 4 N^2 C, E,G = 2 N^2 Ht per direction, + mask; dropped: zero O rows
         return 2 * (4 * n2 * C + 2 * n2 * Ht) * esz + n2 * 4, 2 * (n2 * C) * esz
-    if kind == 'fwd_proj':       # projection-fused forward: X in ONCE (the kernel reads it 4 times: Q rows and K/V rows of
+    if kind == 'fwd_proj':       # projection-fused forward (profiles/HISTORY_rounds_1-4.md §4.1a): X in ONCE (the kernel reads it 4 times: Q rows and K/V rows of
         #                          both directions), Q,K,V out (kept for the backward) + O out per direction, E,G in, + mask
         return (n2 * C + 2 * (4 * n2 * C + 2 * n2 * Ht)) * esz + n2 * 4, 2 * (n2 * C) * esz
     # bwd: Q,K,V,dO in + dQ,dK,dV out = 7 N^2 C, E,G in + dE,dG out = 4 N^2 Ht per direction, + mask; dropped: zero gradient rows
@@ -531,7 +531,7 @@ def main():
                                wire_dtype=cfg.grad_comm_dtype or 'fp32',
                                rccl_stream=('high priority' if (world > 1 and not args.share_device) else None)),
             final_loss=round(loss_val, 5),
-            knobs_not_default=__import__('tgt_amd.knobs', fromlist=['K']).K.non_default(),      # {} = the default path (DESIGN 5.1)
+            knobs_not_default=__import__('tgt_amd.knobs', fromlist=['K']).K.non_default(),      # {} = the default path (DESIGN.md 5.4)
             host_affinity=host_affinity,
             step_ms=dict(min=round(step_ms[0], 3), median=round(step_ms[len(step_ms) // 2], 3), max=round(step_ms[-1], 3),
                          note='GPU-side duration of each timed step (events on the step stream)',

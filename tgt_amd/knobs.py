@@ -1,4 +1,4 @@
-"""The A/B switches of the tgt_amd host side, in ONE place (DESIGN.md 5.1).
+"""The A/B switches of the tgt_amd host side, in ONE place (DESIGN.md 5.4).
 
 Every switch selects between two COMPLETE paths and exists for same-box measurements (`tools/ab_knobs.sh KNOB=v ...`); the
 defaults are the measured winners.  The environment is read once, here, when the package is imported: `K` is the resulting

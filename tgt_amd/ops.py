@@ -22,7 +22,7 @@ _DT = {torch.float32: _lib.TGT_F32, torch.bfloat16: _lib.TGT_BF16, torch.float16
 _PROFILE = None
 
 
-_TRI_SPLIT = K.tri_split        # A/B knobs: tgt_amd/knobs.py reads the environment once (DESIGN 5.1); tests patch these names
+_TRI_SPLIT = K.tri_split        # A/B knobs: tgt_amd/knobs.py reads the environment once (DESIGN.md 5.4); tests patch these names
 _TRI_PROJ = K.tri_proj
 _TRI_COLSUM = K.tri_colsum
 # graph_scale (DropPath-dropped graphs skipped by the triplet kernels) reaches the BACKWARD kernel only with TGT_TRI_SKIP=2: at the
@@ -490,7 +490,7 @@ def _split_projection_ok(x, L):
 
 
 def _proj_fused_ok(x, N, L, cd):
-    """the projection-fused forward kernel (tgt_triplet_attention_proj_fwd, wave roles: DESIGN.md section 4.1a): Q/K/V are
+    """the projection-fused forward kernel (tgt_triplet_attention_proj_fwd, wave roles: DESIGN.md section 4, profiles/HISTORY_rounds_1-4.md 4.1a): Q/K/V are
     projected inside the attention kernel (still written once, for the backward); TGT_TRI_PROJ=0 is the A/B knob"""
     return (_TRI_PROJ and N <= 32 and L.D == 16 and L.H % 8 == 0 and L.width == L.used and
             cd in (torch.bfloat16, torch.float16) and L.C == 256 and x.numel() // L.C >= _SPLIT_MIN_ROWS)
@@ -1332,7 +1332,7 @@ def _ln_backward(dy, s, g, mean, rstd, ds, scale, rps, want_dz):
 
 
 _WGRAD_BIG = 131072      # outputs at least this large (lin_O 256x512, the fused projection) take 64 chunks: +0.3 % same-box over 262144
-_WGRAD_MAXP = 128      # settled (in-step sweep 32..256): cap on the row chunks of a weight gradient
+_WGRAD_MAXP = 128      # settled (in-step sweep 32..256, profiles/HISTORY_rounds_1-4.md 4.6): cap on the row chunks of a weight gradient
 
 
 def _wgrad_chunks(M, out_in=0):

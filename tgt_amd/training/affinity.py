@@ -2,7 +2,7 @@
 
 One process per GPU (reference lib/training/execute.py:91-107 spawns them without any placement).  On the two-socket hosts
 of the MI355X boxes a rank whose threads run on the other socket pays a cross-socket hop for every doorbell write and
-every pinned-memory access; the enqueue path of the training step (~65 ms of host time per step) is what that
+every pinned-memory access; the enqueue path of the training step (67-75 ms of host time per step) is what that
 slows.  Best effort: anything missing (sysfs entries, a container without the topology, an affinity mask already
 narrowed by the launcher) leaves the process as it was and says so.
 """

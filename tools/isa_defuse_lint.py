@@ -4,7 +4,7 @@ stores whose data registers are overwritten before the store has read them (lint
 Why: hipcc (ROCm 7.2) miscompiled one triplet-attention backward instantiation -- a 128-bit
 loop-invariant MFMA operand was spilled as 3 dwords to scratch + 1 dword parked in an AGPR
 ("Reload Reuse"), and the reload restored only the 3 scratch dwords: the MFMA then read an AGPR
-no instruction of the kernel ever writes, i.e. whatever the previous wave left there (DESIGN.md
+no instruction of the kernel ever writes, i.e. whatever the previous wave left there (DESIGN.md section 4 / profiles/HISTORY_rounds_1-4.md
 section 4.1, "bf16 two-tile dropout backward").  The same static def/use check would have caught it
 at build time, so `__graft_entry__.build()` can run it (TGT_ISA_LINT=1) and
 tests/test_isa_lint.py keeps it on the affected translation unit.
@@ -100,7 +100,7 @@ def lint_store_hazard(text, states=1):
     Why: the store reads its data registers after it has issued.  hipcc pads that hazard only for stores without a scalar
     offset; on MI355X a `buffer_store_dwordx4 v[114:117], v72, s[12:15], s28 offen` directly followed by
     `v_cvt_f32_f16 v114, ...` stored the conversion result in place of the first dword (the fp16 column-sum variant of
-    csrc/triplet_attention16.hip: DESIGN.md section 4.1b).  `s_nop N` between the two counts as N + 1 states.
+    csrc/triplet_attention16.hip: DESIGN.md section 4.1b of profiles/HISTORY_rounds_1-4.md).  `s_nop N` between the two counts as N + 1 states.
     states = 1: the distance at which corruption was observed; the same overwrite one instruction later (129 places in
     this library, all in kernels that pass their parity tests) has never shown it."""
     bad = {}
