@@ -213,3 +213,15 @@ def test_affinity_binds_every_thread_of_the_process():
         stop.set()
         affinity.restore_affinity(before)
     assert os.sched_getaffinity(0) == before
+
+
+def test_slow_kernel_family_is_announced_once():
+    """a BASELINE-sized call that falls off the hot kernels says so, once per reason"""
+    import warnings
+    from tgt_amd import ops
+    ops._slow_path_said.discard(('x', 'y'))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        ops._slow_path_notice(('x', 'y'), 'first')
+        ops._slow_path_notice(('x', 'y'), 'second')
+    assert len(w) == 1 and 'first' in str(w[0].message) and issubclass(w[0].category, RuntimeWarning)

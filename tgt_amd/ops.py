@@ -489,6 +489,18 @@ def _split_projection_ok(x, L):
             x.numel() // L.C >= _SPLIT_MIN_ROWS)
 
 
+_slow_path_said = set()
+
+
+def _slow_path_notice(key, msg):
+    """Say ONCE per process (and reason) that a BASELINE-sized call takes a kernel family that is 2-3x off the hot one, instead of
+    doing so silently.  Small problems (tests) never reach the callers' size thresholds."""
+    if key not in _slow_path_said:
+        _slow_path_said.add(key)
+        import warnings
+        warnings.warn('tgt_amd: ' + msg, RuntimeWarning, stacklevel=3)
+
+
 def _proj_fused_ok(x, N, L, cd):
     """the projection-fused forward kernel (tgt_triplet_attention_proj_fwd, wave roles: DESIGN.md section 4, profiles/HISTORY_rounds_1-4.md 4.1a): Q/K/V are
     projected inside the attention kernel (still written once, for the backward); TGT_TRI_PROJ=0 is the A/B knob"""
@@ -537,6 +549,13 @@ class _ProjectedTripletAttention(torch.autograd.Function):
         out = torch.empty(B, N, N, 2 * L.C, dtype=cd, device=x.device)
         eg = None
         proj_skip = None
+        if x.numel() // L.C >= _SPLIT_MIN_ROWS and not (dropout[0] == 0 and _proj_fused_ok(x, N, L, cd)) and _TRI_PROJ:
+            why = ('N > 32' if N > 32 else 'attention dropout > 0' if dropout[0] else 'head dim != 16' if L.D != 16 else
+                   'heads not a multiple of 8' if L.H % 8 else 'edge width != 256' if L.C != 256 else
+                   'fp32' if cd not in (torch.bfloat16, torch.float16) else 'padded / unbiased layout')
+            _slow_path_notice(('tri_proj', why), f'triplet attention: the projection-fused forward / round-4 backward do not take this shape ({why}); '
+                              'running the projection as library GEMMs + the general attention kernels (N in 33..64: 16-wide tiles at 0.39-0.45 of '
+                              'HBM instead of 0.52; see DESIGN.md section 4)')
         if dropout[0] == 0 and _proj_fused_ok(x, N, L, cd):
             # Q/K/V projected inside the attention kernel (it still writes them once, for the
             # backward); only the narrow E/G third-arm projection stays a library GEMM, written
@@ -787,6 +806,10 @@ class _NodeAttention(torch.autograd.Function):
             eg = eg.to(qkv.dtype)
         B, N = qkv.shape[0], qkv.shape[1]
         a, W = _node_args(qkv, eg, mask3, H, scale_degree, False)
+        if B * N * N >= 65536 and (N > 32 or qkv.dtype == torch.float32 or H % 8 or (W // H) not in (8, 12, 16)):
+            why = 'N > 32' if N > 32 else 'fp32' if qkv.dtype == torch.float32 else 'heads not a multiple of 8' if H % 8 else 'head dim not in {8, 12, 16}'
+            _slow_path_notice(('node_mfma', why), f'node attention: the matrix-core kernels do not take this shape ({why}); running the lane-per-head '
+                              'kernels (0.15-0.20 of HBM at N = 48 against 0.33-0.36; DESIGN.md section 4)')
         vatt = torch.empty(B, N, W, dtype=qkv.dtype, device=qkv.device)
         hhat = torch.empty(B, N, N, H, dtype=qkv.dtype, device=qkv.device) if want_edges else None
         lse = torch.empty(B, N, H, dtype=torch.float32, device=qkv.device)
