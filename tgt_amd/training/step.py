@@ -334,10 +334,23 @@ class Trainer:
             return
         start, count, first = 0, 0, 0
         ends = [o + (-(-p.numel() // 64) * 64) for p, o in zip(f.params, f.offsets)]
+        # Buckets are contiguous slices of the flat buffer (= parameter order) and a bucket's all-reduce starts when its LAST gradient
+        # arrives.  Two rules keep the part of the exchange that cannot hide behind the backward small (round 5; only the LAST
+        # bucket(s) to close are exposed):
+        #  * a bucket never spans two top-level modules: `model.parameters()` lists the encoder, then the input embedding, then the
+        #    heads -- the embedding's gradients arrive at the very END of the backward, the heads' and the top layers' at its start,
+        #    and one bucket holding all three would keep the top layers' 60 MB waiting for the embedding (observed launch order
+        #    5, 4, 3, 2, 1, 0, 6 with seven buckets: two full buckets exposed instead of one);
+        #  * the first bucket (the bottom layers: the last gradients of the encoder) is a quarter of the others.
+        names = {id(p): n for n, p in self.model.named_parameters()}
+        group = [names.get(id(p), '').split('.', 1)[0] for p in f.params]
         for i, (p, o) in enumerate(zip(f.params, f.offsets)):
             self._bucket_of[id(p)] = len(self.buckets)
             count += 1
-            if ends[i] - start >= limit or i == len(f.params) - 1:
+            lim = limit // 4 if not self.buckets else limit
+            last = i == len(f.params) - 1
+            # (a module change closes the bucket only once it holds >= 1 MB: the heads' few small tensors share one)
+            if ends[i] - start >= lim or last or (group[i + 1] != group[i] and ends[i] - start >= (1 << 18)):
                 self.buckets.append([start, ends[i], count, first])
                 start, count, first = ends[i], 0, i + 1
         self._pending = [b[2] for b in self.buckets]
