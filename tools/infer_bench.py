@@ -89,7 +89,9 @@ def main():
         gap_model = TGT_Gap(**gk).cuda().train()
         batch = device_batch(B, 32, 12, ragged=False)
         batch['num_nodes'] = batch['node_mask'].sum(-1).long()
-        prof = ops.profile_kernels(True)
+        # (events only around the attention kernels, one launch in three: an event pair around every launch slows the host AND the queue,
+        #  DESIGN.md 5.2)
+        prof = ops.profile_kernels(True, only=('tgt_triplet_aggregate_fwd', 'tgt_node_attention_fwd', 'tgt_node_attention_fwd(logits)'), stride=3)
 
         def run():
             return pp.two_stage_predict(dist_model, gap_model, batch, S, 256, 8, autocast_dtype=torch.float16)
