@@ -435,6 +435,12 @@ NODE_CASES = [  # B, N, num_nodes, W, H
     (1, 40, [33], 64, 8),         # N > 32
     (2, 9, [9, 5], 128, 16),      # D = 8: matrix-core kernels both ways (16-bit)
     (2, 12, [12, 7], 256, 16),    # D = 16: matrix-core forward, lane-per-head backward
+    (2, 48, [48, 37], 768, 64),   # BASELINE config 4's node count at BASELINE width: 16-wide matrix-core tiles, 3 x 3 blocks, D = 12, four head groups
+    (2, 33, [33, 20], 128, 16),   # one node past two blocks, D = 8
+    (1, 64, [57], 128, 16),       # four blocks, D = 8 (the largest backward image that fits the LDS), ragged last block
+    (1, 64, [64], 256, 16),       # four blocks, D = 16
+    (2, 40, [40, 33], 256, 32),   # H = 32, D = 8: key-blocked forward with two heads per wave
+    (1, 33, [33], 512, 32),       # H = 32, D = 16
 ]
 
 

@@ -19,7 +19,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 # (source, extra flags, object suffix): the triplet attention kernels compile one dtype per translation unit
 SOURCES = ['capi.hip', 'optimizer.hip', 'edge_gemm.hip', 'params.hip', 'loss.hip', 'predict.hip', 'gaussian.hip', 'triplet_attention_proj.hip',
            ('triplet_attention.hip', ['-DTGT_TRI_INST=9'], '.f32'), ('triplet_attention.hip', ['-DTGT_TRI_INST=2'], '.bf16'),
-           ('triplet_attention.hip', ['-DTGT_TRI_INST=4'], '.f16'), 'triplet_attention16.hip', 'triplet_attention_bwd2.hip', 'triplet_aggregate.hip', 'node_attention.hip', 'node_attention_mfma.hip', 'layernorm.hip', 'triangular_update.hip', 'elementwise.hip']
+           ('triplet_attention.hip', ['-DTGT_TRI_INST=4'], '.f16'), 'triplet_attention16.hip', 'triplet_attention_bwd2.hip', 'triplet_aggregate.hip', 'node_attention.hip', 'node_attention_mfma.hip', 'node_attention16.hip', 'node_attention_kb.hip', 'layernorm.hip', 'triangular_update.hip', 'elementwise.hip']
 ABI_VERSION = 29
 
 TGT_F32, TGT_BF16, TGT_F16 = 0, 1, 2

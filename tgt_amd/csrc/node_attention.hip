@@ -622,6 +622,12 @@ static int dispatch_node_d(const tgt_node_attention_args& a, bool bwd, hipStream
 // matrix-core kernels for the 16-bit hot shapes (node_attention_mfma.hip)
 bool node_attention_mfma_eligible(const tgt_node_attention_args& a, bool bwd);
 int node_attention_mfma_run(const tgt_node_attention_args& a, bool bwd, hipStream_t st);
+// 16-wide matrix-core tiles for 33 <= N <= 64 (node_attention16.hip): BASELINE config 4
+bool node_attention16_eligible(const tgt_node_attention_args& a, bool bwd);
+int node_attention16_run(const tgt_node_attention_args& a, bool bwd, hipStream_t st);
+// key-blocked, whole 128-byte E | G rows per workgroup (node_attention_kb.hip): H a multiple of 32
+bool node_attention_kb_eligible(const tgt_node_attention_args& a, bool bwd);
+int node_attention_kb_run(const tgt_node_attention_args& a, bool bwd, hipStream_t st);
 
 int node_attention_run(const tgt_node_attention_args* a, bool bwd, hipStream_t st) {
     if (!a) return set_error(TGT_ERR_INVALID, "node attention: null args");
@@ -637,6 +643,8 @@ int node_attention_run(const tgt_node_attention_args* a, bool bwd, hipStream_t s
         if (!a->d_qkv || !a->d_eg) return set_error(TGT_ERR_INVALID, "node attention bwd: null d_qkv/d_eg");
         if (!a->logits_only && !a->d_vatt) return set_error(TGT_ERR_INVALID, "node attention bwd: null d_vatt");
     }
+    if (node_attention_kb_eligible(*a, bwd)) return node_attention_kb_run(*a, bwd, st);    // forward, H % 32 == 0, N <= 64
+    if (node_attention16_eligible(*a, bwd)) return node_attention16_run(*a, bwd, st);      // N > 32 (every N <= 64 under TGT_NODE_MFMA16=2)
     if (node_attention_mfma_eligible(*a, bwd)) return node_attention_mfma_run(*a, bwd, st);
     switch (a->dtype) {
         case TGT_F32: return dispatch_node_d<float>(*a, bwd, st);

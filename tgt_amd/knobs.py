@@ -40,7 +40,7 @@ _SPEC = {
     'defer_edge': ('TGT_DEFER_EDGE', True, 'flag', 'closing edge residual performed by the next layer entry'),
     'gate_node_bwd': ('TGT_GATE_NODE_BWD', 0, 'int', "the node side stream's backward chain of a layer waits for that layer's triplet backward kernel (1) / for the projection's data-gradient GEMM behind it (2)"),
 }
-ENV_OF_LIBRARY = ('TGT_TRI_BWD2', 'TGT_TRI_BWD2_DMA', 'TGT_HIP_LIB', 'TGT_NODE_MFMA', 'TGT_TUNING_FILE')
+ENV_OF_LIBRARY = ('TGT_TRI_BWD2', 'TGT_TRI_BWD2_DMA', 'TGT_HIP_LIB', 'TGT_NODE_MFMA', 'TGT_NODE_MFMA16', 'TGT_NODE_KB', 'TGT_TUNING_FILE')
 
 
 def _read(var, default, kind):

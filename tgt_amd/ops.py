@@ -806,10 +806,10 @@ class _NodeAttention(torch.autograd.Function):
             eg = eg.to(qkv.dtype)
         B, N = qkv.shape[0], qkv.shape[1]
         a, W = _node_args(qkv, eg, mask3, H, scale_degree, False)
-        if B * N * N >= 65536 and (N > 32 or qkv.dtype == torch.float32 or H % 8 or (W // H) not in (8, 12, 16)):
-            why = 'N > 32' if N > 32 else 'fp32' if qkv.dtype == torch.float32 else 'heads not a multiple of 8' if H % 8 else 'head dim not in {8, 12, 16}'
+        if B * N * N >= 65536 and (N > 64 or qkv.dtype == torch.float32 or H % 8 or (W // H) not in (8, 12, 16)):
+            why = 'N > 64' if N > 64 else 'fp32' if qkv.dtype == torch.float32 else 'heads not a multiple of 8' if H % 8 else 'head dim not in {8, 12, 16}'
             _slow_path_notice(('node_mfma', why), f'node attention: the matrix-core kernels do not take this shape ({why}); running the lane-per-head '
-                              'kernels (0.15-0.20 of HBM at N = 48 against 0.33-0.36; DESIGN.md section 4)')
+                              'kernels (0.15-0.20 of HBM at N = 48 against 0.28-0.39; DESIGN.md section 4)')
         vatt = torch.empty(B, N, W, dtype=qkv.dtype, device=qkv.device)
         hhat = torch.empty(B, N, N, H, dtype=qkv.dtype, device=qkv.device) if want_edges else None
         lse = torch.empty(B, N, H, dtype=torch.float32, device=qkv.device)
