@@ -501,8 +501,13 @@ def main():
                     roofline['other_kernels'][kname] = dict(avg_launch_ms=round(avg, 4),
                                                             achieved=round(nb / (avg * 1e-3) / 1e9, 1),
                                                             frac=round(nb / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
-                    # (the matrix-core kernels of csrc/node_attention_mfma.hip: one launch each way)
-                    shorts = ('node_att_mfma_fwd_kernel',) if kind == 'fwd' else ('node_att_mfma_bwd_kernel',)
+                    # (one launch each way: the key-blocked forward of csrc/node_attention_kb.hip when H is a multiple of 32, the matrix-core
+                    # kernels of csrc/node_attention_mfma.hip for N <= 32, the 16-wide tiles of csrc/node_attention16.hip for 33..64)
+                    if kind == 'fwd':
+                        shorts = ('node_att_kb_fwd_kernel',) if mcfg['num_heads'] % 32 == 0 and args.nodes <= 64 else \
+                                 ('node_att_mfma_fwd_kernel',) if args.nodes <= 32 else ('node_att16_fwd_kernel',)
+                    else:
+                        shorts = ('node_att_mfma_bwd_kernel',) if args.nodes <= 32 else ('node_att16_bwd_kernel',)
                     if all(k in pmc and 'hbm_bytes_per_launch' in pmc[k] for k in shorts):
                         roofline['other_kernels'][kname]['traffic'] = sum(pmc[k]['hbm_bytes_per_launch'] for k in shorts)
                         roofline['other_kernels'][kname]['algorithmic_bytes_per_launch'] = nb
