@@ -481,7 +481,7 @@ def test_node_attention(case, dtype, scale_degree, want_edges):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
-@pytest.mark.parametrize('case', [NODE_CASES[1], NODE_CASES[4], NODE_CASES[5]])
+@pytest.mark.parametrize('case', [NODE_CASES[1], NODE_CASES[4], NODE_CASES[5], NODE_CASES[7], NODE_CASES[11]])
 def test_node_attention_hhat_scale(case, dtype):
     """hhat_scale (the DropPath factor of the edge branch folded into the kernel): H_hat comes back times scale[b], V_att is
     untouched, and the backward treats d_hhat as the gradient of the scaled tensor -- both kernel families"""
@@ -505,6 +505,41 @@ def test_node_attention_hhat_scale(case, dtype):
     assert torch.equal(va, vb)
     assert rel(ha, hb.float() * sc4) < tol
     assert rel(qa.grad, qb.grad) < 2 * tol and rel(ea.grad, eb.grad) < 2 * tol
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('case', [(2, 32, 768, 64), (2, 48, 768, 64), (1, 64, 256, 32), (2, 40, 128, 16)])
+def test_node_attention_arbitrary_mask_and_large_logits(case, dtype):
+    """A per-(query, key) additive mask instead of the key-only padding mask, with whole leading key blocks masked for some queries
+    (the key-blocked forward's running maximum starts at -inf and must stay NaN-free until the first live key), scattered masked keys,
+    and edge biases large enough that the running maximum moves by tens of units between key blocks (the O accumulators are rescaled)"""
+    from tgt_amd import ops
+    B, N, W, H = case
+    rng = np.random.default_rng(N + H)
+    qkv = rnd(rng, B, N, 3 * W).to(dtype)
+    eg = rnd(rng, B, N, N, 2 * H)
+    eg[..., :H] *= 6.0                                  # logits spread over ~ +-20
+    eg[:, :, N // 2:, :H] += 12.0                       # later key blocks carry the maximum
+    eg = eg.to(dtype)
+    d_v, d_h = rnd(rng, B, N, W).to(dtype), rnd(rng, B, N, N, H).to(dtype)
+    m = torch.zeros(B, N, N)
+    m[torch.from_numpy(rng.random((B, N, N)) < 0.2)] = -float('inf')
+    m[:, 1::3, :16] = -float('inf')                     # first key block wholly masked for every third query
+    if N > 32:
+        m[:, 2::5, :32] = -float('inf')                 # ... the first two
+    m[:, :, N - 1] = 0.0                                # (every query keeps one live key: the reference NaNs on an empty row)
+    q64, e64 = qkv.double().requires_grad_(True), eg.double().requires_grad_(True)
+    v_ref, h_ref = core.egt_attention_core(q64, e64, m.double().reshape(gu.additive_mask([N] * B, N, torch.float32).shape), H, True)
+    ((v_ref * d_v.double()).sum() + (h_ref * d_h.double()).sum()).backward()
+    qx, ex = qkv.cuda().requires_grad_(True), eg.cuda().requires_grad_(True)
+    v, hh = ops.node_attention(qx, ex, m.cuda(), H, True, True)
+    ((v.float() * d_v.cuda().float()).sum() + (hh.float() * d_h.cuda().float()).sum()).backward()
+    assert torch.isfinite(v).all() and torch.isfinite(qx.grad).all() and torch.isfinite(ex.grad).all()
+    tol = TOL[dtype]
+    assert rel(v, v_ref) < tol, ('vatt', rel(v, v_ref))
+    assert rel(hh, h_ref) < tol, ('hhat', rel(hh, h_ref))
+    assert rel(qx.grad, q64.grad) < 2 * tol, ('dqkv', rel(qx.grad, q64.grad))
+    assert rel(ex.grad, e64.grad) < 2 * tol, ('deg', rel(ex.grad, e64.grad))
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
