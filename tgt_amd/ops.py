@@ -291,6 +291,7 @@ def _colsum_workspace(B, width, used, device):
     return torch.empty(B, width, dtype=torch.float32, device=device)
 
 
+_PROBE_SKIP_SUMS = os.environ.get('TGT_PROBE_SKIP_SUMS') == '1'
 _ATEN_PLANE_SUM = False       # settled (+0.3 % for the kernel; tests patch this): ATen's reduction instead of tgt_sum_planes
 
 
@@ -402,6 +403,8 @@ def sum_planes(part, out, defer=True):
         _deferred_stats[0] += 1
         if len(q[0]) >= _DEFER_MAX:
             _flush_queue(q)
+        return out
+    if _PROBE_SKIP_SUMS:                   # (timing probe only: what the closing sums cost the step -- results are garbage)
         return out
     _lib.check(_lib.lib().tgt_sum_planes(_ptr(part), part.shape[0], out.numel(), _ptr(out), _stream()), 'tgt_sum_planes')
     return out
