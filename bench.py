@@ -505,7 +505,7 @@ def main():
                     # (one launch each way: the key-blocked forward of csrc/node_attention_kb.hip when H is a multiple of 32, the matrix-core
                     # kernels of csrc/node_attention_mfma.hip for N <= 32, the 16-wide tiles of csrc/node_attention16.hip for 33..64)
                     if kind == 'fwd':
-                        shorts = ('node_att_kb_fwd_kernel',) if mcfg['num_heads'] % 32 == 0 and args.nodes <= 64 else \
+                        shorts = ('node_att_kb_fwd_kernel',) if mcfg['num_heads'] % 32 == 0 else \
                                  ('node_att_mfma_fwd_kernel',) if args.nodes <= 32 else ('node_att16_fwd_kernel',)
                     else:
                         shorts = ('node_att_mfma_bwd_kernel',) if args.nodes <= 32 else ('node_att16_bwd_kernel',)

@@ -442,6 +442,7 @@ NODE_CASES = [  # B, N, num_nodes, W, H
     (2, 40, [40, 33], 256, 32),   # H = 32, D = 8: key-blocked forward with two heads per wave
     (1, 33, [33], 512, 32),       # H = 32, D = 16
     (3, 12, [12, 7, 1], 384, 32), # one key block, D = 12, a one-node graph
+    (1, 80, [71], 256, 32),       # N > 64: key-blocked forward (five blocks), lane-per-head backward
 ]
 
 

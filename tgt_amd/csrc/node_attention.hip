@@ -643,7 +643,7 @@ int node_attention_run(const tgt_node_attention_args* a, bool bwd, hipStream_t s
         if (!a->d_qkv || !a->d_eg) return set_error(TGT_ERR_INVALID, "node attention bwd: null d_qkv/d_eg");
         if (!a->logits_only && !a->d_vatt) return set_error(TGT_ERR_INVALID, "node attention bwd: null d_vatt");
     }
-    if (node_attention_kb_eligible(*a, bwd)) return node_attention_kb_run(*a, bwd, st);    // forward, H % 32 == 0, N <= 64
+    if (node_attention_kb_eligible(*a, bwd)) return node_attention_kb_run(*a, bwd, st);    // forward, H % 32 == 0
     if (node_attention16_eligible(*a, bwd)) return node_attention16_run(*a, bwd, st);      // N > 32 (every N <= 64 under TGT_NODE_MFMA16=2)
     if (node_attention_mfma_eligible(*a, bwd)) return node_attention_mfma_run(*a, bwd, st);
     switch (a->dtype) {

@@ -1,4 +1,4 @@
-// Node attention with edge bias and gate (EGT_Attention core), KEY-BLOCKED: the forward for 16-bit dtypes, N <= 64, H a multiple of
+// Node attention with edge bias and gate (EGT_Attention core), KEY-BLOCKED: the forward for 16-bit dtypes, any N, H a multiple of
 // 32, D in {8, 12, 16} -- the bias / softmax path of BASELINE.json's north_star at BASELINE width (H = 64, D = 12).
 //
 // Replaces reference lib/tgt/layers/layers.py:62-77 (einsum -> +E -> softmax * sigmoid gate -> einsum -> degree scaler).
@@ -345,12 +345,12 @@ static int dispatch_fwd(const tgt_node_attention_args& a, hipStream_t st) {
 
 }  // namespace nkb
 
-// Shapes the key-blocked forward takes: 16-bit, N <= 64, H a multiple of 32, D in {8, 12, 16}.  TGT_NODE_KB (A/B): 0 off, 1 N > 32
+// Shapes the key-blocked forward takes: 16-bit, any N <= 1024 (nothing in the kernel is sized by N), H a multiple of 32, D in {8, 12, 16}.  TGT_NODE_KB (A/B): 0 off, 1 N > 32
 // only, 2 (default) every N.
 bool node_attention_kb_eligible(const tgt_node_attention_args& a, bool bwd) {
     static const int mode = getenv("TGT_NODE_KB") ? atoi(getenv("TGT_NODE_KB")) : 2;
     if (!mode || bwd || a.logits_only || a.dtype == TGT_F32) return false;
-    if (a.N > 64 || (a.N <= 32 && mode < 2) || a.H % 32 || !(a.D == 8 || a.D == 12 || a.D == 16)) return false;
+    if (a.N > 1024 || (a.N <= 32 && mode < 2) || a.H % 32 || !(a.D == 8 || a.D == 12 || a.D == 16)) return false;
     if (!a.mask || !a.vatt || !a.lse || !a.gsum) return false;
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     if (a.ld_qkv % 8 || a.q_off % 8 || a.k_off % 8 || a.v_off % 8 || a.ld_eg % 8 || a.e_off % 8 || a.g_off % 8) return false;
