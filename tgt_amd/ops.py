@@ -293,6 +293,7 @@ def _colsum_workspace(B, width, used, device):
 
 _PROBE_SKIP_SUMS = os.environ.get('TGT_PROBE_SKIP_SUMS') == '1'
 _PROBE_SKIP_PROJ_LN = os.environ.get('TGT_PROBE_SKIP_PROJ_LN') == '1'
+_PROBE_SKIP_WGRAD = os.environ.get('TGT_PROBE_SKIP_WGRAD') == '1'
 _ATEN_PLANE_SUM = False       # settled (+0.3 % for the kernel; tests patch this): ATen's reduction instead of tgt_sum_planes
 
 
@@ -1382,6 +1383,8 @@ def _wgrad_into(out, dy2, x2, chunks):
     """out (rows(dy2^T), in) fp32 <- dy2^T x2 as `chunks` batched partial products + their sum; dy2 may
     be a column slice of a wider row-major matrix"""
     M = x2.shape[0]
+    if _PROBE_SKIP_WGRAD and M >= 65536:         # (timing probe only, see _linear_backward)
+        return
     P = chunks
     while P > 1 and (M % P or M // P < 1024):
         P //= 2
@@ -1661,6 +1664,12 @@ def _linear_backward(x2, w, dy2, xs, xdt, wdt, bdt, need_dx, need_dw, need_db, l
         M = x2.shape[0]
         P = _wgrad_chunks(M, dy2.shape[1] * x2.shape[1])
         with _on_stream(ws):
+            if P > 1 and _PROBE_SKIP_WGRAD:       # (timing probe only: the split-M weight gradient left out -- what a wgrad that rides on the dgrad kernels could win at most)
+                dst = _grad_dst(dw_ptr, (dy2.shape[1], x2.shape[1]), torch.float32) if (dw_post is None and wdt == torch.float32) else None
+                dw = dst if dst is not None else torch.zeros(dy2.shape[1], x2.shape[1], dtype=wdt, device=dy2.device)
+                if dw_post is not None:
+                    dw = dw_post(dw)
+                P = 0
             if P > 1:
                 part = torch.bmm(dy2.view(P, M // P, -1).transpose(1, 2), x2.view(P, M // P, -1),
                                  out_dtype=torch.float32) if dy2.dtype != torch.float32 else \
@@ -1672,10 +1681,10 @@ def _linear_backward(x2, w, dy2, xs, xdt, wdt, bdt, need_dx, need_dw, need_db, l
                 if wdt != torch.float32:
                     flush_deferred()
                     dw = dw.to(wdt)
-            else:
+            elif P == 1:
                 dst = _grad_dst(dw_ptr, (dy2.shape[1], x2.shape[1]), wdt) if dw_post is None else None
                 dw = (dy2.t() @ x2).to(wdt) if dst is None else dst.copy_(dy2.t() @ x2)      # (the same cast, into the slice)
-            if dw_post is not None:
+            if dw_post is not None and P:
                 dw = dw_post(dw)
     if need_db:
         with _on_stream(ws):             # (a parameter gradient as well: nothing reads it before the step ends)
