@@ -172,7 +172,11 @@ int tgt_triangular_update_bwd(const void* e4, const void* v4, const float* mask,
  * logits_only != 0: EdgeUpdate -- only hhat is produced (V, G, mask, vatt unused).
  * Backward: the forward's vatt/lse/gsum, d_vatt (B,N,W), d_hhat (B,N,N,H, may be NULL) -> d_qkv (B,N,ld_qkv;
  * Q,K,V columns written), d_eg (B,N,N,ld_eg; E,G columns written).
- * Supported: any N, D <= 32, any H.
+ * Supported: any N, D <= 32, any H.  Kernel families behind the two entry points (one launch each way, chosen by shape; same results
+ * up to the order of the softmax sums): 16-bit with D in {8,12,16} -- forward with H % 32 == 0: key-blocked, 64-byte pieces of the
+ * E | G rows (csrc/node_attention_kb.hip); N <= 32, H % 8 == 0: one 32x32 tile per head (csrc/node_attention_mfma.hip);
+ * 33 <= N <= 64, H % 8 == 0: 16-wide tiles (csrc/node_attention16.hip); everything else (fp32, other D / H, N > 64 backward):
+ * one lane per head (csrc/node_attention.hip).
  * ---------------------------------------------------------------------- */
 typedef struct tgt_node_attention_args {
     int32_t B, N, H, D;
