@@ -1366,7 +1366,7 @@ def _ln_backward(dy, s, g, mean, rstd, ds, scale, rps, want_dz):
 
 
 _WGRAD_BIG = 131072      # outputs at least this large (lin_O 256x512, the fused projection) take 64 chunks: +0.3 % same-box over 262144
-_WGRAD_MAXP = 128      # settled (in-step sweep 32..256, profiles/HISTORY_rounds_1-4.md 4.6): cap on the row chunks of a weight gradient
+_WGRAD_MAXP = int(os.environ.get('TGT_WGRAD_MAXP', '128'))      # settled (in-step sweep 32..256, profiles/HISTORY_rounds_1-4.md 4.6): cap on the row chunks of a weight gradient
 
 
 def _wgrad_chunks(M, out_in=0):
