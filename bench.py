@@ -228,6 +228,11 @@ def main():
     ap.add_argument('--no-gemm-tuning', action='store_true', help='library default GEMM heuristics')
     ap.add_argument('--no-numa-bind', action='store_true', help='leave the CPU affinity of the rank alone (default: the NUMA node of its GPU)')
     ap.add_argument('--write-gemm-tuning', default='', help='tune online and write the TunableOp file here')
+    ap.add_argument('--profile-all', action='store_true',
+                    help='A/B: HIP events around EVERY hand-written launch, as rounds 1-4 did (host-bound: profiles/r06f_ab_events.txt)')
+    ap.add_argument('--timing-probe', default='', choices=['', 'skip_sums', 'skip_proj_ln', 'skip_wgrad'],
+                    help='leave work OUT of the step to bound what it costs (tools/probes/skip_probes.py); the line then carries '
+                         '"value": null and "invalid": ... -- the gradients of such a step are wrong by construction')
     ap.add_argument('--share-device', action='store_true',
                     help='multi-rank dress rehearsal on ONE GPU: every rank runs on cuda:0 and the ranks exchange over gloo (RCCL refuses '
                          'two ranks on one device).  Walks the exact multi-rank branch of this file -- rendezvous, rank-0 broadcast, '
@@ -284,6 +289,10 @@ def main():
     from tgt_amd.training.configs import tgt_at_24l
     from tgt_amd.training.step import Trainer, StepConfig, preprocess_batch
     from tgt_amd.training.synthetic import make_batch, batch_seed
+    if args.timing_probe:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools', 'probes'))
+        import skip_probes
+        skip_probes.install(args.timing_probe)
 
     if not args.no_gemm_tuning:
         from tgt_amd.training.gemm_tuning import enable_gemm_tuning
@@ -343,7 +352,7 @@ def main():
     # (events around the kernels the roofline leg reports, and only those: timing every launch costs the host ~3 us x 1400 per step)
     ROOFLINE_KERNELS = ('tgt_triplet_attention_bwd', 'tgt_triplet_attention_fwd', 'tgt_triplet_attention_proj_fwd',
                         'tgt_node_attention_fwd', 'tgt_node_attention_bwd')
-    if os.environ.get('TGT_BENCH_PROFILE_ALL') == '1':          # (A/B: events around every launch, as rounds 1-4 did)
+    if args.profile_all:          # (A/B: events around every launch, as rounds 1-4 did)
         ROOFLINE_KERNELS = None
     prof = ops.profile_kernels(True, only=ROOFLINE_KERNELS, stride=1 if ROOFLINE_KERNELS is None else 5)
     fence()
@@ -537,7 +546,9 @@ def main():
                                wire_dtype=cfg.grad_comm_dtype or 'fp32',
                                rccl_stream=('high priority' if (world > 1 and not args.share_device) else None)),
             final_loss=round(loss_val, 5),
-            knobs_not_default=__import__('tgt_amd.knobs', fromlist=['K']).K.non_default(),      # {} = the default path
+            # {} = the default path; bench-side A/B flags of this command line ride along
+            knobs_not_default=dict(__import__('tgt_amd.knobs', fromlist=['K']).K.non_default(),
+                                   **({'--profile-all': True} if args.profile_all else {})),
             host_affinity=host_affinity,
             step_ms=dict(min=round(step_ms[0], 3), median=round(step_ms[len(step_ms) // 2], 3), max=round(step_ms[-1], 3),
                          note='GPU-side duration of each timed step (events on the step stream)',
@@ -567,6 +578,10 @@ def main():
                 from tgt_amd.training.affinity import restore_affinity
                 restore_affinity(host_mask)                 # the oracle's step runs on all of the host's cores again (every thread)
             out['cpu_baseline'] = cpu_baseline(full=args.cpu_baseline_full)
+        if args.timing_probe:
+            # work was left out of the step: the milliseconds bound what that work costs, the throughput is not one
+            out.update(value=None, invalid=f'timing probe {args.timing_probe}: work left out of the step, gradients wrong by construction',
+                       graphs_per_s_with_work_missing=round(args.batch * world * args.steps / dt, 2))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -7,14 +7,20 @@ import pytest
 import torch
 
 import golden_util as gu
+import parity_log
 from oracle import core, modules as om
 
 pytestmark = pytest.mark.gpu
 
 
+def tag(mode):
+    """files the comparisons that follow under `<mode>-model` in the parity log (TGT_PARITY_LOG, tests/parity_log.py)"""
+    parity_log.Tol.last = f'{mode}-model'
+
+
 def rel(a, b):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
-    return float((a - b).norm() / (b.norm() + 1e-30))
+    return parity_log.record(float((a - b).norm() / (b.norm() + 1e-30)))
 
 
 def load_gold(name):
@@ -156,9 +162,11 @@ def _sampled_ok(t, z, key, tol):
     flat = t.detach().double().cpu().numpy().reshape(-1)
     if key + '::full' in z.files:
         ref = z[key + '::full'].reshape(-1)
+        parity_log.record(float(np.linalg.norm(flat - ref) / max(np.linalg.norm(ref), 1e-30)))
         return np.linalg.norm(flat - ref) <= tol * max(np.linalg.norm(ref), 1e-30), (key, np.linalg.norm(flat - ref), np.linalg.norm(ref))
     ref_s = z[key + '::samples']
     s = flat[gu.sample_index(flat.size)]
+    parity_log.record(float(np.linalg.norm(s - ref_s) / np.linalg.norm(ref_s)))
     ok = np.linalg.norm(s - ref_s) <= tol * np.linalg.norm(ref_s) and abs(np.linalg.norm(flat) - float(z[key + '::norm'])) <= tol * float(z[key + '::norm'])
     return ok, (key, np.linalg.norm(s - ref_s) / np.linalg.norm(ref_s))
 
@@ -177,12 +185,14 @@ def test_full_width_agx2_12x2_forward_vs_reference_golden():
             l_bf = model(batch)
         with torch.autocast('cuda', dtype=torch.float16):
             l_fp = model(batch)
+    tag('fp32')
     ok, info = _sampled_ok(logits, z, 'logits', 2e-3)
     assert ok, info
     valid = (batch['edge_mask'] > 0).cpu().numpy()
     agree = (logits.argmax(-1).cpu().numpy() == z['logits_argmax::full'])[valid].mean()
     assert agree > 0.99, agree
     for name, l16 in (('bf16', l_bf), ('fp16', l_fp)):
+        tag(name)
         ok, info = _sampled_ok(l16, z, 'logits', 3e-2)
         assert ok, (name, info)
 
@@ -206,11 +216,13 @@ def test_full_width_24L_n32_vs_reference_golden(which):
         gap, logits = model(batch)
         with torch.autocast('cuda', dtype=torch.bfloat16):
             gap16, logits16 = model(batch)
+    tag('fp32')
     ok, info = _sampled_ok(logits, z, 'logits', 2e-3)
     assert ok, info
     assert np.abs(gap.double().cpu().numpy() - z['gap::full']).max() < 1e-3
     valid = (batch['edge_mask'] > 0).cpu().numpy()
     assert (logits.argmax(-1).cpu().numpy() == z['logits_argmax::full'])[valid].mean() > 0.99
+    tag('bf16')
     ok, info = _sampled_ok(logits16, z, 'logits', 3e-2)
     assert ok, info
     assert np.abs(gap16.double().cpu().numpy() - z['gap::full']).max() < 5e-2
@@ -221,6 +233,7 @@ def test_full_width_24L_n32_vs_reference_golden(which):
     for mode, tol_loss, tol_grad in (('fp32', 2e-5, 5e-3), ('bf16', 1e-3, None)):
         model = gu.fill_params(TGT_Multi(**gu.FULL_AT_CFG), seed=seeds[0]).cuda().train()
         ctx = torch.autocast('cuda', dtype=torch.bfloat16) if mode == 'bf16' else torch.autocast('cuda', enabled=False)
+        tag(mode)
         with ctx:
             loss = pretrain_loss(model(batch), batch, cfg)
         loss.backward()
@@ -467,6 +480,7 @@ def test_full_width_24L_training_gradients_vs_oracle():
     for mode, tol_loss, tol_grad in (('fp32', 2e-5, 5e-3), ('bf16', 1e-3, None)):
         model = gu.fill_params(TGT_Multi(**gu.FULL_AT_CFG), seed=910).cuda().train()
         ctx = torch.autocast('cuda', dtype=torch.bfloat16) if mode == 'bf16' else torch.autocast('cuda', enabled=False)
+        tag(mode)
         with ctx:
             loss = pretrain_loss(model(batch), batch, cfg)
         loss.backward()

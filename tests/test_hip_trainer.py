@@ -472,6 +472,14 @@ def test_graph_mode_is_given_back_when_capture_fails_or_the_owner_is_dropped(mon
         del cache
         gc.collect()
         assert not ops._GRAPH_SAFE[0] and not tr.device_lr
+        # an un-closed owner REBOUND by a new one -- the old object's finalizer runs after the new capture finished and
+        # must not switch the mode off under the live owner (ownership token = the registered seed counter)
+        gs = graphed.GraphedTrainingStep(tr, _batch(cfg, 0), warmup=1)
+        gs = graphed.GraphedTrainingStep(tr, _batch(cfg, 0), warmup=1)     # noqa: F841  (the first owner is dropped here)
+        gc.collect()
+        assert ops._GRAPH_SAFE[0] and tr.device_lr and ops._seed_counter[0] is gs.counter
+        gs.close()
+        assert not ops._GRAPH_SAFE[0] and ops._seed_counter[0] is None and not tr.device_lr
 
 
 def test_eager_step_on_a_graph_owned_trainer_advances_rate_and_counter():

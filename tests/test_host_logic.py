@@ -86,6 +86,31 @@ def test_knobs_are_read_once_in_one_place(monkeypatch):
         k.tri_proj = True
 
 
+def test_no_environment_switch_outside_knobs():
+    """every host-side switch is a field of knobs.K (so that bench.py's knobs_not_default names it); the
+    work-skipping timing probes are not in the product at all (tools/probes/skip_probes.py, bench.py --timing-probe)"""
+    import os
+    import re
+    import tgt_amd
+    root = os.path.dirname(tgt_amd.__file__)
+    allowed = {'knobs.py': None, '_lib.py': ('TGT_HIP_LIB', 'HIPCC', 'TGT_KEEP_ISA'), 'torch_ops.py': ('CXX',),
+               os.path.join('training', 'gemm_tuning.py'): ('TGT_TUNING_FILE',)}
+    for d, _, files in os.walk(root):
+        for f in files:
+            if not f.endswith('.py'):
+                continue
+            rel = os.path.relpath(os.path.join(d, f), root)
+            src = open(os.path.join(d, f)).read()
+            assert 'PROBE_SKIP' not in src, rel
+            names = re.findall(r"os\.environ(?:\.get)?[\[(]\s*'([A-Z_0-9]+)'", src)
+            if rel in allowed:
+                assert allowed[rel] is None or set(names) <= set(allowed[rel]), (rel, names)
+            else:
+                assert not [n for n in names if n.startswith('TGT_')], (rel, names)
+    from tgt_amd import knobs
+    assert knobs._SPEC['wgrad_maxp'][0] == 'TGT_WGRAD_MAXP' and knobs._SPEC['embed_gemm'][0] == 'TGT_EMBED_GEMM'
+
+
 def test_parameter_reuse_is_found_in_the_graph():
     """the forked parameter-gradient stream / deferred closing sums are only safe when every parameter that one of the
     package's own autograd Functions differentiates enters the graph once; the Trainer looks for reuse of ANY kind in the graph

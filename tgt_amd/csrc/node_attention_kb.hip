@@ -352,6 +352,10 @@ bool node_attention_kb_eligible(const tgt_node_attention_args& a, bool bwd) {
     if (!mode || bwd || a.logits_only || a.dtype == TGT_F32) return false;
     if (a.N > 1024 || (a.N <= 32 && mode < 2) || a.H % 32 || !(a.D == 8 || a.D == 12 || a.D == 16)) return false;
     if (!a.mask || !a.vatt || !a.lse || !a.gsum) return false;
+    // per-graph buffer resources: every in-range byte offset must stay below the out-of-range sentinel kOob (node_tiles16.hpp), or the
+    // "invalid lane reads offset kOob" trick could alias a real element for very wide rows
+    const int64_t per_graph = (int64_t)a.N * a.N * (a.ld_eg > a.H ? a.ld_eg : a.H) * 2, per_graph_q = (int64_t)a.N * a.ld_qkv * 2;
+    if (per_graph >= (int64_t)0x7ffffff0 || per_graph_q >= (int64_t)0x7ffffff0) return false;
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     if (a.ld_qkv % 8 || a.q_off % 8 || a.k_off % 8 || a.v_off % 8 || a.ld_eg % 8 || a.e_off % 8 || a.g_off % 8) return false;
     if (!al16(a.qkv) || !al16(a.eg) || !al16(a.vatt) || (a.hhat && !al16(a.hhat))) return false;

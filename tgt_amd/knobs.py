@@ -38,6 +38,8 @@ _SPEC = {
     'node_chain': ('TGT_NODE_CHAIN', True, 'flag', "the next layer's node projections chained on the side stream"),
     'flat_grad_dst': ('TGT_FLAT_GRAD_DST', True, 'flag', 'weight gradients written into the flat gradient buffer inside a Trainer backward'),
     'defer_edge': ('TGT_DEFER_EDGE', True, 'flag', 'closing edge residual performed by the next layer entry'),
+    'wgrad_maxp': ('TGT_WGRAD_MAXP', 128, 'int', 'cap on the row chunks of a split-M weight gradient (in-step sweep 32..256: 128)'),
+    'embed_gemm': ('TGT_EMBED_GEMM', True, 'flag', "per-node mul / bias tables of the Gaussian 3-D embedding without nn.Embedding's sort-based backward (a host read)"),
     'gate_node_bwd': ('TGT_GATE_NODE_BWD', 0, 'int', "the node side stream's backward chain of a layer waits for that layer's triplet backward kernel (1) / for the projection's data-gradient GEMM behind it (2)"),
 }
 ENV_OF_LIBRARY = ('TGT_TRI_BWD2', 'TGT_TRI_BWD2_DMA', 'TGT_HIP_LIB', 'TGT_NODE_MFMA', 'TGT_NODE_MFMA16', 'TGT_NODE_KB', 'TGT_TUNING_FILE')
@@ -80,6 +82,8 @@ class Knobs:
     node_chain: bool
     flat_grad_dst: bool
     defer_edge: bool
+    wgrad_maxp: int
+    embed_gemm: bool
     gate_node_bwd: int
 
     @classmethod

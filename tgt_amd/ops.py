@@ -291,9 +291,6 @@ def _colsum_workspace(B, width, used, device):
     return torch.empty(B, width, dtype=torch.float32, device=device)
 
 
-_PROBE_SKIP_SUMS = os.environ.get('TGT_PROBE_SKIP_SUMS') == '1'
-_PROBE_SKIP_PROJ_LN = os.environ.get('TGT_PROBE_SKIP_PROJ_LN') == '1'
-_PROBE_SKIP_WGRAD = os.environ.get('TGT_PROBE_SKIP_WGRAD') == '1'
 _ATEN_PLANE_SUM = False       # settled (+0.3 % for the kernel; tests patch this): ATen's reduction instead of tgt_sum_planes
 
 
@@ -405,8 +402,6 @@ def sum_planes(part, out, defer=True):
         _deferred_stats[0] += 1
         if len(q[0]) >= _DEFER_MAX:
             _flush_queue(q)
-        return out
-    if _PROBE_SKIP_SUMS:                   # (timing probe only: what the closing sums cost the step -- results are garbage)
         return out
     _lib.check(_lib.lib().tgt_sum_planes(_ptr(part), part.shape[0], out.numel(), _ptr(out), _stream()), 'tgt_sum_planes')
     return out
@@ -813,7 +808,10 @@ class _NodeAttention(torch.autograd.Function):
         a, W = _node_args(qkv, eg, mask3, H, scale_degree, False)
         if B * N * N >= 65536 and (N > 64 or qkv.dtype == torch.float32 or H % 8 or (W // H) not in (8, 12, 16)):
             why = 'N > 64' if N > 64 else 'fp32' if qkv.dtype == torch.float32 else 'heads not a multiple of 8' if H % 8 else 'head dim not in {8, 12, 16}'
-            _slow_path_notice(('node_mfma', why), f'node attention: the matrix-core kernels do not take this shape ({why}); running the lane-per-head '
+            # (N > 64 with H a multiple of 32, 16-bit: the FORWARD still runs the key-blocked matrix-core kernel, N <= 1024; only the backward
+            # is lane-per-head there)
+            which = 'the backward runs' if (why == 'N > 64' and H % 32 == 0 and N <= 1024 and (W // H) in (8, 12, 16)) else 'running'
+            _slow_path_notice(('node_mfma', why), f'node attention: the matrix-core kernels do not take this shape ({why}); {which} the lane-per-head '
                               'kernels (0.15-0.20 of HBM at N = 48 against 0.28-0.39; DESIGN.md section 4)')
         vatt = torch.empty(B, N, W, dtype=qkv.dtype, device=qkv.device)
         hhat = torch.empty(B, N, N, H, dtype=qkv.dtype, device=qkv.device) if want_edges else None
@@ -1181,6 +1179,38 @@ class _MultiHotEmbed(torch.autograd.Function):
         return None, gw.to(ctx.wdtype), None, None
 
 
+class _GatherEmbed(torch.autograd.Function):
+    """W[idx] for ONE index per row (the per-node tables of the Gaussian 3-D embedding: 1536 types x 2 columns): the forward is
+    a gather; the weight gradient is counts(idx)^T @ g with the count matrix built in the backward only, over the index range
+    the batch uses, and never saved (the count-matrix forward of _MultiHotEmbed kept a (rows, 1536) fp32 matrix alive per call).
+    Fixed summation order (a GEMM, no atomics), no host read (nn.Embedding's sort-based backward has one)."""
+
+    @staticmethod
+    def forward(ctx, idx, weight, padding_idx):
+        ctx.save_for_backward(idx)
+        ctx.padding_idx, ctx.wshape, ctx.wdtype = padding_idx, weight.shape, weight.dtype
+        return weight.index_select(0, idx.reshape(-1)).view(*idx.shape, weight.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, = ctx.saved_tensors
+        V, C_ = ctx.wshape
+        flat = idx.reshape(-1, 1)
+        g2 = g.reshape(flat.shape[0], C_).float()
+        counts = torch.zeros(flat.shape[0], V, dtype=torch.float32, device=g.device)
+        counts.scatter_(1, flat, 1.0)
+        gw = counts.t() @ g2
+        if ctx.padding_idx is not None:
+            gw[ctx.padding_idx] = 0
+        return None, gw.to(ctx.wdtype), None
+
+
+def gather_embed(idx, weight, padding_idx=None):
+    """idx (...) long with values < weight.shape[0] -> (..., C) = weight[idx]; see _GatherEmbed"""
+    _dev(weight)
+    return _GatherEmbed.apply(idx, weight, padding_idx)
+
+
 def multi_hot_embed(idx, weight, padding_idx=None, out_dtype=None):
     """idx: (..., F) long with values < weight.shape[0]; returns (..., C) = sum over F of rows,
     in weight.dtype unless out_dtype says otherwise."""
@@ -1349,12 +1379,6 @@ def _ln_backward(dy, s, g, mean, rstd, ds, scale, rps, want_dz):
     dg = torch.empty(N, dtype=torch.float32, device=s.device)
     db_cs = torch.empty(2 * N, dtype=torch.float32, device=s.device)
     partial = torch.empty(L.tgt_layer_norm_parts() * 3 * N, dtype=torch.float32, device=s.device)
-    if _PROBE_SKIP_PROJ_LN and rows >= 65536:          # (timing probe only: the projection's standalone LayerNorm backward left out;
-        d_res.copy_(dy.view_as(d_res))                 #  a plain copy (2 E) in its place keeps the gradients finite)
-        dg.zero_(); db_cs.zero_()
-        if d_z is not None:
-            d_z.zero_()
-        return d_res, d_z, dg, db_cs[:N], db_cs[N:]
     p0, p1 = _prof_begin()
     _lib.check(L.tgt_add_layer_norm_bwd(_ptr(dy), _DT[dy.dtype], _ptr(s), _DT[s.dtype], _ptr(ds),
                                         0 if ds is None else _DT[ds.dtype], _ptr(scale), rps, _ptr(g), _ptr(mean),
@@ -1366,7 +1390,7 @@ def _ln_backward(dy, s, g, mean, rstd, ds, scale, rps, want_dz):
 
 
 _WGRAD_BIG = 131072      # outputs at least this large (lin_O 256x512, the fused projection) take 64 chunks: +0.3 % same-box over 262144
-_WGRAD_MAXP = int(os.environ.get('TGT_WGRAD_MAXP', '128'))      # settled (in-step sweep 32..256, profiles/HISTORY_rounds_1-4.md 4.6): cap on the row chunks of a weight gradient
+_WGRAD_MAXP = K.wgrad_maxp      # settled (in-step sweep 32..256, profiles/HISTORY_rounds_1-4.md 4.6): cap on the row chunks of a weight gradient
 
 
 def _wgrad_chunks(M, out_in=0):
@@ -1383,8 +1407,6 @@ def _wgrad_into(out, dy2, x2, chunks):
     """out (rows(dy2^T), in) fp32 <- dy2^T x2 as `chunks` batched partial products + their sum; dy2 may
     be a column slice of a wider row-major matrix"""
     M = x2.shape[0]
-    if _PROBE_SKIP_WGRAD and M >= 65536:         # (timing probe only, see _linear_backward)
-        return
     P = chunks
     while P > 1 and (M % P or M // P < 1024):
         P //= 2
@@ -1664,12 +1686,6 @@ def _linear_backward(x2, w, dy2, xs, xdt, wdt, bdt, need_dx, need_dw, need_db, l
         M = x2.shape[0]
         P = _wgrad_chunks(M, dy2.shape[1] * x2.shape[1])
         with _on_stream(ws):
-            if P > 1 and _PROBE_SKIP_WGRAD:       # (timing probe only: the split-M weight gradient left out -- what a wgrad that rides on the dgrad kernels could win at most)
-                dst = _grad_dst(dw_ptr, (dy2.shape[1], x2.shape[1]), torch.float32) if (dw_post is None and wdt == torch.float32) else None
-                dw = dst if dst is not None else torch.zeros(dy2.shape[1], x2.shape[1], dtype=wdt, device=dy2.device)
-                if dw_post is not None:
-                    dw = dw_post(dw)
-                P = 0
             if P > 1:
                 part = torch.bmm(dy2.view(P, M // P, -1).transpose(1, 2), x2.view(P, M // P, -1),
                                  out_dtype=torch.float32) if dy2.dtype != torch.float32 else \
@@ -1684,7 +1700,7 @@ def _linear_backward(x2, w, dy2, xs, xdt, wdt, bdt, need_dx, need_dw, need_db, l
             elif P == 1:
                 dst = _grad_dst(dw_ptr, (dy2.shape[1], x2.shape[1]), wdt) if dw_post is None else None
                 dw = (dy2.t() @ x2).to(wdt) if dst is None else dst.copy_(dy2.t() @ x2)      # (the same cast, into the slice)
-            if dw_post is not None and P:
+            if dw_post is not None:
                 dw = dw_post(dw)
     if need_db:
         with _on_stream(ws):             # (a parameter gradient as well: nothing reads it before the step ends)

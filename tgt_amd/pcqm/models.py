@@ -14,8 +14,8 @@ from .. import ops
 from ..tgt import TGT_Encoder, Graph
 from ..tgt.layers.blocks import LayerNorm, Linear
 
-import os
-_EMBED_GEMM = os.environ.get('TGT_EMBED_GEMM', '1') != '0'      # A/B knob (round 5): per-node mul / bias lookups as count-matrix GEMMs
+from ..knobs import K as _K
+_EMBED_GEMM = _K.embed_gemm      # A/B knob (round 5): per-node mul / bias lookups without nn.Embedding's backward
 NODE_FEATURES_OFFSET = 128      # reference lib/models/pcqm/consts.py:1-7
 NUM_NODE_FEATURES = 9
 EDGE_FEATURES_OFFSET = 8
@@ -44,13 +44,13 @@ class GaussianLayer(nn.Module):
         broadcast add: same value as embedding the (B,N,N,2) pair tensor, N times fewer
         indices through the embedding backward."""
         if type_i.is_cuda and _EMBED_GEMM:
-            # Both tables through ONE count-matrix GEMM per node role (ops.multi_hot_embed): nn.Embedding's backward
-            # (embedding_dense_backward) sorts the indices and reads the number of distinct ones back on the HOST -- four
+            # Both tables as ONE gather per node role whose backward is a count-matrix GEMM (ops.gather_embed): nn.Embedding's
+            # backward (embedding_dense_backward) sorts the indices and reads the number of distinct ones back on the HOST -- four
             # hipStreamSynchronize per step at the very end of the backward (rocprim radix sort + ~200 us of idle GPU each,
             # profiles/r05y_trace_edges.txt), which also threw away the lead the host had built up over the step.
             w2 = torch.cat([self.mul.weight, self.bias.weight], dim=1)             # (types, 2): [mul | bias]
-            both = ops.multi_hot_embed(type_i.unsqueeze(-1), w2, padding_idx=0).unsqueeze(2) + \
-                ops.multi_hot_embed(type_j.unsqueeze(-1), w2, padding_idx=0).unsqueeze(1)  # (B,N,N,2)
+            both = ops.gather_embed(type_i, w2, padding_idx=0).unsqueeze(2) + \
+                ops.gather_embed(type_j, w2, padding_idx=0).unsqueeze(1)          # (B,N,N,2)
             return both[..., :1], both[..., 1:]
         mul = self.mul(type_i).unsqueeze(2) + self.mul(type_j).unsqueeze(1)        # (B,N,N,1)
         bias = self.bias(type_i).unsqueeze(2) + self.bias(type_j).unsqueeze(1)

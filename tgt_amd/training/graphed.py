@@ -26,10 +26,14 @@ from .. import ops
 from .step import Trainer
 
 
-def _leave_graph_mode(trainer_ref):
+def _leave_graph_mode(trainer_ref, counter=None):
     """back to eager: host seeds, pooled DropPath draws, the learning rate as a kernel argument.  Shared by close(), by the
     failure path of a capture and by the finalizer of an owner that was dropped without close() -- a Trainer left in graph-safe /
-    device-lr mode by accident would silently repeat dropout patterns and keep a stale learning rate."""
+    device-lr mode by accident would silently repeat dropout patterns and keep a stale learning rate.
+    `counter` is the ownership token: the mode is only given back when the registered seed counter is still THIS
+    owner's -- an old owner that is collected (or closed) after a newer one took the mode over must not switch it off under it."""
+    if counter is not None and ops._seed_counter[0] is not counter:
+        return
     ops.set_seed_counter(None)
     ops.graph_safe_rng(False)
     tr = trainer_ref() if isinstance(trainer_ref, weakref.ReferenceType) else trainer_ref
@@ -84,7 +88,7 @@ class GraphedTrainingStep:
             trainer.set_device_lr(True)
             warmup = max(1, warmup)
             # an owner dropped without close() must not leave the process in graph-safe mode
-            self._finalizer = weakref.finalize(self, _leave_graph_mode, weakref.ref(trainer))
+            self._finalizer = weakref.finalize(self, _leave_graph_mode, weakref.ref(trainer), self.counter)
         try:
             self.stream = torch.cuda.Stream(dev)
             self.stream.wait_stream(torch.cuda.current_stream(dev))
@@ -188,7 +192,7 @@ class GraphedStepCache:
         ops.graph_safe_rng(True)
         ops.set_seed_counter(self.counter)
         trainer.set_device_lr(True)
-        self._finalizer = weakref.finalize(self, _leave_graph_mode, weakref.ref(trainer))
+        self._finalizer = weakref.finalize(self, _leave_graph_mode, weakref.ref(trainer), self.counter)
         self.graphs, self.seen = {}, {}            # shape key -> GraphedTrainingStep (insertion order = recency) / eager steps so far
         self.captures = self.evictions = self.replays = self.eager_steps = 0
         self.thrash_window = 8 * self.max_graphs   # steps over which captures are compared with replays
