@@ -321,6 +321,13 @@ typedef struct tgt_edge_linear_args {
     const float* row_scale; const float* out_scale; int64_t rows_per_sample;
     float dropout_p;    uint32_t flags;  uint64_t dropout_seed;      /* flags: TGT_EDGE_* */
     float* colsum_partial;
+    /* ABI 30.  Fused weight gradient (TGT_EPI_GELU_BWD / TGT_EPI_LN_BWD, K = N = 256): when given, the launch ALSO accumulates the weight
+     * gradient of the Linear whose data gradient it computes, dW (N = columns of a, 256) = a^T X over the rows, with X recomputed from the
+     * epilogue operand -- GELU_BWD: X = dropout(gelu(res)) * out_scale (the forward's TGT_EPI_GELU output, bit for bit); LN_BWD:
+     * X = LayerNorm(res; gamma, beta, mean, rstd) (beta REQUIRED) -- so neither a nor X is read a second time by a separate weight-gradient
+     * GEMM (autograd of lib/tgt/layers/layers.py:155-160).  dw_partial: (tgt_edge_linear_parts(M, 256), 256, 256) float32, one plane per
+     * persistent workgroup, every plane written; sum the planes (tgt_sum_planes).  colsum_rows, when > 0, states the planes provided. */
+    float* dw_partial;
 } tgt_edge_linear_args;
 int tgt_edge_linear_supported(const tgt_edge_linear_args* a);
 int tgt_edge_linear_parts(int64_t M, int32_t N);

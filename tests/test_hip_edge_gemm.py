@@ -731,3 +731,139 @@ def test_transpose_many_one_launch(dtype):
         for s_, d_ in zip(src, dst):
             assert torch.equal(d_, s_.t())
     _lib.check(L.tgt_transpose_many(None, 0, 16, C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'empty')
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Fused weight gradient (ABI 30, csrc/edge_wgrad.hip): the data-gradient launch of a 256 -> 256 edge Linear also returns dW = a^T X
+# with X recomputed in the row phase.  The data gradient / column sums must equal the plain launch BIT FOR BIT (same k order, same
+# epilogue arithmetic), dW is held to the float64 product of the stored operands (fp32 accumulation: 1e-5 at 262144 rows).
+# ------------------------------------------------------------------------------------------------------------------
+def _gelu_act64(pre, p, seed, sc, rps, dtype):
+    """the forward's activation on the stored pre-activation: dropout(gelu(pre)) * sample_scale, by the standalone kernel"""
+    act = torch.empty_like(pre)
+    L = _lib.lib()
+    if sc is None:
+        _lib.check(L.tgt_gelu_dropout_fwd(pre.data_ptr(), act.data_ptr(), pre.numel(), ops._DT[dtype], p, seed, None), 'g')
+    else:
+        _lib.check(L.tgt_gelu_dropout_scaled_fwd(pre.data_ptr(), act.data_ptr(), pre.numel(), ops._DT[dtype], p, seed, sc.data_ptr(),
+                                                 rps * pre.shape[1], None), 'g')
+    return act
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('p', [0.0, 0.1])
+@pytest.mark.parametrize('M,cap,with_scale', [(520, 0, True), (33, 0, False), (4096, 3, True), (1000, 1, False), (262144, 0, True)])
+def test_fused_weight_gradient_gelu_backward(M, cap, with_scale, dtype, p):
+    N = K = 256
+    a, w, _, g = _mk(M, K, N, dtype, 11, bias=False)
+    pre = torch.randn(M, N, device='cuda', generator=g).to(dtype)
+    rps = 1024 if M == 262144 else 40
+    sc = (torch.rand(math.ceil(M / rps), device='cuda', generator=g) + 0.5) if with_scale else None
+    seed = 0x5eed if p else 0
+    L = _lib.lib()
+    L.tgt_edge_linear_set_grid_cap(cap)
+    try:
+        parts = L.tgt_edge_linear_parts(M, N)
+        cs0, cs1 = torch.empty(parts, N, device='cuda'), torch.empty(parts, N, device='cuda')
+        dwp = torch.full((parts, N, K), float('nan'), device='cuda')
+        kw = dict(res=pre, out_scale=sc, rows_per_sample=rps if with_scale else 0, dropout=(p, seed))
+        out0 = ops.edge_linear_raw(a, w, None, _lib.EPI_GELU_BWD, colsum_partial=cs0, **kw)
+        out1 = ops.edge_linear_raw(a, w, None, _lib.EPI_GELU_BWD, colsum_partial=cs1, dw_partial=dwp, **kw)
+    finally:
+        L.tgt_edge_linear_set_grid_cap(0)
+    torch.cuda.synchronize()
+    assert torch.equal(out0, out1) and torch.equal(cs0.sum(0), cs1.sum(0))
+    act = _gelu_act64(pre, p, seed, sc, rps, dtype)
+    dw = dwp.sum(0)
+    assert torch.isfinite(dw).all()
+    # chunked float64 reference (a 262144-row float64 product in one piece would take 1 GB)
+    ref = torch.zeros(N, K, dtype=torch.float64, device='cuda')
+    for i in range(0, M, 32768):
+        ref += a[i:i + 32768].double().t() @ act[i:i + 32768].double()
+    assert rel(dw, ref) < 2e-5, rel(dw, ref)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('M,cap,with_ds,with_scale', [(300, 0, True, True), (1024, 2, False, False), (4100, 1, True, False), (262144, 0, True, True)])
+def test_fused_weight_gradient_layernorm_backward(M, cap, with_ds, with_scale, dtype):
+    N = K = 256
+    a, w, _, g = _mk(M, K, N, dtype, 12, bias=False)
+    s = (torch.randn(M, N, device='cuda', generator=g) * 1.3 + 0.2).to(dtype)
+    gamma = torch.rand(N, device='cuda', generator=g) + 0.5
+    beta = torch.randn(N, device='cuda', generator=g) * 0.3
+    # the forward's y / mean / rstd, by the LayerNorm kernel on the stored stream rows
+    y = torch.empty_like(s)
+    mean, rstd = torch.empty(M, device='cuda'), torch.empty(M, device='cuda')
+    L = _lib.lib()
+    _lib.check(L.tgt_layer_norm_fwd(s.data_ptr(), ops._DT[dtype], gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), ops._DT[dtype],
+                                    mean.data_ptr(), rstd.data_ptr(), M, N, 1e-5, None), 'ln')
+    ds = torch.randn(M, N, device='cuda', generator=g).to(dtype) if with_ds else None
+    rps = 1024 if M == 262144 else 50
+    sc = (torch.rand(math.ceil(M / rps), device='cuda', generator=g) + 0.5) if with_scale else None
+    L.tgt_edge_linear_set_grid_cap(cap)
+    try:
+        parts = L.tgt_edge_linear_parts(M, N)
+        outs = []
+        for fused in (False, True):
+            partial = torch.empty(parts, 3 * N, device='cuda')
+            dres = torch.empty(M, N, dtype=dtype, device='cuda')
+            dx = torch.empty(M, N, dtype=dtype, device='cuda') if with_scale else None
+            dwp = torch.full((parts, N, K), float('nan'), device='cuda') if fused else None
+            ops.edge_linear_raw(a, w, None, _lib.EPI_LN_BWD, ln=(gamma, beta if fused else None, 1e-5), stats=(mean, rstd), res=s, ds_in=ds,
+                                out=dres, out2=dx, row_scale=sc, rows_per_sample=rps if with_scale else 0, colsum_partial=partial,
+                                dw_partial=dwp)
+            outs.append((dres, dx, partial.sum(0), dwp))
+    finally:
+        L.tgt_edge_linear_set_grid_cap(0)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][2], outs[1][2])
+    if with_scale:
+        assert torch.equal(outs[0][1], outs[1][1])
+    dw = outs[1][3].sum(0)
+    assert torch.isfinite(dw).all()
+    ref = torch.zeros(N, K, dtype=torch.float64, device='cuda')
+    for i in range(0, M, 32768):
+        ref += a[i:i + 32768].double().t() @ y[i:i + 32768].double()
+    # X is recomputed from (s, mean, rstd): a last-bit difference to the stored y on a few elements is possible (fma contraction), hence
+    # not the 1e-5 of the GELU form
+    assert rel(dw, ref) < 2e-4, rel(dw, ref)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('p', [0.0, 0.1])
+def test_ffn_block_backward_with_fused_weight_gradient_equals_the_unfused_step(dtype, p, monkeypatch):
+    """the edge FFN through ops.linear_gelu_dropout + ops.linear_residual_layer_norm: TGT_EDGE_WGRAD on / off give the same gradients
+    (lin_W2's weight gradient: fp32 sums in another order, everything else bit for bit)"""
+    monkeypatch.setattr(ops, '_EDGE_MIN_ROWS', 1)
+    B, Nn, C_ = 3, 12, 256
+    g = torch.Generator(device='cuda').manual_seed(77)
+    x0 = torch.randn(B, Nn, Nn, C_, device='cuda', generator=g).to(dtype)
+    res0 = torch.randn(B, Nn, Nn, C_, device='cuda', generator=g).to(dtype)
+    W1 = (torch.randn(C_, C_, device='cuda', generator=g) / 16).requires_grad_()
+    b1 = (torch.randn(C_, device='cuda', generator=g) * 0.1).requires_grad_()
+    W2 = (torch.randn(C_, C_, device='cuda', generator=g) / 16).requires_grad_()
+    b2 = (torch.randn(C_, device='cuda', generator=g) * 0.1).requires_grad_()
+    lw = (torch.rand(C_, device='cuda', generator=g) + 0.5).requires_grad_()
+    lb = (torch.randn(C_, device='cuda', generator=g) * 0.1).requires_grad_()
+    scale = torch.tensor([1.25, 0.0, 1.25], device='cuda')
+    gs = torch.randn(B, Nn, Nn, C_, device='cuda', generator=g).to(dtype)
+    gy = torch.randn(B, Nn, Nn, C_, device='cuda', generator=g).to(dtype)
+    results = []
+    for fused in (False, True):
+        monkeypatch.setattr(ops, '_EDGE_WGRAD', fused)
+        ops.reset_random_pools()
+        torch.manual_seed(5)
+        x = x0.clone().requires_grad_()
+        res = res0.clone().requires_grad_()
+        with torch.autocast('cuda', dtype=dtype):
+            act = ops.linear_gelu_dropout(x, W1, b1, p, True, sample_scale=scale)
+            s, y = ops.linear_residual_layer_norm(act, W2, b2, res, scale, lw, lb, prescaled=True)
+        grads = torch.autograd.grad([s, y], [x, res, W1, b1, W2, b2, lw, lb], [gs, gy])
+        results.append(grads)
+    # float64 weight gradient of lin_W2 from the stored operands (at this row count the unfused path is ONE 16-bit GEMM, i.e. rounded
+    # to the storage type; the fused launch keeps fp32)
+    for i, (g0, g1) in enumerate(zip(*results)):
+        if i == 4:
+            assert rel(g1, g0) < TOL[dtype], rel(g1, g0)
+        else:
+            assert torch.equal(g0, g1), i

@@ -17,10 +17,10 @@ LIB_PATH = os.path.join(_HERE, 'libtgt_hip.so')
 LIB_OVERRIDE = os.environ.get('TGT_HIP_LIB')
 CSRC = os.path.join(_HERE, 'csrc')
 # (source, extra flags, object suffix): the triplet attention kernels compile one dtype per translation unit
-SOURCES = ['capi.hip', 'optimizer.hip', 'edge_gemm.hip', 'params.hip', 'loss.hip', 'predict.hip', 'gaussian.hip', 'triplet_attention_proj.hip',
+SOURCES = ['capi.hip', 'optimizer.hip', 'edge_gemm.hip', 'edge_wgrad.hip', 'params.hip', 'loss.hip', 'predict.hip', 'gaussian.hip', 'triplet_attention_proj.hip',
            ('triplet_attention.hip', ['-DTGT_TRI_INST=9'], '.f32'), ('triplet_attention.hip', ['-DTGT_TRI_INST=2'], '.bf16'),
            ('triplet_attention.hip', ['-DTGT_TRI_INST=4'], '.f16'), 'triplet_attention16.hip', 'triplet_attention_bwd2.hip', 'triplet_aggregate.hip', 'node_attention.hip', 'node_attention_mfma.hip', 'node_attention16.hip', 'node_attention_kb.hip', 'layernorm.hip', 'triangular_update.hip', 'elementwise.hip']
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 TGT_F32, TGT_BF16, TGT_F16 = 0, 1, 2
 TRI_BIASED, TRI_GATED, TRI_MASK_OUT = 1, 2, 4
@@ -87,7 +87,7 @@ class EdgeLinearArgs(C.Structure):
         ('res', _vp), ('ldr', _i64), ('ds_in', _vp), ('ld_ds', _i64),
         ('row_scale', _vp), ('out_scale', _vp), ('rows_per_sample', _i64),
         ('dropout_p', _f32), ('flags', C.c_uint32), ('dropout_seed', C.c_uint64),
-        ('colsum_partial', _vp),
+        ('colsum_partial', _vp), ('dw_partial', _vp),
     ]
 
 

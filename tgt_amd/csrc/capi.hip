@@ -88,7 +88,7 @@ using namespace tgt;
 extern "C" {
 
 const char* tgt_last_error(void) { return g_err; }
-int tgt_abi_version(void) { return 29; }
+int tgt_abi_version(void) { return 30; }
 int tgt_set_seed_counter(const void* device_counter) {
     g_seed_counter = reinterpret_cast<const uint64_t*>(device_counter);
     return TGT_OK;

@@ -38,6 +38,8 @@ _SPEC = {
     'node_chain': ('TGT_NODE_CHAIN', True, 'flag', "the next layer's node projections chained on the side stream"),
     'flat_grad_dst': ('TGT_FLAT_GRAD_DST', True, 'flag', 'weight gradients written into the flat gradient buffer inside a Trainer backward'),
     'defer_edge': ('TGT_DEFER_EDGE', True, 'flag', 'closing edge residual performed by the next layer entry'),
+    'edge_wgrad': ('TGT_EDGE_WGRAD', False, 'flag', 'weight gradient of the 256 x 256 edge Linears inside their data-gradient launch (csrc/edge_wgrad.hip)'),
+    'edge_wgrad_spare_cus': ('TGT_EDGE_WGRAD_SPARE_CUS', 0, 'int', 'CUs the fused data + weight gradient launch leaves to the side stream (it takes all 160 KB of LDS where it runs)'),
     'wgrad_maxp': ('TGT_WGRAD_MAXP', 128, 'int', 'cap on the row chunks of a split-M weight gradient (in-step sweep 32..256: 128)'),
     'embed_gemm': ('TGT_EMBED_GEMM', True, 'flag', "per-node mul / bias tables of the Gaussian 3-D embedding without nn.Embedding's sort-based backward (a host read)"),
     'gate_node_bwd': ('TGT_GATE_NODE_BWD', 0, 'int', "the node side stream's backward chain of a layer waits for that layer's triplet backward kernel (1) / for the projection's data-gradient GEMM behind it (2)"),
@@ -82,6 +84,8 @@ class Knobs:
     node_chain: bool
     flat_grad_dst: bool
     defer_edge: bool
+    edge_wgrad: bool
+    edge_wgrad_spare_cus: int
     wgrad_maxp: int
     embed_gemm: bool
     gate_node_bwd: int

@@ -1827,7 +1827,7 @@ def linear(x, weight, bias=None):
 # ---------------------------------------------------------------------------
 def edge_linear_raw(a, w, bias=None, epilogue=_lib.EPI_BIAS, *, ln=None, y=None, out=None, out2=None, res=None, ds_in=None,
                     row_scale=None, out_scale=None, rows_per_sample=0, dropout=(0.0, 0), stats=None, colsum_partial=None,
-                    flags=0):
+                    flags=0, dw_partial=None):
     """One launch of tgt_edge_linear on 2-D operands (rows may be strided views with a contiguous last axis).
     a (M,K), w (N,K), bias (N) in one 16-bit dtype; ln = (gamma, beta, eps) float32 for the LayerNorm prologue /
     the LN_BWD epilogue; stats = (mean, rstd) float32 (M) (written by the prologue, read by LN_BWD).
@@ -1880,6 +1880,13 @@ def edge_linear_raw(a, w, bias=None, epilogue=_lib.EPI_BIAS, *, ln=None, y=None,
     if colsum_partial is not None:
         g.colsum_partial = colsum_partial.data_ptr()
         g.colsum_rows = colsum_partial.shape[0]          # (N = 256: the launch uses exactly this many workgroups, one row each)
+    if dw_partial is not None:
+        # fused weight gradient (ABI 30): one (N, K) fp32 plane per persistent workgroup, every plane written
+        if dw_partial.dtype != torch.float32 or not dw_partial.is_contiguous() or tuple(dw_partial.shape[1:]) != (N, K) or \
+                (colsum_partial is not None and colsum_partial.shape[0] != dw_partial.shape[0]):
+            raise RuntimeError(f'edge_linear: dw_partial must be contiguous float32 (parts, {N}, {K}) with as many planes as colsum_partial has rows')
+        g.dw_partial = dw_partial.data_ptr()
+        g.colsum_rows = dw_partial.shape[0]
     _call('tgt_edge_linear', _lib.lib().tgt_edge_linear, g)
     return out
 
@@ -2117,6 +2124,7 @@ class _LinearResidualLN(torch.autograd.Function):
 
         need_db = bdt is not None and ctx.needs_input_grad[2]
         d_pre = None
+        fused_dw = None
         need_dx = ctx.needs_input_grad[0]
         if ctx.gelu is not None:
             # d_pre = ((d_z W) * sample_scale) * gelu'(pre) * keep / (1 - p): the data gradient and the activation's backward in
@@ -2126,25 +2134,41 @@ class _LinearResidualLN(torch.autograd.Function):
             if ctx.needs_input_grad[11]:
                 d_pre = torch.empty_like(pre)
                 # (256 outputs = the row-phase kernel: it also returns the column sums of d_pre, lin_W1's bias gradient)
-                part = torch.empty(_lib.lib().tgt_edge_linear_parts(rows, 256), 256, dtype=torch.float32, device=pre.device) \
+                # the weight gradient of THIS Linear rides on the same launch (TGT_EDGE_WGRAD): dW = d_z^T x with x = the activation
+                # recomputed from `pre` in the row phase -- neither d_z nor x is read again by a weight-gradient GEMM
+                fuse_dw = (_EDGE_WGRAD and ctx.needs_input_grad[1] and ctx.col_inv is None and N == 256 and pre.shape[-1] == 256 and
+                           x2.shape[1] == 256 and wdt == torch.float32)
+                parts = _lib.lib().tgt_edge_linear_parts(rows, 256)
+                if fuse_dw and parts > 2 * _EDGE_WGRAD_SPARE > 0:
+                    parts -= _EDGE_WGRAD_SPARE          # (the fused launch owns every CU it runs on -- all 160 KB of LDS: leave some to the node side stream)
+                part = torch.empty(parts, 256, dtype=torch.float32, device=pre.device) \
                     if (pre.shape[-1] == 256 and _GELU_BWD_EPI_COLSUM) else None
+                dw_part = torch.empty(parts, 256, 256, dtype=torch.float32, device=pre.device) if fuse_dw else None
                 edge_linear_raw(d_z.reshape(rows, N), weight_t(w), None, _lib.EPI_GELU_BWD, out=d_pre.view(rows, -1),
                                 res=pre.view(rows, -1), out_scale=g_scale, rows_per_sample=rps, dropout=(ctx.gelu[0], ctx.gelu[1]),
-                                colsum_partial=part)
+                                colsum_partial=part, dw_partial=dw_part)
                 if part is not None:
                     with _on_stream(_terminal_fork(rows, part)):
                         _hand_colsum(d_pre, sum_rows(part))
+                if dw_part is not None:
+                    dst = _grad_dst(ctx.wptr, (256, 256), torch.float32)
+                    with _on_stream(_terminal_fork(rows, dw_part)):
+                        fused_dw = sum_planes(dw_part, dst if dst is not None else torch.empty(256, 256, dtype=torch.float32, device=pre.device))
         dx, dw, db = _linear_backward(x2, w, d_z.reshape(rows, N), xs, xdt, torch.float32 if ctx.col_inv is not None else wdt, bdt,
-                                      need_dx, ctx.needs_input_grad[1], need_db and cs is None,
+                                      need_dx, ctx.needs_input_grad[1] and fused_dw is None, need_db and cs is None,
                                       dw_post=None if ctx.col_inv is None else (lambda t: _permute_cols(t.contiguous(), ctx.col_inv, wdt, after_sums=True)),
                                       dw_ptr=ctx.wptr)
         if need_db and cs is not None:
             db = _param_grad(cs, bdt)
+        if fused_dw is not None:
+            dw = fused_dw
         return (dx, dw, db, d_res if rdt == d_res.dtype else d_res.to(rdt), None,
                 _param_grad(dg, lndt), _param_grad(dbeta, lndt), None, None, None, None, d_pre, None, None)
 
 
 _GELU_BWD_EPI_COLSUM = K.gelu_bwd_epi_colsum      # A/B knob: lin_W1's bias gradient from the GELU_BWD epilogue
+_EDGE_WGRAD_SPARE = K.edge_wgrad_spare_cus
+_EDGE_WGRAD = K.edge_wgrad      # A/B knob: weight gradients of the 256 x 256 edge Linears inside their data-gradient launches (csrc/edge_wgrad.hip)
 _EDGE_K512 = K.edge_k512        # A/B knob: lin_O (K = 512) + residual + LayerNorm as one launch
 
 
