@@ -233,6 +233,9 @@ def main():
     ap.add_argument('--timing-probe', default='', choices=['', 'skip_sums', 'skip_proj_ln', 'skip_wgrad'],
                     help='leave work OUT of the step to bound what it costs (tools/probes/skip_probes.py); the line then carries '
                          '"value": null and "invalid": ... -- the gradients of such a step are wrong by construction')
+    ap.add_argument('--grad-exchange', default='all_reduce', choices=['all_reduce', 'reduce_scatter', 'reduce_scatter_sharded'],
+                    help="gradient exchange of the multi-rank step: bucketed all-reduce (default, the reference's DDP), reduce-scatter + all-gather per "
+                         'bucket, or reduce-scatter + Adam on the owned 1/world slices + all-gather of the parameters (StepConfig.shard_optimizer)')
     ap.add_argument('--share-device', action='store_true',
                     help='multi-rank dress rehearsal on ONE GPU: every rank runs on cuda:0 and the ranks exchange over gloo (RCCL refuses '
                          'two ranks on one device).  Walks the exact multi-rank branch of this file -- rendezvous, rank-0 broadcast, '
@@ -305,7 +308,9 @@ def main():
     torch.manual_seed(0)
     model = TGT_Multi(**mcfg).to(dev).train()
     torch.manual_seed(4321 + rank)           # same initial weights on every rank, different dropout streams
-    cfg = StepConfig(mixed_precision=None if args.precision == 'fp32' else args.precision)
+    cfg = StepConfig(mixed_precision=None if args.precision == 'fp32' else args.precision,
+                     grad_exchange=args.grad_exchange.replace('_sharded', ''),
+                     shard_optimizer=args.grad_exchange.endswith('_sharded') and world > 1)
     trainer = Trainer(model, cfg)
 
     # synthetic batches, resident in HBM before timing (4 distinct ones, cycled)
@@ -542,7 +547,7 @@ def main():
             ms_per_step_by_rank=[round(v, 3) for v in rank_ms],
             comm_exposed_ms=round(max(rank_comm), 3), comm_exposed_ms_by_rank=[round(v, 3) for v in rank_comm],
             grad_exchange=dict(buckets=(len(trainer.buckets) if trainer.buckets else 0), bucket_mbytes=cfg.bucket_mbytes,
-                               launch_order_last_step=trainer.bucket_order[:16], mode=cfg.grad_exchange,
+                               launch_order_last_step=trainer.bucket_order[:16], mode=cfg.grad_exchange, optimizer_sharded=bool(trainer.sharded),
                                wire_dtype=cfg.grad_comm_dtype or 'fp32',
                                rccl_stream=('high priority' if (world > 1 and not args.share_device) else None)),
             final_loss=round(loss_val, 5),

@@ -25,11 +25,14 @@ def _bench(args, timeout=900):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('launcher', ['self', 'torchrun'])
+@pytest.mark.parametrize('launcher', ['self', 'torchrun', 'self_sharded'])
 def test_bench_two_ranks_share_one_gpu(launcher):
     common = ['--gpus', '2', '--share-device', '--batch', '16', '--steps', '3', '--warmup', '1', '--settle-steps', '3',
               '--roofline-steps', '1', '--no-cpu-baseline']
-    if launcher == 'self':
+    if launcher == 'self_sharded':                          # the sharded-optimizer exchange (StepConfig.shard_optimizer) through the same branch
+        out = _bench(common + ['--grad-exchange', 'reduce_scatter_sharded'])
+        assert out['grad_exchange']['optimizer_sharded'] is True and out['grad_exchange']['mode'] == 'reduce_scatter'
+    elif launcher == 'self':
         out = _bench(common)
     else:
         # the driver's form: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...

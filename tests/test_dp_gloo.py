@@ -169,3 +169,68 @@ def test_lr_schedule_matches_reference_formula():
     assert abs(lr_at(100, cfg) - 2e-3) < 1e-12
     assert abs(lr_at(1000, cfg) - 1e-6) < 1e-9
     assert abs(lr_at(550, cfg) - (1e-6 + (2e-3 - 1e-6) * 0.5)) < 1e-9
+
+
+def _torch_adam_(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0,
+                 shadow=None, clip_value=0.0, ctl=None):
+    """TEST-SIDE stand-in for ops.adam_step_ (the HIP kernel has no CPU form and the product has no fallback): torch.optim.Adam's
+    update on flat buffers, elementwise -- so a slice of the buffers updates exactly like the same elements inside the whole."""
+    g = grad * grad_scale
+    exp_avg.mul_(betas[0]).add_(g, alpha=1 - betas[0])
+    exp_avg_sq.mul_(betas[1]).addcmul_(g, g, value=1 - betas[1])
+    bc1, bc2 = 1 - betas[0] ** step, 1 - betas[1] ** step
+    param.addcdiv_(exp_avg, (exp_avg_sq / bc2).sqrt_().add_(eps), value=-lr / bc1)
+
+
+def _sharded_worker(rank, world, port, kwargs, shard, result):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from tgt_amd import ops
+    from tgt_amd.training.step import Trainer, StepConfig
+    ops.adam_step_ = _torch_adam_                    # (this process only)
+    torch.set_num_threads(2)
+    tr = Trainer(_make(kwargs, seed=11 + rank), StepConfig(mixed_precision=None, bucket_mbytes=0, grad_exchange='reduce_scatter',
+                                                         shard_optimizer=shard, lr_warmup_steps=2, lr_total_steps=50), loss_fn=_gap_l1)
+    assert tr.sharded == shard
+    owned = tr.owned_slices() if shard else None
+    for step in range(3):
+        full = _batch(4, 6, seed=5 + step)
+        tr.global_step += 1
+        tr.compute_gradients(_slice(full, 2 * rank, 2 * rank + 2))
+        if step == 0:
+            result[f'grad{rank}'] = tr.flat.grad.clone()
+        tr.apply_gradients()
+    if shard:
+        tr.consolidate_optimizer_state()
+    result[f'param{rank}'] = tr.flat.param.clone()
+    result[f'm{rank}'] = tr.flat.exp_avg.clone()
+    result[f'v{rank}'] = tr.flat.exp_avg_sq.clone()
+    if rank == 0:
+        result['owned'] = owned
+        result['buckets'] = [tuple(b[:2]) for b in tr.buckets]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_optimizer_bookkeeping_on_gloo():
+    """StepConfig.shard_optimizer, world 2 on CPU: the reduce-scatter leaves the reduced gradient on each rank's owned slices (the
+    two ranks' slices partition every bucket), and three steps of (owned-slice update + all-gather of the parameters) end with the
+    parameters and -- after the collective consolidate -- the moments of the REPLICATED reduce_scatter run, bit for bit, on both
+    ranks.  (The update itself is a test-side torch restatement here; the HIP kernel's turn is tests/test_hip_trainer.py.)"""
+    kwargs = dict(gu.MODEL_CASES['gap_at_tiny'][1])
+    kwargs['embed_3d_type'] = 'none'
+    mgr = mp.Manager()
+    rep, sh = mgr.dict(), mgr.dict()
+    mp.spawn(_sharded_worker, args=(2, _free_port(), kwargs, False, rep), nprocs=2, join=True)
+    mp.spawn(_sharded_worker, args=(2, _free_port(), kwargs, True, sh), nprocs=2, join=True)
+    owned0, buckets = sh['owned'], sh['buckets']
+    assert len(buckets) > 10
+    for (s0, e0), (a, b) in zip(buckets, owned0):
+        assert a == s0 and b == s0 + (e0 - s0) // 2          # rank 0 owns the first half of every bucket
+        # reduced (summed) gradient on the owned halves: rank 0's first half, rank 1's second half
+        assert torch.equal(sh['grad0'][a:b], rep['grad0'][a:b])
+        assert torch.equal(sh['grad1'][b:e0], rep['grad0'][b:e0])
+    for r in (0, 1):
+        assert torch.equal(sh[f'param{r}'], rep['param0']) and torch.equal(rep[f'param{r}'], rep['param0'])
+        assert torch.equal(sh[f'm{r}'], rep['m0']) and torch.equal(sh[f'v{r}'], rep['v0'])

@@ -597,7 +597,7 @@ def _free_port():
     return p
 
 
-def _world2_worker(rank, world, port, out_dir, side_stream, backend='gloo', exchange='all_reduce'):
+def _world2_worker(rank, world, port, out_dir, side_stream, backend='gloo', exchange='all_reduce', shard=False, tag=''):
     import os
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -617,10 +617,10 @@ def _world2_worker(rank, world, port, out_dir, side_stream, backend='gloo', exch
     kwargs = dict(gu.MODEL_CASES['multi_at_tiny'][1])
     kwargs.update(model_height=4)
     cfg = StepConfig(num_dist_bins=24, mixed_precision='bf16', coords_noise=0.0, bucket_mbytes=0.05,
-                     lr_warmup_steps=10, lr_total_steps=100, grad_exchange=exchange)
+                     lr_warmup_steps=10, lr_total_steps=100, grad_exchange=exchange, shard_optimizer=shard)
     model = gu.fill_params(TGT_Multi(**kwargs), seed=5 + rank).cuda().eval()       # ranks start DIFFERENT: the broadcast fixes it
     tr = Trainer(model, cfg)
-    assert tr.distributed and tr.world == 2 and tr.buckets is not None and len(tr.buckets) > 4
+    assert tr.distributed and tr.world == 2 and tr.buckets is not None and len(tr.buckets) > 4 and tr.sharded == shard
     grads = []
     for step in range(3):
         full = make_batch(8, 12, seed=90 + step, ragged=False)
@@ -631,20 +631,29 @@ def _world2_worker(rank, world, port, out_dir, side_stream, backend='gloo', exch
         grads.append((tr.flat.grad / world).cpu())
         tr.apply_gradients()
     torch.cuda.synchronize()
-    torch.save({'grads': grads, 'param': tr.flat.param.cpu()}, os.path.join(out_dir, f'rank{rank}.pt'))
+    extra = {}
+    if shard:
+        import pytest as _pt
+        with _pt.raises(RuntimeError, match='consolidate_optimizer_state'):
+            tr.optimizer_state_dict()
+        tr.consolidate_optimizer_state()                            # (a collective: both ranks)
+    extra = {'exp_avg': tr.flat.exp_avg.cpu(), 'exp_avg_sq': tr.flat.exp_avg_sq.cpu(), 'shadow': tr.flat.shadow.float().cpu(),
+             'opt_steps': tr.optimizer_state_dict()['state'][0]['step']}
+    torch.save({'grads': grads, 'param': tr.flat.param.cpu(), **extra}, os.path.join(out_dir, f'rank{rank}{tag}.pt'))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _check_world2_against_single_rank(tmp_path):
+def _check_world2_against_single_rank(tmp_path, grads_replicated=True):
     from tgt_amd.pcqm import TGT_Multi
     from tgt_amd.training.step import Trainer, StepConfig, preprocess_batch
     from tgt_amd.training.synthetic import make_batch
     r0 = torch.load(tmp_path / 'rank0.pt')
     r1 = torch.load(tmp_path / 'rank1.pt')
     assert torch.equal(r0['param'], r1['param'])                # replicas stay bit-identical
-    for g0, g1 in zip(r0['grads'], r1['grads']):
-        assert torch.equal(g0, g1)
+    if grads_replicated:                                        # (sharded optimizer: a rank holds the reduced gradient on its slices only)
+        for g0, g1 in zip(r0['grads'], r1['grads']):
+            assert torch.equal(g0, g1)
 
     kwargs = dict(gu.MODEL_CASES['multi_at_tiny'][1])
     kwargs.update(model_height=4)
@@ -656,7 +665,8 @@ def _check_world2_against_single_rank(tmp_path):
         tr.global_step += 1
         tr.compute_gradients(batch)
         # the loss is a mean over the rank's graphs / pairs: halves average to the whole when the halves weigh the same
-        assert rel(r0['grads'][step], tr.flat.grad) < 2e-2, (step, rel(r0['grads'][step], tr.flat.grad))
+        if grads_replicated:
+            assert rel(r0['grads'][step], tr.flat.grad) < 2e-2, (step, rel(r0['grads'][step], tr.flat.grad))
         tr.apply_gradients()
     assert rel(r0['param'], tr.flat.param) < 1e-3
 
@@ -671,7 +681,22 @@ def test_world2_on_one_gpu_matches_single_rank(tmp_path, side_stream):
     _check_world2_against_single_rank(tmp_path)
 
 
-@pytest.mark.parametrize('exchange', ['all_reduce', 'reduce_scatter'])
+def test_sharded_optimizer_equals_the_replicated_step_bit_for_bit(tmp_path):
+    """StepConfig.shard_optimizer: reduce-scatter only, Adam on each rank's 1/world slice of every bucket, all-gather
+    of the updated parameters.  Two ranks sharing cuda:0 over gloo, three steps: parameters, the 16-bit shadow and (after the
+    collective consolidate_optimizer_state) both Adam moments equal the replicated reduce_scatter run BIT FOR BIT on both ranks."""
+    import torch.multiprocessing as mp
+    mp.spawn(_world2_worker, args=(2, _free_port(), str(tmp_path), True, 'gloo', 'reduce_scatter', False, '_rep'), nprocs=2, join=True)
+    mp.spawn(_world2_worker, args=(2, _free_port(), str(tmp_path), True, 'gloo', 'reduce_scatter', True, '_shard'), nprocs=2, join=True)
+    rep = torch.load(tmp_path / 'rank0_rep.pt')
+    for r in (0, 1):
+        sh = torch.load(tmp_path / f'rank{r}_shard.pt')
+        for k in ('param', 'shadow', 'exp_avg', 'exp_avg_sq'):
+            assert torch.equal(sh[k], rep[k]), (r, k)
+        assert float(sh['opt_steps']) == float(rep['opt_steps']) == 3.0
+
+
+@pytest.mark.parametrize('exchange', ['all_reduce', 'reduce_scatter', 'reduce_scatter_sharded'])
 def test_world2_over_rccl_matches_single_rank(tmp_path, exchange):
     """BASELINE config 3's exchange on real links: two ranks, one MI355X each, backend 'nccl' (= RCCL over xGMI) -- bucketed
     all-reduce from the gradient hooks (and the reduce-scatter + all-gather option), rank-0 broadcast, packed loss all-reduce.
@@ -679,5 +704,6 @@ def test_world2_over_rccl_matches_single_rank(tmp_path, exchange):
     if torch.cuda.device_count() < 2:
         pytest.skip(f'needs 2 GPUs for two RCCL ranks, this box has {torch.cuda.device_count()}')
     import torch.multiprocessing as mp
-    mp.spawn(_world2_worker, args=(2, _free_port(), str(tmp_path), True, 'nccl', exchange), nprocs=2, join=True)
-    _check_world2_against_single_rank(tmp_path)
+    shard = exchange.endswith('_sharded')
+    mp.spawn(_world2_worker, args=(2, _free_port(), str(tmp_path), True, 'nccl', exchange.replace('_sharded', ''), shard), nprocs=2, join=True)
+    _check_world2_against_single_rank(tmp_path, grads_replicated=not shard)

@@ -53,6 +53,14 @@ class StepConfig:
     # all-gather of the bucket -- on the fully connected 8-GPU xGMI mesh each rank then owns 1/world of the sum and the two halves
     # use all seven links at once instead of a ring's one; same sums, another summation order
     grad_exchange: str = 'all_reduce'
+    # with grad_exchange='reduce_scatter': ZeRO-1 style sharding of the optimizer step.  Every rank keeps only ITS 1/world shard of each
+    # bucket's reduced gradient (no all-gather of gradients), runs tgt_adam_step on that shard of the flat buffers (the 3.1 GB Adam
+    # sweep becomes 3.1 GB / world per rank) and the UPDATED float32 parameters are all-gathered; the 16-bit shadow is refreshed from
+    # them locally.  Wire bytes equal the replicated reduce_scatter mode's (4 B reduce-scatter + 4 B all-gather per parameter), the
+    # moments exist only on their owner: optimizer_state_dict() is then a COLLECTIVE (every rank calls it).  Needs: no dynamic loss
+    # scale, no gradient clipping (their decisions need the whole gradient), no weight-shared stack.  Opt-in; never run on hardware
+    # with more than one GPU.
+    shard_optimizer: bool = False
     # gradient clipping (reference training.py:446-462; None = off, as in the shipped YAMLs)
     clip_grad_value: float = None
     clip_grad_norm: float = None
@@ -262,10 +270,15 @@ class Trainer:
         self.ctl = torch.zeros(ops.CTL_SIZE, dtype=torch.float32, device=dev)
         self.ctl[ops.CTL_SCALE] = self.cfg.init_scale if self.dynamic_scale else 1.0
         self.ctl[ops.CTL_COEF] = 1.0
+        self.sharded = False               # StepConfig.shard_optimizer in effect (set by _setup_buckets)
+        self.rank = dist.get_rank(process_group) if self.distributed else 0
         if self.distributed:
             # replicas start from rank 0's parameters (DDP's broadcast at wrap, training.py:152)
             dist.broadcast(self.flat.param, src=0, group=self.pg)
             self._setup_buckets()
+        if self.cfg.shard_optimizer and self.distributed and not self.sharded:
+            raise RuntimeError('StepConfig.shard_optimizer needs grad_exchange="reduce_scatter", bucket sizes divisible by the world size, no '
+                               'weight-shared stack, no dynamic loss scale (fp16) and no gradient clipping')
         self._wt = None
         self._shared = getattr(model, 'layer_multiplier', 1) > 1 or getattr(getattr(model, 'encoder', None), 'layer_multiplier', 1) > 1
         self._reuse_checked = False        # the first backward walks its graph once for parameters that enter it more than once
@@ -354,6 +367,10 @@ class Trainer:
                 self.buckets.append([start, ends[i], count, first])
                 start, count, first = ends[i], 0, i + 1
         self._pending = [b[2] for b in self.buckets]
+        cfg = self.cfg
+        self.sharded = bool(cfg.shard_optimizer and cfg.grad_exchange == 'reduce_scatter' and cfg.grad_comm_dtype is None and
+                            self.world > 1 and all((b[1] - b[0]) % self.world == 0 for b in self.buckets) and
+                            cfg.mixed_precision != 'fp16' and not cfg.clip_grad_norm and not cfg.clip_grad_value)
         # The hooks are registered AFTER the first forward (compute_gradients), not here: a post-accumulate hook keeps the
         # parameter's AccumulateGrad node alive for good, and that node runs on the stream that was current when it was CREATED.
         # Created here, every node would sit on the default stream while the node channel's gradients are produced on the side
@@ -381,6 +398,14 @@ class Trainer:
             n = wire.numel() // world
             shard = torch.empty(n, dtype=wire.dtype, device=wire.device)
             h1 = dist.reduce_scatter_tensor(shard, wire, group=pg, async_op=True)
+            if self.sharded:
+                # sharded optimizer: the reduced shard goes back into ITS slice of the flat gradient and that is all -- the rest of the
+                # bucket keeps this rank's local (unreduced) gradients, which nothing reads: Adam runs on the owned slices only
+                class _One:
+                    def wait(_self):
+                        h1.wait()
+                        g[self.rank * n:(self.rank + 1) * n].copy_(shard)
+                return _One()
 
             class _Two:
                 def wait(_self):
@@ -507,6 +532,8 @@ class Trainer:
         # device_lr (a captured step, training/graphed.py): the kernel reads the rate from the control block, which the owner of
         # the graph refreshes before every replay
         lr = -1.0 if self.device_lr else lr_at(self.global_step, cfg)
+        if self.sharded:
+            return self._apply_gradients_sharded(lr)
         if self.use_ctl:
             ops.grad_scaler_step_(f.grad, self.ctl, self.world, cfg.clip_grad_value, cfg.clip_grad_norm, self.dynamic_scale,
                                   cfg.growth_factor, cfg.backoff_factor, cfg.growth_interval)
@@ -519,6 +546,44 @@ class Trainer:
                            shadow=f.shadow, clip_value=cfg.clip_grad_value)
         if self._wt is not None:
             self._wt.refresh()              # (the shadow just changed: every registered W^T follows, one launch)
+
+    def owned_slices(self):
+        """[(start, end)] of the flat buffers this rank owns under the sharded optimizer: its 1/world piece of every bucket"""
+        out = []
+        for s0, e0, _, _ in self.buckets:
+            n = (e0 - s0) // self.world
+            out.append((s0 + self.rank * n, s0 + (self.rank + 1) * n))
+        return out
+
+    def _apply_gradients_sharded(self, lr):
+        """Adam on the owned slices (their gradients are the reduced sums, see _all_reduce_async), then the updated float32 parameters
+        of every bucket are all-gathered in place and the 16-bit shadow follows locally."""
+        cfg, f = self.cfg, self.flat
+        if self.use_ctl or self.device_lr:
+            raise RuntimeError('sharded optimizer: the device control block (dynamic loss scale / clipping / captured steps) is not supported')
+        self._applied_steps += 1
+        for a, b in self.owned_slices():
+            ops.adam_step_(f.param[a:b], f.grad[a:b], f.exp_avg[a:b], f.exp_avg_sq[a:b], self._applied_steps, lr,
+                           betas=cfg.betas, eps=cfg.eps, weight_decay=cfg.weight_decay, grad_scale=1.0 / self.world)
+        handles = []
+        for (s0, e0, _, _), (a, b) in zip(self.buckets, self.owned_slices()):
+            # in place: rank r's input is its own slice of the output
+            handles.append(dist.all_gather_into_tensor(f.param[s0:e0], f.param[a:b], group=self.pg, async_op=True))
+        for h in handles:
+            h.wait()
+        self._moments_consolidated = False
+        self.refresh_shadow()                # (shadow <- parameters, one cast pass; the registered W^T follow)
+
+    def consolidate_optimizer_state(self):
+        """COLLECTIVE (sharded optimizer only): all-gather the Adam moments so that every rank holds all of them -- call it on every
+        rank before optimizer_state_dict() / state_dict(); the next optimizer step un-consolidates them again."""
+        if not self.sharded:
+            return
+        f = self.flat
+        for (s0, e0, _, _), (a, b) in zip(self.buckets, self.owned_slices()):
+            dist.all_gather_into_tensor(f.exp_avg[s0:e0], f.exp_avg[a:b].clone(), group=self.pg)
+            dist.all_gather_into_tensor(f.exp_avg_sq[s0:e0], f.exp_avg_sq[a:b].clone(), group=self.pg)
+        self._moments_consolidated = True
 
     def set_device_lr(self, on=True):
         """the learning rate as a device value (ctl[CTL_LR]) instead of a kernel argument; needs the control-block path of the
@@ -589,6 +654,9 @@ class Trainer:
         parameter order = model.parameters(): loads into torch.optim.Adam(model.parameters())"""
         f = self.flat
         steps = self.step_stats()['applied_steps']
+        if self.sharded and steps > 0 and not getattr(self, '_moments_consolidated', False):
+            raise RuntimeError('sharded optimizer: the Adam moments live on their owner ranks -- call consolidate_optimizer_state() on EVERY rank '
+                               '(a collective) before optimizer_state_dict() / state_dict()')
         state = {i: dict(step=torch.tensor(float(steps)), exp_avg=m.detach().clone().cpu(), exp_avg_sq=v.detach().clone().cpu())
                  for i, (m, v) in enumerate(zip(f.views(f.exp_avg), f.views(f.exp_avg_sq)))} if steps > 0 else {}
         group = dict(lr=lr_at(self.global_step, self.cfg), betas=tuple(self.cfg.betas), eps=self.cfg.eps,
