@@ -1,14 +1,20 @@
-# Round-5 evidence set, one gpurun call:  bash tools/probes/prof_r06.sh <tag>   (kernel sources unchanged since profiles/r05y_pmc_summary.json:
-# bench.py's sha check decides; add `pmc` as a second argument to re-run the counter passes)
+# A round's evidence set, one gpurun call:  bash tools/probes/prof_evidence.sh <tag> [pmc]
+#   the bench lines (default, the driver's command, 50 steps, ragged, config 4, the two-rank rehearsal), kernel micro-benchmarks, the
+#   steady-state single-stream kernel table + one layer's launch sequence, rocprofv3 --stats of the command as the driver runs it.
+#   `pmc`: re-run the hardware-counter passes first (both shapes + the edge row kernels) -- needed whenever tgt_amd/csrc changed:
+#   bench.py quotes `traffic` / `mfma_util` only from a summary whose `_kernel_src_sha` equals the tree's.
 set -x
-tag=${1:-r06y}
+tag=${1:-r07z}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$tag; mkdir -p $O
 export TMPDIR=/tmp
 cd $R
 if [ "$2" = "pmc" ]; then
   tools/pmc_passes.sh $O "tricol node agg proj" > $O/pmc_passes.log 2>&1; tail -3 $O/pmc_passes.log
+  PMC_KB_ARGS="--B 128 --N 48" tools/pmc_passes.sh $O/n48 "tricol node" > $O/pmc_passes_n48.log 2>&1; tail -3 $O/pmc_passes_n48.log
+  bash tools/pmc_edge.sh $O > $O/pmc_edge_summary.txt 2>&1
   cp $O/pmc_summary.json profiles/${tag}_pmc_summary.json 2>/dev/null || true
+  cp $O/n48/pmc_summary.json profiles/${tag}_n48_pmc_summary.json 2>/dev/null || true
 fi
 python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver_cmd.json 2>> $O/bench.err
