@@ -212,7 +212,7 @@ def main():
     ap.add_argument('--ragged', action='store_true',
                     help='SURVEY 8(d) secondary: num_nodes ~ U{nodes/2..nodes} with the first graph at `nodes` (padded batch)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--settle-steps', type=int, default=45,
+    ap.add_argument('--settle-steps', type=int, default=64,
                     help='untimed steps BEFORE the warm-up steps that let the caching allocator reach its steady state (it keeps adding '
                          '12-54 MB segments on the node side stream for ~50 steps, then never again: tools/probes/mem_growth_probe.py); 0: none')
     ap.add_argument('--roofline-steps', type=int, default=3,
@@ -338,7 +338,7 @@ def main():
     if args.settle_steps > 0:
         quiet, last = 0, torch.cuda.memory_stats(dev).get('num_device_alloc', 0)
         # (every step runs the ranks' gradient exchange: with more than one rank the COUNT must not depend on a rank's own allocator)
-        while settled < args.settle_steps and (quiet < 8 or world > 1):
+        while settled < args.settle_steps and (quiet < 16 or world > 1):
             step(settled)
             settled += 1
             now = torch.cuda.memory_stats(dev).get('num_device_alloc', 0)
@@ -567,7 +567,7 @@ def main():
                                               per_step=ahead[:64],
                                               note='step-end marks (of the last 6) the GPU had not reached when the host finished queueing a step: 0 = the stream ran dry')),
             # conditions of the timed region a plain Trainer loop does not get by itself: stated, not hidden
-            timed_region_policy=dict(gc_frozen=True, allocator_settle='up to --settle-steps untimed steps until 8 in a row make no device allocation',
+            timed_region_policy=dict(gc_frozen=True, allocator_settle='up to --settle-steps untimed steps until 16 in a row make no device allocation',
                                      numa_bound=bool(host_affinity.get('bound')), per_kernel_events='roofline kernels only, one launch in five'),
             roofline=roofline,
             # the caching allocator inside the timed region: device allocations / frees there are synchronous driver calls
