@@ -20,6 +20,33 @@ def test_op_library_loads_and_registers_every_schema():
         assert str(getattr(t, name).default._schema).startswith(f'tgt::{name}(')
 
 
+def test_op_library_exports_the_gemm_dispatch_abi():
+    """include/tgt_gemm.h: every declared symbol is exported by libtgt_torch_ops.so, and a C program compiles against the header"""
+    import ctypes
+    import os
+    import re
+    import subprocess
+    import tempfile
+    from tgt_amd import torch_ops
+    torch_ops.build_op_library()
+    torch_ops.load()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, 'include', 'tgt_gemm.h')).read()
+    declared = set(re.findall(r'\b(tgt_gemm_[a-z_0-9]+)\s*\(', hdr))
+    assert declared == {'tgt_gemm_plan', 'tgt_gemm_run', 'tgt_gemm_last_error'}
+    L = ctypes.CDLL(torch_ops.OPS_LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, 't.c')
+        open(c, 'w').write('#include "tgt_gemm.h"\nint main(void){ return tgt_gemm_plan == 0; }\n')
+        subprocess.check_call(['gcc', '-c', '-I', os.path.join(root, 'include'), c, '-o', os.path.join(td, 't.o')])
+    # without a GPU nothing can be planned; the host wrappers then go through torch (same library, same call)
+    from tgt_amd import gemm
+    x, w, b = torch.randn(6, 4), torch.randn(3, 4), torch.randn(3)
+    assert torch.allclose(gemm.linear_tn(x, w, b), x @ w.t() + b) and torch.allclose(gemm.matmul_nn(x, w.t().contiguous()), x @ w.t())
+
+
 def test_cpu_tensors_raise():
     from tgt_amd import torch_ops
     t = torch_ops.load()

@@ -38,6 +38,7 @@ _SPEC = {
     'node_chain': ('TGT_NODE_CHAIN', True, 'flag', "the next layer's node projections chained on the side stream"),
     'flat_grad_dst': ('TGT_FLAT_GRAD_DST', True, 'flag', 'weight gradients written into the flat gradient buffer inside a Trainer backward'),
     'defer_edge': ('TGT_DEFER_EDGE', True, 'flag', 'closing edge residual performed by the next layer entry'),
+    'own_gemm': ('TGT_OWN_GEMM', True, 'flag', 'library GEMMs of the step dispatched from cached plans (tgt_amd/gemm.py) instead of through torch: same library call, less host time'),
     'edge_wgrad': ('TGT_EDGE_WGRAD', False, 'flag', 'weight gradient of the 256 x 256 edge Linears inside their data-gradient launch (csrc/edge_wgrad.hip)'),
     'edge_wgrad_spare_cus': ('TGT_EDGE_WGRAD_SPARE_CUS', 0, 'int', 'CUs the fused data + weight gradient launch leaves to the side stream (it takes all 160 KB of LDS where it runs)'),
     'wgrad_maxp': ('TGT_WGRAD_MAXP', 128, 'int', 'cap on the row chunks of a split-M weight gradient (in-step sweep 32..256: 128)'),
@@ -84,6 +85,7 @@ class Knobs:
     node_chain: bool
     flat_grad_dst: bool
     defer_edge: bool
+    own_gemm: bool
     edge_wgrad: bool
     edge_wgrad_spare_cus: int
     wgrad_maxp: int

@@ -13,6 +13,7 @@ import weakref
 import torch
 
 from . import _lib
+from . import gemm as _gemm
 from .knobs import K
 
 _DT = {torch.float32: _lib.TGT_F32, torch.bfloat16: _lib.TGT_BF16, torch.float16: _lib.TGT_F16}
@@ -1411,9 +1412,10 @@ def _wgrad_into(out, dy2, x2, chunks):
     while P > 1 and (M % P or M // P < 1024):
         P //= 2
     if P > 1:
-        a = dy2.unflatten(0, (P, M // P)).transpose(1, 2)
-        part = torch.bmm(a, x2.view(P, M // P, -1), out_dtype=torch.float32) if dy2.dtype != torch.float32 else \
-            torch.bmm(a, x2.view(P, M // P, -1))
+        if dy2.dtype != torch.float32:
+            part = _gemm.wgrad_chunks(dy2, x2, P)          # (torch.bmm(..., out_dtype=float32) from a cached plan: tgt_amd/gemm.py)
+        else:
+            part = torch.bmm(dy2.unflatten(0, (P, M // P)).transpose(1, 2), x2.view(P, M // P, -1))
         sum_planes(part, out)
     else:
         out.copy_(dy2.t() @ x2)
@@ -1653,10 +1655,7 @@ def _linear_forward(x, weight, bias, cd):
         # narrow outputs (lin_EG: 128, third-arm E/G: 64): 41 vs 47 us and 29 vs 37 us against the tuned library GEMM
         edge_linear_raw(x2, w, b, out=y2)
         return x2, w, y
-    if b is None:
-        torch.mm(x2, w.t(), out=y2)
-    else:
-        torch.addmm(b, x2, w.t(), out=y2)
+    _gemm.linear_tn(x2, w, b, out=y2)                      # (torch.mm / torch.addmm(out=) from a cached plan)
     return x2, w, y
 
 
@@ -1681,14 +1680,13 @@ def _linear_backward(x2, w, dy2, xs, xdt, wdt, bdt, need_dx, need_dw, need_db, l
             # edge_wide512_kernel, narrow ones (lin_O_e: 256 -> 64) on the slice kernel
             dx = edge_linear_raw(dy2.contiguous(), weight_t(w)).view(xs).to(xdt)
         else:
-            dx = (dy2 @ w).view(xs).to(xdt)
+            dx = _gemm.matmul_nn(dy2, w).view(xs).to(xdt)
     if need_dw:
         M = x2.shape[0]
         P = _wgrad_chunks(M, dy2.shape[1] * x2.shape[1])
         with _on_stream(ws):
             if P > 1:
-                part = torch.bmm(dy2.view(P, M // P, -1).transpose(1, 2), x2.view(P, M // P, -1),
-                                 out_dtype=torch.float32) if dy2.dtype != torch.float32 else \
+                part = _gemm.wgrad_chunks(dy2, x2, P) if dy2.dtype != torch.float32 else \
                     torch.bmm(dy2.view(P, M // P, -1).transpose(1, 2), x2.view(P, M // P, -1))
                 # (dw_ptr: the parameter this gradient belongs to -- inside a Trainer's backward the sum lands in its slice of the
                 #  flat gradient buffer, see _grad_dst)

@@ -30,13 +30,15 @@ def build_op_library(force=False):
     import torch
     from torch.utils import cpp_extension as ce
     _lib.build_library()
-    deps = [_SRC, os.path.join(os.path.dirname(_HERE), 'include', 'tgt_hip.h'), _lib.LIB_PATH]
+    gemm_src = os.path.join(os.path.dirname(_SRC), 'gemm_dispatch.cpp')      # cached-descriptor dispatch of the library GEMMs (tgt_amd/gemm.py)
+    deps = [_SRC, gemm_src, os.path.join(os.path.dirname(_HERE), 'include', 'tgt_hip.h'), _lib.LIB_PATH]
     tlib = os.path.join(os.path.dirname(torch.__file__), 'lib')
     cxx = os.environ.get('CXX', 'g++')
     cmd = [cxx, '-O2', '-std=c++17', '-fPIC', '-shared', '-D__HIP_PLATFORM_AMD__=1', '-DUSE_ROCM=1',
            f'-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}']
-    cmd += [f'-I{p}' for p in ce.include_paths()] + ['-I/opt/rocm/include', _SRC, '-o', OPS_LIB_PATH,
+    cmd += [f'-I{p}' for p in ce.include_paths()] + ['-I/opt/rocm/include', _SRC, gemm_src, '-o', OPS_LIB_PATH,
                                                     f'-L{tlib}', '-lc10', '-lc10_hip', '-ltorch_cpu', '-ltorch_hip', '-ltorch',
+                                                    '-l:libhipblaslt.so', '-l:librocblas.so',      # torch's OWN copies (the tuned indices are theirs)
                                                     f'-L{_HERE}', '-l:libtgt_hip.so', '-Wl,-rpath,$ORIGIN', f'-Wl,-rpath,{tlib}']
     # the command line, the compiler and the torch build are part of the library's currency (not only mtimes)
     try:

@@ -98,7 +98,12 @@ class GraphedTrainingStep:
             torch.cuda.current_stream(dev).wait_stream(self.stream)
             torch.cuda.synchronize(dev)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, stream=self.stream):
+            # With a process group alive, RCCL's watchdog THREAD polls events while this thread captures; under the default
+            # ('global') capture mode such a call from another thread is an error that surfaces in that thread -- which answers it
+            # with std::terminate (one abort at destroy_process_group in ~10 runs of the GPU suite, round 6).  'thread_local' is the
+            # mode torch's own DDP-under-graphs path uses: only THIS thread's unsafe calls invalidate the capture.
+            mode = 'thread_local' if trainer.distributed else 'global'
+            with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode=mode):
                 self.out = self._body()
         except BaseException:
             # warm-up or capture failed: give the mode back before the error travels on (the Trainer stays usable eagerly)
