@@ -250,6 +250,9 @@ def main():
         # `python bench.py --gpus N` by itself: one process per GPU, as the reference's launcher does
         # (execute.py:91-107); rank 0 prints the JSON line
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    # (dmabuf IPC is what the host driver of these boxes supports: without it RCCL's hipIpcGetMemHandle fails.  Exported in the image
+    # already; set here too so that a launcher with a scrubbed environment still gets it -- it is read when the HIP runtime starts)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
